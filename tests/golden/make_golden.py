@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Generate golden parity vectors by RUNNING THE REAL REFERENCE (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/<case>.npz
+
+The reference (`/root/reference/vican`) is imported with an empty ``cv2`` stub
+(its geometry.py:7 imports OpenCV only for ``langevin()``, which the solver never
+calls).  Nothing of the reference is copied: the fixtures hold
+only *data* - the flat input arrays of each case in ``tests/golden_cases.py`` and
+the reference's outputs (pose dict as arrays, per-iteration eigenvalues from its
+``eigs`` call, CG iteration count), plus the library versions used.
+
+The reference never travels to the GPU box; tests read only the .npz files.
+"""
+import os
+import sys
+import types
+import io
+import contextlib
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    sys.exit("reference tree not present - goldens can only be generated in the build container")
+
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))       # see module docstring
+sys.path.insert(0, REF)
+import vican.bipgo as ref_bipgo          # noqa: E402  (the REAL reference)
+import vican.geometry as ref_geometry    # noqa: E402
+assert ref_bipgo.__file__.startswith(REF)
+
+import golden_cases as gc                # noqa: E402
+from vican_amd import synth              # noqa: E402
+
+# -- instrumentation of the reference's third-party calls (recorded, not altered)
+_rec = {"evals": [], "cg_iters": None}
+_orig_eigs, _orig_cg = ref_bipgo.eigs, ref_bipgo.cg
+
+
+def _eigs(*a, **k):
+    ev, evec = _orig_eigs(*a, **k)
+    _rec["evals"].append(np.real(ev).astype(np.float64))
+    return ev, evec
+
+
+def _cg(A, b, *a, **k):
+    n = [0]
+
+    def cb(_xk):
+        n[0] += 1
+    x, info = _orig_cg(A, b, *a, callback=cb, **k)
+    _rec["cg_iters"] = n[0]
+    _rec["cg_relres"] = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+    return x, info
+
+
+ref_bipgo.eigs = _eigs
+ref_bipgo.cg = _cg
+
+
+def run_case(name, case):
+    scene, flat = gc.build_flat(case)
+    src = synth.edges_to_dict(flat, ref_geometry.SE3)
+    out = {"name": name}
+    for k in ("cam_key", "marker_key", "R", "t", "reprojected_err"):
+        out["in_" + k] = flat[k]
+    out["in_corners"] = flat["corners"].astype(np.float32)
+    out["in_reprojected_err"] = flat["reprojected_err"].astype(np.float32)
+    out["in_marker_ids"] = scene["marker_ids"]
+    out["in_R_mk"] = scene["R_mk"]
+    out["in_q_mk"] = scene["q_mk"]
+    out["gt_R_cam"], out["gt_p_cam"] = scene["R_cam"], scene["p_cam"]
+    out["gt_R_obj"], out["gt_p_obj"] = scene["R_obj"], scene["p_obj"]
+    nr, nt, ff = (gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
+    for solver, dt in case["runs"]:
+        _rec["evals"], _rec["cg_iters"], _rec["cg_relres"] = [], None, None
+        dtype = np.dtype(dt).type
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            if case["mode"] == "camera":
+                cons = synth.constraints_from_scene(scene, ref_geometry.SE3)
+                res = ref_bipgo.bipartite_se3sync(src, constraints=cons, noise_model_r=nr,
+                                                  noise_model_t=nt, edge_filter=ff,
+                                                  maxiter=gc.MAXITER, lsqr_solver=solver, dtype=dtype)
+            else:
+                res = ref_bipgo.object_bipartite_se3sync(src, noise_model_r=nr, noise_model_t=nt,
+                                                         edge_filter=ff, maxiter=gc.MAXITER,
+                                                         lsqr_solver=solver, dtype=dtype)
+        tag = "out_%s_%s_" % (solver, dt)
+        keys = list(res.keys())
+        out[tag + "keys"] = np.array([str(k) for k in keys])
+        out[tag + "R"] = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in keys])
+        out[tag + "t"] = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in keys])
+        out[tag + "evals"] = np.stack(_rec["evals"]) if _rec["evals"] else np.zeros((0, 5))
+        out[tag + "cg_iters"] = np.int64(-1 if _rec["cg_iters"] is None else _rec["cg_iters"])
+        out[tag + "cg_relres"] = np.float64(np.nan if _rec["cg_relres"] is None else _rec["cg_relres"])
+        print("  %-12s %-20s %-8s nodes=%d cg_iters=%s evals[-1]=%s" % (
+            name, solver, dt, len(keys), _rec["cg_iters"],
+            np.array2string(out[tag + "evals"][-1], precision=3) if len(_rec["evals"]) else "-"))
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__,
+                                "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def polar_case():
+    """G6: inputs for the batched 3x3 polar/dual kernel incl. reflections and
+    near-rank-deficient blocks, with the reference's own project_SO3 outputs."""
+    rng = np.random.default_rng(61)
+    n = 256
+    x = rng.standard_normal((n, 3, 3))
+    rots = synth.random_rotations(rng, n)
+    x[:64] = rots[:64] * rng.uniform(0.5, 20.0, (64, 1, 1))                 # scaled rotations
+    x[64:96] = rots[64:96] @ np.diag([1.0, 1.0, -1.0]) * 3.0                  # reflections
+    u, v = synth.random_rotations(rng, 32), synth.random_rotations(rng, 32)
+    s = np.stack([np.array([5.0, 1.0, 1e-9 * (i + 1)]) for i in range(32)])
+    x[96:128] = (u * s[:, None, :]) @ v                                       # near rank-2
+    x[128:144] = (u[:16] * np.array([3.0, 3.0, 1.0])[None, None, :]) @ v[:16]  # repeated sigma
+    proj = np.stack([ref_geometry.project_SO3(m) for m in x])
+    np.savez_compressed(os.path.join(HERE, "g6_polar.npz"), x=x, project_SO3=proj)
+    print("  g6_polar     %d blocks" % n)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, case in gc.CASES.items():
+        if only and name not in only:
+            continue
+        run_case(name, case)
+    if not only or "g6_polar" in only:
+        polar_case()

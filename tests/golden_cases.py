@@ -1,0 +1,100 @@
+"""Definition of the golden parity cases.
+
+Shared by ``tests/golden/make_golden.py`` (which runs the REAL reference in the
+build container and writes ``tests/golden/*.npz``) and by the tests (which
+rebuild the same edge dicts from the stored arrays and run the oracle / the HIP
+path).  Weight and filter callables are plain functions of the edge value dict,
+standing in for the notebook's shapely lambdas (main.ipynb:75-77,134-136).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from vican_amd import synth
+
+
+def _area(edge):
+    return synth.shoelace_area(np.asarray(edge["corners"], dtype=np.float64))
+
+
+# -- callables (must be importable by name from both sides) -------------------
+def w_unit(edge):
+    return 1.0
+
+
+def w_area_mild(edge):          # O(1) spread, smooth
+    return 0.5 + _area(edge) / 400.0
+
+
+def w_area_mild_t(edge):
+    return 0.8 + _area(edge) / 900.0
+
+
+def w_area_heavy_r(edge):       # notebook-like: 0.001*area
+    return 0.001 * _area(edge)
+
+
+def w_area_heavy_t(edge):       # notebook-like: 0.001*area^2 (ill-conditioned)
+    return 0.001 * _area(edge) ** 2
+
+
+def f_all(edge):
+    return True
+
+
+def f_err(edge):
+    return edge["reprojected_err"] < 0.02
+
+
+CALLABLES = {f.__name__: f for f in
+             (w_unit, w_area_mild, w_area_mild_t, w_area_heavy_r, w_area_heavy_t, f_all, f_err)}
+
+
+# -- case table ---------------------------------------------------------------
+# mode: "camera" -> bipartite_se3sync, "object" -> object_bipartite_se3sync
+CASES = {
+    # G1 object mode: 24 markers x 300 frames x 4 detections (numeric root, inv() path)
+    "g1_object": dict(mode="object", scene=dict(n_cam=1, n_time=300, n_marker=24, seed=11),
+                      edges=dict(mpv=4, sigma_r=1e-4, sigma_t=1e-4, seed=12),
+                      noise_r="w_unit", noise_t="w_unit", filt="f_all",
+                      runs=[("conjugate_gradient", "float64"), ("conjugate_gradient", "float32")]),
+    # G2 small camera case, all solver/dtype combinations
+    "g2_small": dict(mode="camera", scene=dict(n_cam=8, n_time=60, n_marker=6, seed=21),
+                     edges=dict(cpt=3, mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=22),
+                     noise_r="w_unit", noise_t="w_unit", filt="f_all",
+                     runs=[("conjugate_gradient", "float64"), ("conjugate_gradient", "float32"),
+                           ("direct", "float64"), ("direct", "float32")]),
+    # G3 medium camera case, smooth O(1) weights, reprojection filter active
+    "g3_medium": dict(mode="camera", scene=dict(n_cam=40, n_time=400, n_marker=24, seed=31),
+                      edges=dict(cpt=3, mpv=2, sigma_r=2e-2, sigma_t=2e-2, seed=32),
+                      noise_r="w_area_mild", noise_t="w_area_mild_t", filt="f_err",
+                      runs=[("conjugate_gradient", "float64"), ("conjugate_gradient", "float32")]),
+    # G4 heavy-tailed weights: pins the CG iteration count / documents non-parity regime
+    "g4_illcond": dict(mode="camera", scene=dict(n_cam=10, n_time=120, n_marker=6, seed=41),
+                       edges=dict(cpt=3, mpv=2, sigma_r=5e-3, sigma_t=5e-3, seed=42),
+                       noise_r="w_area_heavy_r", noise_t="w_area_heavy_t", filt="f_all",
+                       runs=[("conjugate_gradient", "float64")]),
+    # G5 string-ordering trap: ids sort lexicographically ('10' < '2'), root = min str
+    "g5_strings": dict(mode="camera",
+                       scene=dict(n_cam=3, n_time=4, n_marker=3, seed=51,
+                                  cam_ids=["2", "10", "100"], time_ids=["2", "10", "7", "30"],
+                                  marker_ids=["10", "0", "2"]),
+                       edges=dict(cpt=3, mpv=3, sigma_r=1e-3, sigma_t=1e-3, seed=52),
+                       noise_r="w_unit", noise_t="w_unit", filt="f_all",
+                       runs=[("conjugate_gradient", "float64")]),
+}
+
+MAXITER = 4
+
+
+def build_flat(case: dict):
+    """Scene + flat source-edge arrays of a case (deterministic)."""
+    scene = synth.make_scene(**case["scene"])
+    if case["mode"] == "camera":
+        flat = synth.make_camera_edges(scene, **case["edges"])
+    else:
+        flat = synth.make_object_edges(scene, **case["edges"])
+    # side data stored as float32 in the fixture: round BEFORE anyone consumes it
+    flat["corners"] = flat["corners"].astype(np.float32).astype(np.float64)
+    flat["reprojected_err"] = flat["reprojected_err"].astype(np.float32).astype(np.float64)
+    return scene, flat

@@ -1,0 +1,49 @@
+"""Shared helpers for the tests: golden loading, dict rebuilding, SE(3) comparison."""
+import os
+
+import numpy as np
+
+import golden_cases as gc
+from vican_amd import synth
+from vican_amd.geometry import SE3, geodesic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def rebuild_inputs(name, g=None):
+    """Edge dict + constraints of a golden case from the STORED arrays (not regenerated)."""
+    g = load_golden(name) if g is None else g
+    case = gc.CASES[name]
+    flat = {
+        "cam_key": g["in_cam_key"], "marker_key": g["in_marker_key"],
+        "R": g["in_R"], "t": g["in_t"],
+        "corners": g["in_corners"].astype(np.float64),
+        "reprojected_err": g["in_reprojected_err"].astype(np.float64),
+    }
+    src = synth.edges_to_dict(flat, SE3)
+    cons = {str(m): SE3(R=g["in_R_mk"][i].copy(), t=g["in_q_mk"][i].copy())
+            for i, m in enumerate(g["in_marker_ids"])}
+    fns = tuple(gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
+    return case, src, cons, fns
+
+
+def expected(g, solver, dt):
+    tag = "out_%s_%s_" % (solver, dt)
+    return {k[len(tag):]: v for k, v in g.items() if k.startswith(tag)}
+
+
+def pose_errors(res, exp):
+    """max rotation geodesic (rad) and max translation l2 (m) over the expected keys;
+    also checks the key set and order match the reference's output dict."""
+    keys = [str(k) for k in res.keys()]
+    assert keys == [str(k) for k in exp["keys"]], "output keys/order differ from the reference"
+    R = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res.keys()])
+    t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in res.keys()])
+    rot = float(geodesic(R, exp["R"]).max())
+    tr = float(np.linalg.norm(t - exp["t"], axis=1).max())
+    return rot, tr
