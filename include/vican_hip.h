@@ -1,0 +1,243 @@
+/*
+ * vican_hip.h - C ABI of the MI355X (gfx950) kernels behind
+ *               vican.bipgo.bipartite_se3sync / object_bipartite_se3sync.
+ *
+ * The reference (gabmoreira/vican) is pure Python and has NO plugin / FFI
+ * interface: its boundary is the Python signature (vican/bipgo.py:353-360,
+ * 493-499).  This header is therefore the interface a maintainer would bind
+ * with ctypes to replace the third-party native calls the reference's hot
+ * path makes (SciPy CSR SpGEMM/SpMM, ARPACK eigs, LAPACK 3x3 svd, scipy cg);
+ * each entry point cites the reference lines whose work it takes over.
+ * INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `d_` / device pointer is memory the
+ *     CALLER owns (PyTorch-ROCm tensors in the bundled host code);
+ *   - every function that launches work takes a `stream` (a hipStream_t passed
+ *     as void*) and is asynchronous on it; none allocates, frees or
+ *     synchronises, so call sequences are graph-capturable;
+ *   - return value 0 = OK, negative = error (vican_last_error() gives text);
+ *   - a "3x3 block" is 9 consecutive scalars, row-major; camera-side vectors x, z are
+ *     row-major [3C][3]; the Lanczos basis is column-major (see the spectral section).
+ *
+ * Edge layout ("CSR of 3x3 blocks", timestep-major, chunked):
+ *   merged (camera,timestep) edges sorted by timestep row then camera are cut
+ *   into chunks of whole rows holding at most `slots` edges and `max_rows`
+ *   rows.  A chunk is padded to exactly `slots` entries and stored as
+ *       blk  [n_chunk][9][slots]   block component planes (float or double)
+ *       idx  [n_chunk][slots]      camera | (row - chunk_row0) << 16 ; 0xFFFFFFFF = padding
+ *   so that lane l of a wavefront reads 16 contiguous bytes of every plane
+ *   (fully coalesced dwordx4 loads) and the 4-byte index is the only
+ *   per-edge metadata: algorithmic traffic = E*(9*s+4) bytes.
+ *   Per-edge scalars/vectors of the translation stage use the same slot order.
+ */
+#ifndef VICAN_HIP_H
+#define VICAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VICAN_OK                 0
+#define VICAN_ERR_ARG           -1
+#define VICAN_ERR_LAUNCH        -2
+#define VICAN_ERR_CAPACITY      -3   /* graph does not fit the LDS-resident kernel */
+
+#define VICAN_STORE_F32 0
+#define VICAN_STORE_F64 1
+
+#define VICAN_PAD_SLOT 0xFFFFFFFFu
+
+/* Graph view: sizes + device pointers of the chunked edge layout. */
+typedef struct vican_graph {
+    int32_t n_cam;            /* C  (<= 65535) */
+    int32_t n_time;           /* T  (local timestep rows of this rank) */
+    int32_t n_chunk;
+    int32_t slots;            /* edges per chunk = block_threads * edges_per_lane */
+    int32_t max_rows;         /* max timestep rows in any chunk */
+    int32_t storage;          /* VICAN_STORE_F32 | VICAN_STORE_F64 (type of blk) */
+    int32_t block_threads;    /* 256 or 1024 */
+    int32_t n_wg;             /* persistent workgroups per sweep (= number of partial slabs) */
+    const void*     blk;      /* [n_chunk][9][slots] */
+    const uint32_t* idx;      /* [n_chunk][slots]    */
+    const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
+} vican_graph_t;
+
+const char* vican_last_error(void);
+int vican_abi_version(void);
+
+/* ---- host-side planning (no GPU needed) ---------------------------------
+ * Cut T rows (host row_ptr[T+1]) into chunks of whole rows with at most
+ * `slots` edges and `max_rows` rows.  Writes first-row indices to
+ * chunk_row0_out (capacity cap entries, needs n_chunk+1) and returns n_chunk,
+ * or a negative error (a single row longer than `slots` -> VICAN_ERR_CAPACITY).
+ * Replaces the COO->CSR assembly of bipgo.py:244-270 together with
+ * vican_pack_edges.                                                         */
+int vican_plan_chunks(int32_t n_time, const int32_t* row_ptr_host, int32_t slots,
+                      int32_t max_rows, int32_t* chunk_row0_out, int32_t cap);
+
+/* Bytes of dynamic LDS the sweep kernels need for this graph (x table + z
+ * accumulators + per-row staging), and the LDS the device offers per workgroup. */
+int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows);
+int64_t vican_lds_limit_bytes(void);
+/* Largest max_rows for which every sweep kernel (operator, rhs, CG) fits in LDS
+ * with n_cam cameras; <= 0 means the camera tables alone do not fit.          */
+int32_t vican_max_rows_for(int32_t n_cam);
+
+/* ---- layout: CSR arrays -> chunked planes (device) -----------------------
+ * row_ptr[T+1], col[E] int32; blk_csr [E][9], a_csr [E] in the storage type;
+ * w_csr [E], u_csr [E][3], v_csr [E][3] double (may be NULL together with
+ * their outputs).  Outputs: g->blk, g->idx (cast away const), a_out [n_chunk][slots],
+ * w_out [n_chunk][slots], u_out / v_out [n_chunk][3][slots].
+ * (bipgo.py:244-270 for the rotation arrays; 445-471 for the translation ones) */
+int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, const int32_t* col,
+                     const void* blk_csr, const void* a_csr, const double* w_csr,
+                     const double* u_csr, const double* v_csr,
+                     void* a_out, double* w_out, double* u_out, double* v_out, void* stream);
+
+/* ---- rotation stage ------------------------------------------------------ */
+
+/* Initial duals (bipgo.py:271-276): d_t = sum_c a_ct, lamT_inv[t] = I/d_t,
+ * cam_deg[c] = sum_t a_ct (caller all-reduces cam_deg across ranks, then
+ * vican_scaled_identity makes lamC = cam_deg[c] * I).  cam_deg must be zeroed
+ * by the caller.  a: [n_chunk][slots] storage type.                          */
+int vican_init_duals(const vican_graph_t* g, const void* a, double* lamT_inv /*[T][9]*/,
+                     double* cam_deg /*[C]*/, void* stream);
+int vican_scaled_identity(int32_t n, const double* scale, double* out /*[n][9]*/, void* stream);
+
+/* Fused connection-Laplacian operator  zpart[wg] = sum over the workgroup's
+ * edges of  M_ct * lamT_inv[t] * (sum_c' M_c't^T x_c')   i.e. slabs of
+ * P x = R~ Lambda_T^-1 R~^T x  without ever forming P (replaces the SpGEMM at
+ * bipgo.py:273,334 and the SpMM at bipgo.py:300).  x: [3C][3] double;
+ * zpart: [n_wg][3C][3] double.  Each block is read from HBM exactly once.   */
+int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x,
+                   double* zpart, void* stream);
+
+/* Timestep dual/primal update (bipgo.py:318-332): per row t,
+ * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,
+ * lamT_inv[t] = U S^-1 U^T.  rc: [3C][3]; Rt, lamT_inv: [T][9].             */
+int vican_dual_update(const vican_graph_t* g, const double* rc, double* Rt,
+                      double* lamT_inv, void* stream);
+
+/* out[i] = sum_s part[s][i], s < n_slab, i < n  (fixed order: bitwise reproducible). */
+int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out, void* stream);
+
+/* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
+ * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),
+ * lam_out [n][9] (may be NULL): mode 1 = U S U^T, mode 2 = U S^-1 U^T.       */
+int vican_polar_dual(int32_t n, const double* in, double* R_out, double* lam_out,
+                     int32_t mode, void* stream);
+
+/* Gauge fix + projection (bipgo.py:295-297): X <- X * inv(X[0:3,:]) then each
+ * 3x3 camera block projected to SO(3).  x_in, x_out: [3C][3] (distinct buffers).    */
+int vican_gauge_project(int32_t n_cam, const double* x_in, double* x_out, void* stream);
+
+/* ---- spectral step: camera-side dense helpers for block Lanczos ---------
+ * (together with vican_block_op these replace scipy eigs / ARPACK+SuperLU at
+ * bipgo.py:288).  V is a column-major basis (column k at V + k*ld, ld >= n = 3C);
+ * "block j" = columns 3j..3j+2; the work block R is column-major [3][n].                                                                */
+
+/* aq = Lambda_C q - z  with q = basis columns col0..col0+2 (column-major basis V,
+ * column k at V + k*ld, ld >= 3C), z row-major [3C][3] (the reduced sweep output),
+ * aq column-major [3][3C].                                                    */
+int vican_lap_apply(int32_t n_cam, const double* lamC, const double* V, int32_t ld,
+                    int32_t col0, const double* z, double* aq, void* stream);
+/* H[k][c] = V[:,k] . R[:,c]  for k < ka, c < 3  (R column-major [3][n]); one
+ * workgroup per basis column, fixed summation order.                          */
+int vican_tall_gram(int32_t n, const double* V, int32_t ld, int32_t ka, const double* R,
+                    double* H, void* stream);
+/* R -= V[:, :ka] H ; if H_out: H_out[ka][3] = H (accumulate=0) or += H (accumulate=1) */
+int vican_tall_update(int32_t n, const double* V, int32_t ld, int32_t ka, const double* H,
+                      double* R, double* H_out, int32_t accumulate, void* stream);
+/* G = R^T R (3x3, from vican_tall_gram with V := R, ld := n): upper Cholesky
+ * G = beta^T beta, Q = R beta^-1 -> basis columns col0..col0+2, beta_out[3][3],
+ * and (if x_out) Q row-major [n][3] as the next sweep input.  A pivot <=
+ * max(1e-28 trace(G), pivot_floor) (Krylov space exhausted) yields a zero column
+ * and beta_jj = 0, which the host treats as breakdown.                           */
+int vican_chol_qr3(int32_t n, const double* R, const double* G, double* V, int32_t ld,
+                   int32_t col0, double* beta_out, double* x_out, double pivot_floor,
+                   void* stream);
+/* X[n][3] (row-major) = V[:, :ka] Y[ka][3] */
+int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const double* Y,
+                       double* X, void* stream);
+/* basis columns col0..col0+2 = X (row-major [n][3]) */
+int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_t col0, void* stream);
+
+/* ---- translation stage ---------------------------------------------------
+ * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of
+ * bipgo.py:463-477:  (weighted bipartite Laplacian (x) I3) p = J^T b.          */
+
+/* Degrees of the weighted Laplacian: deg_t[t] = sum_c w_ct (written),
+ * deg_c[c] += sum_t w_ct (atomic; caller zeroes, all-reduces across ranks).  */
+int vican_trans_degrees(const vican_graph_t* g, const double* w, double* deg_t,
+                        double* deg_c, void* stream);
+/* Right-hand side J^T b (bipgo.py:451-461 + J^T): g_ct = Rc_c^T u_ct + Rt_t^T v_ct;
+ * rhs_t[t] = sum_c g_ct (written), rhs_c slabs [n_wg][C][3] = -sum_t g_ct.   */
+int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v,
+                    const double* rc, const double* rt, double* rhs_t, double* rhs_c_part,
+                    void* stream);
+
+/* Device-resident CG state (one struct in device memory, zero-initialised by
+ * vican_cg_init). Doubles first, then ints; mirrors scipy.sparse.linalg.cg
+ * (x0 = 0, no preconditioner, stop when |r| < max(atol, rtol*|b|) tested at the
+ * top of every iteration).                                                  */
+typedef struct vican_cg_state {
+    double rho;        /* r.r of the current residual */
+    double rho_prev;
+    double pq;         /* p.q */
+    double alpha;
+    double beta;
+    double bnorm2;     /* |b|^2 */
+    double atol2;      /* (rtol*|b|)^2 */
+    double rr_cam;     /* camera part of r.r (set by cg_cam_step) */
+    double pq_time;    /* timestep part of p.q (sum of partials; may be all-reduced) */
+    double rr_time;    /* timestep part of r.r */
+    int32_t iter;      /* completed iterations */
+    int32_t done;      /* 1 once converged: all later kernels are no-ops */
+    int32_t first;     /* 1 before the first iteration (p = r) */
+    int32_t pad;
+} vican_cg_state_t;
+
+/* x=0, r=b, p=r for both node sets; |b_t|^2 into st->rr_time (caller all-reduces
+ * it across ranks before cg_begin), |b_c|^2 into st->rr_cam.  ws: >= 512 doubles. */
+int vican_cg_init(int32_t n_cam, int32_t n_time, const double* b_c, const double* b_t,
+                  double* x_c, double* x_t, double* r_c, double* r_t, double* p_c, double* p_t,
+                  vican_cg_state_t* st, double* ws, void* stream);
+/* Top of an iteration.  If n_part > 0 first closes the previous iteration like
+ * vican_cg_end(rr_part, n_part) (single-GPU fast path; multi-GPU callers use
+ * vican_cg_end + all-reduce of st->rr_time and pass n_part = 0).  Then
+ * rho = rr_cam + rr_time; the first call fixes atol2 = rtol^2 |b|^2; sets done
+ * when |r| < atol (scipy's test, before the step); otherwise beta = rho/rho_prev
+ * and p_c = r_c + beta p_c (p_t is updated inside the sweep).                  */
+int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, double rtol,
+                   const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
+/* Timestep-major Laplacian sweep: p_t <- r_t + beta p_t (skipped on the first
+ * iteration), q_t = deg_t p_t - sum_c w_ct p_c (written), slabs
+ * qc_part[wg][C][3] = sum_t w_ct p_t, pq_part[wg] = partial p_t.q_t.          */
+int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
+                   const double* p_c, const double* r_t, double* p_t, double* q_t,
+                   double* qc_part, double* pq_part, const vican_cg_state_t* st, void* stream);
+/* *out = sum pq_part (the timestep part of p.q); `out` is normally the slot right
+ * behind the reduced q_c vector so that ONE all-reduce carries both.           */
+int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out,
+                       const vican_cg_state_t* st, void* stream);
+/* Camera side: q_c = deg_c p_c - qc_sum; pq = *pq_time + p_c.q_c; alpha = rho/pq;
+ * x_c += alpha p_c; r_c -= alpha q_c; rr_cam = r_c.r_c.  qc_sum: [C][3] (slabs
+ * already reduced / all-reduced).                                            */
+int vican_cg_cam_step(int32_t n_cam, const double* deg_c, const double* qc_sum,
+                      const double* pq_time, const double* p_c, double* x_c, double* r_c,
+                      vican_cg_state_t* st, void* stream);
+/* Timestep side: x_t += alpha p_t; r_t -= alpha q_t; rr_part[wg] partial r_t.r_t;
+ * returns the number of partials written (>0).                                */
+int vican_cg_time_step(int32_t n_time, const double* p_t, const double* q_t, double* x_t,
+                       double* r_t, double* rr_part, int32_t part_cap, const vican_cg_state_t* st,
+                       void* stream);
+/* st->rr_time = sum rr_part ; st->iter += 1 ; rho_prev = rho. */
+int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VICAN_HIP_H */

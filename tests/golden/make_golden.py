@@ -58,6 +58,10 @@ def _cg(A, b, *a, **k):
     x, info = _orig_cg(A, b, *a, callback=cb, **k)
     _rec["cg_iters"] = n[0]
     _rec["cg_relres"] = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+    # the fully converged solution of the SAME system (x0 = 0 => same gauge): lets the tests
+    # state how far the reference's loosely converged answer is from it
+    xt, _ = _orig_cg(A, b, rtol=1e-14, maxiter=200000)
+    _rec["t_tight"] = np.asarray(xt, dtype=np.float64).reshape(-1, 3)
     return x, info
 
 
@@ -80,7 +84,7 @@ def run_case(name, case):
     out["gt_R_obj"], out["gt_p_obj"] = scene["R_obj"], scene["p_obj"]
     nr, nt, ff = (gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
     for solver, dt in case["runs"]:
-        _rec["evals"], _rec["cg_iters"], _rec["cg_relres"] = [], None, None
+        _rec["evals"], _rec["cg_iters"], _rec["cg_relres"], _rec["t_tight"] = [], None, None, None
         dtype = np.dtype(dt).type
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
             if case["mode"] == "camera":
@@ -100,6 +104,12 @@ def run_case(name, case):
         out[tag + "evals"] = np.stack(_rec["evals"]) if _rec["evals"] else np.zeros((0, 5))
         out[tag + "cg_iters"] = np.int64(-1 if _rec["cg_iters"] is None else _rec["cg_iters"])
         out[tag + "cg_relres"] = np.float64(np.nan if _rec["cg_relres"] is None else _rec["cg_relres"])
+        if _rec.get("t_tight") is not None:
+            tt = _rec["t_tight"]
+            out[tag + "t_tight"] = tt[:len(keys)] if case["mode"] == "camera" else np.zeros((0, 3))
+            out[tag + "dist_tight"] = np.float64(np.linalg.norm(
+                np.stack([np.asarray(v.t(), dtype=np.float64) for v in res.values()]) - tt[:len(keys)], axis=1).max()
+                if case["mode"] == "camera" else np.nan)
         print("  %-12s %-20s %-8s nodes=%d cg_iters=%s evals[-1]=%s" % (
             name, solver, dt, len(keys), _rec["cg_iters"],
             np.array2string(out[tag + "evals"][-1], precision=3) if len(_rec["evals"]) else "-"))

@@ -1,0 +1,244 @@
+"""NumPy stand-in for ``vican_amd.device.HipBackend`` - TEST INFRASTRUCTURE ONLY.
+
+Implements the same method surface on CPU torch tensors so that the host
+orchestration in ``vican_amd/solver.py`` (block Lanczos driver, CG state machine,
+timestep sharding + all-reduce) can be exercised without a GPU, single-process and
+with world_size-2 gloo.  It restates what each HIP kernel must compute (the
+formulas of SURVEY.md section 3.3) and doubles as the per-kernel oracle in
+``tests/test_kernels_gpu.py``.  The product never imports this file.
+"""
+import numpy as np
+import torch
+
+from vican_amd._lib import CG_F, CG_I
+
+
+def svd_polar(mats, mode):
+    u, s, vt = np.linalg.svd(mats)
+    d = np.linalg.det(u @ vt)
+    fix = np.ones((len(mats), 3)); fix[:, 2] = d
+    R = (u * fix[:, None, :]) @ vt
+    lam = None
+    if mode == 1:
+        lam = (u * s[:, None, :]) @ np.swapaxes(u, 1, 2)
+    elif mode == 2:
+        lam = (u * (1.0 / s)[:, None, :]) @ np.swapaxes(u, 1, 2)
+    return R, lam
+
+
+class NumpyBackend:
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64):
+        self.C = int(n_cam)
+        self.T = len(row_ptr) - 1
+        self.row_ptr = np.asarray(row_ptr, dtype=np.int64)
+        self.col = np.asarray(col, dtype=np.int64)
+        self.row = np.repeat(np.arange(self.T), np.diff(self.row_ptr))
+        self.M = np.asarray(blk, dtype=storage).astype(np.float64).reshape(-1, 3, 3)
+        self.a = np.asarray(a, dtype=storage).astype(np.float64)
+        self.w = None if w is None else np.asarray(w, dtype=np.float64)
+        self.u = None if u is None else np.asarray(u, dtype=np.float64).reshape(-1, 3)
+        self.v = None if v is None else np.asarray(v, dtype=np.float64).reshape(-1, 3)
+        self.rr_part_n = 1
+        self._rr = 0.0
+
+    # allocation
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype)
+
+    zeros = empty
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def synchronize(self):
+        pass
+
+    # rotation stage
+    def init_duals(self, lamT_inv, cam_deg):
+        d = np.zeros(self.T); np.add.at(d, self.row, self.a)
+        cd = np.zeros(self.C); np.add.at(cd, self.col, self.a)
+        if self.T:
+            lamT_inv.numpy()[: self.T] = (np.eye(3)[None] / d[:, None, None]).reshape(self.T, 9)
+        cam_deg.numpy()[:] = cd
+
+    def scaled_identity(self, scale, out):
+        out.numpy()[:] = (np.eye(3)[None] * scale.numpy()[:, None, None]).reshape(-1, 9)
+
+    def _y(self, x):
+        xc = x.numpy().reshape(self.C, 3, 3)[self.col]
+        y = np.zeros((max(self.T, 1), 3, 3))
+        np.add.at(y, self.row, np.swapaxes(self.M, 1, 2) @ xc)
+        return y
+
+    def block_op(self, lamT_inv, x, z_out):
+        y = self._y(x)
+        w = lamT_inv.numpy().reshape(-1, 3, 3) @ y
+        z = np.zeros((self.C, 3, 3))
+        np.add.at(z, self.col, self.M @ w[self.row])
+        z_out.numpy()[:] = z.reshape(3 * self.C, 3)
+
+    def dual_update(self, rc, Rt, lamT_inv):
+        if not self.T:
+            return
+        R, lam = svd_polar(self._y(rc)[: self.T], 2)
+        Rt.numpy()[: self.T] = R.reshape(-1, 9)
+        lamT_inv.numpy()[: self.T] = lam.reshape(-1, 9)
+
+    def polar_dual(self, mats, R_out, lam_out, mode):
+        R, lam = svd_polar(mats.numpy().reshape(-1, 3, 3), mode)
+        if R_out is not None:
+            R_out.numpy().reshape(-1, 9)[:] = R.reshape(-1, 9)
+        if lam_out is not None and mode:
+            lam_out.numpy().reshape(-1, 9)[:] = lam.reshape(-1, 9)
+
+    def gauge_project(self, x_in, x_out):
+        X = x_in.numpy()
+        Xg = X @ np.linalg.inv(X[:3, :])
+        R, _ = svd_polar(Xg.reshape(self.C, 3, 3), 0)
+        x_out.numpy()[:] = R.reshape(-1, 3)
+
+    # Lanczos helpers (V column-major: column k = V[k*ld : k*ld+n])
+    @staticmethod
+    def _cols(V, ld, n, k0, k1):
+        return V.numpy().reshape(-1)[k0 * ld: k1 * ld].reshape(k1 - k0, ld)[:, :n]
+
+    def lap_apply(self, lamC, V, ld, col0, z, aq):
+        n = 3 * self.C
+        q = self._cols(V, ld, n, col0, col0 + 3).T.reshape(self.C, 3, 3)          # rows 3c+i, cols b
+        r = lamC.numpy().reshape(self.C, 3, 3) @ q - z.numpy().reshape(self.C, 3, 3)
+        aq.numpy().reshape(3, n)[:] = r.reshape(n, 3).T
+
+    def tall_gram(self, n, V, ld, ka, R, H):
+        H.numpy().reshape(-1)[: ka * 3] = (self._cols(V, ld, n, 0, ka) @ R.numpy().reshape(3, n).T).reshape(-1)
+
+    def tall_update(self, n, V, ld, ka, H, R, H_out, accumulate):
+        h = H.numpy().reshape(-1)[: ka * 3].reshape(ka, 3).copy()
+        Rv = R.numpy().reshape(3, n)
+        Rv -= (self._cols(V, ld, n, 0, ka).T @ h).T
+        if H_out is not None:
+            ho = H_out.numpy().reshape(-1)
+            ho[: ka * 3] = (ho[: ka * 3] if accumulate else 0.0) + h.reshape(-1)
+
+    def chol_qr3(self, n, R, G, V, ld, col0, beta_out, x_out, pivot_floor=0.0):
+        g = G.numpy().reshape(-1)[:9].reshape(3, 3)
+        floor = max(1e-28 * np.trace(g), pivot_floor)
+        b = np.zeros((3, 3)); inv = np.zeros(3)
+        if g[0, 0] > floor:
+            b[0, 0] = np.sqrt(g[0, 0]); inv[0] = 1 / b[0, 0]; b[0, 1] = g[0, 1] * inv[0]; b[0, 2] = g[0, 2] * inv[0]
+        d11 = g[1, 1] - b[0, 1] ** 2
+        if d11 > floor:
+            b[1, 1] = np.sqrt(d11); inv[1] = 1 / b[1, 1]; b[1, 2] = (g[1, 2] - b[0, 1] * b[0, 2]) * inv[1]
+        d22 = g[2, 2] - b[0, 2] ** 2 - b[1, 2] ** 2
+        if d22 > floor:
+            b[2, 2] = np.sqrt(d22); inv[2] = 1 / b[2, 2]
+        Rv = R.numpy().reshape(3, n)
+        q0 = Rv[0] * inv[0]
+        q1 = (Rv[1] - q0 * b[0, 1]) * inv[1]
+        q2 = (Rv[2] - q0 * b[0, 2] - q1 * b[1, 2]) * inv[2]
+        self._cols(V, ld, n, col0, col0 + 3)[:] = np.stack([q0, q1, q2])
+        if beta_out is not None:
+            beta_out.numpy().reshape(-1)[:9] = b.reshape(-1)
+        if x_out is not None:
+            x_out.numpy()[:] = np.stack([q0, q1, q2], 1)
+
+    def tall_combine(self, n, V, ld, ka, Y, X):
+        X.numpy()[:] = self._cols(V, ld, n, 0, ka).T @ Y.numpy().reshape(ka, 3)
+
+    def rows_to_cols(self, n, X, V, ld, col0):
+        self._cols(V, ld, n, col0, col0 + 3)[:] = X.numpy().T
+
+    # translation stage
+    def trans_degrees(self, deg_t, deg_c):
+        d = np.zeros(max(self.T, 1)); np.add.at(d, self.row, self.w)
+        dc = np.zeros(self.C); np.add.at(dc, self.col, self.w)
+        deg_t.numpy()[:] = d; deg_c.numpy()[:] = dc
+
+    def trans_rhs(self, rc, rt, rhs_t, rhs_c):
+        A = rc.numpy().reshape(self.C, 3, 3)[self.col]
+        B = rt.numpy().reshape(-1, 3, 3)[self.row]
+        g = np.einsum("eji,ej->ei", A, self.u) + np.einsum("eji,ej->ei", B, self.v)
+        bt = np.zeros((max(self.T, 1), 3)); np.add.at(bt, self.row, g)
+        bc = np.zeros((self.C, 3)); np.add.at(bc, self.col, -g)
+        rhs_t.numpy()[:] = bt; rhs_c.numpy()[:] = bc
+
+    @staticmethod
+    def _st(st):
+        return st.numpy(), st.numpy().view(np.int32)
+
+    def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
+        f, i = self._st(st)
+        for x in (x_c, x_t):
+            x.zero_()
+        r_c.copy_(b_c); p_c.copy_(b_c); r_t.copy_(b_t); p_t.copy_(b_t)
+        f[:] = 0.0
+        f[CG_F["rr_cam"]] = float((b_c.numpy() ** 2).sum())
+        f[CG_F["rr_time"]] = float((b_t.numpy()[: self.T] ** 2).sum())
+        i[CG_I["first"]] = 1
+
+    def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return
+        if n_rr_part > 0:
+            self.cg_end(n_rr_part, st)
+        rho = f[CG_F["rr_cam"]] + f[CG_F["rr_time"]]
+        if i[CG_I["iter"]] == 0 and i[CG_I["first"]]:
+            f[CG_F["bnorm2"]] = rho; f[CG_F["atol2"]] = rtol * rtol * rho
+        f[CG_F["rho"]] = rho
+        if np.sqrt(rho) < np.sqrt(f[CG_F["atol2"]]) or rho == 0.0:
+            i[CG_I["done"]] = 1
+            return
+        if not i[CG_I["first"]]:
+            beta = rho / f[CG_F["rho_prev"]]
+            f[CG_F["beta"]] = beta
+            p_c.numpy()[:] = r_c.numpy() + beta * p_c.numpy()
+
+    def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return
+        T = self.T
+        pt = p_t.numpy()
+        if not i[CG_I["first"]]:
+            pt[:T] = r_t.numpy()[:T] + f[CG_F["beta"]] * pt[:T]
+        pc = p_c.numpy()
+        acc = np.zeros((max(T, 1), 3)); np.add.at(acc, self.row, self.w[:, None] * pc[self.col])
+        q = deg_t.numpy()[:, None] * pt - acc
+        q_t.numpy()[:] = q
+        qc = np.zeros((self.C, 3)); np.add.at(qc, self.col, self.w[:, None] * pt[self.row])
+        out = qcpq.numpy()
+        out[: 3 * self.C] = qc.reshape(-1)
+        out[3 * self.C] = float((pt[:T] * q[:T]).sum())
+
+    def cg_cam_step(self, deg_c, qcpq, p_c, x_c, r_c, st):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return
+        pc = p_c.numpy()
+        q = deg_c.numpy()[:, None] * pc - qcpq.numpy()[: 3 * self.C].reshape(self.C, 3)
+        pq = qcpq.numpy()[3 * self.C] + float((pc * q).sum())
+        alpha = f[CG_F["rho"]] / pq
+        f[CG_F["pq"]] = pq; f[CG_F["alpha"]] = alpha
+        x_c.numpy()[:] += alpha * pc
+        r_c.numpy()[:] -= alpha * q
+        f[CG_F["rr_cam"]] = float((r_c.numpy() ** 2).sum())
+
+    def cg_time_step(self, p_t, q_t, x_t, r_t, st):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return 1
+        a = f[CG_F["alpha"]]
+        T = self.T
+        x_t.numpy()[:T] += a * p_t.numpy()[:T]
+        r_t.numpy()[:T] -= a * q_t.numpy()[:T]
+        self._rr = float((r_t.numpy()[:T] ** 2).sum())
+        return 1
+
+    def cg_end(self, n_part, st):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return
+        f[CG_F["rr_time"]] = self._rr
+        i[CG_I["iter"]] += 1
+        f[CG_F["rho_prev"]] = f[CG_F["rho"]]
+        i[CG_I["first"]] = 0

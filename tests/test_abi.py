@@ -1,0 +1,88 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol the header declares;
+host-side planning (no GPU needed) behaves."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from vican_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build_library()
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vican_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vican_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "library does not export %s" % s
+        assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
+    assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
+    assert lib.vican_abi_version() == 1
+
+
+def test_struct_sizes():
+    assert C.sizeof(_lib.Graph) == 8 * 4 + 3 * 8
+    assert _lib.CG_STATE_DOUBLES * 8 == 10 * 8 + 4 * 4
+
+
+def plan(lib, rp, slots, max_rows):
+    rp = np.asarray(rp, dtype=np.int32)
+    out = np.empty(len(rp) + 1, dtype=np.int32)
+    n = lib.vican_plan_chunks(len(rp) - 1, C.c_void_p(rp.ctypes.data), slots, max_rows,
+                              C.c_void_p(out.ctypes.data), len(out))
+    return n, out[: n + 1] if n >= 0 else None
+
+
+def test_plan_chunks_whole_rows_and_caps(lib):
+    rng = np.random.default_rng(0)
+    deg = rng.integers(0, 40, 500)
+    rp = np.concatenate([[0], np.cumsum(deg)])
+    n, c0 = plan(lib, rp, 64, 7)
+    assert n > 0 and c0[0] == 0 and c0[-1] == 500 and np.all(np.diff(c0) > 0)
+    for k in range(n):
+        assert rp[c0[k + 1]] - rp[c0[k]] <= 64 and c0[k + 1] - c0[k] <= 7
+        # greedy: the next row would not have fitted
+        if c0[k + 1] < 500 and c0[k + 1] - c0[k] < 7:
+            assert rp[c0[k + 1] + 1] - rp[c0[k]] > 64
+
+
+def test_plan_chunks_edge_cases(lib):
+    n, c0 = plan(lib, [0], 64, 8)                      # no rows
+    assert n == 0 and list(c0) == [0]
+    n, c0 = plan(lib, [0, 0, 0, 0], 64, 8)             # empty rows are legal
+    assert n == 1 and list(c0) == [0, 3]
+    n, _ = plan(lib, [0, 100], 64, 8)                  # a row longer than a chunk
+    assert n == -3 and b"more edges" in lib.vican_last_error()
+    assert lib.vican_plan_chunks(3, None, 64, 8, None, 0) == -1
+
+
+def test_lds_budget(lib):
+    for c in (3, 24, 340, 1000):
+        m = lib.vican_max_rows_for(c)
+        assert m >= 1
+        assert lib.vican_sweep_lds_bytes(c, m) <= lib.vican_lds_limit_bytes()
+    assert lib.vican_max_rows_for(1200) <= 0           # camera tables alone exceed 160 KiB
+
+
+def test_compute_calls_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vican_amd.bipgo import solve_problem
+    from vican_amd.frontend import Problem
+    with pytest.raises(_lib.VicanError):
+        solve_problem(Problem(), 4, "conjugate_gradient")

@@ -1,0 +1,178 @@
+"""Per-kernel parity on the GPU: every HIP entry point vs the NumPy restatement
+(tests/numpy_backend.py) on seeded random inputs, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from numpy_backend import NumpyBackend, svd_polar       # noqa: E402
+from util import load_golden                            # noqa: E402
+from vican_amd import synth                             # noqa: E402
+
+
+def random_graph(C, T, deg_lo, deg_hi, seed, empty_rows=False):
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(deg_lo, min(deg_hi, C) + 1, T)
+    if empty_rows:
+        deg[rng.random(T) < 0.1] = 0
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(C, d, replace=False)) for d in deg] + [np.zeros(0, int)]).astype(np.int32)
+    E = len(col)
+    a = rng.uniform(0.5, 2.0, E)
+    blk = (synth.random_rotations(rng, E) * a[:, None, None] + 0.05 * rng.standard_normal((E, 3, 3))).reshape(E, 9)
+    w = rng.uniform(0.5, 2.0, E)
+    u = rng.standard_normal((E, 3)); v = rng.standard_normal((E, 3))
+    return rp, col, blk, a, w, u, v
+
+
+def make_backends(C, T, deg_lo, deg_hi, seed, dt, block_threads=None, n_wg=None, empty_rows=False):
+    from vican_amd.device import HipBackend, LocalGraph
+    rp, col, blk, a, w, u, v = random_graph(C, T, deg_lo, deg_hi, seed, empty_rows)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    dev = torch.device("cuda:0")
+    g = LocalGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev),
+                   torch.from_numpy(blk).to(dev, tdt), torch.from_numpy(a).to(dev, tdt),
+                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev),
+                   block_threads=block_threads, n_wg=n_wg)
+    return HipBackend(g), NumpyBackend(C, rp, col, blk, a, w, u, v, storage=dt), g
+
+
+CONFIGS = [  # C, T, deg_lo, deg_hi, block_threads, n_wg, empty_rows
+    (5, 40, 1, 3, 256, None, False),
+    (37, 300, 1, 12, 256, None, True),
+    (64, 500, 20, 64, 256, 7, False),
+    (200, 120, 100, 200, 1024, None, False),
+    (700, 64, 300, 700, 1024, 5, False),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_block_op_dual_update_and_init(cfg, dt):
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 100 + C, dt, bt, nwg, er)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3 * C, 3))
+    # initial duals
+    lamT_h, cd_h = H.empty(T, 9), H.empty(C)
+    lamT_n, cd_n = N.empty(T, 9), N.empty(C)
+    H.init_duals(lamT_h, cd_h); N.init_duals(lamT_n, cd_n)
+    nz = np.diff(N.row_ptr) > 0
+    assert np.allclose(lamT_h.cpu().numpy()[nz], lamT_n.numpy()[nz], rtol=1e-13, atol=0)
+    assert np.allclose(cd_h.cpu().numpy(), cd_n.numpy(), rtol=1e-13)
+    # random SPD-ish duals for rows with edges
+    lam = rng.standard_normal((T, 3, 3)); lam = lam @ np.swapaxes(lam, 1, 2) + np.eye(3)
+    lam_h, lam_n = H.from_numpy(lam.reshape(T, 9)), N.from_numpy(lam.reshape(T, 9))
+    zh, zn = H.empty(3 * C, 3), N.empty(3 * C, 3)
+    H.block_op(lam_h, H.from_numpy(x), zh); N.block_op(lam_n, N.from_numpy(x), zn)
+    ref = zn.numpy()
+    assert np.abs(zh.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # dual update from stacked rotations
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    Rt_h, L_h = H.zeros(T, 9), H.zeros(T, 9)
+    Rt_n, L_n = N.zeros(T, 9), N.zeros(T, 9)
+    H.dual_update(H.from_numpy(rc), Rt_h, L_h); N.dual_update(N.from_numpy(rc), Rt_n, L_n)
+    well = nz & (np.diff(N.row_ptr) >= 2)            # a single noisy block may be ill-conditioned; keep generic rows
+    assert np.abs(Rt_h.cpu().numpy()[well] - Rt_n.numpy()[well]).max() < 1e-10
+    rel = np.abs(L_h.cpu().numpy()[well] - L_n.numpy()[well]).max() / np.abs(L_n.numpy()[well]).max()
+    assert rel < 1e-10
+
+
+def test_polar_dual_against_reference_project_SO3():
+    """G6 golden: outputs of the REAL reference's project_SO3, incl. reflections,
+    near-rank-2 and repeated singular values."""
+    from vican_amd.device import HipBackend
+    H, _, _ = make_backends(5, 8, 1, 3, 7, np.float64)
+    g6 = load_golden("g6_polar")
+    x = g6["x"]
+    n = len(x)
+    R, L1, L2 = H.empty(n, 9), H.empty(n, 9), H.empty(n, 9)
+    xin = H.from_numpy(x.reshape(n, 9))
+    H.polar_dual(xin, R, L1, 1); H.polar_dual(xin, None, L2, 2)
+    Rh = R.cpu().numpy().reshape(n, 3, 3)
+    assert np.abs(Rh - g6["project_SO3"]).max() < 1e-6          # near-rank-2 blocks: sigma3 ~ 1e-9
+    generic = np.r_[0:96, 128:n]
+    assert np.abs(Rh[generic] - g6["project_SO3"][generic]).max() < 1e-12
+    _, l1 = svd_polar(x, 1); _, l2 = svd_polar(x, 2)
+    assert np.abs(L1.cpu().numpy().reshape(n, 3, 3) - l1).max() < 1e-11
+    g2 = np.r_[0:96, 128:n]
+    rel = np.abs(L2.cpu().numpy().reshape(n, 3, 3)[g2] - l2[g2]).max() / np.abs(l2[g2]).max()
+    assert rel < 1e-10
+    assert np.allclose(np.linalg.det(Rh), 1.0, atol=1e-12)
+
+
+def test_gauge_project_and_lanczos_helpers():
+    C = 50
+    H, N, _ = make_backends(C, 100, 2, 6, 3, np.float64)
+    rng = np.random.default_rng(5)
+    n, m = 3 * C, 6
+    X = rng.standard_normal((n, 3))
+    oh, on = H.empty(n, 3), N.empty(n, 3)
+    H.gauge_project(H.from_numpy(X), oh); N.gauge_project(N.from_numpy(X), on)
+    assert np.abs(oh.cpu().numpy() - on.numpy()).max() < 1e-10
+    assert np.abs(oh.cpu().numpy()[:3] - np.eye(3)).max() < 1e-12
+    # basis helpers
+    Vn = rng.standard_normal((3 * m, n))
+    Vh, Vc = H.from_numpy(Vn.reshape(-1).copy()), N.from_numpy(Vn.reshape(-1).copy())
+    R0 = rng.standard_normal((3, n))
+    Rh, Rn = H.from_numpy(R0.reshape(-1).copy()), N.from_numpy(R0.reshape(-1).copy())
+    ka = 3 * m - 3
+    Hh, Hn = H.empty(3 * m * 3), N.empty(3 * m * 3)
+    H.tall_gram(n, Vh, n, ka, Rh, Hh); N.tall_gram(n, Vc, n, ka, Rn, Hn)
+    assert np.abs(Hh.cpu().numpy()[: ka * 3] - Hn.numpy()[: ka * 3]).max() < 1e-11
+    Ho_h, Ho_n = H.zeros(3 * m * 3), N.zeros(3 * m * 3)
+    for acc in (0, 1):
+        H.tall_update(n, Vh, n, ka, Hh, Rh, Ho_h, acc); N.tall_update(n, Vc, n, ka, Hn, Rn, Ho_n, acc)
+    assert np.abs(Rh.cpu().numpy() - Rn.numpy()).max() < 1e-9
+    assert np.abs(Ho_h.cpu().numpy() - Ho_n.numpy()).max() < 1e-10
+    Gh, Gn = H.empty(9), N.empty(9)
+    H.tall_gram(n, Rh, n, 3, Rh, Gh); N.tall_gram(n, Rn, n, 3, Rn, Gn)
+    bh, bn, xh, xn = H.empty(9), N.empty(9), H.empty(n, 3), N.empty(n, 3)
+    H.chol_qr3(n, Rh, Gh, Vh, n, ka, bh, xh, 0.0); N.chol_qr3(n, Rn, Gn, Vc, n, ka, bn, xn, 0.0)
+    assert np.abs(bh.cpu().numpy() - bn.numpy()).max() < 1e-9 * np.abs(bn.numpy()).max()
+    q = xh.cpu().numpy()
+    assert np.abs(q - xn.numpy()).max() < 1e-10
+    assert np.abs(q.T @ q - np.eye(3)).max() < 1e-12
+    assert np.abs(Vh.cpu().numpy().reshape(3 * m, n)[ka:ka + 3] - q.T).max() == 0.0
+    Y = rng.standard_normal((3 * m, 3))
+    Xh, Xn = H.empty(n, 3), N.empty(n, 3)
+    H.tall_combine(n, Vh, n, 3 * m, H.from_numpy(Y), Xh); N.tall_combine(n, Vc, n, 3 * m, N.from_numpy(Y), Xn)
+    assert np.abs(Xh.cpu().numpy() - Xn.numpy()).max() < 1e-11
+    lam = rng.standard_normal((C, 9)); z = rng.standard_normal((n, 3))
+    ah, an = H.empty(3 * n), N.empty(3 * n)
+    H.lap_apply(H.from_numpy(lam), Vh, n, 3, H.from_numpy(z), ah); N.lap_apply(N.from_numpy(lam), Vc, n, 3, N.from_numpy(z), an)
+    assert np.abs(ah.cpu().numpy() - an.numpy()).max() < 1e-11
+    H.rows_to_cols(n, H.from_numpy(X), Vh, n, 0); N.rows_to_cols(n, N.from_numpy(X), Vc, n, 0)
+    assert np.array_equal(Vh.cpu().numpy()[: 3 * n], Vc.numpy()[: 3 * n])
+    # vanished pivot -> zero column + zero beta (breakdown signalling)
+    H.chol_qr3(n, Rh, H.from_numpy(np.diag([1.0, 1e-40, 1.0]).reshape(-1)), Vh, n, 0, bh, xh, 1e-20)
+    b = bh.cpu().numpy().reshape(3, 3)
+    assert b[1, 1] == 0.0 and np.all(xh.cpu().numpy()[:, 1] == 0.0)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS[:4])
+def test_translation_kernels_and_cg(cfg):
+    """rhs / degrees / every CG kernel step by step against the NumPy state machine."""
+    from vican_amd.solver import Comm, TranslationSolver
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 200 + C, np.float64, bt, nwg, False)
+    rng = np.random.default_rng(2)
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    rt = synth.random_rotations(rng, T).reshape(T, 9)
+    outs = []
+    for K in (H, N):
+        ts = TranslationSolver(K, Comm(), rtol=1e-8, poll_every=4)
+        ts.setup(K.from_numpy(rc), K.from_numpy(rt))
+        x_c, x_t = ts.solve(3 * (C + T))
+        outs.append((ts.deg_t.cpu().numpy(), ts.deg_c.cpu().numpy(), ts.b_t.cpu().numpy(), ts.b_c.cpu().numpy(),
+                     x_c.cpu().numpy(), x_t.cpu().numpy(), ts.info))
+    (dt_h, dc_h, bt_h, bc_h, xc_h, xt_h, ih), (dt_n, dc_n, bt_n, bc_n, xc_n, xt_n, inn) = outs
+    assert np.allclose(dt_h, dt_n, rtol=1e-13) and np.allclose(dc_h, dc_n, rtol=1e-13)
+    assert np.abs(bt_h - bt_n).max() < 1e-11 and np.abs(bc_h - bc_n).max() < 1e-10
+    assert ih["converged"] and inn["converged"]
+    assert abs(ih["cg_iters"] - inn["cg_iters"]) <= 1
+    scale = max(np.abs(xt_n).max(), 1.0)
+    assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
+    # translations from x0 = 0 stay in the range of the Laplacian: node sum is zero
+    assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)

@@ -47,3 +47,17 @@ def pose_errors(res, exp):
     rot = float(geodesic(R, exp["R"]).max())
     tr = float(np.linalg.norm(t - exp["t"], axis=1).max())
     return rot, tr
+
+
+def translation_tol(exp, f64=True):
+    """Translation parity tolerance (metres).
+
+    The reference stops CG at relres 1e-5, i.e. its answer is `dist_tight` away from the
+    converged solution of its own system (0.15 mm on g2, 0.8 mm on g3, 17 m on the
+    heavy-tailed g4 - stored in the goldens).  Once CG has lost Lanczos orthogonality
+    (non-unit weights, >~20 iterations) rounding-level input differences move the iterate by
+    a fraction of that distance, so two correct implementations can only agree to within it
+    (SURVEY.md section 7).  Unit-weight cases agree to ~1e-8 m and are held to 1e-6 m."""
+    base = 1e-6 if f64 else 5e-4
+    d = float(exp.get("dist_tight", np.nan))
+    return max(base, 0.25 * d) if np.isfinite(d) else base

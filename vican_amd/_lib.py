@@ -1,0 +1,127 @@
+"""ctypes binding of the C ABI in ``include/vican_hip.h`` (``libvican_hip.so``).
+
+The library is built IN-TREE by ``build_library()`` (``hipcc --offload-arch=gfx950``)
+so it travels with the repository snapshot.  There is no CPU fallback: if the
+shared object is missing, ``load()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
+SOURCES = [os.path.join(CSRC, "vican_kernels.hip")]
+INCLUDE = os.path.join(ROOT, "include")
+
+STORE_F32, STORE_F64 = 0, 1
+PAD_SLOT = 0xFFFFFFFF
+
+
+class Graph(C.Structure):
+    """Mirror of ``vican_graph_t``."""
+    _fields_ = [
+        ("n_cam", C.c_int32), ("n_time", C.c_int32), ("n_chunk", C.c_int32), ("slots", C.c_int32),
+        ("max_rows", C.c_int32), ("storage", C.c_int32), ("block_threads", C.c_int32), ("n_wg", C.c_int32),
+        ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
+    ]
+
+
+# doubles first (10), then 4 int32: 96 bytes == 12 doubles
+CG_STATE_DOUBLES = 12
+CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9)
+CG_I = dict(iter=20, done=21, first=22)     # int32 index into the same buffer viewed as int32
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_G = C.POINTER(Graph)
+
+# name -> (restype, argtypes).  Must list EVERY symbol declared in include/vican_hip.h
+# (tests/test_abi.py checks the header against this table and the built library).
+PROTOTYPES = {
+    "vican_last_error": (C.c_char_p, []),
+    "vican_abi_version": (C.c_int, []),
+    "vican_plan_chunks": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32]),
+    "vican_sweep_lds_bytes": (_i64, [_i32, _i32]),
+    "vican_lds_limit_bytes": (_i64, []),
+    "vican_max_rows_for": (_i32, [_i32]),
+    "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_init_duals": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_scaled_identity": (C.c_int, [_i32, _vp, _vp, _vp]),
+    "vican_block_op": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_dual_update": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_slab_reduce": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
+    "vican_polar_dual": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp]),
+    "vican_gauge_project": (C.c_int, [_i32, _vp, _vp, _vp]),
+    "vican_lap_apply": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "vican_tall_gram": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "vican_tall_update": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "vican_chol_qr3": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp]),
+    "vican_tall_combine": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "vican_rows_to_cols": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp]),
+    "vican_trans_degrees": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _vp, _vp]),
+    "vican_cg_sweep": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_reduce_pq": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "vican_cg_cam_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_time_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "vican_cg_end": (C.c_int, [_vp, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class VicanError(RuntimeError):
+    pass
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise VicanError("hipcc not found - cannot build libvican_hip.so")
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so``."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "vican_hip.h")])
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-shared",
+           "-Wno-unused-value", "-I", INCLUDE, *SOURCES, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and attach prototypes (raises if it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VicanError(
+            "libvican_hip.so is missing (%s). Build it with `python __graft_entry__.py build` "
+            "or vican_amd._lib.build_library(); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = load().vican_last_error()
+        raise VicanError("%s failed (%d): %s" % (what or "vican call", rc, msg.decode() if msg else "?"))
+    return rc

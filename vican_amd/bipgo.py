@@ -1,0 +1,133 @@
+"""Drop-in entry points: ``bipartite_se3sync`` / ``object_bipartite_se3sync``.
+
+Same call signature, argument meaning, output format and error behaviour as the
+reference (vican/bipgo.py:353-360, 493-499): edge dict in, ``{node id: SE3}`` out,
+poses are world<-node, gauge = lexicographically first camera at the identity
+rotation, translations of all nodes summing to zero (CG from x0 = 0).
+
+Everything numerical runs on the GPU through ``include/vican_hip.h``; there is no
+CPU fallback (a missing extension or GPU raises ``VicanError``).
+
+Extra keyword-only arguments (defaults reproduce the reference):
+    info      dict that receives solver statistics (eigenvalues per iteration,
+              Lanczos steps, CG iterations, phase timings)
+    group     torch.distributed process group to shard timesteps over (default:
+              the world group when torch.distributed is initialised)
+    verbose   print phase timings
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import frontend
+from ._lib import VicanError
+from .geometry import SE3
+from .solver import Comm, RotationSolver, TranslationSolver
+
+__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "solve_problem"]
+
+
+def _shard_rows(T, world, rank):
+    return (T * rank) // world, (T * (rank + 1)) // world
+
+
+def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=np.float32,
+                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10):
+    """Solve a flattened problem on this rank's GPU; returns host arrays
+    (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
+    from .device import HipBackend, LocalGraph      # needs the GPU + extension
+
+    if lsqr_solver == "direct":
+        raise NotImplementedError(
+            "lsqr_solver='direct' (scipy LSQR, bipgo.py:479-480) is not implemented on the GPU yet; "
+            "use 'conjugate_gradient'")
+    if lsqr_solver != "conjugate_gradient":
+        # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
+        raise UnboundLocalError("local variable 't_est' referenced before assignment")
+    if not torch.cuda.is_available():
+        raise VicanError("no GPU visible: vican_amd has no CPU fallback")
+    comm = Comm(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    T = prob.n_time
+    r0, r1 = _shard_rows(T, comm.world, comm.rank)
+    e0, e1 = int(prob.row_ptr[r0]), int(prob.row_ptr[r1])
+    t0 = time.perf_counter()
+    to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    g = LocalGraph(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
+                   to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]))
+    K = HipBackend(g)
+    t1 = time.perf_counter()
+    rot = RotationSolver(K, comm, eig_tol=eig_tol)
+    rc, Rt_loc = rot.run(maxiter)
+    K.synchronize()
+    t2 = time.perf_counter()
+    tr = TranslationSolver(K, comm)
+    tr.setup(rc, Rt_loc)
+    x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+    K.synchronize()
+    t3 = time.perf_counter()
+    if not tr.info["converged"]:
+        raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
+    # gather timestep results (zero-filled full arrays + sum: simple and only T x 12 doubles)
+    nloc = r1 - r0
+    if comm.world > 1:
+        full = torch.zeros(T, 12, dtype=torch.float64, device=dev)
+        full[r0:r1, :9] = Rt_loc[:nloc]
+        full[r0:r1, 9:] = x_t[:nloc]
+        comm.allreduce(full)
+        Rt_all, xt_all = full[:, :9], full[:, 9:]
+    else:
+        Rt_all, xt_all = Rt_loc[:nloc], x_t[:nloc]
+    Rc = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()          # bipgo.py:346
+    Rt = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()                # bipgo.py:348
+    if info is not None:
+        info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
+                    eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
+                    cg_iters=tr.info["cg_iters"], cg_relres=tr.info["relres"], n_cam=prob.n_cam, n_time=T,
+                    n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=g.n_chunk, n_wg=g.n_wg,
+                    t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world)
+    return Rc, Rt, x_c.cpu().numpy(), xt_all.cpu().numpy()
+
+
+def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callable, noise_model_t: Callable,
+                      edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
+                      info: Optional[dict] = None, group=None, verbose: bool = False) -> dict:
+    """SE(3) synchronisation of static cameras and a moving marker object
+    (reference bipgo.py:353-490).  See module docstring."""
+    t0 = time.perf_counter()
+    prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype)
+    t1 = time.perf_counter()
+    local = {} if info is None else info
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local)
+    local["t_flatten"] = t1 - t0
+    rot, pos = {}, {}
+    for i, c in enumerate(prob.cam_names):
+        rot[c], pos[c] = Rc[i], pc[i]
+    for i, s in enumerate(prob.time_names):
+        rot[s + "_0"], pos[s + "_0"] = Rt[i], pt[i]
+    out = {}
+    for n in prob.tnodes:                                               # bipgo.py:485-487 (sorted node order)
+        out[n] = SE3(R=np.ascontiguousarray(rot[n]).astype(dtype), t=pos[n].copy())
+    if verbose:
+        print("vican_amd: %d cameras, %d timesteps, %d merged edges | flatten %.3fs pack %.3fs rot %.3fs "
+              "(lanczos steps %s) trans %.3fs (cg %d it)" % (
+                  prob.n_cam, prob.n_time, prob.n_edges, t1 - t0, local["t_pack"], local["t_rot"],
+                  local["lanczos_steps"], local["t_trans"], local["cg_iters"]))
+    return out
+
+
+def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_model_t: Callable,
+                             edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
+                             info: Optional[dict] = None, group=None, verbose: bool = False) -> dict:
+    """Object (marker cube) calibration from a moving camera (reference bipgo.py:493-545):
+    markers take the camera role, frames the timestep role, every pose is inverted, the
+    numerically smallest marker id is pinned to the identity; only marker poses are returned."""
+    root, edges = frontend.invert_object_edges(src_edges)
+    out = bipartite_se3sync(edges, {root: SE3(pose=np.eye(4))}, noise_model_r, noise_model_t, edge_filter,
+                            maxiter, lsqr_solver, dtype, info=info, group=group, verbose=verbose)
+    return {k: v for k, v in out.items() if "_" not in k}               # bipgo.py:543

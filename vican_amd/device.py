@@ -1,0 +1,227 @@
+"""Device side of the solver: chunked edge layout + thin wrappers over the C ABI.
+
+``LocalGraph`` owns (as PyTorch-ROCm tensors) the timestep-major chunked
+CSR-of-3x3-blocks of ONE rank's timestep rows; ``HipBackend`` exposes each entry
+point of ``include/vican_hip.h`` on torch tensors.  PyTorch is only the
+allocator / stream provider here - every numerical step is a hand-written HIP
+kernel.  No CPU fallback: constructing ``HipBackend`` without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_CU = 256
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class LocalGraph:
+    """Chunked layout of this rank's timestep rows.
+
+    Parameters are device tensors in timestep-major CSR order:
+    row_ptr (T+1,) int32, col (E,) int32 (ascending camera index inside a row),
+    blk (E,9) / a (E,) in the storage dtype (float32 or float64), and optionally
+    the translation-stage arrays w (E,), u (E,3), v (E,3) in float64.
+    """
+
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
+                 n_wg=None):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.VicanError("vican_amd needs a GPU (MI355X); there is no CPU fallback")
+        dev = blk.device
+        self.device = dev
+        self.n_cam = int(n_cam)
+        self.n_time = int(row_ptr.numel() - 1)
+        self.n_edges = int(col.numel())
+        self.storage_dtype = blk.dtype
+        storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
+        epl = 4 if storage == _lib.STORE_F32 else 2
+        if self.n_cam > 65535:
+            raise _lib.VicanError("more than 65535 cameras are not supported by the packed edge index")
+        max_rows = int(lib.vican_max_rows_for(self.n_cam))
+        if max_rows < 1:
+            raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % self.n_cam)
+        rp_host = row_ptr.to("cpu", torch.int32).contiguous()
+        deg_max = int((rp_host[1:] - rp_host[:-1]).max()) if self.n_time else 0
+        if block_threads is None:
+            block_threads = 1024 if self.n_edges >= 1024 * epl * N_CU else 256
+            if deg_max > 256 * epl:
+                block_threads = 1024
+        slots = block_threads * epl
+        cap = self.n_time + 2
+        c0 = np.empty(cap, dtype=np.int32)
+        nchunk = _lib.check(lib.vican_plan_chunks(self.n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
+                                                   C.c_void_p(c0.ctypes.data), cap), "vican_plan_chunks")
+        self.chunk_row0_host = c0[: nchunk + 1].copy()
+        rows_per_chunk = np.diff(self.chunk_row0_host) if nchunk else np.zeros(0, np.int32)
+        self.max_rows = int(rows_per_chunk.max()) if nchunk else 1
+        self.n_chunk, self.slots, self.block_threads = int(nchunk), slots, block_threads
+        lds = int(lib.vican_sweep_lds_bytes(self.n_cam, self.max_rows))
+        occ = max(1, min(int(lib.vican_lds_limit_bytes()) // lds, 2048 // block_threads))
+        if n_wg is None:
+            n_wg = max(1, min(self.n_chunk, N_CU * occ))
+        self.n_wg = int(n_wg)
+        self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
+        nslot = max(1, self.n_chunk) * slots
+        self.blk = torch.empty(9 * nslot, dtype=blk.dtype, device=dev)
+        self.idx = torch.empty(nslot, dtype=torch.int32, device=dev)
+        self.a = torch.empty(nslot, dtype=blk.dtype, device=dev)
+        have_t = w is not None
+        self.w = torch.empty(nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.u = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.v = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.desc = _lib.Graph(self.n_cam, self.n_time, self.n_chunk, slots, self.max_rows, storage, block_threads,
+                               self.n_wg, self.blk.data_ptr(), self.idx.data_ptr(), self.chunk_row0.data_ptr())
+        row_ptr = row_ptr.to(dev, torch.int32).contiguous()
+        col = col.to(dev, torch.int32).contiguous()
+        blk = blk.contiguous(); a = a.to(blk.dtype).contiguous()
+        if have_t:
+            w, u, v = (t.to(dev, torch.float64).contiguous() for t in (w, u, v))
+        _lib.check(lib.vican_pack_edges(C.byref(self.desc), _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w),
+                                        _ptr(u), _ptr(v), _ptr(self.a), _ptr(self.w), _ptr(self.u), _ptr(self.v),
+                                        _stream()), "vican_pack_edges")
+        torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
+
+    # algorithmic HBM bytes of one operator sweep (B_op)
+    def op_bytes(self, ncols=3):
+        s = 4 if self.storage_dtype == torch.float32 else 8
+        return self.n_edges * (9 * s + 4) + (self.n_time + 1) * 4 + self.n_time * 9 * 8 + 2 * 3 * self.n_cam * ncols * 8
+
+    def padded_slots(self):
+        return self.n_chunk * self.slots
+
+
+class HipBackend:
+    """Kernel interface used by ``solver.py`` (one instance per rank / LocalGraph)."""
+
+    def __init__(self, graph: LocalGraph):
+        self.lib = _lib.load()
+        self.g = graph
+        self.dev = graph.device
+        self.C, self.T = graph.n_cam, graph.n_time
+        self._gref = C.byref(graph.desc)
+        nwg = graph.n_wg
+        self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)
+        self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
+        self.rr_part = torch.empty(512, dtype=torch.float64, device=self.dev)
+        self.ws = torch.empty(512, dtype=torch.float64, device=self.dev)
+
+    # -- allocation helpers -------------------------------------------------
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+
+    def synchronize(self):
+        torch.cuda.current_stream().synchronize()
+
+    def _ck(self, rc, what):
+        return _lib.check(rc, what)
+
+    # -- rotation stage -----------------------------------------------------
+    def init_duals(self, lamT_inv, cam_deg):
+        cam_deg.zero_()
+        self._ck(self.lib.vican_init_duals(self._gref, _ptr(self.g.a), _ptr(lamT_inv), _ptr(cam_deg), _stream()),
+                 "vican_init_duals")
+
+    def scaled_identity(self, scale, out):
+        self._ck(self.lib.vican_scaled_identity(scale.numel(), _ptr(scale), _ptr(out), _stream()), "vican_scaled_identity")
+
+    def block_op(self, lamT_inv, x, z_out):
+        """z_out[3C,3] = local slab-reduced  P x  (caller all-reduces across ranks)."""
+        self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _stream()), "vican_block_op")
+        self._ck(self.lib.vican_slab_reduce(_ptr(self.zpart), self.g.n_wg, 9 * self.C, _ptr(z_out), _stream()),
+                 "vican_slab_reduce")
+
+    def block_op_raw(self, lamT_inv, x):
+        """Only the sweep kernel (used by the benchmark to time the dominant kernel)."""
+        self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _stream()), "vican_block_op")
+
+    def dual_update(self, rc, Rt, lamT_inv):
+        self._ck(self.lib.vican_dual_update(self._gref, _ptr(rc), _ptr(Rt), _ptr(lamT_inv), _stream()), "vican_dual_update")
+
+    def polar_dual(self, mats, R_out, lam_out, mode):
+        self._ck(self.lib.vican_polar_dual(mats.numel() // 9, _ptr(mats), _ptr(R_out), _ptr(lam_out), mode, _stream()),
+                 "vican_polar_dual")
+
+    def gauge_project(self, x_in, x_out):
+        self._ck(self.lib.vican_gauge_project(self.C, _ptr(x_in), _ptr(x_out), _stream()), "vican_gauge_project")
+
+    # -- Lanczos helpers ----------------------------------------------------
+    def lap_apply(self, lamC, V, ld, col0, z, aq):
+        self._ck(self.lib.vican_lap_apply(self.C, _ptr(lamC), _ptr(V), ld, col0, _ptr(z), _ptr(aq), _stream()), "vican_lap_apply")
+
+    def tall_gram(self, n, V, ld, ka, R, H):
+        self._ck(self.lib.vican_tall_gram(n, _ptr(V), ld, ka, _ptr(R), _ptr(H), _stream()), "vican_tall_gram")
+
+    def tall_update(self, n, V, ld, ka, H, R, H_out, accumulate):
+        self._ck(self.lib.vican_tall_update(n, _ptr(V), ld, ka, _ptr(H), _ptr(R), _ptr(H_out), int(accumulate), _stream()),
+                 "vican_tall_update")
+
+    def chol_qr3(self, n, R, G, V, ld, col0, beta_out, x_out, pivot_floor=0.0):
+        self._ck(self.lib.vican_chol_qr3(n, _ptr(R), _ptr(G), _ptr(V), ld, col0, _ptr(beta_out), _ptr(x_out),
+                                         float(pivot_floor), _stream()),
+                 "vican_chol_qr3")
+
+    def tall_combine(self, n, V, ld, ka, Y, X):
+        self._ck(self.lib.vican_tall_combine(n, _ptr(V), ld, ka, _ptr(Y), _ptr(X), _stream()), "vican_tall_combine")
+
+    def rows_to_cols(self, n, X, V, ld, col0):
+        self._ck(self.lib.vican_rows_to_cols(n, _ptr(X), _ptr(V), ld, col0, _stream()), "vican_rows_to_cols")
+
+    # -- translation stage --------------------------------------------------
+    def trans_degrees(self, deg_t, deg_c):
+        deg_c.zero_()
+        self._ck(self.lib.vican_trans_degrees(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(deg_c), _stream()), "vican_trans_degrees")
+
+    def trans_rhs(self, rc, rt, rhs_t, rhs_c):
+        nwg = self.g.n_wg
+        part = self.zpart[: nwg * 3 * self.C]
+        self._ck(self.lib.vican_trans_rhs(self._gref, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t),
+                                          _ptr(part), _stream()), "vican_trans_rhs")
+        self._ck(self.lib.vican_slab_reduce(_ptr(part), nwg, 3 * self.C, _ptr(rhs_c), _stream()), "vican_slab_reduce")
+
+    def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
+        self._ck(self.lib.vican_cg_init(self.C, self.T, _ptr(b_c), _ptr(b_t), _ptr(x_c), _ptr(x_t), _ptr(r_c), _ptr(r_t),
+                                        _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), _stream()), "vican_cg_init")
+
+    def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
+        self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),
+                                         _ptr(st), _stream()), "vican_cg_begin")
+
+    def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
+        """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
+        nwg = self.g.n_wg
+        part = self.zpart[: nwg * 3 * self.C]
+        self._ck(self.lib.vican_cg_sweep(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
+                                         _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
+        self._ck(self.lib.vican_slab_reduce(_ptr(part), nwg, 3 * self.C, _ptr(qcpq), _stream()), "vican_slab_reduce")
+        self._ck(self.lib.vican_cg_reduce_pq(_ptr(self.pq_part), nwg, C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C),
+                                             _ptr(st), _stream()), "vican_cg_reduce_pq")
+
+    def cg_cam_step(self, deg_c, qcpq, p_c, x_c, r_c, st):
+        self._ck(self.lib.vican_cg_cam_step(self.C, _ptr(deg_c), _ptr(qcpq), C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C),
+                                            _ptr(p_c), _ptr(x_c), _ptr(r_c), _ptr(st), _stream()), "vican_cg_cam_step")
+
+    def cg_time_step(self, p_t, q_t, x_t, r_t, st):
+        return self._ck(self.lib.vican_cg_time_step(self.T, _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
+                                                    self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_time_step")
+
+    def cg_end(self, n_part, st):
+        self._ck(self.lib.vican_cg_end(_ptr(self.rr_part), int(n_part), _ptr(st), _stream()), "vican_cg_end")

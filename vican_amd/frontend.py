@@ -1,0 +1,116 @@
+"""Host front-end: reference edge dict -> flat arrays -> merged timestep-major CSR.
+
+Covers the host-side rows of the hot path:
+the user callables (``edge_filter``, ``noise_model_r``, ``noise_model_t``) are
+arbitrary Python and are evaluated once per edge (reference bipgo.py:204,212,
+423,449 - the reference calls the filter twice; callables are treated as pure);
+everything else is vectorised NumPy.  Output feeds ``device.LocalGraph``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Problem:
+    """Flattened, merged problem (all float64 on the host)."""
+    __slots__ = ("cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "root",
+                 "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v")
+
+    @property
+    def n_cam(self):
+        return len(self.cam_names)
+
+    @property
+    def n_time(self):
+        return len(self.time_names)
+
+    @property
+    def n_edges(self):
+        return len(self.col)
+
+
+def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype=np.float32) -> Problem:
+    """Filter, weight, apply marker constraints and merge multi-marker edges.
+
+    Per kept source edge e = (c, "t_m") (bipgo.py:203-221, 445-468):
+        M_ct += k_r * R~_e R_m^T R_root,   a_ct += k_r
+        w_ct += kf^2,  u_ct += kf k_t t~_e,  v_ct += kf k_t (R_root^T R_m) tau_m
+    with tau_m = trans(S_m^-1 S_root) and kf = k_t rounded to ``dtype`` (the reference
+    stores the incidence matrix in ``dtype`` but the measurements in float64,
+    bipgo.py:434-439).
+    """
+    root = str(min(list(constraints.keys())))                      # bipgo.py:196,411 (string min)
+    r_root = np.asarray(constraints[root].R(), dtype=np.float64)
+    cams, times, marks, poses, kr, kt = [], [], [], [], [], []
+    for key, val in src_edges.items():                             # the only per-edge Python loop
+        if not edge_filter(val):
+            continue
+        ts, mid = key[1].split("_")
+        cams.append(key[0]); times.append(ts); marks.append(mid)
+        poses.append(val["pose"])
+        kr.append(noise_model_r(val)); kt.append(noise_model_t(val))
+    n = len(cams)
+    if n == 0:
+        raise ValueError("no edge passes edge_filter")
+    # per-marker constraint tables (KeyError for an unknown marker id, as bipgo.py:209)
+    mk_names, mk_idx = np.unique(np.array(marks, dtype=str), return_inverse=True)
+    CmT = np.empty((len(mk_names), 3, 3)); Q = np.empty((len(mk_names), 3, 3)); tau = np.empty((len(mk_names), 3))
+    for i, m in enumerate(mk_names):
+        cm = constraints[str(m)]
+        r_m = np.asarray(cm.R(), dtype=np.float64)
+        CmT[i] = r_m.T @ r_root                                    # bipgo.py:213
+        Q[i] = r_root.T @ r_m                                      # bipgo.py:451
+        tau[i] = np.asarray((cm.inv() @ constraints[root]).t(), dtype=np.float64)   # bipgo.py:452
+    qtau = np.einsum("mij,mj->mi", Q, tau)
+    R = np.stack([np.asarray(p.R(), dtype=np.float64) for p in poses])
+    t = np.stack([np.asarray(p.t(), dtype=np.float64).reshape(3) for p in poses])
+    kr = np.asarray(kr, dtype=np.float64); kt = np.asarray(kt, dtype=np.float64)
+    kf = kt.astype(dtype).astype(np.float64)
+    wR = (kr[:, None, None] * R) @ CmT[mk_idx]
+
+    cam_s, time_s = np.array(cams, dtype=str), np.array(times, dtype=str)
+    cam_nodes, ci = np.unique(np.char.add("c", cam_s), return_inverse=True)      # bipgo.py:225-229
+    time_nodes, ti = np.unique(np.char.add("t", time_s), return_inverse=True)
+    C, T = len(cam_nodes), len(time_nodes)
+    key = ti.astype(np.int64) * C + ci                              # timestep-major merged-edge key
+    ukey, inv = np.unique(key, return_inverse=True)
+    E = len(ukey)
+    order = np.argsort(inv, kind="stable")                          # source edges grouped by merged edge
+    starts = np.searchsorted(inv[order], np.arange(E))
+
+    def seg(x):
+        return np.add.reduceat(x[order], starts, axis=0)
+
+    p = Problem()
+    p.root, p.n_src = root, n
+    p.cam_names = np.array([c[1:] for c in cam_nodes])
+    p.time_names = np.array([s[1:] for s in time_nodes])
+    p.tnodes = np.unique(np.concatenate([cam_s, np.char.add(time_s, "_0")]))     # bipgo.py:426-430
+    pos = {s: i for i, s in enumerate(p.tnodes)}
+    p.tnode_of_cam = np.array([pos[c] for c in p.cam_names], dtype=np.int64)
+    p.tnode_of_time = np.array([pos[s + "_0"] for s in p.time_names], dtype=np.int64)
+    p.col = (ukey % C).astype(np.int32)
+    rows = (ukey // C).astype(np.int64)
+    p.row_ptr = np.zeros(T + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=T), out=p.row_ptr[1:])
+    p.blk = seg(wR).reshape(E, 9)
+    p.a = seg(kr)
+    w = seg(kf * kf)
+    p.w = w.astype(dtype).astype(np.float64)
+    kk = (kf * kt)[:, None]
+    p.u = seg(kk * t)
+    p.v = seg(kk * qtau[mk_idx])
+    return p
+
+
+def invert_object_edges(src_edges):
+    """Re-key a moving-camera / static-object edge dict so that markers play the
+    camera role (bipgo.py:523-531): (marker, "<t>_<root>") -> inverted pose."""
+    root = str(min(int(k[1].split("_")[1]) for k in src_edges.keys()))           # numeric min
+    edges = {}
+    for k, v in src_edges.items():
+        ts, mid = k[1].split("_")
+        e = dict(v)
+        e["pose"] = v["pose"].inv()
+        edges[(mid, ts + "_" + root)] = e
+    return root, edges
