@@ -126,7 +126,9 @@ def polar_case():
     x = rng.standard_normal((n, 3, 3))
     rots = synth.random_rotations(rng, n)
     x[:64] = rots[:64] * rng.uniform(0.5, 20.0, (64, 1, 1))                 # scaled rotations
-    x[64:96] = rots[64:96] @ np.diag([1.0, 1.0, -1.0]) * 3.0                  # reflections
+    # reflections (det < 0) with DISTINCT singular values: the nearest rotation of a scaled
+    # reflection c*Q is not unique, so equal singular values cannot be a parity vector
+    x[64:96] = rots[64:96] @ np.diag([3.0, 2.0, -1.0]) @ np.swapaxes(rots[96:128], 1, 2)
     u, v = synth.random_rotations(rng, 32), synth.random_rotations(rng, 32)
     s = np.stack([np.array([5.0, 1.0, 1e-9 * (i + 1)]) for i in range(32)])
     x[96:128] = (u * s[:, None, :]) @ v                                       # near rank-2
