@@ -58,8 +58,10 @@ typedef struct vican_graph {
     int32_t slots;            /* edges per chunk = block_threads * edges_per_lane */
     int32_t max_rows;         /* max timestep rows in any chunk */
     int32_t storage;          /* VICAN_STORE_F32 | VICAN_STORE_F64 (type of blk) */
-    int32_t block_threads;    /* 256 or 1024 */
+    int32_t block_threads;    /* 256, 512 or 1024 */
     int32_t n_wg;             /* persistent workgroups per sweep (= number of partial slabs) */
+    int32_t n_copy;           /* lane-striped copies of the per-row accumulators (power of 2, <= 32) */
+    int32_t reserved;
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
@@ -78,51 +80,80 @@ int vican_abi_version(void);
 int vican_plan_chunks(int32_t n_time, const int32_t* row_ptr_host, int32_t slots,
                       int32_t max_rows, int32_t* chunk_row0_out, int32_t cap);
 
-/* Bytes of dynamic LDS the sweep kernels need for this graph (x table + z
- * accumulators + per-row staging), and the LDS the device offers per workgroup. */
-int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows);
+/* Bytes of dynamic LDS the operator sweep needs (x table + fixed-point z accumulators per
+ * camera; duals, y sums, w and n_copy striped accumulators per row), and the LDS the device
+ * offers per workgroup.                                                        */
+int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy);
 int64_t vican_lds_limit_bytes(void);
-/* Largest max_rows for which every sweep kernel (operator, rhs, CG) fits in LDS
- * with n_cam cameras; <= 0 means the camera tables alone do not fit.          */
-int32_t vican_max_rows_for(int32_t n_cam);
+/* Largest max_rows for which every sweep kernel (operator, rhs, CG) fits in LDS;
+ * <= 0 means the camera tables alone do not fit.                              */
+int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy);
 
 /* ---- layout: CSR arrays -> chunked planes (device) -----------------------
  * row_ptr[T+1], col[E] int32; blk_csr [E][9], a_csr [E] in the storage type;
  * w_csr [E], u_csr [E][3], v_csr [E][3] double (may be NULL together with
  * their outputs).  Outputs: g->blk, g->idx (cast away const), a_out [n_chunk][slots],
- * w_out [n_chunk][slots], u_out / v_out [n_chunk][3][slots].
+ * w_out [n_chunk][slots], u_out / v_out [n_chunk][3][slots].  Inside a chunk the slots are
+ * assigned bank-aware (lane l gets cameras = l mod 32, CSR order within a class), so the
+ * order of edges in a chunk is NOT the CSR order; perm_ws is scratch for that assignment,
+ * int32 [n_chunk][slots] (slot -> CSR edge or -1).
  * (bipgo.py:244-270 for the rotation arrays; 445-471 for the translation ones) */
 int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, const int32_t* col,
                      const void* blk_csr, const void* a_csr, const double* w_csr,
                      const double* u_csr, const double* v_csr,
-                     void* a_out, double* w_out, double* u_out, double* v_out, void* stream);
+                     void* a_out, double* w_out, double* u_out, double* v_out,
+                     int32_t* perm_ws, void* stream);
+
+/* ---- graph constants (once per graph, at pack time) ------------------------
+ * row_sum[t] = sum_c val_ct (written), cam_sum[c] += sum_t val_ct (atomic; caller zeroes and
+ * all-reduces across ranks).  val: [n_chunk][slots], float or double (val_is_f64).  Used for
+ * d_t / camera degrees of the rotation weights a (bipgo.py:271-276) and for the degrees of
+ * the translation Laplacian (weights w).                                       */
+int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double* row_sum,
+                    double* cam_sum, void* stream);
+
+/* Fixed-point bookkeeping.  The sweeps accumulate in 64-bit fixed point (the fastest LDS
+ * atomic on gfx950, and order-independent => bit-reproducible).  `fx` is a device buffer of
+ * VICAN_FX_DOUBLES doubles: [0] y scale, [1] its inverse, [2] z scale, [3] its inverse,
+ * [4] omega = max_t |lamT_inv[t]|_F * rnorm[t], [5] max block norm, [6] max_t rnorm[t], [7] spare.
+ * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
+ * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
+ * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup. */
+#define VICAN_FX_DOUBLES 8
+int vican_block_norms(const vican_graph_t* g, double* rnorm /*[T]*/, double* fx, void* stream);
+int vican_fx_finish(double* fx, double x_bound, double n_add, void* stream);
 
 /* ---- rotation stage ------------------------------------------------------ */
 
-/* Initial duals (bipgo.py:271-276): d_t = sum_c a_ct, lamT_inv[t] = I/d_t,
- * cam_deg[c] = sum_t a_ct (caller all-reduces cam_deg across ranks, then
- * vican_scaled_identity makes lamC = cam_deg[c] * I).  cam_deg must be zeroed
- * by the caller.  a: [n_chunk][slots] storage type.                          */
-int vican_init_duals(const vican_graph_t* g, const void* a, double* lamT_inv /*[T][9]*/,
-                     double* cam_deg /*[C]*/, void* stream);
+/* Initial duals (bipgo.py:271-276) from the stored row sums d_t of the rotation weights:
+ * lamT_inv[t] = I/d_t; refreshes fx[4].  (lamC = cam_sum[c] * I via vican_scaled_identity.) */
+int vican_init_duals(int32_t n_time, const double* row_sum_a, const double* rnorm,
+                     double* lamT_inv /*[T][9]*/, double* fx, void* stream);
 int vican_scaled_identity(int32_t n, const double* scale, double* out /*[n][9]*/, void* stream);
 
 /* Fused connection-Laplacian operator  zpart[wg] = sum over the workgroup's
  * edges of  M_ct * lamT_inv[t] * (sum_c' M_c't^T x_c')   i.e. slabs of
  * P x = R~ Lambda_T^-1 R~^T x  without ever forming P (replaces the SpGEMM at
- * bipgo.py:273,334 and the SpMM at bipgo.py:300).  x: [3C][3] double;
- * zpart: [n_wg][3C][3] double.  Each block is read from HBM exactly once.   */
+ * bipgo.py:273,334 and the SpMM at bipgo.py:300).  x: [3C][3] double with |x_c|_F <= the
+ * x_bound given to vican_fx_finish; zpart: [n_wg][9][C] planes of 64-bit fixed point (scale fx[2]),
+ * to be folded by vican_slab_reduce_fx.  Each block is read from HBM exactly once; products
+ * are formed in the storage type (f32 for f32 blocks), sums are exact integers.       */
 int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x,
-                   double* zpart, void* stream);
+                   void* zpart, double* fx, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,
- * lamT_inv[t] = U S^-1 U^T.  rc: [3C][3]; Rt, lamT_inv: [T][9].             */
+ * lamT_inv[t] = U S^-1 U^T.  rc: [3C][3]; Rt, lamT_inv: [T][9].  Refreshes fx[4]
+ * (call vican_fx_finish afterwards).                                            */
 int vican_dual_update(const vican_graph_t* g, const double* rc, double* Rt,
-                      double* lamT_inv, void* stream);
+                      double* lamT_inv, const double* rnorm, double* fx, void* stream);
 
 /* out[i] = sum_s part[s][i], s < n_slab, i < n  (fixed order: bitwise reproducible). */
 int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out, void* stream);
+/* z[c][q] = fx[3] * sum_s part[s][q][c]: folds the fixed-point plane slabs of vican_block_op
+ * (n = 9C) into the row-major camera vector [3C][3]; exact integer sum.        */
+int vican_slab_reduce_fx(const void* part, int32_t n_slab, int64_t n, const double* fx,
+                         double* out, void* stream);
 
 /* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
  * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),
@@ -169,10 +200,6 @@ int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_
  * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of
  * bipgo.py:463-477:  (weighted bipartite Laplacian (x) I3) p = J^T b.          */
 
-/* Degrees of the weighted Laplacian: deg_t[t] = sum_c w_ct (written),
- * deg_c[c] += sum_t w_ct (atomic; caller zeroes, all-reduces across ranks).  */
-int vican_trans_degrees(const vican_graph_t* g, const double* w, double* deg_t,
-                        double* deg_c, void* stream);
 /* Right-hand side J^T b (bipgo.py:451-461 + J^T): g_ct = Rc_c^T u_ct + Rt_t^T v_ct;
  * rhs_t[t] = sum_c g_ct (written), rhs_c slabs [n_wg][C][3] = -sum_t g_ct.   */
 int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v,

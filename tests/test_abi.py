@@ -31,11 +31,11 @@ def test_every_header_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), "library does not export %s" % s
         assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
-    assert lib.vican_abi_version() == 1
+    assert lib.vican_abi_version() == 2
 
 
 def test_struct_sizes():
-    assert C.sizeof(_lib.Graph) == 8 * 4 + 3 * 8
+    assert C.sizeof(_lib.Graph) == 10 * 4 + 3 * 8
     assert _lib.CG_STATE_DOUBLES * 8 == 10 * 8 + 4 * 4
 
 
@@ -71,11 +71,14 @@ def test_plan_chunks_edge_cases(lib):
 
 
 def test_lds_budget(lib):
-    for c in (3, 24, 340, 1000):
-        m = lib.vican_max_rows_for(c)
-        assert m >= 1
-        assert lib.vican_sweep_lds_bytes(c, m) <= lib.vican_lds_limit_bytes()
-    assert lib.vican_max_rows_for(1200) <= 0           # camera tables alone exceed 160 KiB
+    for storage in (_lib.STORE_F32, _lib.STORE_F64):
+        for c in (3, 24, 340, 1000):
+            for ncopy in (1, 8, 32):
+                m = lib.vican_max_rows_for(c, storage, ncopy)
+                assert m >= 1
+                assert lib.vican_sweep_lds_bytes(c, m, storage, ncopy) <= lib.vican_lds_limit_bytes()
+    assert lib.vican_max_rows_for(1200, _lib.STORE_F64, 1) <= 0       # camera tables alone exceed 160 KiB
+    assert lib.vican_max_rows_for(1200, _lib.STORE_F32, 1) >= 1
 
 
 def test_compute_calls_fail_loudly_without_gpu():

@@ -43,6 +43,7 @@ CONFIGS = [  # C, T, deg_lo, deg_hi, block_threads, n_wg, empty_rows
     (37, 300, 1, 12, 256, None, True),
     (64, 500, 20, 64, 256, 7, False),
     (200, 120, 100, 200, 1024, None, False),
+    (300, 200, 50, 300, 512, 9, False),
     (700, 64, 300, 700, 1024, 5, False),
 ]
 
@@ -53,7 +54,7 @@ def test_block_op_dual_update_and_init(cfg, dt):
     C, T, lo, hi, bt, nwg, er = cfg
     H, N, g = make_backends(C, T, lo, hi, 100 + C, dt, bt, nwg, er)
     rng = np.random.default_rng(1)
-    x = rng.standard_normal((3 * C, 3))
+    x = np.linalg.qr(rng.standard_normal((3 * C, 3)))[0]            # |x_c|_F <= sqrt(3): the sweep's precondition
     # initial duals
     lamT_h, cd_h = H.empty(T, 9), H.empty(C)
     lamT_n, cd_n = N.empty(T, 9), N.empty(C)
@@ -67,16 +68,22 @@ def test_block_op_dual_update_and_init(cfg, dt):
     zh, zn = H.empty(3 * C, 3), N.empty(3 * C, 3)
     H.block_op(lam_h, H.from_numpy(x), zh); N.block_op(lam_n, N.from_numpy(x), zn)
     ref = zn.numpy()
-    assert np.abs(zh.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    # f64 blocks: f64 products + exact fixed-point sums; f32 blocks: f32 products (x rounded to f32)
+    assert np.abs(zh.cpu().numpy() - ref).max() <= (1e-11 if dt == np.float64 else 2e-6) * np.abs(ref).max()
+    # integer accumulation => bit-identical on a repeat launch
+    z2 = H.empty(3 * C, 3)
+    H.block_op(lam_h, H.from_numpy(x), z2)
+    assert torch.equal(zh, z2)
     # dual update from stacked rotations
     rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
     Rt_h, L_h = H.zeros(T, 9), H.zeros(T, 9)
     Rt_n, L_n = N.zeros(T, 9), N.zeros(T, 9)
     H.dual_update(H.from_numpy(rc), Rt_h, L_h); N.dual_update(N.from_numpy(rc), Rt_n, L_n)
     well = nz & (np.diff(N.row_ptr) >= 2)            # a single noisy block may be ill-conditioned; keep generic rows
-    assert np.abs(Rt_h.cpu().numpy()[well] - Rt_n.numpy()[well]).max() < 1e-10
+    tol = 1e-10 if dt == np.float64 else 2e-3      # f32 products; S^-1 amplifies by cond(Z_t) on 2-edge rows
+    assert np.abs(Rt_h.cpu().numpy()[well] - Rt_n.numpy()[well]).max() < tol
     rel = np.abs(L_h.cpu().numpy()[well] - L_n.numpy()[well]).max() / np.abs(L_n.numpy()[well]).max()
-    assert rel < 1e-10
+    assert rel < tol
 
 
 def test_polar_dual_against_reference_project_SO3():
@@ -151,7 +158,7 @@ def test_gauge_project_and_lanczos_helpers():
     assert b[1, 1] == 0.0 and np.all(xh.cpu().numpy()[:, 1] == 0.0)
 
 
-@pytest.mark.parametrize("cfg", CONFIGS[:4])
+@pytest.mark.parametrize("cfg", CONFIGS[:5])
 def test_translation_kernels_and_cg(cfg):
     """rhs / degrees / every CG kernel step by step against the NumPy state machine."""
     from vican_amd.solver import Comm, TranslationSolver

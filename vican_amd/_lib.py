@@ -15,7 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
-SOURCES = [os.path.join(CSRC, "vican_kernels.hip")]
+SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip")]
+HEADERS = [os.path.join(CSRC, "common.cuh")]
+FX_DOUBLES = 8
 INCLUDE = os.path.join(ROOT, "include")
 
 STORE_F32, STORE_F64 = 0, 1
@@ -27,6 +29,7 @@ class Graph(C.Structure):
     _fields_ = [
         ("n_cam", C.c_int32), ("n_time", C.c_int32), ("n_chunk", C.c_int32), ("slots", C.c_int32),
         ("max_rows", C.c_int32), ("storage", C.c_int32), ("block_threads", C.c_int32), ("n_wg", C.c_int32),
+        ("n_copy", C.c_int32), ("reserved", C.c_int32),
         ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
     ]
 
@@ -45,14 +48,18 @@ PROTOTYPES = {
     "vican_last_error": (C.c_char_p, []),
     "vican_abi_version": (C.c_int, []),
     "vican_plan_chunks": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32]),
-    "vican_sweep_lds_bytes": (_i64, [_i32, _i32]),
+    "vican_sweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_lds_limit_bytes": (_i64, []),
-    "vican_max_rows_for": (_i32, [_i32]),
-    "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vican_init_duals": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_max_rows_for": (_i32, [_i32, _i32, _i32]),
+    "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _vp, _vp, _vp]),
+    "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
+    "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _vp]),
+    "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_init_duals": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "vican_scaled_identity": (C.c_int, [_i32, _vp, _vp, _vp]),
-    "vican_block_op": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
-    "vican_dual_update": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_block_op": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
+    "vican_dual_update": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_slab_reduce": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "vican_polar_dual": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp]),
     "vican_gauge_project": (C.c_int, [_i32, _vp, _vp, _vp]),
@@ -62,7 +69,6 @@ PROTOTYPES = {
     "vican_chol_qr3": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp]),
     "vican_tall_combine": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vican_rows_to_cols": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp]),
-    "vican_trans_degrees": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
     "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _vp, _vp]),
@@ -90,11 +96,11 @@ def hipcc_path() -> str:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so``."""
     if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "vican_hip.h")])
+        newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")])
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", INCLUDE, *SOURCES, "-o", LIB_PATH]
+           "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

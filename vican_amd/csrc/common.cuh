@@ -1,0 +1,172 @@
+// common.cuh - shared helpers of the vican HIP kernels (error plumbing, wavefront
+// reductions, 3x3 SVD / polar factor, LDS budget).  Included by every .hip file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vican_hip.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing (one message buffer per host thread, defined in vican_sweep.hip)
+// ---------------------------------------------------------------------------
+extern thread_local char g_vican_err[512];
+
+static inline int set_err(int code, const char* fmt, const char* a = "") {
+    snprintf(g_vican_err, sizeof(g_vican_err), fmt, a);
+    return code;
+}
+#define LAUNCH_CHECK(name)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) {                                                                \
+            snprintf(g_vican_err, sizeof(g_vican_err), "%s: %s", name, hipGetErrorString(e_)); \
+            return VICAN_ERR_LAUNCH;                                                           \
+        }                                                                                      \
+    } while (0)
+
+int vican_check_graph(const vican_graph_t* g, const char* who);   // vican_sweep.hip
+static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (12LL * n_cam + 12LL * max_rows) + 256; }
+static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (6LL * n_cam + 6LL * max_rows + 16); }
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+
+// Sum over the workgroup; result valid in thread 0.  `red` holds >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + WAVE - 1) / WAVE;
+        for (int i = 0; i < nw; ++i) t += red[i];   // fixed order
+    }
+    return t;
+}
+
+__device__ __forceinline__ void lds_add(double* p, double v) {
+    // ds_add_f64 (no return) under -munsafe-fp-atomics
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// --- 3x3 SVD by one-sided Jacobi (Hestenes), double precision ---------------
+// A (row-major) = U diag(s) V^T, s sorted descending.  High relative accuracy
+// (no A^T A squaring); U completed to an orthonormal basis when A is rank deficient.
+__device__ void svd3(const double* A, double* U, double* s, double* V) {
+    double a[3][3], v[3][3];   // a[j] = column j of the working matrix, v[j] = column j of V
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { a[j][i] = A[i * 3 + j]; v[j][i] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+            const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
+            const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
+            const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
+            if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double ap = a[p][i], aq = a[q][i];
+                    a[p][i] = c * ap - sn * aq;
+                    a[q][i] = sn * ap + c * aq;
+                    const double vp = v[p][i], vq = v[q][i];
+                    v[p][i] = c * vp - sn * vq;
+                    v[q][i] = sn * vp + c * vq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    double n[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) n[j] = sqrt(a[j][0] * a[j][0] + a[j][1] * a[j][1] + a[j][2] * a[j][2]);
+    // sort descending (3-element network), permuting columns of a and v together
+#define SWAPCOL(x, y)                                                      \
+    if (n[x] < n[y]) {                                                     \
+        double tn = n[x]; n[x] = n[y]; n[y] = tn;                          \
+        for (int i = 0; i < 3; ++i) {                                      \
+            double ta = a[x][i]; a[x][i] = a[y][i]; a[y][i] = ta;          \
+            double tv = v[x][i]; v[x][i] = v[y][i]; v[y][i] = tv;          \
+        }                                                                  \
+    }
+    SWAPCOL(0, 1) SWAPCOL(1, 2) SWAPCOL(0, 1)
+#undef SWAPCOL
+    double u[3][3];
+    const double tiny = 1e-300;
+    if (n[0] > tiny) { for (int i = 0; i < 3; ++i) u[0][i] = a[0][i] / n[0]; }
+    else { u[0][0] = 1.0; u[0][1] = 0.0; u[0][2] = 0.0; }
+    if (n[1] > tiny && n[1] > 1e-15 * n[0]) { for (int i = 0; i < 3; ++i) u[1][i] = a[1][i] / n[1]; }
+    else {   // any unit vector orthogonal to u0
+        int k = 0; double m = fabs(u[0][0]);
+        if (fabs(u[0][1]) < m) { k = 1; m = fabs(u[0][1]); }
+        if (fabs(u[0][2]) < m) { k = 2; }
+        double e[3] = {0.0, 0.0, 0.0}; e[k] = 1.0;
+        const double d = u[0][k];
+        double w[3] = {e[0] - d * u[0][0], e[1] - d * u[0][1], e[2] - d * u[0][2]};
+        const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        for (int i = 0; i < 3; ++i) u[1][i] = w[i] / wn;
+    }
+    if (n[2] > tiny && n[2] > 1e-15 * n[0]) { for (int i = 0; i < 3; ++i) u[2][i] = a[2][i] / n[2]; }
+    else {   // u2 = u0 x u1 (sign is irrelevant for U diag(1,1,det) V^T and U f(S) U^T)
+        u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+        u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+        u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        s[j] = n[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { U[i * 3 + j] = u[j][i]; V[i * 3 + j] = v[j][i]; }
+    }
+}
+
+__device__ __forceinline__ double det3(const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+           m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// Polar rotation with det fix and dual block from one SVD.
+// mode: 0 none, 1 lam = U S U^T, 2 lam = U S^-1 U^T   (S NOT sign corrected: bipgo.py:312,329)
+__device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
+    double U[9], s[3], V[9];
+    svd3(A, U, s, V);
+    const double d = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
+    if (R) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                R[i * 3 + j] = U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1] +
+                               d * U[i * 3 + 2] * V[j * 3 + 2];
+    }
+    if (lam && mode) {
+        double f[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f[k] = (mode == 1) ? s[k] : 1.0 / s[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                lam[i * 3 + j] = f[0] * U[i * 3 + 0] * U[j * 3 + 0] + f[1] * U[i * 3 + 1] * U[j * 3 + 1] +
+                                 f[2] * U[i * 3 + 2] * U[j * 3 + 2];
+    }
+}
+

@@ -1,569 +1,7 @@
-// vican_kernels.hip - hand-written CDNA4 (gfx950) kernels of the primal-dual
-// bipartite SE(3) solver.  C ABI in include/vican_hip.h; design notes in DESIGN.md.
-//
-// Nothing here is GEMM-shaped: the hot loops stream 3x3 edge blocks from HBM once
-// per sweep (coalesced 16 B/lane plane loads), keep the camera-side vectors in
-// LDS, and reduce with LDS atomics + wavefront shuffles.  64-wide wavefronts
-// throughout; no MFMA, no CUDA compatibility paths.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-
-#include "vican_hip.h"
-
-// ---------------------------------------------------------------------------
-// error plumbing
-// ---------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int set_err(int code, const char* fmt, const char* a = "") {
-    snprintf(g_err, sizeof(g_err), fmt, a);
-    return code;
-}
-#define LAUNCH_CHECK(name)                                                         \
-    do {                                                                           \
-        hipError_t e_ = hipGetLastError();                                         \
-        if (e_ != hipSuccess) {                                                    \
-            snprintf(g_err, sizeof(g_err), "%s: %s", name, hipGetErrorString(e_)); \
-            return VICAN_ERR_LAUNCH;                                               \
-        }                                                                          \
-    } while (0)
-
-extern "C" const char* vican_last_error(void) { return g_err; }
-extern "C" int vican_abi_version(void) { return 1; }
-
-// ---------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------
-#define WAVE 64
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-    return v;
-}
-
-// Sum over the workgroup; result valid in thread 0.  `red` holds >= blockDim/64 doubles.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0) {
-        const int nw = (blockDim.x + WAVE - 1) / WAVE;
-        for (int i = 0; i < nw; ++i) t += red[i];   // fixed order
-    }
-    return t;
-}
-
-__device__ __forceinline__ void lds_add(double* p, double v) {
-    // ds_add_f64 (no return) under -munsafe-fp-atomics
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// --- 3x3 SVD by one-sided Jacobi (Hestenes), double precision ---------------
-// A (row-major) = U diag(s) V^T, s sorted descending.  High relative accuracy
-// (no A^T A squaring); U completed to an orthonormal basis when A is rank deficient.
-__device__ void svd3(const double* A, double* U, double* s, double* V) {
-    double a[3][3], v[3][3];   // a[j] = column j of the working matrix, v[j] = column j of V
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { a[j][i] = A[i * 3 + j]; v[j][i] = (i == j) ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        bool rotated = false;
-#pragma unroll
-        for (int pq = 0; pq < 3; ++pq) {
-            const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
-            const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
-            const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
-            const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
-            if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
-                rotated = true;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double ap = a[p][i], aq = a[q][i];
-                    a[p][i] = c * ap - sn * aq;
-                    a[q][i] = sn * ap + c * aq;
-                    const double vp = v[p][i], vq = v[q][i];
-                    v[p][i] = c * vp - sn * vq;
-                    v[q][i] = sn * vp + c * vq;
-                }
-            }
-        }
-        if (!rotated) break;
-    }
-    double n[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) n[j] = sqrt(a[j][0] * a[j][0] + a[j][1] * a[j][1] + a[j][2] * a[j][2]);
-    // sort descending (3-element network), permuting columns of a and v together
-#define SWAPCOL(x, y)                                                      \
-    if (n[x] < n[y]) {                                                     \
-        double tn = n[x]; n[x] = n[y]; n[y] = tn;                          \
-        for (int i = 0; i < 3; ++i) {                                      \
-            double ta = a[x][i]; a[x][i] = a[y][i]; a[y][i] = ta;          \
-            double tv = v[x][i]; v[x][i] = v[y][i]; v[y][i] = tv;          \
-        }                                                                  \
-    }
-    SWAPCOL(0, 1) SWAPCOL(1, 2) SWAPCOL(0, 1)
-#undef SWAPCOL
-    double u[3][3];
-    const double tiny = 1e-300;
-    if (n[0] > tiny) { for (int i = 0; i < 3; ++i) u[0][i] = a[0][i] / n[0]; }
-    else { u[0][0] = 1.0; u[0][1] = 0.0; u[0][2] = 0.0; }
-    if (n[1] > tiny && n[1] > 1e-15 * n[0]) { for (int i = 0; i < 3; ++i) u[1][i] = a[1][i] / n[1]; }
-    else {   // any unit vector orthogonal to u0
-        int k = 0; double m = fabs(u[0][0]);
-        if (fabs(u[0][1]) < m) { k = 1; m = fabs(u[0][1]); }
-        if (fabs(u[0][2]) < m) { k = 2; }
-        double e[3] = {0.0, 0.0, 0.0}; e[k] = 1.0;
-        const double d = u[0][k];
-        double w[3] = {e[0] - d * u[0][0], e[1] - d * u[0][1], e[2] - d * u[0][2]};
-        const double wn = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-        for (int i = 0; i < 3; ++i) u[1][i] = w[i] / wn;
-    }
-    if (n[2] > tiny && n[2] > 1e-15 * n[0]) { for (int i = 0; i < 3; ++i) u[2][i] = a[2][i] / n[2]; }
-    else {   // u2 = u0 x u1 (sign is irrelevant for U diag(1,1,det) V^T and U f(S) U^T)
-        u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
-        u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
-        u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        s[j] = n[j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { U[i * 3 + j] = u[j][i]; V[i * 3 + j] = v[j][i]; }
-    }
-}
-
-__device__ __forceinline__ double det3(const double* m) {
-    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
-           m[2] * (m[3] * m[7] - m[4] * m[6]);
-}
-
-// Polar rotation with det fix and dual block from one SVD.
-// mode: 0 none, 1 lam = U S U^T, 2 lam = U S^-1 U^T   (S NOT sign corrected: bipgo.py:312,329)
-__device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
-    double U[9], s[3], V[9];
-    svd3(A, U, s, V);
-    const double d = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
-    if (R) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                R[i * 3 + j] = U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1] +
-                               d * U[i * 3 + 2] * V[j * 3 + 2];
-    }
-    if (lam && mode) {
-        double f[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) f[k] = (mode == 1) ? s[k] : 1.0 / s[k];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                lam[i * 3 + j] = f[0] * U[i * 3 + 0] * U[j * 3 + 0] + f[1] * U[i * 3 + 1] * U[j * 3 + 1] +
-                                 f[2] * U[i * 3 + 2] * U[j * 3 + 2];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// host-side planning
-// ---------------------------------------------------------------------------
-extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slots, int32_t max_rows,
-                                 int32_t* out, int32_t cap) {
-    if (n_time < 0 || !rp || slots <= 0 || max_rows <= 0 || max_rows > 65535)
-        return set_err(VICAN_ERR_ARG, "vican_plan_chunks: bad argument");
-    int32_t nc = 0, r = 0;
-    while (r < n_time) {
-        if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks: output too small"); out[nc] = r; }
-        const int32_t e0 = rp[r];
-        int32_t r1 = r;
-        while (r1 < n_time && (r1 - r) < max_rows && (rp[r1 + 1] - e0) <= slots) ++r1;
-        if (r1 == r) return set_err(VICAN_ERR_CAPACITY, "vican_plan_chunks: a timestep row has more edges than a chunk holds");
-        r = r1;
-        ++nc;
-    }
-    if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks: output too small"); out[nc] = n_time; }
-    return nc;
-}
-
-extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows) {
-    // x table 9C + z accumulators 9C + per-row staging 9*max_rows, doubles; + reduction scratch
-    return (int64_t)8 * (18LL * n_cam + 9LL * max_rows) + 256;
-}
-extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024; }
-static int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (12LL * n_cam + 12LL * max_rows) + 256; }
-static int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (6LL * n_cam + 6LL * max_rows + 16); }
-extern "C" int32_t vican_max_rows_for(int32_t n_cam) {
-    const int64_t lim = vican_lds_limit_bytes();
-    int64_t a = (lim - 256 - 144LL * n_cam) / 72, b = (lim - 256 - 96LL * n_cam) / 96, c = (lim - 128 - 48LL * n_cam) / 48;
-    int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
-    return (int32_t)m;
-}
-
-static int check_graph(const vican_graph_t* g, const char* who) {
-    if (!g || g->n_cam <= 0 || g->n_cam > 65535 || g->n_time < 0 || g->n_chunk < 0 || !g->idx || !g->blk ||
-        !g->chunk_row0 || g->n_wg <= 0)
-        return set_err(VICAN_ERR_ARG, "%s: bad graph descriptor", who);
-    const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
-    if ((g->block_threads != 256 && g->block_threads != 1024) || g->slots != g->block_threads * epl)
-        return set_err(VICAN_ERR_ARG, "%s: slots must be block_threads * (16 / sizeof(storage))", who);
-    if (g->max_rows <= 0 || g->max_rows > 65535) return set_err(VICAN_ERR_ARG, "%s: bad max_rows", who);
-    if (g->max_rows > vican_max_rows_for(g->n_cam))
-        return set_err(VICAN_ERR_CAPACITY, "%s: camera tables do not fit in LDS", who);
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// layout: CSR -> chunked planes
-// ---------------------------------------------------------------------------
-template <typename S>
-__global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr,
-                                  const int32_t* __restrict__ col, const S* __restrict__ blk_csr,
-                                  const S* __restrict__ a_csr, const double* __restrict__ w_csr,
-                                  const double* __restrict__ u_csr, const double* __restrict__ v_csr,
-                                  S* __restrict__ a_out, double* __restrict__ w_out,
-                                  double* __restrict__ u_out, double* __restrict__ v_out) {
-    const int k = blockIdx.y;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= g.slots) return;
-    const int r0 = g.chunk_row0[k], r1 = g.chunk_row0[k + 1];
-    const int e0 = row_ptr[r0], e1 = row_ptr[r1];
-    const int e = e0 + s;
-    S* blk = (S*)g.blk;
-    uint32_t* idx = (uint32_t*)g.idx;
-    const size_t base = (size_t)k * g.slots + s;
-    if (e < e1) {
-        int lo = r0, hi = r1;           // row_ptr[lo] <= e < row_ptr[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (row_ptr[mid] <= e) lo = mid; else hi = mid;
-        }
-        idx[base] = (uint32_t)col[e] | ((uint32_t)(lo - r0) << 16);
-#pragma unroll
-        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = blk_csr[(size_t)e * 9 + p];
-        if (a_out) a_out[base] = a_csr[e];
-        if (w_out) w_out[base] = w_csr[e];
-        if (u_out)
-            for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = u_csr[(size_t)e * 3 + p];
-        if (v_out)
-            for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = v_csr[(size_t)e * 3 + p];
-    } else {
-        idx[base] = VICAN_PAD_SLOT;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = (S)0;
-        if (a_out) a_out[base] = (S)0;
-        if (w_out) w_out[base] = 0.0;
-        if (u_out) for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
-        if (v_out) for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
-    }
-}
-
-extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, const int32_t* col,
-                                const void* blk_csr, const void* a_csr, const double* w_csr,
-                                const double* u_csr, const double* v_csr, void* a_out, double* w_out,
-                                double* u_out, double* v_out, void* stream) {
-    if (int rc = check_graph(g, "vican_pack_edges")) return rc;
-    if (!row_ptr || !col || !blk_csr) return set_err(VICAN_ERR_ARG, "vican_pack_edges: null input");
-    if (g->n_chunk == 0) return VICAN_OK;
-    dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (g->storage == VICAN_STORE_F32)
-        hipLaunchKernelGGL(pack_edges_kernel<float>, grid, block, 0, st, *g, row_ptr, col, (const float*)blk_csr,
-                           (const float*)a_csr, w_csr, u_csr, v_csr, (float*)a_out, w_out, u_out, v_out);
-    else
-        hipLaunchKernelGGL(pack_edges_kernel<double>, grid, block, 0, st, *g, row_ptr, col, (const double*)blk_csr,
-                           (const double*)a_csr, w_csr, u_csr, v_csr, (double*)a_out, w_out, u_out, v_out);
-    LAUNCH_CHECK("vican_pack_edges");
-    return VICAN_OK;
-}
-
-// ---------------------------------------------------------------------------
-// per-chunk scalar sums: row sums (written) + camera sums (global atomics, one-off)
-// ---------------------------------------------------------------------------
-template <typename S, bool IDENTITY_OUT>
-__global__ void row_cam_sums_kernel(vican_graph_t g, const S* __restrict__ val, double* __restrict__ row_out,
-                                    double* __restrict__ cam_acc) {
-    extern __shared__ double lds[];
-    const int k = blockIdx.x;
-    const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) lds[r] = 0.0;
-    __syncthreads();
-    const size_t base = (size_t)k * g.slots;
-    for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
-        const uint32_t id = g.idx[base + s];
-        if (id == VICAN_PAD_SLOT) continue;
-        const double v = (double)val[base + s];
-        lds_add(&lds[id >> 16], v);
-        unsafeAtomicAdd(&cam_acc[id & 0xFFFFu], v);
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
-        const double d = lds[r];
-        if (IDENTITY_OUT) {
-            double* o = row_out + (size_t)(r0 + r) * 9;
-            const double inv = 1.0 / d;
-            o[0] = inv; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = inv; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = inv;
-        } else {
-            row_out[r0 + r] = d;
-        }
-    }
-}
-
-extern "C" int vican_init_duals(const vican_graph_t* g, const void* a, double* lamT_inv, double* cam_deg,
-                                void* stream) {
-    if (int rc = check_graph(g, "vican_init_duals")) return rc;
-    if (!a || !lamT_inv || !cam_deg) return set_err(VICAN_ERR_ARG, "vican_init_duals: null pointer");
-    if (g->n_chunk == 0) return VICAN_OK;
-    const size_t lds = (size_t)g->max_rows * 8;
-    if (g->storage == VICAN_STORE_F32)
-        hipLaunchKernelGGL((row_cam_sums_kernel<float, true>), dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream,
-                           *g, (const float*)a, lamT_inv, cam_deg);
-    else
-        hipLaunchKernelGGL((row_cam_sums_kernel<double, true>), dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream,
-                           *g, (const double*)a, lamT_inv, cam_deg);
-    LAUNCH_CHECK("vican_init_duals");
-    return VICAN_OK;
-}
-
-extern "C" int vican_trans_degrees(const vican_graph_t* g, const double* w, double* deg_t, double* deg_c,
-                                   void* stream) {
-    if (int rc = check_graph(g, "vican_trans_degrees")) return rc;
-    if (!w || !deg_t || !deg_c) return set_err(VICAN_ERR_ARG, "vican_trans_degrees: null pointer");
-    if (g->n_chunk == 0) return VICAN_OK;
-    hipLaunchKernelGGL((row_cam_sums_kernel<double, false>), dim3(g->n_chunk), dim3(256), (size_t)g->max_rows * 8,
-                       (hipStream_t)stream, *g, w, deg_t, deg_c);
-    LAUNCH_CHECK("vican_trans_degrees");
-    return VICAN_OK;
-}
-
-__global__ void scaled_identity_kernel(int n, const double* __restrict__ sc, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double s = sc[i];
-    double* o = out + (size_t)i * 9;
-    o[0] = s; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = s; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = s;
-}
-extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out, void* stream) {
-    if (n < 0 || !scale || !out) return set_err(VICAN_ERR_ARG, "vican_scaled_identity: bad argument");
-    if (n == 0) return VICAN_OK;
-    hipLaunchKernelGGL(scaled_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, scale, out);
-    LAUNCH_CHECK("vican_scaled_identity");
-    return VICAN_OK;
-}
-
-// ---------------------------------------------------------------------------
-// THE HOT KERNEL: fused timestep-major block operator / dual update
-// ---------------------------------------------------------------------------
-template <typename S> struct Vec;
-template <> struct Vec<float>  { typedef float4  type; static constexpr int N = 4; };
-template <> struct Vec<double> { typedef double2 type; static constexpr int N = 2; };
-
-template <typename S> __device__ __forceinline__ double vget(const typename Vec<S>::type& v, int j);
-template <> __device__ __forceinline__ double vget<float>(const float4& v, int j) {
-    return (double)(j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w);
-}
-template <> __device__ __forceinline__ double vget<double>(const double2& v, int j) { return j == 0 ? v.x : v.y; }
-
-// MODE 0: zpart[wg] = sum M * (lamT_inv * (sum M^T x))      (operator P x)
-// MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv          (dual update)
-template <typename S, int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, const double* __restrict__ lamT_inv,
-                                                            const double* __restrict__ x,
-                                                            double* __restrict__ zpart,
-                                                            double* __restrict__ Rt_out,
-                                                            double* __restrict__ lamT_out) {
-    typedef typename Vec<S>::type V;
-    constexpr int EPL = Vec<S>::N;
-    extern __shared__ double lds[];
-    const int nx = 9 * g.n_cam;
-    double* xs = lds;                // [C][3][3] camera-side input vectors
-    double* zs = lds + nx;           // [C][3][3] camera-side accumulators
-    double* ys = lds + 2 * nx;       // [max_rows][3][3] per-row staging (y, then w)
-    const int tid = threadIdx.x;
-
-    for (int i = tid; i < nx; i += BLOCK) { xs[i] = x[i]; if (MODE == 0) zs[i] = 0.0; }
-
-    const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
-    const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
-    const S* __restrict__ blk = (const S*)g.blk;
-
-    for (int k = k0; k < k1; ++k) {
-        const int r0 = g.chunk_row0[k];
-        const int nrows = g.chunk_row0[k + 1] - r0;
-        // issue the global loads first so they overlap the LDS zeroing + barrier
-        V m[9];
-        const size_t pbase = (size_t)k * 9 * g.slots + (size_t)tid * EPL;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) m[p] = *(const V*)(blk + pbase + (size_t)p * g.slots);
-        const uint32_t* ip = g.idx + (size_t)k * g.slots + (size_t)tid * EPL;
-        uint32_t id[EPL];
-        if (EPL == 4) { const uint4 t = *(const uint4*)ip; id[0] = t.x; id[1] = t.y; id[2] = t.z; id[3] = t.w; }
-        else          { const uint2 t = *(const uint2*)ip; id[0] = t.x; id[1] = t.y; }
-
-        __syncthreads();                       // previous chunk's phase 3 done with ys
-        for (int i = tid; i < 9 * nrows; i += BLOCK) ys[i] = 0.0;
-        __syncthreads();
-
-        // ---- phase 1: y_row += M^T x_cam, consecutive same-row edges pre-summed in registers
-        {
-            double acc[9];
-            uint32_t cur = 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                if (id[j] == VICAN_PAD_SLOT) continue;
-                const uint32_t cam = id[j] & 0xFFFFu, row = id[j] >> 16;
-                const double* xc = xs + cam * 9;
-                double c[9];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        c[a * 3 + b] = vget<S>(m[0 + a], j) * xc[b] + vget<S>(m[3 + a], j) * xc[3 + b] +
-                                       vget<S>(m[6 + a], j) * xc[6 + b];
-                if (row != cur) {
-                    if (cur != 0xFFFFFFFFu) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) lds_add(&ys[cur * 9 + q], acc[q]);
-                    }
-                    cur = row;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) acc[q] = c[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) acc[q] += c[q];
-                }
-            }
-            if (cur != 0xFFFFFFFFu) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) lds_add(&ys[cur * 9 + q], acc[q]);
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 2: per row, w = lamT_inv * y   (or SVD -> Rt, lamT_inv)
-        for (int r = tid; r < nrows; r += BLOCK) {
-            double y[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) y[q] = ys[r * 9 + q];
-            if (MODE == 0) {
-                const double* L = lamT_inv + (size_t)(r0 + r) * 9;
-                double l[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) l[q] = L[q];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        ys[r * 9 + a * 3 + b] = l[a * 3 + 0] * y[b] + l[a * 3 + 1] * y[3 + b] + l[a * 3 + 2] * y[6 + b];
-            } else {
-                double R[9], lam[9];
-                polar_dual3(y, R, lam, 2);
-                double* Ro = Rt_out + (size_t)(r0 + r) * 9;
-                double* Lo = lamT_out + (size_t)(r0 + r) * 9;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { Ro[q] = R[q]; Lo[q] = lam[q]; }
-            }
-        }
-        if (MODE == 0) {
-            __syncthreads();
-            // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                if (id[j] == VICAN_PAD_SLOT) continue;
-                const uint32_t cam = id[j] & 0xFFFFu, row = id[j] >> 16;
-                const double* w = ys + row * 9;
-                double* zc = zs + cam * 9;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        lds_add(&zc[i * 3 + b], vget<S>(m[i * 3 + 0], j) * w[b] + vget<S>(m[i * 3 + 1], j) * w[3 + b] +
-                                                    vget<S>(m[i * 3 + 2], j) * w[6 + b]);
-            }
-        }
-    }
-    if (MODE == 0) {
-        __syncthreads();
-        double* zp = zpart + (size_t)blockIdx.x * nx;
-        for (int i = tid; i < nx; i += BLOCK) zp[i] = zs[i];
-    }
-}
-
-template <typename S, int BLOCK, int MODE>
-static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, double* zpart, double* Rt,
-                        double* lamT_out, hipStream_t st) {
-    const size_t lds = (size_t)vican_sweep_lds_bytes(g->n_cam, g->max_rows);
-    auto kern = block_sweep_kernel<S, BLOCK, MODE>;
-    static size_t configured = 0;       // per instantiation
-    if (lds > configured) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican sweep");
-        configured = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, *g, lamT_inv, x, zpart, Rt, lamT_out);
-    return 0;
-}
-
-template <int MODE>
-static int dispatch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, double* zpart, double* Rt,
-                          double* lamT_out, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (g->storage == VICAN_STORE_F32)
-        rc = (g->block_threads == 1024) ? launch_sweep<float, 1024, MODE>(g, lamT_inv, x, zpart, Rt, lamT_out, st)
-                                        : launch_sweep<float, 256, MODE>(g, lamT_inv, x, zpart, Rt, lamT_out, st);
-    else
-        rc = (g->block_threads == 1024) ? launch_sweep<double, 1024, MODE>(g, lamT_inv, x, zpart, Rt, lamT_out, st)
-                                        : launch_sweep<double, 256, MODE>(g, lamT_inv, x, zpart, Rt, lamT_out, st);
-    return rc;
-}
-
-extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x, double* zpart,
-                              void* stream) {
-    if (int rc = check_graph(g, "vican_block_op")) return rc;
-    if (!lamT_inv || !x || !zpart) return set_err(VICAN_ERR_ARG, "vican_block_op: null pointer");
-    if (int rc = dispatch_sweep<0>(g, lamT_inv, x, zpart, nullptr, nullptr, stream)) return rc;
-    LAUNCH_CHECK("vican_block_op");
-    return VICAN_OK;
-}
-
-extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, double* Rt, double* lamT_inv,
-                                 void* stream) {
-    if (int rc = check_graph(g, "vican_dual_update")) return rc;
-    if (!rc_ || !Rt || !lamT_inv) return set_err(VICAN_ERR_ARG, "vican_dual_update: null pointer");
-    if (g->n_chunk == 0) return VICAN_OK;
-    if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, stream)) return rc;
-    LAUNCH_CHECK("vican_dual_update");
-    return VICAN_OK;
-}
-
-// ---------------------------------------------------------------------------
-// slab reduction (fixed order => bitwise reproducible)
-// ---------------------------------------------------------------------------
-__global__ void slab_reduce_kernel(const double* __restrict__ part, int n_slab, long long n, double* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int k = 0; k < n_slab; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
-}
-extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out, void* stream) {
-    if (!part || !out || n_slab <= 0 || n < 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce: bad argument");
-    if (n == 0) return VICAN_OK;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
-                       n_slab, (long long)n, out);
-    LAUNCH_CHECK("vican_slab_reduce");
-    return VICAN_OK;
-}
+// vican_kernels.hip - camera-side and translation-stage kernels: batched 3x3 polar /
+// gauge fix, dense helpers of the block Lanczos iteration, right-hand side and the
+// conjugate-gradient kernels.  The hot edge sweep lives in vican_sweep.hip.
+#include "common.cuh"
 
 // ---------------------------------------------------------------------------
 // batched polar / gauge
@@ -837,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
 
 extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
                                const double* rt, double* rhs_t, double* rhs_c_part, void* stream) {
-    if (int r = check_graph(g, "vican_trans_rhs")) return r;
+    if (int r = vican_check_graph(g, "vican_trans_rhs")) return r;
     if (!u || !v || !rc || !rt || !rhs_t || !rhs_c_part) return set_err(VICAN_ERR_ARG, "vican_trans_rhs: null pointer");
     const size_t lds = (size_t)rhs_lds_bytes(g->n_cam, g->max_rows);
     const int epl = g->slots / g->block_threads;
@@ -849,8 +287,9 @@ extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const do
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, st, *g, u, v, rc, rt, rhs_t, rhs_c_part);         \
     } while (0)
-    if (g->block_threads == 1024) { if (epl == 4) RHS_LAUNCH(1024, 4); else RHS_LAUNCH(1024, 2); }
-    else                          { if (epl == 4) RHS_LAUNCH(256, 4);  else RHS_LAUNCH(256, 2); }
+    if (g->block_threads == 1024)     { if (epl == 4) RHS_LAUNCH(1024, 4); else RHS_LAUNCH(1024, 2); }
+    else if (g->block_threads == 512) { if (epl == 4) RHS_LAUNCH(512, 4);  else RHS_LAUNCH(512, 2); }
+    else                              { if (epl == 4) RHS_LAUNCH(256, 4);  else RHS_LAUNCH(256, 2); }
 #undef RHS_LAUNCH
     LAUNCH_CHECK("vican_trans_rhs");
     return VICAN_OK;
@@ -1002,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
 extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
                               const double* r_t, double* p_t, double* q_t, double* qc_part, double* pq_part,
                               const vican_cg_state_t* st, void* stream) {
-    if (int r = check_graph(g, "vican_cg_sweep")) return r;
+    if (int r = vican_check_graph(g, "vican_cg_sweep")) return r;
     if (!w || !deg_t || !p_c || !r_t || !p_t || !q_t || !qc_part || !pq_part || !st)
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows);
@@ -1015,8 +454,9 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st); \
     } while (0)
-    if (g->block_threads == 1024) { if (epl == 4) CG_LAUNCH(1024, 4); else CG_LAUNCH(1024, 2); }
-    else                          { if (epl == 4) CG_LAUNCH(256, 4);  else CG_LAUNCH(256, 2); }
+    if (g->block_threads == 1024)     { if (epl == 4) CG_LAUNCH(1024, 4); else CG_LAUNCH(1024, 2); }
+    else if (g->block_threads == 512) { if (epl == 4) CG_LAUNCH(512, 4);  else CG_LAUNCH(512, 2); }
+    else                              { if (epl == 4) CG_LAUNCH(256, 4);  else CG_LAUNCH(256, 2); }
 #undef CG_LAUNCH
     LAUNCH_CHECK("vican_cg_sweep");
     return VICAN_OK;

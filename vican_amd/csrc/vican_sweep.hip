@@ -1,0 +1,653 @@
+// vican_sweep.hip - edge layout + THE hot kernel of the solver: the fused timestep-major
+// sweep over the chunked CSR-of-3x3-blocks (operator z = R~ Lambda_T^-1 R~^T x and the
+// per-timestep dual update).  Design notes: DESIGN.md section 3.
+//
+// What the sweep is built around (measured on MI355X, tools/lds_atomic_bench.hip):
+//   * HBM-bound streaming of the block planes: 9 x 16 B coalesced loads per lane per chunk,
+//     next chunk prefetched into a second register set while the current one is processed;
+//   * LDS float atomics are the scarce resource: ds_add_f64 costs 9 clk/wave-instr without
+//     conflicts, 23 with random camera indices and serialises completely when all lanes hit
+//     one address; ds_add_f32 is ~190 clk; ds_add_u64 is 7.7 (12 with random cameras).
+//     => every accumulator is a 64-bit FIXED-POINT integer: fastest atomic on this chip
+//     and, because integer addition is associative, every sweep is bit-reproducible;
+//   * the row accumulators (y_t) are striped over `n_copy` lane-indexed copies so the 64
+//     lanes of a wavefront that sit in the same timestep row never share an address;
+//   * phase 2 (w_t = Lambda_T^-1 y_t) runs on 9*rows threads from LDS-staged duals.
+#include "common.cuh"
+
+thread_local char g_vican_err[512] = "";
+extern "C" const char* vican_last_error(void) { return g_vican_err; }
+extern "C" int vican_abi_version(void) { return 2; }
+
+// ---------------------------------------------------------------------------
+// host-side planning + LDS budget
+// ---------------------------------------------------------------------------
+extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slots, int32_t max_rows,
+                                 int32_t* out, int32_t cap) {
+    if (n_time < 0 || !rp || slots <= 0 || max_rows <= 0 || max_rows > 65535)
+        return set_err(VICAN_ERR_ARG, "vican_plan_chunks: bad argument");
+    int32_t nc = 0, r = 0;
+    while (r < n_time) {
+        if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks: output too small"); out[nc] = r; }
+        const int32_t e0 = rp[r];
+        int32_t r1 = r;
+        while (r1 < n_time && (r1 - r) < max_rows && (rp[r1 + 1] - e0) <= slots) ++r1;
+        if (r1 == r) return set_err(VICAN_ERR_CAPACITY, "vican_plan_chunks: a timestep row has more edges than a chunk holds");
+        r = r1;
+        ++nc;
+    }
+    if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks: output too small"); out[nc] = n_time; }
+    return nc;
+}
+
+extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024; }
+
+static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32 ? 4 : 8; }
+
+// operator sweep: x table (storage type) + z accumulators (u64) per camera; per row:
+// duals (f64) + y sums (f64) + w (storage type) + n_copy striped u64 accumulators
+extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy) {
+    const int64_t s = ssize(storage);
+    return 9LL * n_cam * (s + 8) + (int64_t)max_rows * (144 + 9 * s + 72LL * n_copy) + 256;
+}
+extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy) {
+    const int64_t lim = vican_lds_limit_bytes(), s = ssize(storage);
+    int64_t a = (lim - 256 - 9LL * n_cam * (s + 8)) / (144 + 9 * s + 72LL * n_copy);
+    int64_t b = (lim - 256 - 96LL * n_cam) / 96;        // rhs kernel   (vican_kernels.hip)
+    int64_t c = (lim - 128 - 48LL * n_cam) / 48;        // CG sweep
+    int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
+    return (int32_t)m;
+}
+
+int vican_check_graph(const vican_graph_t* g, const char* who) {
+    if (!g || g->n_cam <= 0 || g->n_cam > 65535 || g->n_time < 0 || g->n_chunk < 0 || !g->idx || !g->blk ||
+        !g->chunk_row0 || g->n_wg <= 0)
+        return set_err(VICAN_ERR_ARG, "%s: bad graph descriptor", who);
+    const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
+    if ((g->block_threads != 256 && g->block_threads != 512 && g->block_threads != 1024) || g->slots != g->block_threads * epl)
+        return set_err(VICAN_ERR_ARG, "%s: slots must be block_threads * (16 / sizeof(storage))", who);
+    const int nc = g->n_copy;
+    if (nc < 1 || nc > 32 || (nc & (nc - 1))) return set_err(VICAN_ERR_ARG, "%s: n_copy must be a power of two <= 32", who);
+    if (g->max_rows <= 0 || g->max_rows > vican_max_rows_for(g->n_cam, g->storage, nc))
+        return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", who);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// layout: CSR -> chunked planes
+//
+// Slot assignment inside a chunk is BANK-AWARE: lane l of the sweep workgroup owns slots
+// EPL*l .. EPL*l+EPL-1 and is fed edges whose camera index is congruent to l modulo 32.
+// With the camera-side LDS tables stored as planes [component][camera], every gather of
+// x_cam, every fixed-point atomic on z_cam and every striped atomic on y_row then hits 32
+// distinct banks per 32-lane group - the conflict-free rate instead of the 4x slower
+// "random" one (PMC: 75 % of LDS cycles were bank conflicts before this).  Within a class
+// the edges keep CSR order (row-major), so a lane's EPL edges mostly share a row.  Classes
+// that overflow their lanes spill into the free slots of the others.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ col, int32_t* __restrict__ perm,
+                                                        int epl) {
+    extern __shared__ int32_t sh[];                 // overflow list [slots]
+    const int k = blockIdx.x, lane = threadIdx.x;
+    int novf = 0;                                   // wave-uniform
+    const int e0 = row_ptr[g.chunk_row0[k]], e1 = row_ptr[g.chunk_row0[k + 1]];
+    int32_t* pm = perm + (size_t)k * g.slots;
+    for (int s = lane; s < g.slots; s += 64) pm[s] = -1;
+    __syncthreads();
+    const int cap = (g.block_threads / 32) * epl;   // slots per camera class
+    int cnt = 0;                                    // lane c (< 32) holds the running count of class c
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = e0; base < e1; base += 64) {
+        const int e = base + lane;
+        const bool valid = e < e1;
+        const int c = valid ? (col[e] & 31) : -1;
+        int rank = 0;
+        for (int kk = 0; kk < 32; ++kk) {
+            const unsigned long long m = __ballot(c == kk);
+            const int before = __shfl(cnt, kk, 64);
+            if (c == kk) rank = before + __popcll(m & lt);
+            if (lane == kk) cnt += __popcll(m);
+        }
+        const bool spill = valid && rank >= cap;
+        const unsigned long long sm = __ballot(spill);      // ordered compaction: deterministic layout
+        if (valid && !spill) pm[(c + 32 * (rank / epl)) * epl + (rank % epl)] = e;
+        if (spill) sh[novf + __popcll(sm & lt)] = e;
+        novf += __popcll(sm);
+    }
+    __syncthreads();
+    if (lane == 0 && novf > 0) {                    // spill: few edges, any free slot will do
+        int o = 0;
+        for (int s = 0; s < g.slots && o < novf; ++s)
+            if (pm[s] < 0) pm[s] = sh[o++];
+    }
+}
+
+template <typename S>
+__global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr,
+                                  const int32_t* __restrict__ col, const S* __restrict__ blk_csr,
+                                  const S* __restrict__ a_csr, const double* __restrict__ w_csr,
+                                  const double* __restrict__ u_csr, const double* __restrict__ v_csr,
+                                  S* __restrict__ a_out, double* __restrict__ w_out,
+                                  double* __restrict__ u_out, double* __restrict__ v_out,
+                                  const int32_t* __restrict__ perm) {
+    const int k = blockIdx.y;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.slots) return;
+    const int r0 = g.chunk_row0[k], r1 = g.chunk_row0[k + 1];
+    S* blk = (S*)g.blk;
+    uint32_t* idx = (uint32_t*)g.idx;
+    const size_t base = (size_t)k * g.slots + s;
+    const int e = perm[base];
+    if (e >= 0) {
+        int lo = r0, hi = r1;           // row_ptr[lo] <= e < row_ptr[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (row_ptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        idx[base] = (uint32_t)col[e] | ((uint32_t)(lo - r0) << 16);
+#pragma unroll
+        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = blk_csr[(size_t)e * 9 + p];
+        if (a_out) a_out[base] = a_csr[e];
+        if (w_out) w_out[base] = w_csr[e];
+        if (u_out)
+            for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = u_csr[(size_t)e * 3 + p];
+        if (v_out)
+            for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = v_csr[(size_t)e * 3 + p];
+    } else {
+        idx[base] = VICAN_PAD_SLOT;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = (S)0;
+        if (a_out) a_out[base] = (S)0;
+        if (w_out) w_out[base] = 0.0;
+        if (u_out) for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
+        if (v_out) for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
+    }
+}
+
+extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, const int32_t* col,
+                                const void* blk_csr, const void* a_csr, const double* w_csr,
+                                const double* u_csr, const double* v_csr, void* a_out, double* w_out,
+                                double* u_out, double* v_out, int32_t* perm_ws, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_pack_edges")) return rc;
+    if (!row_ptr || !col || !blk_csr || !perm_ws) return set_err(VICAN_ERR_ARG, "vican_pack_edges: null input");
+    if (g->n_chunk == 0) return VICAN_OK;
+    dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int epl = g->slots / g->block_threads;
+    hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
+    const int32_t* perm = perm_ws;
+    if (g->storage == VICAN_STORE_F32)
+        hipLaunchKernelGGL(pack_edges_kernel<float>, grid, block, 0, st, *g, row_ptr, col, (const float*)blk_csr,
+                           (const float*)a_csr, w_csr, u_csr, v_csr, (float*)a_out, w_out, u_out, v_out, perm);
+    else
+        hipLaunchKernelGGL(pack_edges_kernel<double>, grid, block, 0, st, *g, row_ptr, col, (const double*)blk_csr,
+                           (const double*)a_csr, w_csr, u_csr, v_csr, (double*)a_out, w_out, u_out, v_out, perm);
+    LAUNCH_CHECK("vican_pack_edges");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// graph constants (computed once per graph at pack time, not per solve):
+//   row sums / camera sums of a per-edge scalar, and the block-norm bounds that size
+//   the fixed-point scales.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
+    // non-negative doubles order like their bit patterns
+    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+template <typename S>
+__global__ void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double* __restrict__ row_out,
+                                 double* __restrict__ cam_acc) {
+    extern __shared__ double lds[];
+    const int k = blockIdx.x;
+    const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) lds[r] = 0.0;
+    __syncthreads();
+    const size_t base = (size_t)k * g.slots;
+    for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
+        const uint32_t id = g.idx[base + s];
+        if (id == VICAN_PAD_SLOT) continue;
+        const double v = (double)val[base + s];
+        lds_add(&lds[id >> 16], v);
+        unsafeAtomicAdd(&cam_acc[id & 0xFFFFu], v);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) row_out[r0 + r] = lds[r];
+}
+
+extern "C" int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double* row_sum,
+                               double* cam_sum, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_edge_sums")) return rc;
+    if (!val || !row_sum || !cam_sum) return set_err(VICAN_ERR_ARG, "vican_edge_sums: null pointer");
+    if (g->n_chunk == 0) return VICAN_OK;
+    const size_t lds = (size_t)g->max_rows * 8;
+    if (val_is_f64)
+        hipLaunchKernelGGL(edge_sums_kernel<double>, dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream, *g,
+                           (const double*)val, row_sum, cam_sum);
+    else
+        hipLaunchKernelGGL(edge_sums_kernel<float>, dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream, *g,
+                           (const float*)val, row_sum, cam_sum);
+    LAUNCH_CHECK("vican_edge_sums");
+    return VICAN_OK;
+}
+
+// rnorm[t] = sum_c |M_ct|_F ; fx[5] = max |M_ct|_F ; fx[6] = max_t rnorm[t]
+template <typename S>
+__global__ void block_norms_kernel(vican_graph_t g, double* __restrict__ rnorm, double* __restrict__ fx) {
+    extern __shared__ double lds[];
+    const int k = blockIdx.x;
+    const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) lds[r] = 0.0;
+    __syncthreads();
+    const S* blk = (const S*)g.blk;
+    double amax = 0.0;
+    for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
+        const uint32_t id = g.idx[(size_t)k * g.slots + s];
+        if (id == VICAN_PAD_SLOT) continue;
+        double q = 0.0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) { const double v = (double)blk[((size_t)k * 9 + p) * g.slots + s]; q += v * v; }
+        q = sqrt(q);
+        amax = fmax(amax, q);
+        lds_add(&lds[id >> 16], q);
+    }
+    __syncthreads();
+    double rmax = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) { rnorm[r0 + r] = lds[r]; rmax = fmax(rmax, lds[r]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { amax = fmax(amax, __shfl_down(amax, o, 64)); rmax = fmax(rmax, __shfl_down(rmax, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomic_max_pos(&fx[5], amax); atomic_max_pos(&fx[6], rmax); }
+}
+
+extern "C" int vican_block_norms(const vican_graph_t* g, double* rnorm, double* fx, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_block_norms")) return rc;
+    if (!rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_block_norms: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(fx, 0, VICAN_FX_DOUBLES * sizeof(double), st) != hipSuccess)
+        return set_err(VICAN_ERR_LAUNCH, "vican_block_norms: memset failed");
+    if (g->n_chunk == 0) return VICAN_OK;
+    const size_t lds = (size_t)g->max_rows * 8;
+    if (g->storage == VICAN_STORE_F32)
+        hipLaunchKernelGGL(block_norms_kernel<float>, dim3(g->n_chunk), dim3(256), lds, st, *g, rnorm, fx);
+    else
+        hipLaunchKernelGGL(block_norms_kernel<double>, dim3(g->n_chunk), dim3(256), lds, st, *g, rnorm, fx);
+    LAUNCH_CHECK("vican_block_norms");
+    return VICAN_OK;
+}
+
+// Initial duals from the stored row sums d_t (bipgo.py:271-276): lamT_inv[t] = I/d_t, and the
+// fixed-point bound omega = max_t |lamT_inv[t]|_F * rnorm[t].
+__global__ void init_duals_kernel(int n_time, const double* __restrict__ d, const double* __restrict__ rnorm,
+                                  double* __restrict__ lamT_inv, double* __restrict__ fx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double om = 0.0;
+    if (t < n_time) {
+        const double inv = 1.0 / d[t];
+        double* o = lamT_inv + (size_t)t * 9;
+        o[0] = inv; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = inv; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = inv;
+        if (d[t] > 0.0) om = 1.7320508075688772 * inv * rnorm[t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
+    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
+}
+
+extern "C" int vican_init_duals(int32_t n_time, const double* row_sum_a, const double* rnorm, double* lamT_inv,
+                                double* fx, void* stream) {
+    if (n_time < 0 || !row_sum_a || !rnorm || !lamT_inv || !fx) return set_err(VICAN_ERR_ARG, "vican_init_duals: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(fx + 4, 0, sizeof(double), st) != hipSuccess) return set_err(VICAN_ERR_LAUNCH, "vican_init_duals: memset failed");
+    if (n_time == 0) return VICAN_OK;
+    hipLaunchKernelGGL(init_duals_kernel, dim3((n_time + 255) / 256), dim3(256), 0, st, n_time, row_sum_a, rnorm, lamT_inv, fx);
+    LAUNCH_CHECK("vican_init_duals");
+    return VICAN_OK;
+}
+
+__global__ void scaled_identity_kernel(int n, const double* __restrict__ sc, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = sc[i];
+    double* o = out + (size_t)i * 9;
+    o[0] = s; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = s; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = s;
+}
+extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out, void* stream) {
+    if (n < 0 || !scale || !out) return set_err(VICAN_ERR_ARG, "vican_scaled_identity: bad argument");
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(scaled_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, scale, out);
+    LAUNCH_CHECK("vican_scaled_identity");
+    return VICAN_OK;
+}
+
+// Fixed-point scales (powers of two) from the recorded bounds:
+//   y contributions  |M^T x|      <= amax * xb          row totals <= rmax * xb
+//   z contributions  |M w|        <= amax * omega * xb  per-accumulator totals <= n_add * that
+// A single contribution must stay below 2^51 (magic-number conversion), a total below 2^62.
+__global__ void fx_finish_kernel(double* fx, double x_bound, double n_add) {
+    if (threadIdx.x || blockIdx.x) return;
+    const double amax = fmax(fx[5], 1e-300), rmax = fmax(fx[6], 1e-300), om = fmax(fx[4], 1e-300);
+    const double cy = amax * x_bound, ty = rmax * x_bound;
+    const double cz = amax * om * x_bound, tz = cz * n_add;
+    // 2^47: a lane pre-sums up to 4 contributions before converting (4 * 2^47 < 2^51)
+    int ey = min(47 - (int)ceil(log2(cy)), 61 - (int)ceil(log2(ty)));
+    int ez = min(47 - (int)ceil(log2(cz)), 61 - (int)ceil(log2(tz)));
+    ey = max(min(ey, 1000), -1000); ez = max(min(ez, 1000), -1000);
+    fx[0] = ldexp(1.0, ey); fx[1] = ldexp(1.0, -ey);
+    fx[2] = ldexp(1.0, ez); fx[3] = ldexp(1.0, -ez);
+}
+extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, void* stream) {
+    if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");
+    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add);
+    LAUNCH_CHECK("vican_fx_finish");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// THE HOT KERNEL
+// ---------------------------------------------------------------------------
+template <typename S> struct Vec;
+template <> struct Vec<float>  { typedef float4  type; static constexpr int N = 4; };
+template <> struct Vec<double> { typedef double2 type; static constexpr int N = 2; };
+
+template <typename S> __device__ __forceinline__ S vget(const typename Vec<S>::type& v, int j);
+template <> __device__ __forceinline__ float vget<float>(const float4& v, int j) {
+    return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+}
+template <> __device__ __forceinline__ double vget<double>(const double2& v, int j) { return j == 0 ? v.x : v.y; }
+
+typedef unsigned long long u64;
+
+// double -> 64-bit fixed point (round to nearest) by the magic-number trick; |v*scale| < 2^51
+__device__ __forceinline__ u64 to_fix(double v, double scale) {
+    const double magic = 6755399441055744.0;          // 1.5 * 2^52
+    return (u64)(__double_as_longlong(fma(v, scale, magic)) - __double_as_longlong(magic));
+}
+__device__ __forceinline__ void lds_add_fix(u64* p, u64 v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add_u64
+}
+
+template <typename S, int EPL>
+struct ChunkRegs {
+    typename Vec<S>::type m[9];
+    uint32_t id[EPL];
+};
+
+template <typename S, int EPL>
+__device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int tid) {
+    typedef typename Vec<S>::type V;
+    const S* blk = (const S*)g.blk;
+    const size_t pbase = (size_t)k * 9 * g.slots + (size_t)tid * EPL;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) c.m[p] = *(const V*)(blk + pbase + (size_t)p * g.slots);
+    const uint32_t* ip = g.idx + (size_t)k * g.slots + (size_t)tid * EPL;
+    if (EPL == 4) { const uint4 t = *(const uint4*)ip; c.id[0] = t.x; c.id[1] = t.y; c.id[2] = t.z; c.id[3] = t.w; }
+    else          { const uint2 t = *(const uint2*)ip; c.id[0] = t.x; c.id[1] = t.y; }
+}
+
+// MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
+// MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
+// Arithmetic in the storage type S (f32 products for f32 blocks), accumulation in 64-bit fixed point.
+template <typename S, int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, const double* __restrict__ lamT_inv,
+                                                            const double* __restrict__ x,
+                                                            u64* __restrict__ zpart,
+                                                            double* __restrict__ Rt_out,
+                                                            double* __restrict__ lamT_out,
+                                                            const double* __restrict__ rnorm,
+                                                            double* __restrict__ fx) {
+    constexpr int EPL = Vec<S>::N;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int nx = 9 * g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1;
+    // 8-byte arrays first, then the storage-type tables
+    u64* zs = (u64*)lds_raw;                                   // [9][C] planes (MODE 0)
+    double* lam_s = (double*)(zs + (MODE == 0 ? nx : 0));      // [max_rows][9] (MODE 0)
+    double* ysum = lam_s + (MODE == 0 ? 9 * g.max_rows : 0);   // [max_rows][9]
+    u64* ys = (u64*)(ysum + 9 * g.max_rows);                   // [max_rows*9][ncopy]
+    S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][C] planes
+    S* wv = xs + nx;                                           // [max_rows][9] (MODE 0)
+    const int tid = threadIdx.x, lane_copy = tid & cmask;
+    const double y_scale = fx[0], y_inv = fx[1], z_scale = fx[2];
+
+    const int C = g.n_cam;
+    for (int i = tid; i < nx; i += BLOCK) { xs[(i % 9) * C + i / 9] = (S)x[i]; if (MODE == 0) zs[i] = 0ull; }
+    for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
+
+    const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    double om_max = 0.0;
+
+    ChunkRegs<S, EPL> cur, nxt;
+    if (k0 < k1) load_chunk<S, EPL>(cur, g, k0, tid);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int k = k0; k < k1; ++k) {
+        const int r0 = g.chunk_row0[k];
+        const int nrows = g.chunk_row0[k + 1] - r0;
+        if (k + 1 < k1) load_chunk<S, EPL>(nxt, g, k + 1, tid);      // prefetch: lands during this chunk
+        double lam_pre = 0.0;
+        if (MODE == 0 && tid < 9 * nrows) lam_pre = lamT_inv[(size_t)r0 * 9 + tid];
+
+        // ---- phase 1: y_row += M^T x_cam ; same-row edges of a lane pre-summed in registers,
+        //      then ONE striped fixed-point atomic group per (lane,row)
+        {
+            S acc[9];
+            uint32_t currow = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                if (cur.id[j] == VICAN_PAD_SLOT) continue;
+                const uint32_t cam = cur.id[j] & 0xFFFFu, row = cur.id[j] >> 16;
+                S xc[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) xc[q] = xs[q * C + cam];
+                S c[9];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        c[a * 3 + b] = vget<S>(cur.m[0 + a], j) * xc[b] + vget<S>(cur.m[3 + a], j) * xc[3 + b] +
+                                       vget<S>(cur.m[6 + a], j) * xc[6 + b];
+                if (row != currow) {
+                    if (currow != 0xFFFFFFFFu) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) lds_add_fix(&ys[(currow * 9 + q) * ncopy + lane_copy], to_fix((double)acc[q], y_scale));
+                    }
+                    currow = row;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) acc[q] = c[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) acc[q] += c[q];
+                }
+            }
+            if (currow != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) lds_add_fix(&ys[(currow * 9 + q) * ncopy + lane_copy], to_fix((double)acc[q], y_scale));
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2a: fold the striped copies (exact integer sum), re-zero them, stage the duals
+        //      (PART adjacent lanes share one accumulator; the copy index is rotated by the
+        //       accumulator index so that the lanes of a wavefront walk distinct banks)
+        {
+            const int part_n = ncopy < 4 ? ncopy : 4, per = ncopy / part_n;
+            for (int t = tid; t < 9 * nrows * part_n; t += BLOCK) {
+                const int i = t / part_n, part = t - i * part_n;
+                long long s = 0;
+                for (int c = 0; c < per; ++c) {
+                    const int a = i * ncopy + ((part * per + c + i) & cmask);
+                    s += (long long)ys[a];
+                    ys[a] = 0ull;
+                }
+                // fold the PART partial sums (t is wave-aligned: BLOCK and part_n are powers of two)
+                if (part_n > 1) s += __shfl_xor(s, 1, 64);
+                if (part_n > 2) s += __shfl_xor(s, 2, 64);
+                if (part == 0) ysum[i] = (double)s * y_inv;
+            }
+            if (MODE == 0)
+                for (int i = tid; i < 9 * nrows; i += BLOCK) lam_s[i] = (i == tid) ? lam_pre : lamT_inv[(size_t)r0 * 9 + i];
+        }
+        __syncthreads();
+
+        // ---- phase 2b: w = lamT_inv * y  on 9*rows threads   (or the per-row SVD)
+        if (MODE == 0) {
+            for (int i = tid; i < 9 * nrows; i += BLOCK) {
+                const int r = i / 9, a = (i % 9) / 3, b = i % 3;
+                const double* L = lam_s + r * 9 + a * 3;
+                const double* y = ysum + r * 9 + b;
+                wv[i] = (S)(L[0] * y[0] + L[1] * y[3] + L[2] * y[6]);
+            }
+            __syncthreads();
+            // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
+            S w[9];
+            uint32_t wrow = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                if (cur.id[j] == VICAN_PAD_SLOT) continue;
+                const uint32_t cam = cur.id[j] & 0xFFFFu, row = cur.id[j] >> 16;
+                if (row != wrow) {
+                    wrow = row;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) w[q] = wv[row * 9 + q];
+                }
+                u64* zc = zs + cam;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const S v = vget<S>(cur.m[i * 3 + 0], j) * w[b] + vget<S>(cur.m[i * 3 + 1], j) * w[3 + b] +
+                                    vget<S>(cur.m[i * 3 + 2], j) * w[6 + b];
+                        lds_add_fix(&zc[(i * 3 + b) * C], to_fix((double)v, z_scale));
+                    }
+            }
+        } else {
+            for (int r = tid; r < nrows; r += BLOCK) {
+                double R[9], lam[9];
+                polar_dual3(ysum + r * 9, R, lam, 2);
+                double* Ro = Rt_out + (size_t)(r0 + r) * 9;
+                double* Lo = lamT_out + (size_t)(r0 + r) * 9;
+                double fro = 0.0;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) { Ro[q] = R[q]; Lo[q] = lam[q]; fro += lam[q] * lam[q]; }
+                om_max = fmax(om_max, sqrt(fro) * rnorm[r0 + r]);
+            }
+        }
+        if (k + 1 < k1) cur = nxt;
+        // (the barrier after the next chunk's phase 1 separates this chunk's phase 3 reads of wv
+        //  from the next phase 2b writes; ys is already re-zeroed for the next phase 1)
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        u64* zp = zpart + (size_t)blockIdx.x * nx;
+        for (int i = tid; i < nx; i += BLOCK) zp[i] = zs[i];
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) om_max = fmax(om_max, __shfl_down(om_max, o, 64));
+        if ((tid & 63) == 0 && om_max > 0.0) atomic_max_pos(&fx[4], om_max);
+    }
+}
+
+template <typename S, int BLOCK, int MODE>
+static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+                        double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
+    const size_t lds = (size_t)vican_sweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy);
+    auto kern = block_sweep_kernel<S, BLOCK, MODE>;
+    static size_t configured = 0;       // per instantiation
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican sweep");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
+    return 0;
+}
+
+template <int MODE>
+static int dispatch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+                          double* lamT_out, const double* rnorm, double* fx, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+#define SWEEP_ARGS g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st
+    if (g->storage == VICAN_STORE_F32) {
+        if (g->block_threads == 1024) return launch_sweep<float, 1024, MODE>(SWEEP_ARGS);
+        if (g->block_threads == 512) return launch_sweep<float, 512, MODE>(SWEEP_ARGS);
+        return launch_sweep<float, 256, MODE>(SWEEP_ARGS);
+    }
+    if (g->block_threads == 1024) return launch_sweep<double, 1024, MODE>(SWEEP_ARGS);
+    if (g->block_threads == 512) return launch_sweep<double, 512, MODE>(SWEEP_ARGS);
+    return launch_sweep<double, 256, MODE>(SWEEP_ARGS);
+#undef SWEEP_ARGS
+}
+
+extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart,
+                              double* fx, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_block_op")) return rc;
+    if (!lamT_inv || !x || !zpart || !fx) return set_err(VICAN_ERR_ARG, "vican_block_op: null pointer");
+    if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, nullptr, nullptr, nullptr, fx, stream)) return rc;
+    LAUNCH_CHECK("vican_block_op");
+    return VICAN_OK;
+}
+
+extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, double* Rt, double* lamT_inv,
+                                 const double* rnorm, double* fx, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_dual_update")) return rc;
+    if (!rc_ || !Rt || !lamT_inv || !rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_dual_update: null pointer");
+    if (hipMemsetAsync(fx + 4, 0, sizeof(double), (hipStream_t)stream) != hipSuccess)
+        return set_err(VICAN_ERR_LAUNCH, "vican_dual_update: memset failed");
+    if (g->n_chunk == 0) return VICAN_OK;
+    if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;
+    LAUNCH_CHECK("vican_dual_update");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// slab reductions (fixed order; the fixed-point one is exact)
+// ---------------------------------------------------------------------------
+// 256 threads = 64 elements x 4 slab groups
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ part, int n_slab, long long n,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[256];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    double s = 0.0;
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 4) s += part[(size_t)k * n + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) out[i] = (sh[e] + sh[64 + e]) + (sh[128 + e] + sh[192 + e]);
+}
+extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out, void* stream) {
+    if (!part || !out || n_slab <= 0 || n < 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce: bad argument");
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part,
+                       n_slab, (long long)n, out);
+    LAUNCH_CHECK("vican_slab_reduce");
+    return VICAN_OK;
+}
+
+// slabs hold planes [9][C]; the output is the row-major camera vector [C][9]
+__global__ __launch_bounds__(256) void slab_reduce_fx_kernel(const long long* __restrict__ part, int n_slab, long long n,
+                                                             const double* __restrict__ fx, double* __restrict__ out) {
+    __shared__ long long sh[256];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    long long s = 0;
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 4) s += part[(size_t)k * n + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const long long C = n / 9, q = i / C, cam = i % C;
+        out[cam * 9 + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * fx[3];
+    }
+}
+extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int64_t n, const double* fx, double* out,
+                                    void* stream) {
+    if (!part || !out || !fx || n_slab <= 0 || n < 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce_fx: bad argument");
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(slab_reduce_fx_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)part, n_slab, (long long)n, fx, out);
+    LAUNCH_CHECK("vican_slab_reduce_fx");
+    return VICAN_OK;
+}

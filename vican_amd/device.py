@@ -1,14 +1,16 @@
 """Device side of the solver: chunked edge layout + thin wrappers over the C ABI.
 
 ``LocalGraph`` owns (as PyTorch-ROCm tensors) the timestep-major chunked
-CSR-of-3x3-blocks of ONE rank's timestep rows; ``HipBackend`` exposes each entry
-point of ``include/vican_hip.h`` on torch tensors.  PyTorch is only the
-allocator / stream provider here - every numerical step is a hand-written HIP
-kernel.  No CPU fallback: constructing ``HipBackend`` without a GPU raises.
+CSR-of-3x3-blocks of ONE rank's timestep rows plus the graph constants computed
+once at pack time (row / camera weight sums, block-norm bounds); ``HipBackend``
+exposes each entry point of ``include/vican_hip.h`` on torch tensors.  PyTorch is
+only the allocator / stream provider here - every numerical step is a
+hand-written HIP kernel.  No CPU fallback: without a GPU construction raises.
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -16,6 +18,7 @@ import torch
 from . import _lib
 
 N_CU = 256
+X_BOUND = math.sqrt(3.0)      # |x_c|_F of every sweep input: orthonormal columns / stacked rotations
 
 
 def _ptr(t):
@@ -36,7 +39,7 @@ class LocalGraph:
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None):
+                 n_wg=None, n_copy=None):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VicanError("vican_amd needs a GPU (MI355X); there is no CPU fallback")
@@ -50,16 +53,25 @@ class LocalGraph:
         epl = 4 if storage == _lib.STORE_F32 else 2
         if self.n_cam > 65535:
             raise _lib.VicanError("more than 65535 cameras are not supported by the packed edge index")
-        max_rows = int(lib.vican_max_rows_for(self.n_cam))
-        if max_rows < 1:
-            raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % self.n_cam)
         rp_host = row_ptr.to("cpu", torch.int32).contiguous()
-        deg_max = int((rp_host[1:] - rp_host[:-1]).max()) if self.n_time else 0
+        deg = (rp_host[1:] - rp_host[:-1]) if self.n_time else torch.zeros(1, dtype=torch.int32)
+        deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
         if block_threads is None:
             block_threads = 1024 if self.n_edges >= 1024 * epl * N_CU else 256
             if deg_max > 256 * epl:
                 block_threads = 1024
         slots = block_threads * epl
+        # lane-striped copies of the row accumulators: as many as LDS allows while a chunk can
+        # still hold its natural number of rows (slots / average degree)
+        rows_target = min(65535, int(math.ceil(1.25 * slots / deg_avg)) + 1)
+        if n_copy is None:
+            n_copy = 32
+            while n_copy > 1 and lib.vican_max_rows_for(self.n_cam, storage, n_copy) < rows_target:
+                n_copy //= 2
+        max_rows = int(lib.vican_max_rows_for(self.n_cam, storage, n_copy))
+        if max_rows < 1:
+            raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % self.n_cam)
+        max_rows = min(max_rows, max(rows_target, 1))
         cap = self.n_time + 2
         c0 = np.empty(cap, dtype=np.int32)
         nchunk = _lib.check(lib.vican_plan_chunks(self.n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
@@ -67,12 +79,15 @@ class LocalGraph:
         self.chunk_row0_host = c0[: nchunk + 1].copy()
         rows_per_chunk = np.diff(self.chunk_row0_host) if nchunk else np.zeros(0, np.int32)
         self.max_rows = int(rows_per_chunk.max()) if nchunk else 1
-        self.n_chunk, self.slots, self.block_threads = int(nchunk), slots, block_threads
-        lds = int(lib.vican_sweep_lds_bytes(self.n_cam, self.max_rows))
+        self.n_chunk, self.slots, self.block_threads, self.n_copy = int(nchunk), slots, block_threads, int(n_copy)
+        lds = int(lib.vican_sweep_lds_bytes(self.n_cam, self.max_rows, storage, n_copy))
         occ = max(1, min(int(lib.vican_lds_limit_bytes()) // lds, 2048 // block_threads))
         if n_wg is None:
             n_wg = max(1, min(self.n_chunk, N_CU * occ))
         self.n_wg = int(n_wg)
+        # max timestep rows one workgroup handles (bounds the adds into one z accumulator)
+        bounds = (np.arange(self.n_wg + 1, dtype=np.int64) * self.n_chunk) // self.n_wg
+        self.rows_per_wg_max = int(np.diff(self.chunk_row0_host[bounds]).max()) if nchunk else 1
         self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
         nslot = max(1, self.n_chunk) * slots
         self.blk = torch.empty(9 * nslot, dtype=blk.dtype, device=dev)
@@ -83,15 +98,31 @@ class LocalGraph:
         self.u = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
         self.v = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
         self.desc = _lib.Graph(self.n_cam, self.n_time, self.n_chunk, slots, self.max_rows, storage, block_threads,
-                               self.n_wg, self.blk.data_ptr(), self.idx.data_ptr(), self.chunk_row0.data_ptr())
+                               self.n_wg, self.n_copy, 0, self.blk.data_ptr(), self.idx.data_ptr(),
+                               self.chunk_row0.data_ptr())
+        gref = C.byref(self.desc)
         row_ptr = row_ptr.to(dev, torch.int32).contiguous()
         col = col.to(dev, torch.int32).contiguous()
         blk = blk.contiguous(); a = a.to(blk.dtype).contiguous()
         if have_t:
             w, u, v = (t.to(dev, torch.float64).contiguous() for t in (w, u, v))
-        _lib.check(lib.vican_pack_edges(C.byref(self.desc), _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w),
-                                        _ptr(u), _ptr(v), _ptr(self.a), _ptr(self.w), _ptr(self.u), _ptr(self.v),
-                                        _stream()), "vican_pack_edges")
+        st = _stream()
+        perm_ws = torch.empty(nslot, dtype=torch.int32, device=dev)
+        _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w), _ptr(u), _ptr(v),
+                                        _ptr(self.a), _ptr(self.w), _ptr(self.u), _ptr(self.v), _ptr(perm_ws), st),
+                   "vican_pack_edges")
+        # graph constants
+        T1 = max(self.n_time, 1)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.row_sum_a, self.cam_sum_a = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
+        self.rnorm, self.fx = torch.zeros(T1, **f64), torch.zeros(_lib.FX_DOUBLES, **f64)
+        _lib.check(lib.vican_edge_sums(gref, _ptr(self.a), int(storage == _lib.STORE_F64), _ptr(self.row_sum_a),
+                                       _ptr(self.cam_sum_a), st), "vican_edge_sums")
+        _lib.check(lib.vican_block_norms(gref, _ptr(self.rnorm), _ptr(self.fx), st), "vican_block_norms")
+        if have_t:
+            self.row_sum_w, self.cam_sum_w = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
+            _lib.check(lib.vican_edge_sums(gref, _ptr(self.w), 1, _ptr(self.row_sum_w), _ptr(self.cam_sum_w), st),
+                       "vican_edge_sums")
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
 
     # algorithmic HBM bytes of one operator sweep (B_op)
@@ -113,7 +144,7 @@ class HipBackend:
         self.C, self.T = graph.n_cam, graph.n_time
         self._gref = C.byref(graph.desc)
         nwg = graph.n_wg
-        self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)
+        self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
         self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
         self.rr_part = torch.empty(512, dtype=torch.float64, device=self.dev)
         self.ws = torch.empty(512, dtype=torch.float64, device=self.dev)
@@ -134,27 +165,36 @@ class HipBackend:
     def _ck(self, rc, what):
         return _lib.check(rc, what)
 
+    def _fx_finish(self):
+        self._ck(self.lib.vican_fx_finish(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_max + 1), _stream()),
+                 "vican_fx_finish")
+
     # -- rotation stage -----------------------------------------------------
     def init_duals(self, lamT_inv, cam_deg):
-        cam_deg.zero_()
-        self._ck(self.lib.vican_init_duals(self._gref, _ptr(self.g.a), _ptr(lamT_inv), _ptr(cam_deg), _stream()),
-                 "vican_init_duals")
+        """lamT_inv[t] = I/d_t from the stored row sums; cam_deg = local camera sums of a."""
+        cam_deg.copy_(self.g.cam_sum_a)
+        self._ck(self.lib.vican_init_duals(self.T, _ptr(self.g.row_sum_a), _ptr(self.g.rnorm), _ptr(lamT_inv),
+                                           _ptr(self.g.fx), _stream()), "vican_init_duals")
+        self._fx_finish()
 
     def scaled_identity(self, scale, out):
         self._ck(self.lib.vican_scaled_identity(scale.numel(), _ptr(scale), _ptr(out), _stream()), "vican_scaled_identity")
 
+    def block_op_raw(self, lamT_inv, x):
+        """Only the sweep kernel (the benchmark brackets it with HIP events)."""
+        self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx), _stream()),
+                 "vican_block_op")
+
     def block_op(self, lamT_inv, x, z_out):
         """z_out[3C,3] = local slab-reduced  P x  (caller all-reduces across ranks)."""
-        self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _stream()), "vican_block_op")
-        self._ck(self.lib.vican_slab_reduce(_ptr(self.zpart), self.g.n_wg, 9 * self.C, _ptr(z_out), _stream()),
-                 "vican_slab_reduce")
-
-    def block_op_raw(self, lamT_inv, x):
-        """Only the sweep kernel (used by the benchmark to time the dominant kernel)."""
-        self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _stream()), "vican_block_op")
+        self.block_op_raw(lamT_inv, x)
+        self._ck(self.lib.vican_slab_reduce_fx(_ptr(self.zpart), self.g.n_wg, 9 * self.C, _ptr(self.g.fx), _ptr(z_out),
+                                               _stream()), "vican_slab_reduce_fx")
 
     def dual_update(self, rc, Rt, lamT_inv):
-        self._ck(self.lib.vican_dual_update(self._gref, _ptr(rc), _ptr(Rt), _ptr(lamT_inv), _stream()), "vican_dual_update")
+        self._ck(self.lib.vican_dual_update(self._gref, _ptr(rc), _ptr(Rt), _ptr(lamT_inv), _ptr(self.g.rnorm),
+                                            _ptr(self.g.fx), _stream()), "vican_dual_update")
+        self._fx_finish()
 
     def polar_dual(self, mats, R_out, lam_out, mode):
         self._ck(self.lib.vican_polar_dual(mats.numel() // 9, _ptr(mats), _ptr(R_out), _ptr(lam_out), mode, _stream()),
@@ -176,8 +216,7 @@ class HipBackend:
 
     def chol_qr3(self, n, R, G, V, ld, col0, beta_out, x_out, pivot_floor=0.0):
         self._ck(self.lib.vican_chol_qr3(n, _ptr(R), _ptr(G), _ptr(V), ld, col0, _ptr(beta_out), _ptr(x_out),
-                                         float(pivot_floor), _stream()),
-                 "vican_chol_qr3")
+                                         float(pivot_floor), _stream()), "vican_chol_qr3")
 
     def tall_combine(self, n, V, ld, ka, Y, X):
         self._ck(self.lib.vican_tall_combine(n, _ptr(V), ld, ka, _ptr(Y), _ptr(X), _stream()), "vican_tall_combine")
@@ -187,8 +226,9 @@ class HipBackend:
 
     # -- translation stage --------------------------------------------------
     def trans_degrees(self, deg_t, deg_c):
-        deg_c.zero_()
-        self._ck(self.lib.vican_trans_degrees(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(deg_c), _stream()), "vican_trans_degrees")
+        """Degrees of the weighted Laplacian (graph constants from pack time)."""
+        deg_t[: self.g.row_sum_w.numel()].copy_(self.g.row_sum_w)
+        deg_c.copy_(self.g.cam_sum_w)
 
     def trans_rhs(self, rc, rt, rhs_t, rhs_c):
         nwg = self.g.n_wg
