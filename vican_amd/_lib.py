@@ -53,7 +53,7 @@ PROTOTYPES = {
     "vican_max_rows_for": (_i32, [_i32, _i32, _i32]),
     "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
-    "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _vp]),
+    "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
     "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_init_duals": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),

@@ -324,21 +324,23 @@ extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out
 //   y contributions  |M^T x|      <= amax * xb          row totals <= rmax * xb
 //   z contributions  |M w|        <= amax * omega * xb  per-accumulator totals <= n_add * that
 // A single contribution must stay below 2^51 (magic-number conversion), a total below 2^62.
-__global__ void fx_finish_kernel(double* fx, double x_bound, double n_add) {
+__global__ void fx_finish_kernel(double* fx, double x_bound, double n_add, int bits) {
     if (threadIdx.x || blockIdx.x) return;
     const double amax = fmax(fx[5], 1e-300), rmax = fmax(fx[6], 1e-300), om = fmax(fx[4], 1e-300);
     const double cy = amax * x_bound, ty = rmax * x_bound;
     const double cz = amax * om * x_bound, tz = cz * n_add;
-    // 2^47: a lane pre-sums up to 4 contributions before converting (4 * 2^47 < 2^51)
-    int ey = min(47 - (int)ceil(log2(cy)), 61 - (int)ceil(log2(ty)));
-    int ez = min(47 - (int)ceil(log2(cz)), 61 - (int)ceil(log2(tz)));
+    // a lane pre-sums up to 4 contributions before converting: bits = 47 on the f64 path
+    // (4 * 2^47 < 2^51, magic-number conversion) and 28 on the f32 path (4 * 2^28 < 2^31, v_cvt_i32_f32)
+    int ey = min(bits - (int)ceil(log2(cy)), 61 - (int)ceil(log2(ty)));
+    int ez = min(bits - (int)ceil(log2(cz)), 61 - (int)ceil(log2(tz)));
     ey = max(min(ey, 1000), -1000); ez = max(min(ez, 1000), -1000);
     fx[0] = ldexp(1.0, ey); fx[1] = ldexp(1.0, -ey);
     fx[2] = ldexp(1.0, ez); fx[3] = ldexp(1.0, -ez);
 }
-extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, void* stream) {
+extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
     if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");
-    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add);
+    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add,
+                       storage == VICAN_STORE_F32 ? 28 : 47);
     LAUNCH_CHECK("vican_fx_finish");
     return VICAN_OK;
 }
@@ -362,6 +364,13 @@ typedef unsigned long long u64;
 __device__ __forceinline__ u64 to_fix(double v, double scale) {
     const double magic = 6755399441055744.0;          // 1.5 * 2^52
     return (u64)(__double_as_longlong(fma(v, scale, magic)) - __double_as_longlong(magic));
+}
+// storage-type front ends: f64 values go through the 2^51 magic-number path; f32 values are
+// scaled in f32 and converted with ONE v_cvt_i32_f32 (|v*scale| < 2^31), then sign-extended
+template <typename S> __device__ __forceinline__ u64 to_fix_s(S v, double scale_d, float scale_f);
+template <> __device__ __forceinline__ u64 to_fix_s<double>(double v, double scale_d, float) { return to_fix(v, scale_d); }
+template <> __device__ __forceinline__ u64 to_fix_s<float>(float v, double, float scale_f) {
+    return (u64)(long long)__float2int_rn(v * scale_f);
 }
 __device__ __forceinline__ void lds_add_fix(u64* p, u64 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add_u64
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     S* wv = xs + nx;                                           // [max_rows][9] (MODE 0)
     const int tid = threadIdx.x, lane_copy = tid & cmask;
     const double y_scale = fx[0], y_inv = fx[1], z_scale = fx[2];
+    const float y_scale_f = (float)y_scale, z_scale_f = (float)z_scale;      // powers of two: exact
 
     const int C = g.n_cam;
     for (int i = tid; i < nx; i += BLOCK) { xs[(i % 9) * C + i / 9] = (S)x[i]; if (MODE == 0) zs[i] = 0ull; }
@@ -430,40 +440,45 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         if (MODE == 0 && tid < 9 * nrows) lam_pre = lamT_inv[(size_t)r0 * 9 + tid];
 
         // ---- phase 1: y_row += M^T x_cam ; same-row edges of a lane pre-summed in registers,
-        //      then ONE striped fixed-point atomic group per (lane,row)
+        //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
+        //      blocks and are processed like edges of (row 0, camera lane%32): no branches; the
+        //      x gather of edge j+1 is in flight while edge j is multiplied.
+        uint32_t cam[EPL], row[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            cam[j] = pad ? (uint32_t)(tid & 31) : (cur.id[j] & 0xFFFFu);
+            row[j] = pad ? 0u : (cur.id[j] >> 16);
+        }
         {
-            S acc[9];
-            uint32_t currow = 0xFFFFFFFFu;
+            S acc[9], xc[9], xn[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xc[q] = xs[q * C + cam[0]];
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                if (cur.id[j] == VICAN_PAD_SLOT) continue;
-                const uint32_t cam = cur.id[j] & 0xFFFFu, row = cur.id[j] >> 16;
-                S xc[9];
+                if (j + 1 < EPL) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) xc[q] = xs[q * C + cam];
-                S c[9];
+                    for (int q = 0; q < 9; ++q) xn[q] = xs[q * C + cam[j + 1]];
+                }
+                const bool cont = j > 0 && row[j] == row[j - 1];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        c[a * 3 + b] = vget<S>(cur.m[0 + a], j) * xc[b] + vget<S>(cur.m[3 + a], j) * xc[3 + b] +
-                                       vget<S>(cur.m[6 + a], j) * xc[6 + b];
-                if (row != currow) {
-                    if (currow != 0xFFFFFFFFu) {
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) lds_add_fix(&ys[(currow * 9 + q) * ncopy + lane_copy], to_fix((double)acc[q], y_scale));
+                    for (int b = 0; b < 3; ++b) {
+                        const S c = vget<S>(cur.m[0 + a], j) * xc[b] + vget<S>(cur.m[3 + a], j) * xc[3 + b] +
+                                    vget<S>(cur.m[6 + a], j) * xc[6 + b];
+                        acc[a * 3 + b] = cont ? acc[a * 3 + b] + c : c;
                     }
-                    currow = row;
+                const bool last = (j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j];
+                if (last) {
+                    u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) acc[q] = c[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) acc[q] += c[q];
+                    for (int q = 0; q < 9; ++q) lds_add_fix(yr + q * ncopy, to_fix_s<S>(acc[q], y_scale, y_scale_f));
                 }
-            }
-            if (currow != 0xFFFFFFFFu) {
+                if (j + 1 < EPL) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) lds_add_fix(&ys[(currow * 9 + q) * ncopy + lane_copy], to_fix((double)acc[q], y_scale));
+                    for (int q = 0; q < 9; ++q) xc[q] = xn[q];
+                }
             }
         }
         __syncthreads();
@@ -502,24 +517,20 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
             __syncthreads();
             // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
             S w[9];
-            uint32_t wrow = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                if (cur.id[j] == VICAN_PAD_SLOT) continue;
-                const uint32_t cam = cur.id[j] & 0xFFFFu, row = cur.id[j] >> 16;
-                if (row != wrow) {
-                    wrow = row;
+                if (j == 0 || row[j] != row[j - 1]) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) w[q] = wv[row * 9 + q];
+                    for (int q = 0; q < 9; ++q) w[q] = wv[row[j] * 9 + q];
                 }
-                u64* zc = zs + cam;
+                u64* zc = zs + cam[j];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
                         const S v = vget<S>(cur.m[i * 3 + 0], j) * w[b] + vget<S>(cur.m[i * 3 + 1], j) * w[3 + b] +
                                     vget<S>(cur.m[i * 3 + 2], j) * w[6 + b];
-                        lds_add_fix(&zc[(i * 3 + b) * C], to_fix((double)v, z_scale));
+                        lds_add_fix(&zc[(i * 3 + b) * C], to_fix_s<S>(v, z_scale, z_scale_f));
                     }
             }
         } else {

@@ -166,7 +166,8 @@ class HipBackend:
         return _lib.check(rc, what)
 
     def _fx_finish(self):
-        self._ck(self.lib.vican_fx_finish(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_max + 1), _stream()),
+        self._ck(self.lib.vican_fx_finish(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_max + 1),
+                                          self.g.desc.storage, _stream()),
                  "vican_fx_finish")
 
     # -- rotation stage -----------------------------------------------------
