@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage type of the 3x3 blocks")
     ap.add_argument("--maxiter", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 1024])
+    ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
     ap.add_argument("--n-copy", type=int, default=None)
     ap.add_argument("--cpu-sample-timesteps", type=int, default=None)
     return ap.parse_args()

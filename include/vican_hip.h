@@ -58,7 +58,7 @@ typedef struct vican_graph {
     int32_t slots;            /* edges per chunk = block_threads * edges_per_lane */
     int32_t max_rows;         /* max timestep rows in any chunk */
     int32_t storage;          /* VICAN_STORE_F32 | VICAN_STORE_F64 (type of blk) */
-    int32_t block_threads;    /* 256, 512 or 1024 */
+    int32_t block_threads;    /* 256, 512, 768 or 1024 */
     int32_t n_wg;             /* persistent workgroups per sweep (= number of partial slabs) */
     int32_t n_copy;           /* lane-striped copies of the per-row accumulators (power of 2, <= 32) */
     int32_t reserved;
@@ -115,14 +115,19 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
 /* Fixed-point bookkeeping.  The sweeps accumulate in 64-bit fixed point (the fastest LDS
  * atomic on gfx950, and order-independent => bit-reproducible).  `fx` is a device buffer of
  * VICAN_FX_DOUBLES doubles: [0] y scale, [1] its inverse, [2] z scale, [3] its inverse,
- * [4] omega = max_t |lamT_inv[t]|_F * rnorm[t], [5] max block norm, [6] max_t rnorm[t], [7] spare.
+ * [4] omega = max_t |lamT_inv[t]|_F * rnorm[t], [5] max block norm, [6] max_t rnorm[t],
+ * [7] 2^-shift of the last vican_block_op (its scales are raised by 2^shift when the actual
+ * max_c |x_c|_F is below x_bound), [8] x_bound, [9..11] spare.
  * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
  * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
  * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup;
  * one contribution gets 47 bits on the f64 path, 28 on the f32 path (single v_cvt_i32_f32). */
-#define VICAN_FX_DOUBLES 8
+#define VICAN_FX_DOUBLES 12
 int vican_block_norms(const vican_graph_t* g, double* rnorm /*[T]*/, double* fx, void* stream);
 int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream);
+/* fx[4] for caller-supplied duals (instead of vican_init_duals / vican_dual_update). */
+int vican_duals_bound(int32_t n_time, const double* lamT_inv, const double* rnorm, double* fx,
+                      void* stream);
 
 /* ---- rotation stage ------------------------------------------------------ */
 

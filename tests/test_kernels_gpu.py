@@ -44,6 +44,7 @@ CONFIGS = [  # C, T, deg_lo, deg_hi, block_threads, n_wg, empty_rows
     (64, 500, 20, 64, 256, 7, False),
     (200, 120, 100, 200, 1024, None, False),
     (300, 200, 50, 300, 512, 9, False),
+    (400, 300, 100, 400, 768, 6, False),
     (700, 64, 300, 700, 1024, 5, False),
 ]
 
@@ -66,10 +67,12 @@ def test_block_op_dual_update_and_init(cfg, dt):
     lam = rng.standard_normal((T, 3, 3)); lam = lam @ np.swapaxes(lam, 1, 2) + np.eye(3)
     lam_h, lam_n = H.from_numpy(lam.reshape(T, 9)), N.from_numpy(lam.reshape(T, 9))
     zh, zn = H.empty(3 * C, 3), N.empty(3 * C, 3)
+    H.set_duals(lam_h)                      # duals not produced by the library: refresh the fixed-point bound
     H.block_op(lam_h, H.from_numpy(x), zh); N.block_op(lam_n, N.from_numpy(x), zn)
     ref = zn.numpy()
     # f64 blocks: f64 products + exact fixed-point sums; f32 blocks: f32 products (x rounded to f32)
-    assert np.abs(zh.cpu().numpy() - ref).max() <= (1e-11 if dt == np.float64 else 2e-6) * np.abs(ref).max()
+    # (fixed-point resolution is 2^-47 of the contribution BOUND |M|max*omega*|x|max, not of each value)
+    assert np.abs(zh.cpu().numpy() - ref).max() <= (1e-10 if dt == np.float64 else 2e-6) * np.abs(ref).max()
     # integer accumulation => bit-identical on a repeat launch
     z2 = H.empty(3 * C, 3)
     H.block_op(lam_h, H.from_numpy(x), z2)
@@ -80,7 +83,7 @@ def test_block_op_dual_update_and_init(cfg, dt):
     Rt_n, L_n = N.zeros(T, 9), N.zeros(T, 9)
     H.dual_update(H.from_numpy(rc), Rt_h, L_h); N.dual_update(N.from_numpy(rc), Rt_n, L_n)
     well = nz & (np.diff(N.row_ptr) >= 2)            # a single noisy block may be ill-conditioned; keep generic rows
-    tol = 1e-10 if dt == np.float64 else 2e-3      # f32 products; S^-1 amplifies by cond(Z_t) on 2-edge rows
+    tol = 1e-9 if dt == np.float64 else 2e-3       # fixed-point y sums / f32 products; S^-1 amplifies by cond(Z_t)
     assert np.abs(Rt_h.cpu().numpy()[well] - Rt_n.numpy()[well]).max() < tol
     rel = np.abs(L_h.cpu().numpy()[well] - L_n.numpy()[well]).max() / np.abs(L_n.numpy()[well]).max()
     assert rel < tol
@@ -158,7 +161,7 @@ def test_gauge_project_and_lanczos_helpers():
     assert b[1, 1] == 0.0 and np.all(xh.cpu().numpy()[:, 1] == 0.0)
 
 
-@pytest.mark.parametrize("cfg", CONFIGS[:5])
+@pytest.mark.parametrize("cfg", CONFIGS[:6])
 def test_translation_kernels_and_cg(cfg):
     """rhs / degrees / every CG kernel step by step against the NumPy state machine."""
     from vican_amd.solver import Comm, TranslationSolver
@@ -178,7 +181,7 @@ def test_translation_kernels_and_cg(cfg):
     assert np.allclose(dt_h, dt_n, rtol=1e-13) and np.allclose(dc_h, dc_n, rtol=1e-13)
     assert np.abs(bt_h - bt_n).max() < 1e-11 and np.abs(bc_h - bc_n).max() < 1e-10
     assert ih["converged"] and inn["converged"]
-    assert abs(ih["cg_iters"] - inn["cg_iters"]) <= 1
+    assert abs(ih["cg_iters"] - inn["cg_iters"]) <= max(1, inn["cg_iters"] // 20)     # rtol 1e-8: ~100 iterations
     scale = max(np.abs(xt_n).max(), 1.0)
     assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
     # translations from x0 = 0 stay in the range of the Laplacian: node sum is zero

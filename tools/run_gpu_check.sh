@@ -3,8 +3,8 @@
 # GPU tests + stress bench at two workgroup sizes + PMC pass for the sweep kernel.
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -W ignore 2>&1 | grep -E "^E|FAILED|passed|failed|Error" | head -30 > $O/pytest_gpu.log
-for bt in 1024 512; do python bench.py --steps 2 --warmup 1 --no-cpu-baseline --block-threads $bt "$@" > $O/bench_bt$bt.log 2>&1; done
+python -m pytest tests -m gpu -q -W ignore --tb=line 2>&1 | grep -E "Error|FAILED|passed|failed" | cut -c1-300 | head -30 > $O/pytest_gpu.log
+for bt in 1024 768 512; do python bench.py --steps 2 --warmup 1 --no-cpu-baseline --block-threads $bt "$@" > $O/bench_bt$bt.log 2>&1; done
 cd /tmp && export TMPDIR=/tmp
 B="python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
 rm -rf $O/pmc1 $O/pmc2

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip")]
 HEADERS = [os.path.join(CSRC, "common.cuh")]
-FX_DOUBLES = 8
+FX_DOUBLES = 12
 INCLUDE = os.path.join(ROOT, "include")
 
 STORE_F32, STORE_F64 = 0, 1
@@ -54,6 +54,7 @@ PROTOTYPES = {
     "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
     "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
+    "vican_duals_bound": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
     "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_init_duals": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),

@@ -288,6 +288,7 @@ extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const do
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, st, *g, u, v, rc, rt, rhs_t, rhs_c_part);         \
     } while (0)
     if (g->block_threads == 1024)     { if (epl == 4) RHS_LAUNCH(1024, 4); else RHS_LAUNCH(1024, 2); }
+    else if (g->block_threads == 768) { if (epl == 4) RHS_LAUNCH(768, 4);  else RHS_LAUNCH(768, 2); }
     else if (g->block_threads == 512) { if (epl == 4) RHS_LAUNCH(512, 4);  else RHS_LAUNCH(512, 2); }
     else                              { if (epl == 4) RHS_LAUNCH(256, 4);  else RHS_LAUNCH(256, 2); }
 #undef RHS_LAUNCH
@@ -455,6 +456,7 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st); \
     } while (0)
     if (g->block_threads == 1024)     { if (epl == 4) CG_LAUNCH(1024, 4); else CG_LAUNCH(1024, 2); }
+    else if (g->block_threads == 768) { if (epl == 4) CG_LAUNCH(768, 4);  else CG_LAUNCH(768, 2); }
     else if (g->block_threads == 512) { if (epl == 4) CG_LAUNCH(512, 4);  else CG_LAUNCH(512, 2); }
     else                              { if (epl == 4) CG_LAUNCH(256, 4);  else CG_LAUNCH(256, 2); }
 #undef CG_LAUNCH

@@ -45,14 +45,14 @@ extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024; }
 static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32 ? 4 : 8; }
 
 // operator sweep: x table (storage type) + z accumulators (u64) per camera; per row:
-// duals (f64) + y sums (f64) + w (storage type) + n_copy striped u64 accumulators
+// y sums (f64) + w (storage type) + n_copy striped u64 accumulators
 extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy) {
     const int64_t s = ssize(storage);
-    return 9LL * n_cam * (s + 8) + (int64_t)max_rows * (144 + 9 * s + 72LL * n_copy) + 256;
+    return 9LL * n_cam * (s + 8) + (int64_t)max_rows * (72 + 9 * s + 72LL * n_copy) + 256;
 }
 extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy) {
     const int64_t lim = vican_lds_limit_bytes(), s = ssize(storage);
-    int64_t a = (lim - 256 - 9LL * n_cam * (s + 8)) / (144 + 9 * s + 72LL * n_copy);
+    int64_t a = (lim - 256 - 9LL * n_cam * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
     int64_t b = (lim - 256 - 96LL * n_cam) / 96;        // rhs kernel   (vican_kernels.hip)
     int64_t c = (lim - 128 - 48LL * n_cam) / 48;        // CG sweep
     int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
@@ -64,7 +64,8 @@ int vican_check_graph(const vican_graph_t* g, const char* who) {
         !g->chunk_row0 || g->n_wg <= 0)
         return set_err(VICAN_ERR_ARG, "%s: bad graph descriptor", who);
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
-    if ((g->block_threads != 256 && g->block_threads != 512 && g->block_threads != 1024) || g->slots != g->block_threads * epl)
+    if ((g->block_threads != 256 && g->block_threads != 512 && g->block_threads != 768 && g->block_threads != 1024) ||
+        g->slots != g->block_threads * epl)
         return set_err(VICAN_ERR_ARG, "%s: slots must be block_threads * (16 / sizeof(storage))", who);
     const int nc = g->n_copy;
     if (nc < 1 || nc > 32 || (nc & (nc - 1))) return set_err(VICAN_ERR_ARG, "%s: n_copy must be a power of two <= 32", who);
@@ -305,6 +306,31 @@ extern "C" int vican_init_duals(int32_t n_time, const double* row_sum_a, const d
     return VICAN_OK;
 }
 
+// omega for caller-supplied duals: fx[4] = max_t |lamT_inv[t]|_F * rnorm[t]
+__global__ void duals_bound_kernel(int n_time, const double* __restrict__ lamT_inv, const double* __restrict__ rnorm,
+                                   double* __restrict__ fx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double om = 0.0;
+    if (t < n_time) {
+        double q = 0.0;
+        for (int i = 0; i < 9; ++i) { const double v = lamT_inv[(size_t)t * 9 + i]; q += v * v; }
+        om = sqrt(q) * rnorm[t];
+        if (!(om >= 0.0) || om > 1e300) om = 0.0;          // rows without edges carry inf/nan duals
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
+    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
+}
+extern "C" int vican_duals_bound(int32_t n_time, const double* lamT_inv, const double* rnorm, double* fx, void* stream) {
+    if (n_time < 0 || !lamT_inv || !rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_duals_bound: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(fx + 4, 0, sizeof(double), st) != hipSuccess) return set_err(VICAN_ERR_LAUNCH, "vican_duals_bound: memset failed");
+    if (n_time == 0) return VICAN_OK;
+    hipLaunchKernelGGL(duals_bound_kernel, dim3((n_time + 255) / 256), dim3(256), 0, st, n_time, lamT_inv, rnorm, fx);
+    LAUNCH_CHECK("vican_duals_bound");
+    return VICAN_OK;
+}
+
 __global__ void scaled_identity_kernel(int n, const double* __restrict__ sc, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -333,14 +359,20 @@ __global__ void fx_finish_kernel(double* fx, double x_bound, double n_add, int b
     // (4 * 2^47 < 2^51, magic-number conversion) and 28 on the f32 path (4 * 2^28 < 2^31, v_cvt_i32_f32)
     int ey = min(bits - (int)ceil(log2(cy)), 61 - (int)ceil(log2(ty)));
     int ez = min(bits - (int)ceil(log2(cz)), 61 - (int)ceil(log2(tz)));
-    ey = max(min(ey, 1000), -1000); ez = max(min(ez, 1000), -1000);
+    ey = max(min(ey, 100), -100); ez = max(min(ez, 100), -100);     // pre-scaled f32 tables stay finite
     fx[0] = ldexp(1.0, ey); fx[1] = ldexp(1.0, -ey);
     fx[2] = ldexp(1.0, ez); fx[3] = ldexp(1.0, -ez);
+    fx[7] = 1.0; fx[8] = x_bound;
 }
 extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
     if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");
-    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add,
-                       storage == VICAN_STORE_F32 ? 28 : 47);
+#ifdef VICAN_F32_FIX28
+    const int bits = storage == VICAN_STORE_F32 ? 28 : 47;
+#else
+    const int bits = 47;
+    (void)storage;
+#endif
+    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add, bits);
     LAUNCH_CHECK("vican_fx_finish");
     return VICAN_OK;
 }
@@ -365,13 +397,6 @@ __device__ __forceinline__ u64 to_fix(double v, double scale) {
     const double magic = 6755399441055744.0;          // 1.5 * 2^52
     return (u64)(__double_as_longlong(fma(v, scale, magic)) - __double_as_longlong(magic));
 }
-// storage-type front ends: f64 values go through the 2^51 magic-number path; f32 values are
-// scaled in f32 and converted with ONE v_cvt_i32_f32 (|v*scale| < 2^31), then sign-extended
-template <typename S> __device__ __forceinline__ u64 to_fix_s(S v, double scale_d, float scale_f);
-template <> __device__ __forceinline__ u64 to_fix_s<double>(double v, double scale_d, float) { return to_fix(v, scale_d); }
-template <> __device__ __forceinline__ u64 to_fix_s<float>(float v, double, float scale_f) {
-    return (u64)(long long)__float2int_rn(v * scale_f);
-}
 __device__ __forceinline__ void lds_add_fix(u64* p, u64 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add_u64
 }
@@ -394,9 +419,37 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
     else          { const uint2 t = *(const uint2*)ip; c.id[0] = t.x; c.id[1] = t.y; }
 }
 
+// Pre-scaling: on the f32 path the fixed-point scale is folded into the LDS tables (x is staged
+// as x*y_scale, w as w*z_scale: powers of two, exact), so a contribution converts with ONE
+// v_cvt_rpi_i32_f32 (floor(v + 0.5)) + sign extension; the f64 path scales inside the FMA of the
+// magic-number conversion.
+template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);
+#ifdef VICAN_F32_FIX28
+template <> __device__ __forceinline__ float pre_scale<float>(double v, double scale) { return (float)(v * scale); }
+#else
+template <> __device__ __forceinline__ float pre_scale<float>(double v, double) { return (float)v; }
+#endif
+template <> __device__ __forceinline__ double pre_scale<double>(double v, double) { return v; }
+template <typename S> __device__ __forceinline__ u64 fix_of(S v, double scale);
+template <> __device__ __forceinline__ u64 fix_of<double>(double v, double scale) { return to_fix(v, scale); }
+#ifdef VICAN_F32_FIX28
+template <> __device__ __forceinline__ u64 fix_of<float>(float v, double) {
+    int r;
+    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
+    return (u64)(long long)r;
+}
+#else
+// lossless: a 24-bit f32 product keeps all its bits down to 2^-23 of the contribution bound
+template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) { return to_fix((double)v, scale); }
+#endif
+
 // MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
 // MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
 // Arithmetic in the storage type S (f32 products for f32 blocks), accumulation in 64-bit fixed point.
+//
+// Per chunk:  [phase 3 of the previous chunk | phase 1]  barrier  [phase 2: one wavefront per
+// row, no workgroup barrier inside]  barrier  ...   - two barriers per chunk; the register
+// set of the next chunk is loaded while the current one is processed (ping-pong, no copies).
 template <typename S, int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, const double* __restrict__ lamT_inv,
                                                             const double* __restrict__ x,
@@ -406,38 +459,66 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                                                             const double* __restrict__ rnorm,
                                                             double* __restrict__ fx) {
     constexpr int EPL = Vec<S>::N;
+    constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int nx = 9 * g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1;
+    const int C = g.n_cam, nx = 9 * C, ncopy = g.n_copy, cmask = ncopy - 1;
     // 8-byte arrays first, then the storage-type tables
     u64* zs = (u64*)lds_raw;                                   // [9][C] planes (MODE 0)
-    double* lam_s = (double*)(zs + (MODE == 0 ? nx : 0));      // [max_rows][9] (MODE 0)
-    double* ysum = lam_s + (MODE == 0 ? 9 * g.max_rows : 0);   // [max_rows][9]
+    double* ysum = (double*)(zs + (MODE == 0 ? nx : 0));       // [max_rows][9] (MODE 1)
     u64* ys = (u64*)(ysum + 9 * g.max_rows);                   // [max_rows*9][ncopy]
-    S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][C] planes
-    S* wv = xs + nx;                                           // [max_rows][9] (MODE 0)
-    const int tid = threadIdx.x, lane_copy = tid & cmask;
-    const double y_scale = fx[0], y_inv = fx[1], z_scale = fx[2];
-    const float y_scale_f = (float)y_scale, z_scale_f = (float)z_scale;      // powers of two: exact
+    S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][C] planes (pre-scaled on the f32 path)
+    S* wv = xs + nx;                                           // [max_rows][9] (MODE 0; pre-scaled likewise)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane_copy = tid & cmask;
+    const int part_n = ncopy < 4 ? ncopy : 4, per = ncopy / part_n;   // phase 2: part_n lanes per accumulator
 
-    const int C = g.n_cam;
-    for (int i = tid; i < nx; i += BLOCK) { xs[(i % 9) * C + i / 9] = (S)x[i]; if (MODE == 0) zs[i] = 0ull; }
+    // The scales in fx assume |x_c|_F <= x_bound (sqrt 3).  Krylov vectors are far smaller
+    // (~sqrt(3/C)), so every workgroup measures max_c |x_c|_F of THIS input (all find the same
+    // value) and shifts both scales up by the power of two that still keeps it below the bound:
+    // 4-5 more bits of fixed-point resolution for free.  Workgroup 0 records 2^-shift in fx[7]
+    // for vican_slab_reduce_fx.
+    double xm2 = 0.0;
+    for (int c = tid; c < C; c += BLOCK) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double v = x[(size_t)c * 9 + i]; q += v * v; }
+        xm2 = fmax(xm2, q);
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) xm2 = fmax(xm2, __shfl_xor(xm2, o2, 64));
+    if (lane == 0) ysum[wave] = xm2;                     // scratch: ysum is not used before phase 2
+    __syncthreads();
+    xm2 = 0.0;
+    for (int i = 0; i < NWAVE; ++i) xm2 = fmax(xm2, ysum[i]);
+    int shift = 0;
+    if (xm2 > 0.0) shift = (int)floor(log2(fx[8] / sqrt(xm2)));     // fx[8] = x_bound
+    shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
+    const double up = ldexp(1.0, shift);
+    const double y_scale = fx[0] * up, y_inv = fx[1] / up, z_scale = fx[2] * up;
+    if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    __syncthreads();
+
+    for (int i = tid; i < nx; i += BLOCK) { xs[(i % 9) * C + i / 9] = pre_scale<S>(x[i], y_scale); if (MODE == 0) zs[i] = 0ull; }
     for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
 
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
     double om_max = 0.0;
 
-    ChunkRegs<S, EPL> cur, nxt;
-    if (k0 < k1) load_chunk<S, EPL>(cur, g, k0, tid);
+    ChunkRegs<S, EPL> ra, rb;
+    if (k0 < k1) load_chunk<S, EPL>(ra, g, k0, tid);
     __syncthreads();
 
-#pragma unroll 1
-    for (int k = k0; k < k1; ++k) {
+    auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int k) {
         const int r0 = g.chunk_row0[k];
         const int nrows = g.chunk_row0[k + 1] - r0;
         if (k + 1 < k1) load_chunk<S, EPL>(nxt, g, k + 1, tid);      // prefetch: lands during this chunk
-        double lam_pre = 0.0;
-        if (MODE == 0 && tid < 9 * nrows) lam_pre = lamT_inv[(size_t)r0 * 9 + tid];
+        // duals of the row this wavefront will fold in phase 2 (lane -> accumulator o = lane / part_n)
+        const int o = lane / part_n, oa = o / 3, ob = o - 3 * oa;
+        double L0 = 0, L1 = 0, L2 = 0;
+        if (MODE == 0 && wave < nrows && o < 9) {
+            const double* L = lamT_inv + (size_t)(r0 + wave) * 9 + oa * 3;
+            L0 = L[0]; L1 = L[1]; L2 = L[2];
+        }
 
         // ---- phase 1: y_row += M^T x_cam ; same-row edges of a lane pre-summed in registers,
         //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
@@ -473,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                 if (last) {
                     u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) lds_add_fix(yr + q * ncopy, to_fix_s<S>(acc[q], y_scale, y_scale_f));
+                    for (int q = 0; q < 9; ++q) lds_add_fix(yr + q * ncopy, fix_of<S>(acc[q], y_scale));
                 }
                 if (j + 1 < EPL) {
 #pragma unroll
@@ -483,71 +564,82 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         }
         __syncthreads();
 
-        // ---- phase 2a: fold the striped copies (exact integer sum), re-zero them, stage the duals
-        //      (PART adjacent lanes share one accumulator; the copy index is rotated by the
-        //       accumulator index so that the lanes of a wavefront walk distinct banks)
-        {
-            const int part_n = ncopy < 4 ? ncopy : 4, per = ncopy / part_n;
-            for (int t = tid; t < 9 * nrows * part_n; t += BLOCK) {
-                const int i = t / part_n, part = t - i * part_n;
-                long long s = 0;
+        // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
+        //      rotated by the accumulator index => distinct banks), re-zero them, then
+        //      w = lamT_inv * y (or the SVD) with wave shuffles only - no workgroup barrier inside
+        for (int r = wave; r < nrows; r += NWAVE) {
+            long long s = 0;
+            if (o < 9) {
+                const int part = lane - o * part_n;
                 for (int c = 0; c < per; ++c) {
-                    const int a = i * ncopy + ((part * per + c + i) & cmask);
+                    const int a = (r * 9 + o) * ncopy + ((part * per + c + o) & cmask);
                     s += (long long)ys[a];
                     ys[a] = 0ull;
                 }
-                // fold the PART partial sums (t is wave-aligned: BLOCK and part_n are powers of two)
-                if (part_n > 1) s += __shfl_xor(s, 1, 64);
-                if (part_n > 2) s += __shfl_xor(s, 2, 64);
-                if (part == 0) ysum[i] = (double)s * y_inv;
             }
-            if (MODE == 0)
-                for (int i = tid; i < 9 * nrows; i += BLOCK) lam_s[i] = (i == tid) ? lam_pre : lamT_inv[(size_t)r0 * 9 + i];
+            if (part_n > 1) s += __shfl_xor(s, 1, 64);
+            if (part_n > 2) s += __shfl_xor(s, 2, 64);
+            const double y = (double)s * y_inv;                  // valid where lane == o * part_n
+            if (MODE == 0) {
+                if (r != wave && o < 9) {
+                    const double* L = lamT_inv + (size_t)(r0 + r) * 9 + oa * 3;
+                    L0 = L[0]; L1 = L[1]; L2 = L[2];
+                }
+                const double y0 = __shfl(y, (0 + ob) * part_n, 64), y1 = __shfl(y, (3 + ob) * part_n, 64),
+                             y2 = __shfl(y, (6 + ob) * part_n, 64);
+                if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0 * y0 + L1 * y1 + L2 * y2, z_scale);
+            } else {
+                if (o < 9 && lane == o * part_n) ysum[r * 9 + o] = y;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane == 0) {
+                    double R[9], lam[9];
+                    polar_dual3(ysum + r * 9, R, lam, 2);
+                    double* Ro = Rt_out + (size_t)(r0 + r) * 9;
+                    double* Lo = lamT_out + (size_t)(r0 + r) * 9;
+                    double fro = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) { Ro[q] = R[q]; Lo[q] = lam[q]; fro += lam[q] * lam[q]; }
+                    om_max = fmax(om_max, sqrt(fro) * rnorm[r0 + r]);
+                }
+            }
         }
+        // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
         __syncthreads();
-
-        // ---- phase 2b: w = lamT_inv * y  on 9*rows threads   (or the per-row SVD)
         if (MODE == 0) {
-            for (int i = tid; i < 9 * nrows; i += BLOCK) {
-                const int r = i / 9, a = (i % 9) / 3, b = i % 3;
-                const double* L = lam_s + r * 9 + a * 3;
-                const double* y = ysum + r * 9 + b;
-                wv[i] = (S)(L[0] * y[0] + L[1] * y[3] + L[2] * y[6]);
-            }
-            __syncthreads();
             // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
             S w[9];
+            uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                if (j == 0 || row[j] != row[j - 1]) {
+                const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+                const uint32_t camj = pad ? (uint32_t)(tid & 31) : (cur.id[j] & 0xFFFFu);
+                const uint32_t rowj = pad ? 0u : (cur.id[j] >> 16);
+                if (rowj != prow) {
+                    prow = rowj;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) w[q] = wv[row[j] * 9 + q];
+                    for (int q = 0; q < 9; ++q) w[q] = wv[rowj * 9 + q];
                 }
-                u64* zc = zs + cam[j];
+                u64* zc = zs + camj;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
                         const S v = vget<S>(cur.m[i * 3 + 0], j) * w[b] + vget<S>(cur.m[i * 3 + 1], j) * w[3 + b] +
                                     vget<S>(cur.m[i * 3 + 2], j) * w[6 + b];
-                        lds_add_fix(&zc[(i * 3 + b) * C], to_fix_s<S>(v, z_scale, z_scale_f));
+                        lds_add_fix(&zc[(i * 3 + b) * C], fix_of<S>(v, z_scale));
                     }
             }
-        } else {
-            for (int r = tid; r < nrows; r += BLOCK) {
-                double R[9], lam[9];
-                polar_dual3(ysum + r * 9, R, lam, 2);
-                double* Ro = Rt_out + (size_t)(r0 + r) * 9;
-                double* Lo = lamT_out + (size_t)(r0 + r) * 9;
-                double fro = 0.0;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) { Ro[q] = R[q]; Lo[q] = lam[q]; fro += lam[q] * lam[q]; }
-                om_max = fmax(om_max, sqrt(fro) * rnorm[r0 + r]);
-            }
         }
-        if (k + 1 < k1) cur = nxt;
         // (the barrier after the next chunk's phase 1 separates this chunk's phase 3 reads of wv
-        //  from the next phase 2b writes; ys is already re-zeroed for the next phase 1)
+        //  from the next phase 2 writes; ys is already re-zeroed for the next phase 1)
+    };
+
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ra, rb, k);
+        if (k + 1 < k1) body(rb, ra, k + 1);
     }
     if (MODE == 0) {
         __syncthreads();
@@ -555,8 +647,8 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         for (int i = tid; i < nx; i += BLOCK) zp[i] = zs[i];
     } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) om_max = fmax(om_max, __shfl_down(om_max, o, 64));
-        if ((tid & 63) == 0 && om_max > 0.0) atomic_max_pos(&fx[4], om_max);
+        for (int o2 = 32; o2 > 0; o2 >>= 1) om_max = fmax(om_max, __shfl_down(om_max, o2, 64));
+        if (lane == 0 && om_max > 0.0) atomic_max_pos(&fx[4], om_max);
     }
 }
 
@@ -582,10 +674,12 @@ static int dispatch_sweep(const vican_graph_t* g, const double* lamT_inv, const 
 #define SWEEP_ARGS g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st
     if (g->storage == VICAN_STORE_F32) {
         if (g->block_threads == 1024) return launch_sweep<float, 1024, MODE>(SWEEP_ARGS);
+        if (g->block_threads == 768) return launch_sweep<float, 768, MODE>(SWEEP_ARGS);
         if (g->block_threads == 512) return launch_sweep<float, 512, MODE>(SWEEP_ARGS);
         return launch_sweep<float, 256, MODE>(SWEEP_ARGS);
     }
     if (g->block_threads == 1024) return launch_sweep<double, 1024, MODE>(SWEEP_ARGS);
+    if (g->block_threads == 768) return launch_sweep<double, 768, MODE>(SWEEP_ARGS);
     if (g->block_threads == 512) return launch_sweep<double, 512, MODE>(SWEEP_ARGS);
     return launch_sweep<double, 256, MODE>(SWEEP_ARGS);
 #undef SWEEP_ARGS
@@ -650,7 +744,7 @@ __global__ __launch_bounds__(256) void slab_reduce_fx_kernel(const long long* __
     __syncthreads();
     if (grp == 0 && i < n) {
         const long long C = n / 9, q = i / C, cam = i % C;
-        out[cam * 9 + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * fx[3];
+        out[cam * 9 + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * (fx[3] * fx[7]);
     }
 }
 extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int64_t n, const double* fx, double* out,

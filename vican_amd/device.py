@@ -57,8 +57,13 @@ class LocalGraph:
         deg = (rp_host[1:] - rp_host[:-1]) if self.n_time else torch.zeros(1, dtype=torch.int32)
         deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
         if block_threads is None:
-            block_threads = 1024 if self.n_edges >= 1024 * epl * N_CU else 256
+            # 768 threads (12 wavefronts, <= 168 VGPRs) holds two register sets of a chunk without
+            # spilling and measured fastest on the HBM-bound stress graph; small graphs use 256 so
+            # that there are enough chunks to occupy the chip
+            block_threads = 768 if self.n_edges >= 768 * epl * N_CU else 256
             if deg_max > 256 * epl:
+                block_threads = 768
+            if deg_max > 768 * epl:
                 block_threads = 1024
         slots = block_threads * epl
         # lane-striped copies of the row accumulators: as many as LDS allows while a chunk can
@@ -176,6 +181,12 @@ class HipBackend:
         cam_deg.copy_(self.g.cam_sum_a)
         self._ck(self.lib.vican_init_duals(self.T, _ptr(self.g.row_sum_a), _ptr(self.g.rnorm), _ptr(lamT_inv),
                                            _ptr(self.g.fx), _stream()), "vican_init_duals")
+        self._fx_finish()
+
+    def set_duals(self, lamT_inv):
+        """Caller-supplied duals: refresh the fixed-point bound before block_op."""
+        self._ck(self.lib.vican_duals_bound(self.T, _ptr(lamT_inv), _ptr(self.g.rnorm), _ptr(self.g.fx), _stream()),
+                 "vican_duals_bound")
         self._fx_finish()
 
     def scaled_identity(self, scale, out):
