@@ -156,10 +156,12 @@ int vican_dual_update(const vican_graph_t* g, const double* rc, double* Rt,
 
 /* out[i] = sum_s part[s][i], s < n_slab, i < n  (fixed order: bitwise reproducible). */
 int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out, void* stream);
-/* z[c][q] = fx[3] * sum_s part[s][q][c]: folds the fixed-point plane slabs of vican_block_op
- * (n = 9C) into the row-major camera vector [3C][3]; exact integer sum.        */
-int vican_slab_reduce_fx(const void* part, int32_t n_slab, int64_t n, const double* fx,
-                         double* out, void* stream);
+/* out[c][q] = scale * (*pa) * (*pb) * sum_s part[s][q][c]: folds 64-bit fixed-point plane slabs
+ * [n_slab][ncomp][n_cam] into a row-major camera vector [n_cam][ncomp] (exact integer sum).
+ * pa / pb may be NULL (= 1).  vican_block_op slabs: ncomp 9, pa = fx+3, pb = fx+7;
+ * vican_cg_sweep slabs: ncomp 3, pa = &state->qinv; vican_trans_rhs slabs: ncomp 3, scale = *inv_out. */
+int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_t ncomp, double scale,
+                         const double* pa, const double* pb, double* out, void* stream);
 
 /* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
  * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),
@@ -207,15 +209,17 @@ int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_
  * bipgo.py:463-477:  (weighted bipartite Laplacian (x) I3) p = J^T b.          */
 
 /* Right-hand side J^T b (bipgo.py:451-461 + J^T): g_ct = Rc_c^T u_ct + Rt_t^T v_ct;
- * rhs_t[t] = sum_c g_ct (written), rhs_c slabs [n_wg][C][3] = -sum_t g_ct.   */
+ * rhs_t[t] = sum_c g_ct (written), rhs_c_part = fixed-point slabs [n_wg][3][C] of -sum_t g_ct
+ * (fold with vican_slab_reduce_fx, scale = *inv_out).  gmax >= max_e (|u_e| + |v_e|) and
+ * n_add >= the number of edges added into one accumulator by one workgroup size the scale.   */
 int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v,
-                    const double* rc, const double* rt, double* rhs_t, double* rhs_c_part,
-                    void* stream);
+                    const double* rc, const double* rt, double* rhs_t, void* rhs_c_part,
+                    double gmax, double n_add, double* inv_out, void* stream);
 
-/* Device-resident CG state (one struct in device memory, zero-initialised by
- * vican_cg_init). Doubles first, then ints; mirrors scipy.sparse.linalg.cg
- * (x0 = 0, no preconditioner, stop when |r| < max(atol, rtol*|b|) tested at the
- * top of every iteration).                                                  */
+/* Device-resident CG state (one struct in device memory, initialised by vican_cg_init).
+ * Mirrors scipy.sparse.linalg.cg (x0 = 0, no preconditioner, stop when |r| < rtol*|b| tested at
+ * the top of every iteration).  The sweeps accumulate q = A p in 64-bit fixed point; its scale
+ * follows the running bound pmax >= max|p| (|p_new| <= max|r| + beta |p|).                 */
 typedef struct vican_cg_state {
     double rho;        /* r.r of the current residual */
     double rho_prev;
@@ -225,33 +229,42 @@ typedef struct vican_cg_state {
     double bnorm2;     /* |b|^2 */
     double atol2;      /* (rtol*|b|)^2 */
     double rr_cam;     /* camera part of r.r (set by cg_cam_step) */
-    double pq_time;    /* timestep part of p.q (sum of partials; may be all-reduced) */
-    double rr_time;    /* timestep part of r.r */
+    double pq_time;    /* timestep part of p.q */
+    double rr_time;    /* timestep part of r.r (all-reduced across ranks) */
+    double rmax_cam;   /* max |r_c| */
+    double rmax_time;  /* max |r_t| over THIS rank's rows */
+    double pmax;       /* bound on max |p| (this rank) */
+    double qscale;     /* fixed-point scale of the current sweep, and its inverse */
+    double qinv;
+    double wmax;       /* max edge weight (graph constant) */
     int32_t iter;      /* completed iterations */
     int32_t done;      /* 1 once converged: all later kernels are no-ops */
     int32_t first;     /* 1 before the first iteration (p = r) */
     int32_t pad;
 } vican_cg_state_t;
 
-/* x=0, r=b, p=r for both node sets; |b_t|^2 into st->rr_time (caller all-reduces
- * it across ranks before cg_begin), |b_c|^2 into st->rr_cam.  ws: >= 512 doubles. */
+/* x=0, r=b, p=r for both node sets; |b_t|^2 into st->rr_time (caller all-reduces it across
+ * ranks before cg_begin), |b_c|^2 into st->rr_cam.  ws: >= 1024 doubles.              */
 int vican_cg_init(int32_t n_cam, int32_t n_time, const double* b_c, const double* b_t,
                   double* x_c, double* x_t, double* r_c, double* r_t, double* p_c, double* p_t,
-                  vican_cg_state_t* st, double* ws, void* stream);
+                  vican_cg_state_t* st, double* ws, double wmax, void* stream);
 /* Top of an iteration.  If n_part > 0 first closes the previous iteration like
  * vican_cg_end(rr_part, n_part) (single-GPU fast path; multi-GPU callers use
  * vican_cg_end + all-reduce of st->rr_time and pass n_part = 0).  Then
  * rho = rr_cam + rr_time; the first call fixes atol2 = rtol^2 |b|^2; sets done
- * when |r| < atol (scipy's test, before the step); otherwise beta = rho/rho_prev
- * and p_c = r_c + beta p_c (p_t is updated inside the sweep).                  */
+ * when |r| < atol (scipy's test, before the step); otherwise beta = rho/rho_prev,
+ * p_c = r_c + beta p_c (p_t is updated inside the sweep) and the sweep's fixed-point scale
+ * from wmax * pmax and n_add (adds into one accumulator by one workgroup).        */
 int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, double rtol,
-                   const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
+                   const double* rr_part, int32_t n_part, double n_add, vican_cg_state_t* st,
+                   void* stream);
 /* Timestep-major Laplacian sweep: p_t <- r_t + beta p_t (skipped on the first
- * iteration), q_t = deg_t p_t - sum_c w_ct p_c (written), slabs
- * qc_part[wg][C][3] = sum_t w_ct p_t, pq_part[wg] = partial p_t.q_t.          */
+ * iteration), q_t = deg_t p_t - sum_c w_ct p_c (written), fixed-point slabs
+ * qc_part[wg][3][C] = sum_t w_ct p_t (fold with vican_slab_reduce_fx, pa = &st->qinv),
+ * pq_part[wg] = partial p_t.q_t.                                               */
 int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
                    const double* p_c, const double* r_t, double* p_t, double* q_t,
-                   double* qc_part, double* pq_part, const vican_cg_state_t* st, void* stream);
+                   void* qc_part, double* pq_part, const vican_cg_state_t* st, void* stream);
 /* *out = sum pq_part (the timestep part of p.q); `out` is normally the slot right
  * behind the reduced q_c vector so that ONE all-reduce carries both.           */
 int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out,
@@ -262,12 +275,13 @@ int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out,
 int vican_cg_cam_step(int32_t n_cam, const double* deg_c, const double* qc_sum,
                       const double* pq_time, const double* p_c, double* x_c, double* r_c,
                       vican_cg_state_t* st, void* stream);
-/* Timestep side: x_t += alpha p_t; r_t -= alpha q_t; rr_part[wg] partial r_t.r_t;
- * returns the number of partials written (>0).                                */
+/* Timestep side: x_t += alpha p_t; r_t -= alpha q_t; rr_part[blk] partial r_t.r_t and
+ * rr_part[512 + blk] partial max|r_t| (rr_part: >= 1024 doubles); returns the number of
+ * partials written (>0).                                                       */
 int vican_cg_time_step(int32_t n_time, const double* p_t, const double* q_t, double* x_t,
                        double* r_t, double* rr_part, int32_t part_cap, const vican_cg_state_t* st,
                        void* stream);
-/* st->rr_time = sum rr_part ; st->iter += 1 ; rho_prev = rho. */
+/* st->rr_time = sum rr_part ; st->rmax_time = max ; st->iter += 1 ; rho_prev = rho. */
 int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
 
 #ifdef __cplusplus

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
-SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip")]
+SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
+           os.path.join(CSRC, "vican_trans.hip")]
 HEADERS = [os.path.join(CSRC, "common.cuh")]
 FX_DOUBLES = 12
 INCLUDE = os.path.join(ROOT, "include")
@@ -34,10 +35,11 @@ class Graph(C.Structure):
     ]
 
 
-# doubles first (10), then 4 int32: 96 bytes == 12 doubles
-CG_STATE_DOUBLES = 12
-CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9)
-CG_I = dict(iter=20, done=21, first=22)     # int32 index into the same buffer viewed as int32
+# doubles first (16), then 4 int32: 144 bytes == 18 doubles
+CG_STATE_DOUBLES = 18
+CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9,
+            rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15)
+CG_I = dict(iter=32, done=33, first=34)     # int32 index into the same buffer viewed as int32
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _G = C.POINTER(Graph)
@@ -55,7 +57,7 @@ PROTOTYPES = {
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
     "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_duals_bound": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
-    "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
+    "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_init_duals": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp]),
     "vican_scaled_identity": (C.c_int, [_i32, _vp, _vp, _vp]),
@@ -70,9 +72,9 @@ PROTOTYPES = {
     "vican_chol_qr3": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp]),
     "vican_tall_combine": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vican_rows_to_cols": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp]),
-    "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _vp, _vp]),
+    "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
+    "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
+    "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_sweep": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_reduce_pq": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "vican_cg_cam_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

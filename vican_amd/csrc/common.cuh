@@ -27,8 +27,8 @@ static inline int set_err(int code, const char* fmt, const char* a = "") {
     } while (0)
 
 int vican_check_graph(const vican_graph_t* g, const char* who);   // vican_sweep.hip
-static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (12LL * n_cam + 12LL * max_rows) + 256; }
-static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows) { return (int64_t)8 * (6LL * n_cam + 6LL * max_rows + 16); }
+static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 96LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 72) + 256; }
+static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 48LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 24) + 256; }
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
@@ -168,5 +168,23 @@ __device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
                 lam[i * 3 + j] = f[0] * U[i * 3 + 0] * U[j * 3 + 0] + f[1] * U[i * 3 + 1] * U[j * 3 + 1] +
                                  f[2] * U[i * 3 + 2] * U[j * 3 + 2];
     }
+}
+
+// --- 64-bit fixed-point accumulation helpers (see vican_sweep.hip header) -----
+typedef unsigned long long u64;
+
+// double -> 64-bit fixed point (round to nearest) by the magic-number trick; |v*scale| < 2^51
+__device__ __forceinline__ u64 to_fix(double v, double scale) {
+    const double magic = 6755399441055744.0;          // 1.5 * 2^52
+    return (u64)(__double_as_longlong(fma(v, scale, magic)) - __double_as_longlong(magic));
+}
+__device__ __forceinline__ void lds_add_fix(u64* p, u64 v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add_u64
+}
+
+
+__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
+    // non-negative doubles order like their bit patterns
+    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
 }
 

@@ -53,8 +53,8 @@ extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_
 extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy) {
     const int64_t lim = vican_lds_limit_bytes(), s = ssize(storage);
     int64_t a = (lim - 256 - 9LL * n_cam * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
-    int64_t b = (lim - 256 - 96LL * n_cam) / 96;        // rhs kernel   (vican_kernels.hip)
-    int64_t c = (lim - 128 - 48LL * n_cam) / 48;        // CG sweep
+    int64_t b = (lim - 256 - 96LL * n_cam) / (24LL * n_copy + 72);   // rhs kernel (vican_trans.hip)
+    int64_t c = (lim - 256 - 48LL * n_cam) / (24LL * n_copy + 24);   // CG sweep
     int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
     return (int32_t)m;
 }
@@ -193,11 +193,6 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
 //   row sums / camera sums of a per-edge scalar, and the block-norm bounds that size
 //   the fixed-point scales.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_max_pos(double* addr, double v) {
-    // non-negative doubles order like their bit patterns
-    atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
-}
-
 template <typename S>
 __global__ void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double* __restrict__ row_out,
                                  double* __restrict__ cam_acc) {
@@ -390,17 +385,6 @@ template <> __device__ __forceinline__ float vget<float>(const float4& v, int j)
 }
 template <> __device__ __forceinline__ double vget<double>(const double2& v, int j) { return j == 0 ? v.x : v.y; }
 
-typedef unsigned long long u64;
-
-// double -> 64-bit fixed point (round to nearest) by the magic-number trick; |v*scale| < 2^51
-__device__ __forceinline__ u64 to_fix(double v, double scale) {
-    const double magic = 6755399441055744.0;          // 1.5 * 2^52
-    return (u64)(__double_as_longlong(fma(v, scale, magic)) - __double_as_longlong(magic));
-}
-__device__ __forceinline__ void lds_add_fix(u64* p, u64 v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add_u64
-}
-
 template <typename S, int EPL>
 struct ChunkRegs {
     typename Vec<S>::type m[9];
@@ -469,6 +453,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][C] planes (pre-scaled on the f32 path)
     S* wv = xs + nx;                                           // [max_rows][9] (MODE 0; pre-scaled likewise)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane_copy = tid & cmask;
+    const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
     const int part_n = ncopy < 4 ? ncopy : 4, per = ncopy / part_n;   // phase 2: part_n lanes per accumulator
 
     // The scales in fx assume |x_c|_F <= x_bound (sqrt 3).  Krylov vectors are far smaller
@@ -528,7 +513,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
-            cam[j] = pad ? (uint32_t)(tid & 31) : (cur.id[j] & 0xFFFFu);
+            cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
             row[j] = pad ? 0u : (cur.id[j] >> 16);
         }
         {
@@ -589,13 +574,13 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                              y2 = __shfl(y, (6 + ob) * part_n, 64);
                 if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0 * y0 + L1 * y1 + L2 * y2, z_scale);
             } else {
-                if (o < 9 && lane == o * part_n) ysum[r * 9 + o] = y;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // gather the 9 sums to lane 0 with wave shuffles (no LDS round trip, no fence)
+                double yy[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) yy[q] = __shfl(y, q * part_n, 64);
                 if (lane == 0) {
                     double R[9], lam[9];
-                    polar_dual3(ysum + r * 9, R, lam, 2);
+                    polar_dual3(yy, R, lam, 2);
                     double* Ro = Rt_out + (size_t)(r0 + r) * 9;
                     double* Lo = lamT_out + (size_t)(r0 + r) * 9;
                     double fro = 0.0;
@@ -614,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const bool pad = cur.id[j] == VICAN_PAD_SLOT;
-                const uint32_t camj = pad ? (uint32_t)(tid & 31) : (cur.id[j] & 0xFFFFu);
+                const uint32_t camj = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
                 const uint32_t rowj = pad ? 0u : (cur.id[j] >> 16);
                 if (rowj != prow) {
                     prow = rowj;
@@ -731,9 +716,10 @@ extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, 
     return VICAN_OK;
 }
 
-// slabs hold planes [9][C]; the output is the row-major camera vector [C][9]
+// slabs hold planes [ncomp][C]; the output is the row-major camera vector [C][ncomp]
 __global__ __launch_bounds__(256) void slab_reduce_fx_kernel(const long long* __restrict__ part, int n_slab, long long n,
-                                                             const double* __restrict__ fx, double* __restrict__ out) {
+                                                             int ncomp, double scale, const double* __restrict__ pa,
+                                                             const double* __restrict__ pb, double* __restrict__ out) {
     __shared__ long long sh[256];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
@@ -743,16 +729,17 @@ __global__ __launch_bounds__(256) void slab_reduce_fx_kernel(const long long* __
     sh[threadIdx.x] = s;
     __syncthreads();
     if (grp == 0 && i < n) {
-        const long long C = n / 9, q = i / C, cam = i % C;
-        out[cam * 9 + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * (fx[3] * fx[7]);
+        const long long C = n / ncomp, q = i / C, cam = i % C;
+        const double sc = scale * (pa ? *pa : 1.0) * (pb ? *pb : 1.0);
+        out[cam * ncomp + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * sc;
     }
 }
-extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int64_t n, const double* fx, double* out,
-                                    void* stream) {
-    if (!part || !out || !fx || n_slab <= 0 || n < 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce_fx: bad argument");
-    if (n == 0) return VICAN_OK;
+extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_t ncomp, double scale,
+                                    const double* pa, const double* pb, double* out, void* stream) {
+    if (!part || !out || n_slab <= 0 || n_cam <= 0 || ncomp <= 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce_fx: bad argument");
+    const long long n = (long long)n_cam * ncomp;
     hipLaunchKernelGGL(slab_reduce_fx_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)part, n_slab, (long long)n, fx, out);
+                       (const long long*)part, n_slab, n, ncomp, scale, pa, pb, out);
     LAUNCH_CHECK("vican_slab_reduce_fx");
     return VICAN_OK;
 }

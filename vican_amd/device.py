@@ -128,6 +128,9 @@ class LocalGraph:
             self.row_sum_w, self.cam_sum_w = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
             _lib.check(lib.vican_edge_sums(gref, _ptr(self.w), 1, _ptr(self.row_sum_w), _ptr(self.cam_sum_w), st),
                        "vican_edge_sums")
+            # bounds that size the fixed-point scales of the translation stage (host scalars, once)
+            self.wmax = float(w.max()) if self.n_edges else 1.0
+            self.gmax = float((u.norm(dim=1) + v.norm(dim=1)).max()) if self.n_edges else 1.0
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
 
     # algorithmic HBM bytes of one operator sweep (B_op)
@@ -151,8 +154,10 @@ class HipBackend:
         nwg = graph.n_wg
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
         self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
-        self.rr_part = torch.empty(512, dtype=torch.float64, device=self.dev)
-        self.ws = torch.empty(512, dtype=torch.float64, device=self.dev)
+        self.rr_part = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+        self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+        # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
+        self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
 
     # -- allocation helpers -------------------------------------------------
     def empty(self, *shape, dtype=torch.float64):
@@ -200,8 +205,9 @@ class HipBackend:
     def block_op(self, lamT_inv, x, z_out):
         """z_out[3C,3] = local slab-reduced  P x  (caller all-reduces across ranks)."""
         self.block_op_raw(lamT_inv, x)
-        self._ck(self.lib.vican_slab_reduce_fx(_ptr(self.zpart), self.g.n_wg, 9 * self.C, _ptr(self.g.fx), _ptr(z_out),
-                                               _stream()), "vican_slab_reduce_fx")
+        fxp = self.g.fx.data_ptr()
+        self._ck(self.lib.vican_slab_reduce_fx(_ptr(self.zpart), self.g.n_wg, self.C, 9, 1.0, C.c_void_p(fxp + 24),
+                                               C.c_void_p(fxp + 56), _ptr(z_out), _stream()), "vican_slab_reduce_fx")
 
     def dual_update(self, rc, Rt, lamT_inv):
         self._ck(self.lib.vican_dual_update(self._gref, _ptr(rc), _ptr(Rt), _ptr(lamT_inv), _ptr(self.g.rnorm),
@@ -245,17 +251,19 @@ class HipBackend:
     def trans_rhs(self, rc, rt, rhs_t, rhs_c):
         nwg = self.g.n_wg
         part = self.zpart[: nwg * 3 * self.C]
+        inv = C.c_double(0.0)
         self._ck(self.lib.vican_trans_rhs(self._gref, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t),
-                                          _ptr(part), _stream()), "vican_trans_rhs")
-        self._ck(self.lib.vican_slab_reduce(_ptr(part), nwg, 3 * self.C, _ptr(rhs_c), _stream()), "vican_slab_reduce")
+                                          _ptr(part), self.g.gmax, self.n_add, C.byref(inv), _stream()), "vican_trans_rhs")
+        self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(rhs_c), _stream()),
+                 "vican_slab_reduce_fx")
 
     def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
         self._ck(self.lib.vican_cg_init(self.C, self.T, _ptr(b_c), _ptr(b_t), _ptr(x_c), _ptr(x_t), _ptr(r_c), _ptr(r_t),
-                                        _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), _stream()), "vican_cg_init")
+                                        _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), self.g.wmax, _stream()), "vican_cg_init")
 
     def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),
-                                         _ptr(st), _stream()), "vican_cg_begin")
+                                         self.n_add, _ptr(st), _stream()), "vican_cg_begin")
 
     def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
         """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
@@ -263,7 +271,8 @@ class HipBackend:
         part = self.zpart[: nwg * 3 * self.C]
         self._ck(self.lib.vican_cg_sweep(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
                                          _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
-        self._ck(self.lib.vican_slab_reduce(_ptr(part), nwg, 3 * self.C, _ptr(qcpq), _stream()), "vican_slab_reduce")
+        self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, 1.0, C.c_void_p(st.data_ptr() + 8 * _lib.CG_F["qinv"]),
+                                               None, _ptr(qcpq), _stream()), "vican_slab_reduce_fx")
         self._ck(self.lib.vican_cg_reduce_pq(_ptr(self.pq_part), nwg, C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C),
                                              _ptr(st), _stream()), "vican_cg_reduce_pq")
 
