@@ -167,6 +167,18 @@ def main():
     achieved = op_bytes / (kern_ms.mean() * 1e-3) / 1e9 if len(kern_ms) else 0.0
     E_total = E_local * world
     value = E_total * args.maxiter * args.steps / elapsed
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
+    # (profiles/<tag>_sweep_counters.json, written by tools/collect_profiles.py); null if none matches
+    traffic = None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sweep_counters.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+            if pj.get("traffic") and pj.get("bytes_per_launch_algorithmic") == op_bytes:
+                traffic = pj["traffic"]["hbm_bytes"]
+                break
+        except Exception:
+            pass
     out = {
         "metric": "edges/sec through bipartite_se3sync primal-dual iter",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,7 +190,7 @@ def main():
                    "parallelism": "timestep-sharded x%d, camera side replicated" % world},
         "roofline": {"bound": "hbm", "kernel": "block_sweep_kernel<MODE=0> (vican_block_op)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)),
+                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)),
                      "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
                      "padded_slots_over_edges": g.padded_slots() / max(E_local, 1)},
         "detail": {"rot_loop_ms_per_step": t_rot / args.steps * 1e3, "cg_ms_per_step": t_tr / args.steps * 1e3,

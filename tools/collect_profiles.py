@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/profile_<tag>/ (rocprofv3 csv) into profiles/<tag>_*.{csv,json,md}."""
+import collections, csv, glob, json, os, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = "gpurun_out/profile_%s" % tag
+os.makedirs("profiles", exist_ok=True)
+OURS = ("block_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs",
+        "dual_svd", "edge_sums", "block_norms", "pack_edges", "plan_slots", "init_duals", "fx_finish", "duals_bound",
+        "scaled_identity", "rows_to_cols")
+
+def first(pat):
+    f = glob.glob(os.path.join(src, pat), recursive=True)
+    return f[0] if f else None
+
+# 1. kernel stats of the default bench command (only this project's kernels + total)
+out = []
+f = first("stats/**/*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open("profiles/%s_kernel_stats.csv" % tag, "w") as o:
+        w = csv.writer(o); w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for r in rows:
+            if any(k in r["Name"] for k in OURS):
+                w.writerow([r["Name"][:100], r["Calls"], "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (float(r["MinNs"]) / 1e3),
+                            "%.2f" % (float(r["MaxNs"]) / 1e3), "%.3f" % (float(r["TotalDurationNs"]) / 1e6)])
+    out.append("kernel stats: profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)" % tag)
+
+# 2. counters per dispatch of the dominant kernel
+def counters(sub):
+    f = first(sub + "/**/*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "block_sweep_kernel" in r["Kernel_Name"] and ", 0>" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+pm = {}
+for sub in ("fetch", "write", "sq1", "sq2"):
+    c, n = counters(sub)
+    pm.update(c)
+traffic = None
+if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+    # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly
+    # half of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE is exact.
+    traffic = dict(fetch_bytes=2.0 * pm["FETCH_SIZE"] * 1024, write_bytes=pm["WRITE_SIZE"] * 1024)
+    traffic["hbm_bytes"] = traffic["fetch_bytes"] + traffic["write_bytes"]
+bench = None
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    lines = [l for l in open(bj) if l.startswith("{")]
+    if lines:
+        bench = json.loads(lines[-1])
+        json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
+summary = dict(tag=tag, kernel="block_sweep_kernel<.,.,0> (vican_block_op)", counters_mean_per_dispatch=pm, traffic=traffic,
+               workload=bench["config"]["workload"] if bench else None,
+               bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None)
+json.dump(summary, open("profiles/%s_sweep_counters.json" % tag, "w"), indent=1)
+print("\n".join(out)); print(json.dumps(summary, indent=1)[:1500])

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (GPU box, repo root):  tools/profile_round.sh r01
+# rocprofv3 evidence for bench.py's default command: kernel-trace stats + HBM traffic counters
+# (separate --pmc passes, as MI355X_MICROARCH.md prescribes).  Output: gpurun_out/profile_<tag>/ ;
+# copy the summaries into profiles/ with tools/collect_profiles.py.
+TAG=${1:-r01}
+O=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq1 -- $B --steps 1 --warmup 0 > $O/bench_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > $O/bench_sq2.log 2>&1
+cd $GRAFT_REPO_ROOT && python bench.py > $O/bench.json 2> $O/bench.err

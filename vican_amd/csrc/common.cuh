@@ -69,7 +69,7 @@ __device__ void svd3(const double* A, double* U, double* s, double* V) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int i = 0; i < 3; ++i) { a[j][i] = A[i * 3 + j]; v[j][i] = (i == j) ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    for (int sweep = 0; sweep < 20; ++sweep) {
         bool rotated = false;
 #pragma unroll
         for (int pq = 0; pq < 3; ++pq) {
@@ -77,7 +77,9 @@ __device__ void svd3(const double* A, double* U, double* s, double* V) {
             const double al = a[p][0] * a[p][0] + a[p][1] * a[p][1] + a[p][2] * a[p][2];
             const double be = a[q][0] * a[q][0] + a[q][1] * a[q][1] + a[q][2] * a[q][2];
             const double ga = a[p][0] * a[q][0] + a[p][1] * a[q][1] + a[p][2] * a[q][2];
-            if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
+            // columns count as orthogonal at |a_p.a_q| <= 4 eps |a_p||a_q| (quadratic convergence:
+            // typically 4-6 sweeps; the old 1e-16 threshold sat below rounding noise and always ran 30)
+            if (ga != 0.0 && fabs(ga) > 8.9e-16 * sqrt(al * be)) {
                 rotated = true;
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -487,8 +487,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
 
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
-    double om_max = 0.0;
-
     ChunkRegs<S, EPL> ra, rb;
     if (k0 < k1) load_chunk<S, EPL>(ra, g, k0, tid);
     __syncthreads();
@@ -574,20 +572,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                              y2 = __shfl(y, (6 + ob) * part_n, 64);
                 if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0 * y0 + L1 * y1 + L2 * y2, z_scale);
             } else {
-                // gather the 9 sums to lane 0 with wave shuffles (no LDS round trip, no fence)
-                double yy[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) yy[q] = __shfl(y, q * part_n, 64);
-                if (lane == 0) {
-                    double R[9], lam[9];
-                    polar_dual3(yy, R, lam, 2);
-                    double* Ro = Rt_out + (size_t)(r0 + r) * 9;
-                    double* Lo = lamT_out + (size_t)(r0 + r) * 9;
-                    double fro = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) { Ro[q] = R[q]; Lo[q] = lam[q]; fro += lam[q] * lam[q]; }
-                    om_max = fmax(om_max, sqrt(fro) * rnorm[r0 + r]);
-                }
+                // Z_t goes to global memory; the per-row SVDs run afterwards in a fully parallel
+                // kernel (one thread per row) instead of serialising this streaming sweep
+                if (o < 9 && lane == o * part_n) lamT_out[(size_t)(r0 + r) * 9 + o] = y;
             }
         }
         // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
@@ -630,11 +617,28 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * nx;
         for (int i = tid; i < nx; i += BLOCK) zp[i] = zs[i];
-    } else {
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) om_max = fmax(om_max, __shfl_down(om_max, o2, 64));
-        if (lane == 0 && om_max > 0.0) atomic_max_pos(&fx[4], om_max);
     }
+}
+
+// Rt[t], lamT_inv[t] from Z_t (stored in lamT_inv by the MODE 1 sweep), in place; omega bound.
+__global__ __launch_bounds__(128) void dual_svd_kernel(int n_time, double* __restrict__ Rt, double* __restrict__ lamT_inv,
+                                                       const double* __restrict__ rnorm, double* __restrict__ fx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double om = 0.0;
+    if (t < n_time) {
+        double Z[9], R[9], lam[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Z[q] = lamT_inv[(size_t)t * 9 + q];
+        polar_dual3(Z, R, lam, 2);
+        double fro = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { Rt[(size_t)t * 9 + q] = R[q]; lamT_inv[(size_t)t * 9 + q] = lam[q]; fro += lam[q] * lam[q]; }
+        om = sqrt(fro) * rnorm[t];
+        if (!(om >= 0.0) || om > 1e300) om = 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
+    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
 }
 
 template <typename S, int BLOCK, int MODE>
@@ -687,6 +691,8 @@ extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, doub
         return set_err(VICAN_ERR_LAUNCH, "vican_dual_update: memset failed");
     if (g->n_chunk == 0) return VICAN_OK;
     if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;
+    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g->n_time, Rt,
+                       lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update");
     return VICAN_OK;
 }
