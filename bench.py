@@ -112,14 +112,15 @@ def main():
         events = []
         record = False
 
-        def block_op_raw(self, lamT_inv, x):
+        def block_op(self, lamT_inv, x, z_out):
             if not self.record:
-                return super().block_op_raw(lamT_inv, x)
+                return super().block_op(lamT_inv, x, z_out)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            super().block_op_raw(lamT_inv, x)
+            self.block_op_raw(lamT_inv, x)                 # the sweep kernel alone ...
             e1.record()
             self.events.append((e0, e1))
+            self.fold_z(z_out)                             # ... then the slab fold
 
     K = TimedBackend(g)
     comm = Comm()
@@ -196,6 +197,8 @@ def main():
         "detail": {"rot_loop_ms_per_step": t_rot / args.steps * 1e3, "cg_ms_per_step": t_tr / args.steps * 1e3,
                    "sweeps_per_step": rot.stats["sweeps"], "lanczos_steps": rot.stats["lanczos_steps"],
                    "eig_resid": rot.stats["resid"], "cg_iters": tr.info.get("cg_iters"),
+                   "lanczos_checks": rot.stats.get("n_check"), "lanczos_sync_ms": 1e3 * rot.stats.get("t_sync", 0.0),
+                   "lanczos_host_ms": 1e3 * rot.stats.get("t_host", 0.0),
                    "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
                    "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
                    "rot_edges_per_s": E_total * args.maxiter * args.steps / t_rot if t_rot else None},

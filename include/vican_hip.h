@@ -146,6 +146,9 @@ int vican_scaled_identity(int32_t n, const double* scale, double* out /*[n][9]*/
  * are formed in the storage type (f32 for f32 blocks), sums are exact integers.       */
 int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x,
                    void* zpart, double* fx, void* stream);
+/* Composite: vican_block_op + vican_slab_reduce_fx -> z [3C][3] (this rank's partial of P x). */
+int vican_block_op_z(const vican_graph_t* g, const double* lamT_inv, const double* x,
+                     void* zpart, double* fx, double* z, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,
@@ -203,6 +206,13 @@ int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const
                        double* X, void* stream);
 /* basis columns col0..col0+2 = X (row-major [n][3]) */
 int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_t col0, void* stream);
+/* Composite = the camera-side half of block-Lanczos step j as one host call: vican_lap_apply,
+ * two Gram-Schmidt passes (vican_tall_gram + vican_tall_update, coefficients summed into
+ * Hcol[3(j+1)][3]), R^T R, vican_chol_qr3 into basis block j+1 / beta / x_out.  R [3][3C],
+ * H [>= 3(j+1)*3], G [9] are scratch.                                              */
+int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
+                           const double* z, double* R, double* H, double* G, double* Hcol,
+                           double* beta, double* x_out, double pivot_floor, void* stream);
 
 /* ---- translation stage ---------------------------------------------------
  * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of
@@ -283,6 +293,17 @@ int vican_cg_time_step(int32_t n_time, const double* p_t, const double* q_t, dou
                        void* stream);
 /* st->rr_time = sum rr_part ; st->rmax_time = max ; st->iter += 1 ; rho_prev = rho. */
 int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
+/* Composites: one CG iteration as two host calls.  vican_cg_iter_local = cg_begin + cg_sweep +
+ * slab fold + reduce_pq, leaving [q_c partial | p.q partial] in qcpq[3C+1] (all-reduce it when
+ * sharded); vican_cg_iter_finish = cg_cam_step + cg_time_step (returns the number of rr partials). */
+int vican_cg_iter_local(const vican_graph_t* g, const double* w, const double* deg_t, const double* r_c,
+                        double* p_c, const double* r_t, double* p_t, double* q_t, void* qc_part,
+                        double* pq_part, double* qcpq, double rtol, const double* rr_part,
+                        int32_t n_part, double n_add, vican_cg_state_t* st, void* stream);
+int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, const double* qcpq,
+                         const double* p_c, double* x_c, double* r_c, const double* p_t,
+                         const double* q_t, double* x_t, double* r_t, double* rr_part,
+                         int32_t part_cap, vican_cg_state_t* st, void* stream);
 
 #ifdef __cplusplus
 }

@@ -234,6 +234,23 @@ class NumpyBackend:
         self._rr = float((r_t.numpy()[:T] ** 2).sum())
         return 1
 
+    # composites (same call surface as HipBackend)
+    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
+        n, ka = 3 * self.C, 3 * (j + 1)
+        self.lap_apply(lamC, V, ld, 3 * j, z, R)
+        self.tall_gram(n, V, ld, ka, R, H); self.tall_update(n, V, ld, ka, H, R, Hcol, 0)
+        self.tall_gram(n, V, ld, ka, R, H); self.tall_update(n, V, ld, ka, H, R, Hcol, 1)
+        self.tall_gram(n, R, n, 3, R, G)
+        self.chol_qr3(n, R, G, V, ld, 3 * (j + 1), beta, x_out, pivot_floor)
+
+    def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
+        self.cg_begin(r_c, p_c, rtol, st, n_rr_part)
+        self.cg_sweep(deg_t, p_c, r_t, p_t, q_t, qcpq, st)
+
+    def cg_iter_finish(self, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t, st):
+        self.cg_cam_step(deg_c, qcpq, p_c, x_c, r_c, st)
+        return self.cg_time_step(p_t, q_t, x_t, r_t, st)
+
     def cg_end(self, n_part, st):
         f, i = self._st(st)
         if i[CG_I["done"]]:

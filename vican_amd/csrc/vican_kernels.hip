@@ -219,3 +219,23 @@ extern "C" int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t
     LAUNCH_CHECK("vican_rows_to_cols");
     return VICAN_OK;
 }
+
+// ---------------------------------------------------------------------------
+// composite: the camera-side half of one block-Lanczos step as ONE host call
+// (7 launches; the host-side cost of issuing them one by one from Python was larger than the
+// kernels themselves).  z = reduced P Q_j; on return basis block j+1 and x_out (next sweep input)
+// are written, Hcol (this step's projected column, 3(j+1) x 3) and beta (3x3) recorded.
+// ---------------------------------------------------------------------------
+extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
+                                      const double* z, double* R, double* H, double* G, double* Hcol, double* beta,
+                                      double* x_out, double pivot_floor, void* stream) {
+    const int n = 3 * n_cam, ka = 3 * (j + 1);
+    int rc;
+    if ((rc = vican_lap_apply(n_cam, lamC, V, ld, 3 * j, z, R, stream)) < 0) return rc;
+    if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;
+    if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 0, stream)) < 0) return rc;
+    if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;          // second Gram-Schmidt pass
+    if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 1, stream)) < 0) return rc;
+    if ((rc = vican_tall_gram(n, R, n, 3, R, G, stream)) < 0) return rc;
+    return vican_chol_qr3(n, R, G, V, ld, 3 * (j + 1), beta, x_out, pivot_floor, stream);
+}

@@ -722,30 +722,42 @@ extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, 
     return VICAN_OK;
 }
 
-// slabs hold planes [ncomp][C]; the output is the row-major camera vector [C][ncomp]
-__global__ __launch_bounds__(256) void slab_reduce_fx_kernel(const long long* __restrict__ part, int n_slab, long long n,
-                                                             int ncomp, double scale, const double* __restrict__ pa,
-                                                             const double* __restrict__ pb, double* __restrict__ out) {
-    __shared__ long long sh[256];
+// slabs hold planes [ncomp][C]; the output is the row-major camera vector [C][ncomp].
+// 1024 threads = 64 elements x 16 slab groups (256 slabs -> 16 loads per thread in flight).
+__global__ __launch_bounds__(1024) void slab_reduce_fx_kernel(const long long* __restrict__ part, int n_slab, long long n,
+                                                              int ncomp, double scale, const double* __restrict__ pa,
+                                                              const double* __restrict__ pb, double* __restrict__ out) {
+    __shared__ long long sh[1024];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
     long long s = 0;
     if (i < n)
-        for (int k = grp; k < n_slab; k += 4) s += part[(size_t)k * n + i];
+        for (int k = grp; k < n_slab; k += 16) s += part[(size_t)k * n + i];
     sh[threadIdx.x] = s;
     __syncthreads();
     if (grp == 0 && i < n) {
+        long long t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k * 64 + e];
         const long long C = n / ncomp, q = i / C, cam = i % C;
         const double sc = scale * (pa ? *pa : 1.0) * (pb ? *pb : 1.0);
-        out[cam * ncomp + q] = (double)(sh[e] + sh[64 + e] + sh[128 + e] + sh[192 + e]) * sc;
+        out[cam * ncomp + q] = (double)t * sc;
     }
 }
 extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_t ncomp, double scale,
                                     const double* pa, const double* pb, double* out, void* stream) {
     if (!part || !out || n_slab <= 0 || n_cam <= 0 || ncomp <= 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce_fx: bad argument");
     const long long n = (long long)n_cam * ncomp;
-    hipLaunchKernelGGL(slab_reduce_fx_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(slab_reduce_fx_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
                        (const long long*)part, n_slab, n, ncomp, scale, pa, pb, out);
     LAUNCH_CHECK("vican_slab_reduce_fx");
     return VICAN_OK;
+}
+
+// composite: operator sweep + slab fold as one host call (z = local P x, row-major [3C][3])
+extern "C" int vican_block_op_z(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart,
+                                double* fx, double* z, void* stream) {
+    int rc = vican_block_op(g, lamT_inv, x, zpart, fx, stream);
+    if (rc < 0) return rc;
+    return vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 3, fx + 7, z, stream);
 }

@@ -454,3 +454,26 @@ extern "C" int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_stat
     LAUNCH_CHECK("vican_cg_end");
     return VICAN_OK;
 }
+
+// ---------------------------------------------------------------------------
+// composites: one CG iteration as two host calls (local half up to the point where a sharded
+// run all-reduces [q_c | p.q]; finishing half).  qcpq: [3C + 1] doubles.
+// ---------------------------------------------------------------------------
+extern "C" int vican_cg_iter_local(const vican_graph_t* g, const double* w, const double* deg_t, const double* r_c,
+                                   double* p_c, const double* r_t, double* p_t, double* q_t, void* qc_part,
+                                   double* pq_part, double* qcpq, double rtol, const double* rr_part, int32_t n_part,
+                                   double n_add, vican_cg_state_t* st, void* stream) {
+    int rc;
+    if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, stream)) < 0) return rc;
+    if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
+    if ((rc = vican_slab_reduce_fx(qc_part, g->n_wg, g->n_cam, 3, 1.0, &st->qinv, nullptr, qcpq, stream)) < 0) return rc;
+    return vican_cg_reduce_pq(pq_part, g->n_wg, qcpq + 3 * g->n_cam, st, stream);
+}
+extern "C" int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, const double* qcpq,
+                                    const double* p_c, double* x_c, double* r_c, const double* p_t, const double* q_t,
+                                    double* x_t, double* r_t, double* rr_part, int32_t part_cap, vican_cg_state_t* st,
+                                    void* stream) {
+    int rc = vican_cg_cam_step(n_cam, deg_c, qcpq, qcpq + 3 * n_cam, p_c, x_c, r_c, st, stream);
+    if (rc < 0) return rc;
+    return vican_cg_time_step(n_time, p_t, q_t, x_t, r_t, rr_part, part_cap, st, stream);
+}

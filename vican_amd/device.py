@@ -25,8 +25,17 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_stream_cache = {}
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream (cached per stream object: the lookup is on the
+    host critical path of every launch)."""
+    s = torch.cuda.current_stream()
+    h = _stream_cache.get(s)
+    if h is None:
+        h = _stream_cache[s] = C.c_void_p(s.cuda_stream)
+    return h
 
 
 class LocalGraph:
@@ -202,9 +211,32 @@ class HipBackend:
         self._ck(self.lib.vican_block_op(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx), _stream()),
                  "vican_block_op")
 
+    # -- composites: several launches behind one host call (the per-call Python/ctypes cost
+    #    exceeded the run time of the small camera-side kernels) ----------------------------
     def block_op(self, lamT_inv, x, z_out):
         """z_out[3C,3] = local slab-reduced  P x  (caller all-reduces across ranks)."""
-        self.block_op_raw(lamT_inv, x)
+        self._ck(self.lib.vican_block_op_z(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx),
+                                           _ptr(z_out), _stream()), "vican_block_op_z")
+
+    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
+        self._ck(self.lib.vican_lanczos_cam_step(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
+                                                 _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _stream()),
+                 "vican_lanczos_cam_step")
+
+    def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
+        part = self.zpart[: self.g.n_wg * 3 * self.C]
+        self._ck(self.lib.vican_cg_iter_local(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
+                                              _ptr(p_t), _ptr(q_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq), float(rtol),
+                                              _ptr(self.rr_part), int(n_rr_part), self.n_add, _ptr(st), _stream()),
+                 "vican_cg_iter_local")
+
+    def cg_iter_finish(self, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t, st):
+        return self._ck(self.lib.vican_cg_iter_finish(self.C, self.T, _ptr(deg_c), _ptr(qcpq), _ptr(p_c), _ptr(x_c), _ptr(r_c),
+                                                      _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
+                                                      self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_iter_finish")
+
+    def fold_z(self, z_out):
+        """Fold the fixed-point slabs of the last block_op_raw into z_out[3C,3]."""
         fxp = self.g.fx.data_ptr()
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(self.zpart), self.g.n_wg, self.C, 9, 1.0, C.c_void_p(fxp + 24),
                                                C.c_void_p(fxp + 56), _ptr(z_out), _stream()), "vican_slab_reduce_fx")

@@ -96,8 +96,13 @@ class RotationSolver:
 
     def _project(self, steps):
         """Host: assemble T = V^T L V from the recorded columns and solve it."""
+        import time as _t
+        t0 = _t.perf_counter()
         Hh = self.Hbuf[:steps].cpu().numpy().reshape(steps, -1, 3)
         Bh = self.Bbuf[:steps].cpu().numpy().reshape(steps, 3, 3)
+        t1 = _t.perf_counter()
+        self.stats["t_sync"] = self.stats.get("t_sync", 0.0) + (t1 - t0)
+        self.stats["n_check"] = self.stats.get("n_check", 0) + 1
         # a vanished pivot in beta_j means the Krylov space was exhausted at block j+1:
         # everything after it is zero padding and must not enter the projected problem
         dead = [j for j in range(steps) if np.any(np.diag(Bh[j]) == 0.0)]
@@ -115,6 +120,7 @@ class RotationSolver:
         res = np.linalg.norm(beta @ Y[ka - 3:ka, :3], axis=0)
         scale = max(abs(th[0]), abs(th[-1]), 1e-300)
         breakdown = bool(np.all(np.diag(beta) == 0.0))
+        self.stats["t_host"] = self.stats.get("t_host", 0.0) + (_t.perf_counter() - t1)
         return th, Y, res, scale, breakdown, steps
 
     def spectral(self, x0, warm=False):
@@ -132,14 +138,10 @@ class RotationSolver:
             while True:
                 j = steps
                 self.apply_P(self.xrow, self.z)
-                K.lap_apply(self.lamC, self.V, ld, 3 * j, self.z, self.R)
-                ka = 3 * (j + 1)
-                K.tall_gram(n, self.V, ld, ka, self.R, self.H)
-                K.tall_update(n, self.V, ld, ka, self.H, self.R, self.Hbuf[j], 0)
-                K.tall_gram(n, self.V, ld, ka, self.R, self.H)          # second Gram-Schmidt pass
-                K.tall_update(n, self.V, ld, ka, self.H, self.R, self.Hbuf[j], 1)
-                K.tall_gram(n, self.R, n, 3, self.R, self.G)
-                K.chol_qr3(n, self.R, self.G, self.V, ld, 3 * (j + 1), self.Bbuf[j], self.xrow, self.pivot_floor)
+                # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
+                # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
+                K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.Hbuf[j], self.Bbuf[j],
+                                   self.xrow, self.pivot_floor)
                 steps += 1
                 total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
@@ -229,12 +231,11 @@ class TranslationSolver:
         while True:
             burst = min(self.poll_every, maxiter + 1 - it_launched)
             for _ in range(burst):
-                K.cg_begin(self.r_c, self.p_c, self.rtol, st, n_part)
-                K.cg_sweep(self.deg_t, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, st)
+                K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
                 if multi:
                     comm.allreduce(self.qcpq)
-                K.cg_cam_step(self.deg_c, self.qcpq, self.p_c, self.x_c, self.r_c, st)
-                n_part = K.cg_time_step(self.p_t, self.q_t, self.x_t, self.r_t, st)
+                n_part = K.cg_iter_finish(self.deg_c, self.qcpq, self.p_c, self.x_c, self.r_c, self.p_t, self.q_t,
+                                          self.x_t, self.r_t, st)
                 if multi:
                     K.cg_end(n_part, st)
                     comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
