@@ -105,12 +105,13 @@ int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, const int32
                      int32_t* perm_ws, void* stream);
 
 /* ---- graph constants (once per graph, at pack time) ------------------------
- * row_sum[t] = sum_c val_ct (written), cam_sum[c] += sum_t val_ct (atomic; caller zeroes and
- * all-reduces across ranks).  val: [n_chunk][slots], float or double (val_is_f64).  Used for
- * d_t / camera degrees of the rotation weights a (bipgo.py:271-276) and for the degrees of
- * the translation Laplacian (weights w).                                       */
-int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double* row_sum,
-                    double* cam_sum, void* stream);
+ * row_sum[t] = sum_c val_ct, cam_sum[c] = sum_t val_ct over THIS rank's rows (caller all-reduces
+ * cam_sum across ranks).  val: [n_chunk][slots], float or double (val_is_f64); vmax >= max|val|.
+ * Sums are 64-bit fixed point relative to vmax (order-independent => reproducible);
+ * cam_ws: scratch of n_cam 8-byte words.  Used for d_t / camera degrees of the rotation weights
+ * a (bipgo.py:271-276) and for the degrees of the translation Laplacian (weights w).        */
+int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double vmax,
+                    double* row_sum, double* cam_sum, void* cam_ws, void* stream);
 
 /* Fixed-point bookkeeping.  The sweeps accumulate in 64-bit fixed point (the fastest LDS
  * atomic on gfx950, and order-independent => bit-reproducible).  `fx` is a device buffer of

@@ -77,8 +77,9 @@ def test_lds_budget(lib):
                 m = lib.vican_max_rows_for(c, storage, ncopy)
                 assert m >= 1
                 assert lib.vican_sweep_lds_bytes(c, m, storage, ncopy) <= lib.vican_lds_limit_bytes()
-    assert lib.vican_max_rows_for(1200, _lib.STORE_F64, 1) <= 0       # camera tables alone exceed 160 KiB
-    assert lib.vican_max_rows_for(1200, _lib.STORE_F32, 1) >= 1
+    assert lib.vican_max_rows_for(1025, _lib.STORE_F32, 1) <= 0       # LDS-resident camera planes: C <= 1024
+    assert lib.vican_max_rows_for(1024, _lib.STORE_F32, 32) >= 8
+    assert lib.vican_max_rows_for(1024, _lib.STORE_F64, 1) >= 1
 
 
 def test_compute_calls_fail_loudly_without_gpu():

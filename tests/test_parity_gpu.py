@@ -78,3 +78,18 @@ def test_roundtrip_property_at_scale():
     assert geodesic(G @ Rtt, gr["R_obj"].cpu().numpy()).max() < 1e-9
     pc, pgt = x_c.cpu().numpy() @ G.T, gr["p_cam"].cpu().numpy()
     assert np.abs((pc - pc.mean(0)) - (pgt - pgt.mean(0))).max() < 1e-6
+
+
+def test_solve_is_bit_reproducible():
+    """All edge-side sums are 64-bit fixed point (integer atomics) and all camera-side reductions
+    have a fixed order, so two solves of the same problem - including a fresh pack of the graph -
+    return bit-identical poses (the reference's loose CG would amplify summation-order noise)."""
+    from vican_amd.bipgo import bipartite_se3sync
+    g = load_golden("g3_medium")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g3_medium", g)
+    outs = []
+    for _ in range(3):
+        res = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+        outs.append((np.stack([p.R() for p in res.values()]), np.stack([p.t() for p in res.values()])))
+    for R, t in outs[1:]:
+        assert np.array_equal(R, outs[0][0]) and np.array_equal(t, outs[0][1])

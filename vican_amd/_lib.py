@@ -53,7 +53,7 @@ PROTOTYPES = {
     "vican_sweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_lds_limit_bytes": (_i64, []),
     "vican_max_rows_for": (_i32, [_i32, _i32, _i32]),
-    "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _vp, _vp, _vp]),
+    "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
     "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_duals_bound": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
@@ -107,7 +107,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", LIB_PATH]
+           "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *os.environ.get("VICAN_CFLAGS", "").split(), *SOURCES,
+           "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -46,13 +46,17 @@ static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32
 
 // operator sweep: x table (storage type) + z accumulators (u64) per camera; per row:
 // y sums (f64) + w (storage type) + n_copy striped u64 accumulators
+// camera planes are padded to a compile-time stride CP (256 or 1024 entries) so that the nine
+// component planes are reached with LDS immediate offsets instead of per-access address math
+static inline int64_t plane_stride(int32_t n_cam) { return n_cam <= 256 ? 256 : 1024; }
 extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy) {
-    const int64_t s = ssize(storage);
-    return 9LL * n_cam * (s + 8) + (int64_t)max_rows * (72 + 9 * s + 72LL * n_copy) + 256;
+    const int64_t s = ssize(storage), cp = plane_stride(n_cam);
+    return 9LL * cp * (s + 8) + (int64_t)max_rows * (72 + 9 * s + 72LL * n_copy) + 256;
 }
 extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy) {
     const int64_t lim = vican_lds_limit_bytes(), s = ssize(storage);
-    int64_t a = (lim - 256 - 9LL * n_cam * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
+    if (n_cam > 1024) return 0;
+    int64_t a = (lim - 256 - 9LL * plane_stride(n_cam) * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
     int64_t b = (lim - 256 - 96LL * n_cam) / (24LL * n_copy + 72);   // rhs kernel (vican_trans.hip)
     int64_t c = (lim - 256 - 48LL * n_cam) / (24LL * n_copy + 24);   // CG sweep
     int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
@@ -193,38 +197,54 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
 //   row sums / camera sums of a per-edge scalar, and the block-norm bounds that size
 //   the fixed-point scales.
 // ---------------------------------------------------------------------------
+// Deterministic (order-independent) sums: 64-bit fixed point relative to vmax >= max|val|.
 template <typename S>
-__global__ void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double* __restrict__ row_out,
-                                 double* __restrict__ cam_acc) {
-    extern __shared__ double lds[];
+__global__ void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double scale, double inv,
+                                 double* __restrict__ row_out, u64* __restrict__ cam_acc) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    u64* rows = (u64*)lds_raw;
     const int k = blockIdx.x;
     const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) lds[r] = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) rows[r] = 0ull;
     __syncthreads();
     const size_t base = (size_t)k * g.slots;
     for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
         const uint32_t id = g.idx[base + s];
         if (id == VICAN_PAD_SLOT) continue;
-        const double v = (double)val[base + s];
-        lds_add(&lds[id >> 16], v);
-        unsafeAtomicAdd(&cam_acc[id & 0xFFFFu], v);
+        const u64 f = to_fix((double)val[base + s], scale);
+        lds_add_fix(&rows[id >> 16], f);
+        atomicAdd(&cam_acc[id & 0xFFFFu], f);
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) row_out[r0 + r] = lds[r];
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) row_out[r0 + r] = (double)(long long)rows[r] * inv;
+}
+__global__ void fix_to_double_kernel(int n, const u64* __restrict__ in, double inv, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)(long long)in[i] * inv;
 }
 
-extern "C" int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double* row_sum,
-                               double* cam_sum, void* stream) {
+extern "C" int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64, double vmax, double* row_sum,
+                               double* cam_sum, void* cam_ws, void* stream) {
     if (int rc = vican_check_graph(g, "vican_edge_sums")) return rc;
-    if (!val || !row_sum || !cam_sum) return set_err(VICAN_ERR_ARG, "vican_edge_sums: null pointer");
-    if (g->n_chunk == 0) return VICAN_OK;
-    const size_t lds = (size_t)g->max_rows * 8;
-    if (val_is_f64)
-        hipLaunchKernelGGL(edge_sums_kernel<double>, dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream, *g,
-                           (const double*)val, row_sum, cam_sum);
-    else
-        hipLaunchKernelGGL(edge_sums_kernel<float>, dim3(g->n_chunk), dim3(256), lds, (hipStream_t)stream, *g,
-                           (const float*)val, row_sum, cam_sum);
+    if (!val || !row_sum || !cam_sum || !cam_ws || !(vmax >= 0)) return set_err(VICAN_ERR_ARG, "vican_edge_sums: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(cam_ws, 0, (size_t)g->n_cam * 8, st) != hipSuccess) return set_err(VICAN_ERR_LAUNCH, "vican_edge_sums: memset failed");
+    // one value <= 2^44 so that a camera may collect up to 2^17 rows... bounded by n_time adds
+    double c = vmax > 1e-300 ? vmax : 1e-300;
+    int e = 47 - (int)ceil(log2(c));
+    const int e2 = 61 - (int)ceil(log2(c * (g->n_time > 1 ? (double)g->n_time : 1.0)));
+    if (e2 < e) e = e2;
+    const double scale = ldexp(1.0, e), inv = ldexp(1.0, -e);
+    if (g->n_chunk > 0) {
+        const size_t lds = (size_t)g->max_rows * 8;
+        if (val_is_f64)
+            hipLaunchKernelGGL(edge_sums_kernel<double>, dim3(g->n_chunk), dim3(256), lds, st, *g, (const double*)val, scale, inv,
+                               row_sum, (u64*)cam_ws);
+        else
+            hipLaunchKernelGGL(edge_sums_kernel<float>, dim3(g->n_chunk), dim3(256), lds, st, *g, (const float*)val, scale, inv,
+                               row_sum, (u64*)cam_ws);
+    }
+    hipLaunchKernelGGL(fix_to_double_kernel, dim3((g->n_cam + 255) / 256), dim3(256), 0, st, g->n_cam, (const u64*)cam_ws, inv, cam_sum);
     LAUNCH_CHECK("vican_edge_sums");
     return VICAN_OK;
 }
@@ -434,7 +454,7 @@ template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) 
 // Per chunk:  [phase 3 of the previous chunk | phase 1]  barrier  [phase 2: one wavefront per
 // row, no workgroup barrier inside]  barrier  ...   - two barriers per chunk; the register
 // set of the next chunk is loaded while the current one is processed (ping-pong, no copies).
-template <typename S, int BLOCK, int MODE>
+template <typename S, int BLOCK, int MODE, int CP>
 __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, const double* __restrict__ lamT_inv,
                                                             const double* __restrict__ x,
                                                             u64* __restrict__ zpart,
@@ -445,12 +465,12 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int C = g.n_cam, nx = 9 * C, ncopy = g.n_copy, cmask = ncopy - 1;
+    const int C = g.n_cam, nx = 9 * CP, ncopy = g.n_copy, cmask = ncopy - 1;
     // 8-byte arrays first, then the storage-type tables
-    u64* zs = (u64*)lds_raw;                                   // [9][C] planes (MODE 0)
+    u64* zs = (u64*)lds_raw;                                   // [9][CP] planes (MODE 0)
     double* ysum = (double*)(zs + (MODE == 0 ? nx : 0));       // [max_rows][9] (MODE 1)
     u64* ys = (u64*)(ysum + 9 * g.max_rows);                   // [max_rows*9][ncopy]
-    S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][C] planes (pre-scaled on the f32 path)
+    S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][CP] planes
     S* wv = xs + nx;                                           // [max_rows][9] (MODE 0; pre-scaled likewise)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane_copy = tid & cmask;
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
@@ -482,7 +502,8 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     __syncthreads();
 
-    for (int i = tid; i < nx; i += BLOCK) { xs[(i % 9) * C + i / 9] = pre_scale<S>(x[i], y_scale); if (MODE == 0) zs[i] = 0ull; }
+    for (int i = tid; i < 9 * C; i += BLOCK) xs[(i % 9) * CP + i / 9] = pre_scale<S>(x[i], y_scale);
+    if (MODE == 0) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
     for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
 
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
@@ -507,6 +528,15 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
         //      blocks and are processed like edges of (row 0, camera lane%32): no branches; the
         //      x gather of edge j+1 is in flight while edge j is multiplied.
+#if defined(VICAN_ABLATE) && VICAN_ABLATE == 3      /* loads only: pure streaming rate of this access pattern */
+        {
+            float keep = 0.f;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
+            if (keep == 123.456f && cur.id[0] == 77u) zs[0] = 1ull;
+            return;
+        }
+#endif
         uint32_t cam[EPL], row[EPL];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -517,12 +547,12 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
         {
             S acc[9], xc[9], xn[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) xc[q] = xs[q * C + cam[0]];
+            for (int q = 0; q < 9; ++q) xc[q] = xs[q * CP + cam[0]];
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 if (j + 1 < EPL) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) xn[q] = xs[q * C + cam[j + 1]];
+                    for (int q = 0; q < 9; ++q) xn[q] = xs[q * CP + cam[j + 1]];
                 }
                 const bool cont = j > 0 && row[j] == row[j - 1];
 #pragma unroll
@@ -600,7 +630,13 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                     for (int b = 0; b < 3; ++b) {
                         const S v = vget<S>(cur.m[i * 3 + 0], j) * w[b] + vget<S>(cur.m[i * 3 + 1], j) * w[3 + b] +
                                     vget<S>(cur.m[i * 3 + 2], j) * w[6 + b];
-                        lds_add_fix(&zc[(i * 3 + b) * C], fix_of<S>(v, z_scale));
+#if defined(VICAN_ABLATE) && VICAN_ABLATE == 1      /* no phase-3 atomics */
+                        asm volatile("" :: "v"(v));
+#elif defined(VICAN_ABLATE) && VICAN_ABLATE == 2    /* phase-3 atomics without the products */
+                        lds_add_fix(&zc[(i * 3 + b) * CP], (u64)(camj + i));
+#else
+                        lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
+#endif
                     }
             }
         }
@@ -615,8 +651,8 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     }
     if (MODE == 0) {
         __syncthreads();
-        u64* zp = zpart + (size_t)blockIdx.x * nx;
-        for (int i = tid; i < nx; i += BLOCK) zp[i] = zs[i];
+        u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
+        for (int i = tid; i < 9 * C; i += BLOCK) zp[i] = zs[(i / C) * CP + i % C];
     }
 }
 
@@ -641,11 +677,11 @@ __global__ __launch_bounds__(128) void dual_svd_kernel(int n_time, double* __res
     if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
 }
 
-template <typename S, int BLOCK, int MODE>
-static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+template <typename S, int BLOCK, int MODE, int CP>
+static int launch_sweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
                         double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
     const size_t lds = (size_t)vican_sweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy);
-    auto kern = block_sweep_kernel<S, BLOCK, MODE>;
+    auto kern = block_sweep_kernel<S, BLOCK, MODE, CP>;
     static size_t configured = 0;       // per instantiation
     if (lds > configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -654,6 +690,13 @@ static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const do
     }
     hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
     return 0;
+}
+
+template <typename S, int BLOCK, int MODE>
+static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+                        double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
+    if (g->n_cam <= 256) return launch_sweep1<S, BLOCK, MODE, 256>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
+    return launch_sweep1<S, BLOCK, MODE, 1024>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
 }
 
 template <int MODE>

@@ -130,15 +130,17 @@ class LocalGraph:
         f64 = dict(dtype=torch.float64, device=dev)
         self.row_sum_a, self.cam_sum_a = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
         self.rnorm, self.fx = torch.zeros(T1, **f64), torch.zeros(_lib.FX_DOUBLES, **f64)
-        _lib.check(lib.vican_edge_sums(gref, _ptr(self.a), int(storage == _lib.STORE_F64), _ptr(self.row_sum_a),
-                                       _ptr(self.cam_sum_a), st), "vican_edge_sums")
+        cam_ws = torch.empty(self.n_cam, dtype=torch.int64, device=dev)
+        amax_a = float(a.abs().max()) if self.n_edges else 1.0
+        _lib.check(lib.vican_edge_sums(gref, _ptr(self.a), int(storage == _lib.STORE_F64), amax_a, _ptr(self.row_sum_a),
+                                       _ptr(self.cam_sum_a), _ptr(cam_ws), st), "vican_edge_sums")
         _lib.check(lib.vican_block_norms(gref, _ptr(self.rnorm), _ptr(self.fx), st), "vican_block_norms")
         if have_t:
             self.row_sum_w, self.cam_sum_w = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
-            _lib.check(lib.vican_edge_sums(gref, _ptr(self.w), 1, _ptr(self.row_sum_w), _ptr(self.cam_sum_w), st),
-                       "vican_edge_sums")
             # bounds that size the fixed-point scales of the translation stage (host scalars, once)
             self.wmax = float(w.max()) if self.n_edges else 1.0
+            _lib.check(lib.vican_edge_sums(gref, _ptr(self.w), 1, self.wmax, _ptr(self.row_sum_w), _ptr(self.cam_sum_w),
+                                           _ptr(cam_ws), st), "vican_edge_sums")
             self.gmax = float((u.norm(dim=1) + v.norm(dim=1)).max()) if self.n_edges else 1.0
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
 
