@@ -306,6 +306,33 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
                          const double* q_t, double* x_t, double* r_t, double* rr_part,
                          int32_t part_cap, vican_cg_state_t* st, void* stream);
 
+/* ---- LSQR translation solve (lsqr_solver="direct", bipgo.py:479-480) -------------------
+ * scipy.sparse.linalg.lsqr on the incidence matrix is reproduced on the MERGED system
+ *   J~ p = b~ :  s_e (p_t - p_c) = g_e / s_e,  s_e = sqrt(w_e),  g_e = Rc_c^T u_e + Rt_t^T v_e
+ * (same normal equations => same iterates; residual norms differ by the constant
+ * |b|^2 - |b~|^2, added back by the host driver).  The Golub-Kahan scalars stay on the host.
+ * u: per-edge 3-vectors in slot order [n_chunk][3][slots]; part: >= max(n_wg, 1024) doubles of
+ * scratch; the *_out scalars are single device doubles (all-reduce them when sharded).        */
+/* u <- b~ (unnormalised);  *nrm2_out = |u|^2 over this rank's edges */
+int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
+                      const double* rc, const double* rt, double* u, double* part, double* nrm2_out,
+                      void* stream);
+/* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
+int vican_lsqr_u_step(const vican_graph_t* g, const double* w, const double* v_c, const double* v_t,
+                      double coef, double* u, double* part, double* nrm2_out, void* stream);
+/* v_t <- sum_c s u inv_beta - beta v_t (in place), *nrm2_t_out = |v_t|^2; camera side as
+ * fixed-point slabs vc_part[n_wg][3][C] of -sum_t s u inv_beta (fold with
+ * vican_slab_reduce_fx, scale = *inv_out, then vican_lsqr_cam_v).  smax >= max sqrt(w_e).      */
+int vican_lsqr_v_step(const vican_graph_t* g, const double* w, const double* u, double inv_beta,
+                      double beta, double* v_t, void* vc_part, double* part, double* nrm2_t_out,
+                      double smax, double n_add, double* inv_out, void* stream);
+/* v_c <- acc - beta v_c ; *nrm2_out = |v_c|^2 */
+int vican_lsqr_cam_v(int32_t n_cam, const double* acc, double beta, double* v_c, double* nrm2_out,
+                     void* stream);
+/* v *= inv_alfa ; x += t1 w ; w <- v + t2 w ; *nrm2_w_out = |w_new|^2   (vectors of length n) */
+int vican_lsqr_update(int64_t n, double inv_alfa, double t1, double t2, double* v, double* w,
+                      double* x, double* part, double* nrm2_w_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

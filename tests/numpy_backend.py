@@ -234,6 +234,41 @@ class NumpyBackend:
         self._rr = float((r_t.numpy()[:T] ** 2).sum())
         return 1
 
+    # LSQR on the merged system  s_e (p_t - p_c) = g_e / s_e   (vican_lsqr.hip)
+    def lsqr_init_u(self, rc, rt, nrm2_out):
+        A = rc.numpy().reshape(self.C, 3, 3)[self.col]
+        B = rt.numpy().reshape(-1, 3, 3)[self.row]
+        g = np.einsum("eji,ej->ei", A, self.u) + np.einsum("eji,ej->ei", B, self.v)
+        self._lu = g / np.sqrt(self.w)[:, None]
+        nrm2_out.numpy()[0] = float((self._lu ** 2).sum())
+
+    def lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
+        s = np.sqrt(self.w)[:, None]
+        self._lu = s * (v_t.numpy()[self.row] - v_c.numpy()[self.col]) - coef * self._lu
+        nrm2_out.numpy()[0] = float((self._lu ** 2).sum())
+
+    def lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
+        a = np.sqrt(self.w)[:, None] * self._lu * inv_beta
+        rows = np.zeros((max(self.T, 1), 3)); np.add.at(rows, self.row, a)
+        cams = np.zeros((self.C, 3)); np.add.at(cams, self.col, -a)
+        vt = v_t.numpy()
+        vt[:] = rows - beta * vt
+        acc_c.numpy()[:] = cams.reshape(-1)
+        nrm2_t_out.numpy()[0] = float((vt[: self.T] ** 2).sum())
+
+    def lsqr_cam_v(self, acc_c, beta, v_c, nrm2_out):
+        vc = v_c.numpy()
+        vc[:] = acc_c.numpy().reshape(self.C, 3) - beta * vc
+        nrm2_out.numpy()[0] = float((vc ** 2).sum())
+
+    def lsqr_update(self, inv_alfa, t1, t2, v, w, x, nrm2_w_out):
+        vn, wn, xn = v.numpy(), w.numpy(), x.numpy()
+        vn *= inv_alfa
+        xn += t1 * wn
+        wn[:] = vn + t2 * wn
+        rows = self.T if vn.shape[0] != self.C else self.C
+        nrm2_w_out.numpy()[0] = float((wn[:rows] ** 2).sum())
+
     # composites (same call surface as HipBackend)
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
         n, ka = 3 * self.C, 3 * (j + 1)

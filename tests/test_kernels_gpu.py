@@ -186,3 +186,23 @@ def test_translation_kernels_and_cg(cfg):
     assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
     # translations from x0 = 0 stay in the range of the Laplacian: node sum is zero
     assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4]])
+def test_lsqr_kernels(cfg):
+    """LSQR translation solve: HIP kernels vs the NumPy restatement, same host driver."""
+    from vican_amd.solver import Comm, LsqrTranslationSolver
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 300 + C, np.float64, bt, nwg, False)
+    rng = np.random.default_rng(3)
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    rt = synth.random_rotations(rng, T).reshape(T, 9)
+    outs = []
+    for K in (H, N):
+        ls = LsqrTranslationSolver(K, Comm(), atol=1e-10, btol=1e-10)
+        x_c, x_t = ls.solve(K.from_numpy(rc), K.from_numpy(rt), 3 * (C + T))
+        outs.append((x_c.cpu().numpy(), x_t.cpu().numpy(), ls.info))
+    (xc_h, xt_h, ih), (xc_n, xt_n, inn) = outs
+    assert ih["istop"] == inn["istop"] and abs(ih["lsqr_iters"] - inn["lsqr_iters"]) <= max(1, inn["lsqr_iters"] // 20)
+    scale = max(np.abs(xt_n).max(), 1.0)
+    assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale

@@ -93,3 +93,22 @@ def test_solve_is_bit_reproducible():
         outs.append((np.stack([p.R() for p in res.values()]), np.stack([p.t() for p in res.values()])))
     for R, t in outs[1:]:
         assert np.array_equal(R, outs[0][0]) and np.array_equal(t, outs[0][1])
+
+
+LSQR_RUNS = [(n, d) for n, c in gc.CASES.items() for (s, d) in c["runs"] if s == "direct"]
+
+
+@pytest.mark.parametrize("name,dt", LSQR_RUNS)
+def test_dropin_direct_lsqr_matches_reference(name, dt):
+    """lsqr_solver="direct" (scipy LSQR in the reference, bipgo.py:479-480) through the HIP LSQR kernels."""
+    from vican.bipgo import bipartite_se3sync
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "direct", dt)
+    info = {}
+    res = bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff,
+                            maxiter=gc.MAXITER, lsqr_solver="direct", dtype=np.dtype(dt).type, info=info)
+    rot, tr = pose_errors(res, exp)
+    assert rot < ROT_TOL[dt]
+    assert tr < (2e-6 if dt == "float64" else 5e-4), tr
+    assert info["lsqr_istop"] in (1, 2) and info["lsqr_iters"] > 0

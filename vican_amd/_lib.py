@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
-           os.path.join(CSRC, "vican_trans.hip")]
+           os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip")]
 HEADERS = [os.path.join(CSRC, "common.cuh")]
 FX_DOUBLES = 12
 INCLUDE = os.path.join(ROOT, "include")
@@ -84,6 +84,11 @@ PROTOTYPES = {
     "vican_cg_cam_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_time_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vican_cg_end": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
+    "vican_lsqr_cam_v": (C.c_int, [_i32, _vp, _f64, _vp, _vp, _vp]),
+    "vican_lsqr_update": (C.c_int, [_i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -26,7 +26,7 @@ import torch
 from . import frontend
 from ._lib import VicanError
 from .geometry import SE3
-from .solver import Comm, RotationSolver, TranslationSolver
+from .solver import Comm, LsqrTranslationSolver, RotationSolver, TranslationSolver
 
 __all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "solve_problem"]
 
@@ -41,11 +41,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
     from .device import HipBackend, LocalGraph      # needs the GPU + extension
 
-    if lsqr_solver == "direct":
-        raise NotImplementedError(
-            "lsqr_solver='direct' (scipy LSQR, bipgo.py:479-480) is not implemented on the GPU yet; "
-            "use 'conjugate_gradient'")
-    if lsqr_solver != "conjugate_gradient":
+    if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
         raise UnboundLocalError("local variable 't_est' referenced before assignment")
     if not torch.cuda.is_available():
@@ -66,29 +62,37 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     rc, Rt_loc = rot.run(maxiter)
     K.synchronize()
     t2 = time.perf_counter()
-    tr = TranslationSolver(K, comm)
-    tr.setup(rc, Rt_loc)
-    x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+    nloc = r1 - r0
+
+    def gather_rows(loc, width):          # zero-filled full array + sum: simple, T x width doubles
+        if comm.world == 1:
+            return loc[:nloc]
+        full = torch.zeros(T, width, dtype=torch.float64, device=dev)
+        full[r0:r1] = loc[:nloc]
+        return comm.allreduce(full)
+
+    Rt_all = gather_rows(Rt_loc, 9)
+    if lsqr_solver == "direct":                                          # bipgo.py:479-480
+        Rc_h = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()
+        Rt_h = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()
+        tr = LsqrTranslationSolver(K, comm)
+        x_c, x_t = tr.solve(rc, Rt_loc, 3 * (prob.n_cam + T), frontend.bnorm2(prob, Rc_h, Rt_h))
+    else:                                                                # bipgo.py:476-478
+        tr = TranslationSolver(K, comm)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+        if not tr.info["converged"]:
+            raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
     K.synchronize()
     t3 = time.perf_counter()
-    if not tr.info["converged"]:
-        raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
-    # gather timestep results (zero-filled full arrays + sum: simple and only T x 12 doubles)
-    nloc = r1 - r0
-    if comm.world > 1:
-        full = torch.zeros(T, 12, dtype=torch.float64, device=dev)
-        full[r0:r1, :9] = Rt_loc[:nloc]
-        full[r0:r1, 9:] = x_t[:nloc]
-        comm.allreduce(full)
-        Rt_all, xt_all = full[:, :9], full[:, 9:]
-    else:
-        Rt_all, xt_all = Rt_loc[:nloc], x_t[:nloc]
+    xt_all = gather_rows(x_t, 3)
     Rc = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()          # bipgo.py:346
     Rt = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()                # bipgo.py:348
     if info is not None:
         info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
                     eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
-                    cg_iters=tr.info["cg_iters"], cg_relres=tr.info["relres"], n_cam=prob.n_cam, n_time=T,
+                    cg_iters=tr.info.get("cg_iters"), cg_relres=tr.info.get("relres"), lsqr_iters=tr.info.get("lsqr_iters"),
+                    lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T,
                     n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=g.n_chunk, n_wg=g.n_wg,
                     t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world)
     return Rc, Rt, x_c.cpu().numpy(), xt_all.cpu().numpy()
@@ -115,9 +119,9 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
         out[n] = SE3(R=np.ascontiguousarray(rot[n]).astype(dtype), t=pos[n].copy())
     if verbose:
         print("vican_amd: %d cameras, %d timesteps, %d merged edges | flatten %.3fs pack %.3fs rot %.3fs "
-              "(lanczos steps %s) trans %.3fs (cg %d it)" % (
+              "(lanczos steps %s) trans %.3fs (%s it)" % (
                   prob.n_cam, prob.n_time, prob.n_edges, t1 - t0, local["t_pack"], local["t_rot"],
-                  local["lanczos_steps"], local["t_trans"], local["cg_iters"]))
+                  local["lanczos_steps"], local["t_trans"], local.get("cg_iters") or local.get("lsqr_iters")))
     return out
 
 

@@ -320,3 +320,50 @@ class HipBackend:
 
     def cg_end(self, n_part, st):
         self._ck(self.lib.vican_cg_end(_ptr(self.rr_part), int(n_part), _ptr(st), _stream()), "vican_cg_end")
+
+
+# -- LSQR ("direct") wrappers, attached to HipBackend ------------------------------------------
+def _lsqr_alloc(self):
+    if not hasattr(self, "_lsqr_u"):
+        nslot = max(1, self.g.n_chunk) * self.g.slots
+        self._lsqr_u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
+        self._lsqr_part = torch.zeros(max(self.g.n_wg, 1024), dtype=torch.float64, device=self.dev)
+
+
+def _lsqr_init_u(self, rc, rt, nrm2_out):
+    _lsqr_alloc(self)
+    self._ck(self.lib.vican_lsqr_init_u(self._gref, _ptr(self.g.w), _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt),
+                                        _ptr(self._lsqr_u), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_init_u")
+
+
+def _lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
+    self._ck(self.lib.vican_lsqr_u_step(self._gref, _ptr(self.g.w), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
+                                        _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
+
+
+def _lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
+    """v_t updated in place; acc_c[3C] = this rank's camera-side sums (all-reduce, then lsqr_cam_v)."""
+    nwg = self.g.n_wg
+    part = self.zpart[: nwg * 3 * self.C]
+    inv = C.c_double(0.0)
+    self._ck(self.lib.vican_lsqr_v_step(self._gref, _ptr(self.g.w), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
+                                        _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self.n_add,
+                                        C.byref(inv), _stream()), "vican_lsqr_v_step")
+    self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
+             "vican_slab_reduce_fx")
+
+
+def _lsqr_cam_v(self, acc_c, beta, v_c, nrm2_out):
+    self._ck(self.lib.vican_lsqr_cam_v(self.C, _ptr(acc_c), float(beta), _ptr(v_c), _ptr(nrm2_out), _stream()), "vican_lsqr_cam_v")
+
+
+def _lsqr_update(self, inv_alfa, t1, t2, v, w, x, nrm2_w_out):
+    self._ck(self.lib.vican_lsqr_update(v.numel(), float(inv_alfa), float(t1), float(t2), _ptr(v), _ptr(w), _ptr(x),
+                                        _ptr(self._lsqr_part), _ptr(nrm2_w_out), _stream()), "vican_lsqr_update")
+
+
+HipBackend.lsqr_init_u = _lsqr_init_u
+HipBackend.lsqr_u_step = _lsqr_u_step
+HipBackend.lsqr_v_step = _lsqr_v_step
+HipBackend.lsqr_cam_v = _lsqr_cam_v
+HipBackend.lsqr_update = _lsqr_update

@@ -14,7 +14,8 @@ import numpy as np
 class Problem:
     """Flattened, merged problem (all float64 on the host)."""
     __slots__ = ("cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "root",
-                 "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v")
+                 "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v",
+                 "src_cam", "src_time", "src_t", "src_qtau", "src_kt")
 
     @property
     def n_cam(self):
@@ -100,7 +101,17 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     kk = (kf * kt)[:, None]
     p.u = seg(kk * t)
     p.v = seg(kk * qtau[mk_idx])
+    # per-source-edge data of the un-merged right-hand side b (bipgo.py:451-461); only its norm is
+    # needed (LSQR stopping tests), see bnorm2()
+    p.src_cam, p.src_time, p.src_t, p.src_qtau, p.src_kt = ci, ti, t, qtau[mk_idx], kt
     return p
+
+
+def bnorm2(prob: Problem, Rc: np.ndarray, Rt: np.ndarray) -> float:
+    """|b|^2 of the reference's stacked measurement vector (bipgo.py:454-461) for world<-node
+    rotations Rc [C,3,3], Rt [T,3,3]:  b_e = k_t (R_c t~_e + R_t R_root^T R_m tau_m)."""
+    be = np.einsum("eij,ej->ei", Rc[prob.src_cam], prob.src_t) + np.einsum("eij,ej->ei", Rt[prob.src_time], prob.src_qtau)
+    return float(np.sum((prob.src_kt[:, None] * be) ** 2))
 
 
 def invert_object_edges(src_edges):

@@ -262,16 +262,156 @@ class TranslationSolver:
         return self.x_c, self.x_t
 
 
-def solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol=1e-10, rtol=1e-5):
+def solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol=1e-10, rtol=1e-5, lsqr_solver="conjugate_gradient",
+                     bnorm2_fn=None):
     """Rotation stage then translation stage on one rank's backend ``K``.
-    Returns (rc [3C,3] node<-world stacked, Rt_local [T,9], x_c [C,3], x_t [T,3], stats)."""
+    Returns (rc [3C,3] node<-world stacked, Rt_local [T,9], x_c [C,3], x_t [T,3], stats).
+    ``bnorm2_fn(rc, Rt_local) -> |b|^2`` of the reference's un-merged system (LSQR stopping tests)."""
     rot = RotationSolver(K, comm, eig_tol=eig_tol)
     rc, Rt_loc = rot.run(maxiter)
     K.synchronize()
-    tr = TranslationSolver(K, comm, rtol=rtol)
-    tr.setup(rc, Rt_loc)
-    x_c, x_t = tr.solve(n_unknowns_total)
+    if lsqr_solver == "direct":
+        tr = LsqrTranslationSolver(K, comm)
+        x_c, x_t = tr.solve(rc, Rt_loc, n_unknowns_total, None if bnorm2_fn is None else bnorm2_fn(rc, Rt_loc))
+    else:
+        tr = TranslationSolver(K, comm, rtol=rtol)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(n_unknowns_total)
     K.synchronize()
     stats = dict(rot.stats)
     stats.update(tr.info)
     return rc, Rt_loc, x_c, x_t, stats
+
+
+def _sym_ortho(a, b):
+    """Stable Givens rotation (c, s, r) with c*a + s*b = r (Paige & Saunders' SymOrtho)."""
+    if b == 0:
+        return np.sign(a), 0.0, abs(a)
+    if a == 0:
+        return 0.0, np.sign(b), abs(b)
+    if abs(b) > abs(a):
+        tau = a / b
+        s = np.sign(b) / np.sqrt(1 + tau * tau)
+        return s * tau, s, b / s
+    tau = b / a
+    c = np.sign(a) / np.sqrt(1 + tau * tau)
+    return c, c * tau, a / c
+
+
+class LsqrTranslationSolver:
+    """LSQR (Paige & Saunders 1982) with scipy.sparse.linalg.lsqr's defaults and stopping tests
+    (atol = btol = 1e-6, conlim = 1e8, iter_lim = 2n, damp = 0) - the reference's
+    ``lsqr_solver="direct"`` path (bipgo.py:479-480).
+
+    The O(E) vector work runs on the device on the MERGED system J~ p = b~ (see
+    csrc/vican_lsqr.hip); it has the same normal equations as the reference's 3E' x 3N system,
+    hence the same iterates, while every residual norm differs by the constant
+    c^2 = |b|^2 - |b~|^2, which ``bnorm2_true`` lets this driver add back so that the stopping
+    iteration is the reference's.  The Golub-Kahan / QR scalars are host doubles (two tiny
+    device->host reads per iteration)."""
+
+    def __init__(self, K, comm=None, atol=1e-6, btol=1e-6, conlim=1e8):
+        self.K, self.comm = K, comm or Comm()
+        self.atol, self.btol, self.conlim = atol, btol, conlim
+        C, T = K.C, max(K.T, 1)
+        self.v_c, self.w_c, self.x_c = K.zeros(C, 3), K.zeros(C, 3), K.zeros(C, 3)
+        self.v_t, self.w_t, self.x_t = K.zeros(T, 3), K.zeros(T, 3), K.zeros(T, 3)
+        self.acc = K.zeros(3 * C + 1)          # [camera sums | partial |v_t|^2]  (one all-reduce)
+        self.s2 = K.zeros(4)                   # scalar slots: |u|^2, |w_t|^2, |v_c|^2, |w_c|^2
+        self.info = {}
+
+    def _get(self, t):
+        return t.cpu().numpy().copy()
+
+    def solve(self, rc, rt, n_unknowns_total, bnorm2_true=None, iter_lim=None):
+        K, comm = self.K, self.comm
+        multi = comm.world > 1
+        eps = np.finfo(np.float64).eps
+        for t in (self.v_c, self.w_c, self.x_c, self.v_t, self.w_t, self.x_t):
+            t.zero_()
+        iter_lim = 2 * n_unknowns_total if iter_lim is None else iter_lim
+        ctol = 1.0 / self.conlim if self.conlim > 0 else 0.0
+        # u1 = b~ / beta1
+        K.lsqr_init_u(rc, rt, self.s2[0:1])
+        if multi:
+            comm.allreduce(self.s2[0:1])
+        beta = float(np.sqrt(self._get(self.s2)[0]))
+        c2 = 0.0 if bnorm2_true is None else max(bnorm2_true - beta * beta, 0.0)
+        bnorm = np.sqrt(beta * beta + c2)
+        alfa = 0.0
+        if beta > 0:
+            K.lsqr_v_step(1.0 / beta, 0.0, self.v_t, self.acc[: 3 * K.C], self.acc[3 * K.C:])
+            if multi:
+                comm.allreduce(self.acc)
+            K.lsqr_cam_v(self.acc[: 3 * K.C], 0.0, self.v_c, self.s2[2:3])
+            alfa = float(np.sqrt(self._get(self.s2)[2] + self._get(self.acc)[3 * K.C]))
+        self.info = dict(lsqr_iters=0, istop=0, converged=True)
+        if alfa * beta == 0.0:
+            return self.x_c, self.x_t
+        # v1 = v/alfa, w1 = v1, x = 0
+        K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_c, self.w_c, self.x_c, self.s2[3:4])
+        K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_t, self.w_t, self.x_t, self.s2[1:2])
+        rhobar, phibar = alfa, beta
+        anorm = acond = ddnorm = xnorm = xxnorm = z = 0.0
+        cs2, sn2 = -1.0, 0.0
+        beta_prev = beta
+        itn, istop = 0, 0
+        while itn < iter_lim:
+            itn += 1
+            # bidiagonalisation: beta u = J~ v - alfa u ; alfa v = J~^T u - beta v
+            K.lsqr_u_step(self.v_c, self.v_t, alfa / beta_prev, self.s2[0:1])
+            if multi:
+                comm.allreduce(self.s2[0:2])                   # |u|^2 and the pending |w_t|^2
+            h = self._get(self.s2)
+            beta = float(np.sqrt(h[0]))
+            wnorm2 = float(h[1] + h[3])                        # |w_k|^2 of the CURRENT direction
+            if beta > 0:
+                anorm = np.sqrt(anorm * anorm + alfa * alfa + beta * beta)
+                K.lsqr_v_step(1.0 / beta, beta, self.v_t, self.acc[: 3 * K.C], self.acc[3 * K.C:])
+                if multi:
+                    comm.allreduce(self.acc)
+                K.lsqr_cam_v(self.acc[: 3 * K.C], beta, self.v_c, self.s2[2:3])
+                alfa = float(np.sqrt(self._get(self.s2)[2] + self._get(self.acc)[3 * K.C]))
+            # QR of the bidiagonal matrix, solution update coefficients
+            cs, sn, rho = _sym_ortho(rhobar, beta)
+            theta = sn * alfa
+            rhobar = -cs * alfa
+            phi = cs * phibar
+            phibar = sn * phibar
+            tau = sn * phi
+            t1, t2 = phi / rho, -theta / rho
+            ddnorm += wnorm2 / (rho * rho)
+            inv_alfa = 1.0 / alfa if alfa > 0 else 1.0
+            K.lsqr_update(inv_alfa, t1, t2, self.v_c, self.w_c, self.x_c, self.s2[3:4])
+            K.lsqr_update(inv_alfa, t1, t2, self.v_t, self.w_t, self.x_t, self.s2[1:2])
+            beta_prev = beta if beta > 0 else beta_prev
+            # norm estimates and scipy's stopping tests (residuals corrected by c2)
+            delta = sn2 * rho
+            gambar = -cs2 * rho
+            rhs = phi - delta * z
+            zbar = rhs / gambar
+            xnorm = np.sqrt(xxnorm + zbar * zbar)
+            gamma = np.sqrt(gambar * gambar + theta * theta)
+            cs2, sn2 = gambar / gamma, theta / gamma
+            z = rhs / gamma
+            xxnorm += z * z
+            acond = anorm * np.sqrt(ddnorm)
+            rnorm = np.sqrt(phibar * phibar + c2)
+            arnorm = alfa * abs(tau)
+            test1 = rnorm / bnorm
+            test2 = arnorm / (anorm * rnorm + eps)
+            test3 = 1.0 / (acond + eps)
+            tt1 = test1 / (1 + anorm * xnorm / bnorm)
+            rtol = self.btol + self.atol * anorm * xnorm / bnorm
+            if itn >= iter_lim: istop = 7
+            if 1 + test3 <= 1: istop = 6
+            if 1 + test2 <= 1: istop = 5
+            if 1 + tt1 <= 1: istop = 4
+            if test3 <= ctol: istop = 3
+            if test2 <= self.atol: istop = 2
+            if test1 <= rtol: istop = 1
+            if istop:
+                break
+        self.info = dict(lsqr_iters=itn, istop=istop, converged=True, rnorm=float(rnorm), arnorm=float(arnorm),
+                         anorm=float(anorm), acond=float(acond), xnorm=float(xnorm))
+        return self.x_c, self.x_t
