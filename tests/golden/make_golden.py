@@ -138,6 +138,28 @@ def polar_case():
     print("  g6_polar     %d blocks" % n)
 
 
+def pickle_case():
+    """A small `cam_marker_edges.pt`-style file written with the REFERENCE's SE3 class (torch.save of
+    the edge dict, main.ipynb:68): the fixture is pickled data that names `vican.geometry.SE3`; the
+    test loads it through this repository's shim to prove reference caches unpickle unchanged."""
+    import torch
+    scene, flat = gc.build_flat(gc.CASES["g5_strings"])
+    src = synth.edges_to_dict(flat, ref_geometry.SE3)
+    some = dict(list(src.items())[:6])
+    # one pose built from a 4x4 (float32 views) as cam.py would after SE3(pose=...), one inverted
+    k0 = next(iter(some))
+    some[k0]["pose"] = ref_geometry.SE3(pose=np.eye(4) + 0.01 * np.arange(16).reshape(4, 4))
+    k1 = list(some)[1]
+    some[k1]["pose"] = some[k1]["pose"].inv()
+    torch.save(some, os.path.join(HERE, "ref_edges_pickle.pt"))
+    np.savez_compressed(os.path.join(HERE, "ref_edges_pickle_expect.npz"),
+                        keys=np.array(["|".join(k) for k in some]),
+                        R=np.stack([np.asarray(v["pose"].R(), dtype=np.float64) for v in some.values()]),
+                        t=np.stack([np.asarray(v["pose"].t(), dtype=np.float64) for v in some.values()]),
+                        R_dtype=np.array([str(np.asarray(v["pose"].R()).dtype) for v in some.values()]))
+    print("  ref_edges_pickle.pt  %d edges" % len(some))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -146,3 +168,5 @@ if __name__ == "__main__":
         run_case(name, case)
     if not only or "g6_polar" in only:
         polar_case()
+    if not only or "pickle" in only:
+        pickle_case()
