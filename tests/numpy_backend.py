@@ -142,7 +142,7 @@ class NumpyBackend:
             x_out.numpy()[:] = np.stack([q0, q1, q2], 1)
 
     def tall_combine(self, n, V, ld, ka, Y, X):
-        X.numpy()[:] = self._cols(V, ld, n, 0, ka).T @ Y.numpy().reshape(ka, 3)
+        X.numpy()[:] = self._cols(V, ld, n, 0, ka).T @ Y.numpy().reshape(-1)[: ka * 3].reshape(ka, 3)
 
     def rows_to_cols(self, n, X, V, ld, col0):
         self._cols(V, ld, n, col0, col0 + 3)[:] = X.numpy().T

@@ -180,6 +180,10 @@ class HipBackend:
     def from_numpy(self, a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
 
+    def pinned(self, *shape):
+        """Page-locked host buffer for small asynchronous device<->host copies."""
+        return torch.zeros(*shape, dtype=torch.float64, pin_memory=True)
+
     def synchronize(self):
         torch.cuda.current_stream().synchronize()
 
