@@ -206,3 +206,24 @@ def test_lsqr_kernels(cfg):
     assert ih["istop"] == inn["istop"] and abs(ih["lsqr_iters"] - inn["lsqr_iters"]) <= max(1, inn["lsqr_iters"] // 20)
     scale = max(np.abs(xt_n).max(), 1.0)
     assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
+
+
+def test_fused_lanczos_cam_step_matches_fine_grained():
+    C = 60
+    H, N, _ = make_backends(C, 80, 2, 6, 9, np.float64)
+    rng = np.random.default_rng(11)
+    n, m, j = 3 * C, 6, 3
+    Q, _ = np.linalg.qr(rng.standard_normal((n, 3 * (j + 1))))
+    Vn = np.zeros((3 * (m + 1), n)); Vn[: 3 * (j + 1)] = Q.T
+    lam = rng.standard_normal((C, 3, 3)); lam = (lam @ np.swapaxes(lam, 1, 2) + np.eye(3)).reshape(C, 9)
+    z = rng.standard_normal((n, 3))
+    outs = []
+    for K in (H, N):
+        V = K.from_numpy(Vn.reshape(-1).copy())
+        R, Hs, G, Hcol, beta, x = K.zeros(3 * n), K.zeros(3 * (m + 1) * 3), K.zeros(9), K.zeros(3 * (m + 1) * 3), K.zeros(9), K.zeros(n, 3)
+        K.lanczos_cam_step(K.from_numpy(lam), V, n, j, K.from_numpy(z), R, Hs, G, Hcol, beta, x, 0.0)
+        outs.append([t.cpu().numpy() for t in (V, Hcol, beta, x)])
+    for a, b, tol in zip(outs[0], outs[1], (1e-10, 1e-10, 1e-10, 1e-10)):
+        assert np.abs(a - b).max() < tol * max(1.0, np.abs(b).max())
+    q = outs[0][3]
+    assert np.abs(q.T @ q - np.eye(3)).max() < 1e-12 and np.abs(Q.T @ q).max() < 1e-12

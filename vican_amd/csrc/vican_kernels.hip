@@ -221,21 +221,133 @@ extern "C" int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t
 }
 
 // ---------------------------------------------------------------------------
-// composite: the camera-side half of one block-Lanczos step as ONE host call
-// (7 launches; the host-side cost of issuing them one by one from Python was larger than the
-// kernels themselves).  z = reduced P Q_j; on return basis block j+1 and x_out (next sweep input)
-// are written, Hcol (this step's projected column, 3(j+1) x 3) and beta (3x3) recorded.
+// The camera-side half of one block-Lanczos step in ONE single-workgroup launch.
+// The seven fine-grained kernels above (kept as entry points) are each 5-7 us of mostly launch
+// latency on a 3C x 3(j+1) problem; fused, the whole step is one launch of 1024 threads with
+// workgroup barriers between the stages.  Same arithmetic and the same (fixed) summation orders
+// per stage, hence reproducible; z = reduced P Q_j; writes basis block j+1, x_out (next sweep
+// input), Hcol (this step's projected column, 3(j+1) x 3) and beta (3 x 3).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void fused_gram(int n, const double* __restrict__ V, int ld, int ka,
+                                           const double* __restrict__ R, double* __restrict__ h /* LDS [ka][3] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wave; k < ka; k += nw) {
+        const double* v = V + (size_t)k * ld;
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = lane; i < n; i += 64) {
+            const double vi = v[i];
+            s0 += vi * R[i]; s1 += vi * R[(size_t)n + i]; s2 += vi * R[(size_t)2 * n + i];
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { h[k * 3] = s0; h[k * 3 + 1] = s1; h[k * 3 + 2] = s2; }
+    }
+}
+__device__ __forceinline__ void fused_update(int n, const double* __restrict__ V, int ld, int ka,
+                                             const double* __restrict__ h, double* __restrict__ R) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double r0 = R[i], r1 = R[(size_t)n + i], r2 = R[(size_t)2 * n + i];
+        for (int k = 0; k < ka; ++k) {
+            const double v = V[(size_t)k * ld + i];
+            r0 -= v * h[k * 3]; r1 -= v * h[k * 3 + 1]; r2 -= v * h[k * 3 + 2];
+        }
+        R[i] = r0; R[(size_t)n + i] = r1; R[(size_t)2 * n + i] = r2;
+    }
+}
+#define VICAN_FUSED_CAM_MAX 400
+__global__ __launch_bounds__(1024) void lanczos_cam_fused_kernel(int n_cam, const double* __restrict__ lamC, double* V,
+                                                                 int ld, int j, const double* __restrict__ z, double* R,
+                                                                 double* __restrict__ Hcol, double* __restrict__ beta_out,
+                                                                 double* __restrict__ x_out, double pivot_floor) {
+    __shared__ double h[KA_MAX * 3];
+    __shared__ double h2[KA_MAX * 3];
+    __shared__ double gpart[16][6];
+    const int n = 3 * n_cam, ka = 3 * (j + 1), tid = threadIdx.x;
+    // A Q_j = Lambda_C Q_j - z    (R column-major [3][n])
+    for (int c = tid; c < n_cam; c += blockDim.x) {
+        double L[9], q[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L[k] = lamC[(size_t)c * 9 + k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) q[i * 3 + b] = V[(size_t)(3 * j + b) * ld + 3 * c + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                R[(size_t)b * n + 3 * c + i] = L[i * 3] * q[b] + L[i * 3 + 1] * q[3 + b] + L[i * 3 + 2] * q[6 + b] -
+                                              z[(size_t)(3 * c + i) * 3 + b];
+    }
+    __syncthreads();
+    fused_gram(n, V, ld, ka, R, h);                 // Gram-Schmidt pass 1
+    __syncthreads();
+    fused_update(n, V, ld, ka, h, R);
+    __syncthreads();
+    fused_gram(n, V, ld, ka, R, h2);                // pass 2 ("twice is enough")
+    __syncthreads();
+    fused_update(n, V, ld, ka, h2, R);
+    for (int i = tid; i < ka * 3; i += blockDim.x) Hcol[i] = h[i] + h2[i];
+    __syncthreads();
+    // G = R^T R  (6 unique entries), fixed order: per-thread -> wave -> 16 waves
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += blockDim.x) {
+        const double r0 = R[i], r1 = R[(size_t)n + i], r2 = R[(size_t)2 * n + i];
+        g[0] += r0 * r0; g[1] += r0 * r1; g[2] += r0 * r2; g[3] += r1 * r1; g[4] += r1 * r2; g[5] += r2 * r2;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) gpart[tid >> 6][q] = g[q];
+    __syncthreads();
+    double G6[6] = {0, 0, 0, 0, 0, 0};
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) G6[q] += gpart[wv][q];
+    // upper Cholesky G = beta^T beta, Q = R beta^-1  (same pivot rule as chol_qr3_kernel)
+    const double g00 = G6[0], g01 = G6[1], g02 = G6[2], g11 = G6[3], g12 = G6[4], g22 = G6[5];
+    const double tr = g00 + g11 + g22, floor_ = fmax(1e-28 * tr, pivot_floor);
+    double b00 = 0, b01 = 0, b02 = 0, b11 = 0, b12 = 0, b22 = 0, i00 = 0, i11 = 0, i22 = 0;
+    if (g00 > floor_) { b00 = sqrt(g00); i00 = 1.0 / b00; b01 = g01 * i00; b02 = g02 * i00; }
+    const double d11 = g11 - b01 * b01;
+    if (d11 > floor_) { b11 = sqrt(d11); i11 = 1.0 / b11; b12 = (g12 - b01 * b02) * i11; }
+    const double d22 = g22 - b02 * b02 - b12 * b12;
+    if (d22 > floor_) { b22 = sqrt(d22); i22 = 1.0 / b22; }
+    if (tid == 0) {
+        beta_out[0] = b00; beta_out[1] = b01; beta_out[2] = b02; beta_out[3] = 0; beta_out[4] = b11; beta_out[5] = b12;
+        beta_out[6] = 0; beta_out[7] = 0; beta_out[8] = b22;
+    }
+    const int col0 = 3 * (j + 1);
+    for (int i = tid; i < n; i += blockDim.x) {
+        const double r0 = R[i], r1 = R[(size_t)n + i], r2 = R[(size_t)2 * n + i];
+        const double q0 = r0 * i00;
+        const double q1 = (r1 - q0 * b01) * i11;
+        const double q2 = (r2 - q0 * b02 - q1 * b12) * i22;
+        V[(size_t)col0 * ld + i] = q0; V[(size_t)(col0 + 1) * ld + i] = q1; V[(size_t)(col0 + 2) * ld + i] = q2;
+        x_out[(size_t)i * 3] = q0; x_out[(size_t)i * 3 + 1] = q1; x_out[(size_t)i * 3 + 2] = q2;
+    }
+}
+
 extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                                       const double* z, double* R, double* H, double* G, double* Hcol, double* beta,
                                       double* x_out, double pivot_floor, void* stream) {
-    const int n = 3 * n_cam, ka = 3 * (j + 1);
-    int rc;
-    if ((rc = vican_lap_apply(n_cam, lamC, V, ld, 3 * j, z, R, stream)) < 0) return rc;
-    if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;
-    if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 0, stream)) < 0) return rc;
-    if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;          // second Gram-Schmidt pass
-    if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 1, stream)) < 0) return rc;
-    if ((rc = vican_tall_gram(n, R, n, 3, R, G, stream)) < 0) return rc;
-    return vican_chol_qr3(n, R, G, V, ld, 3 * (j + 1), beta, x_out, pivot_floor, stream);
+    if (n_cam <= 0 || !lamC || !V || !z || !R || !H || !G || !Hcol || !beta || !x_out || j < 0 || 3 * (j + 1) > KA_MAX ||
+        ld < 3 * n_cam)
+        return set_err(VICAN_ERR_ARG, "vican_lanczos_cam_step: bad argument");
+    if (n_cam > VICAN_FUSED_CAM_MAX) {
+        // large camera sets: the stages are bandwidth-bound enough to want many workgroups
+        const int n = 3 * n_cam, ka = 3 * (j + 1);
+        int rc;
+        if ((rc = vican_lap_apply(n_cam, lamC, V, ld, 3 * j, z, R, stream)) < 0) return rc;
+        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;
+        if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 0, stream)) < 0) return rc;
+        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;          // second Gram-Schmidt pass
+        if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 1, stream)) < 0) return rc;
+        if ((rc = vican_tall_gram(n, R, n, 3, R, G, stream)) < 0) return rc;
+        return vican_chol_qr3(n, R, G, V, ld, 3 * (j + 1), beta, x_out, pivot_floor, stream);
+    }
+    hipLaunchKernelGGL(lanczos_cam_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, R,
+                       Hcol, beta, x_out, pivot_floor);
+    LAUNCH_CHECK("vican_lanczos_cam_step");
+    return VICAN_OK;
 }

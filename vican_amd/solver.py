@@ -83,6 +83,7 @@ class RotationSolver:
         self.Y_host = K.pinned(3 * (m + 1), 3) if hasattr(K, "pinned") else None
         self.Yd = K.zeros(3 * (m + 1), 3)
         self.pred_steps = {}                        # iteration index -> steps needed last time
+        self.floor_level = {}                       # iteration index -> residual level at which it stalled
         self.xrow = K.empty(n, 3)                   # current Lanczos block, row-major (sweep input)
         self.z = K.empty(n, 3)
         self.X = K.empty(n, 3)
@@ -146,7 +147,7 @@ class RotationSolver:
         """3 algebraically smallest eigenvectors of L = Lambda_C - P (up to a 3x3 mixing,
         which the gauge fix removes).  Returns eigenvalue estimates (host array)."""
         K, n, ld = self.K, self.n, self.ld
-        total_steps = 0
+        total_steps, floor_at = 0, 0
         for restart in range(self.max_restarts + 1):
             self._seed_block(x0)
             steps = 0
@@ -158,7 +159,7 @@ class RotationSolver:
                 # the same graph was solved before (time series, benchmark loop): go straight to the step
                 # count that sufficed last time instead of paying for checks that are known to fail
                 next_check = min(max(self.pred_steps[it], 1), self.m_max)
-            prev_res, floor_hit = None, False
+            prev_res, floor_hit, prev_steps = None, False, 0
             while True:
                 j = steps
                 self.apply_P(self.xrow, self.z)
@@ -174,7 +175,13 @@ class RotationSolver:
                     # residual stalls somewhere below `floor_tol`; a stalled residual there is converged
                     r = res.max() / scale
                     floor_hit = (prev_res is not None and r > 0.25 * prev_res and r <= self.floor_tol)
-                    prev_res = r
+                    if restart == 0 and it in self.floor_level and r <= 2.0 * self.floor_level[it]:
+                        floor_hit = True                      # the stagnation level seen on this graph before
+                    if floor_hit and restart == 0 and it is not None:
+                        # remember where the floor was first reached (the earlier of the two checks) and its level
+                        self.floor_level[it] = max(r, prev_res) if prev_res is not None else max(r, self.floor_level.get(it, r))
+                        floor_at = prev_steps if (prev_res is not None and prev_res <= 2.0 * self.floor_level[it]) else steps
+                    prev_res, prev_steps = r, steps
                     if eff < steps or breakdown or r <= self.eig_tol or floor_hit or steps >= self.m_max:
                         steps = eff
                         break
@@ -192,7 +199,7 @@ class RotationSolver:
             self.stats["restarts"] += 1
         self.stats["lanczos_steps"].append(total_steps)
         if it is not None and self.stats["restarts"] == 0:
-            self.pred_steps[it] = total_steps
+            self.pred_steps[it] = floor_at if (floor_hit and floor_at > 0) else total_steps
         self.stats["resid"].append(float(res.max() / scale))
         ev = np.full(5, np.nan)                     # 3 smallest + 2 largest Ritz values (cf. eigs k=5)
         ev[:3] = th[:3]
