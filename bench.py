@@ -86,11 +86,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; VICAN_DIST_BACKEND=gloo lets several ranks share one device (functional test of
+    # the sharded path on a 1-GPU box - RCCL refuses two ranks on the same GPU)
+    backend = os.environ.get("VICAN_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     from vican_amd import synth
     from vican_amd.device import HipBackend, LocalGraph
     from vican_amd.solver import Comm, RotationSolver, TranslationSolver
