@@ -116,7 +116,15 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
         }
         const bool spill = valid && rank >= cap;
         const unsigned long long sm = __ballot(spill);      // ordered compaction: deterministic layout
-        if (valid && !spill) pm[(c + 32 * (rank / epl)) * epl + (rank % epl)] = e;
+        if (valid && !spill) {
+            // lane group of this rank, rotated by the class and interleaved over the wavefronts: the
+            // partially filled tail groups of the 32 classes (and the spill slots that fill them) end up
+            // spread over all wavefronts instead of piling irregular work onto the last one
+            const int G = g.block_threads / 32, W = G / 2 > 0 ? G / 2 : 1;
+            const int pos = (rank / epl + c) % G;
+            const int grp = (G > 1) ? (pos % W) * 2 + pos / W : 0;
+            pm[(c + 32 * grp) * epl + (rank % epl)] = e;
+        }
         if (spill) sh[novf + __popcll(sm & lt)] = e;
         novf += __popcll(sm);
     }
@@ -508,21 +516,38 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
 
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
-    ChunkRegs<S, EPL> ra, rb;
+#ifdef VICAN_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t;
+#define STAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP0() do {} while (0)
+#define STAMP(i) do {} while (0)
+#endif
+    // Register ring: DEPTH chunks in flight ahead of the one being processed.  512-thread workgroups
+    // have 256 VGPRs per lane and keep two chunks in flight (the memory system then always has work
+    // from this CU); 768/1024-thread workgroups only have room for one.
+    constexpr int DEPTH = (BLOCK <= 512) ? 2 : 1;
+    ChunkRegs<S, EPL> ra, rb, rc;
     if (k0 < k1) load_chunk<S, EPL>(ra, g, k0, tid);
+    if (DEPTH == 2 && k0 + 1 < k1) load_chunk<S, EPL>(rb, g, k0 + 1, tid);
     __syncthreads();
 
+    STAMP0();
     auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int k) {
         const int r0 = g.chunk_row0[k];
         const int nrows = g.chunk_row0[k + 1] - r0;
-        if (k + 1 < k1) load_chunk<S, EPL>(nxt, g, k + 1, tid);      // prefetch: lands during this chunk
-        // duals of the row this wavefront will fold in phase 2 (lane -> accumulator o = lane / part_n)
+        // duals of the row this wavefront will fold in phase 2 (lane -> accumulator o = lane / part_n).
+        // Issued BEFORE the chunk prefetch: vector-memory results retire in issue order, so a wait for
+        // these three doubles placed after the prefetch would also wait for the whole next chunk.
         const int o = lane / part_n, oa = o / 3, ob = o - 3 * oa;
         double L0 = 0, L1 = 0, L2 = 0;
         if (MODE == 0 && wave < nrows && o < 9) {
             const double* L = lamT_inv + (size_t)(r0 + wave) * 9 + oa * 3;
             L0 = L[0]; L1 = L[1]; L2 = L[2];
         }
+        __builtin_amdgcn_sched_barrier(0);                              // keep these loads ahead of the prefetch
+        if (k + DEPTH < k1) load_chunk<S, EPL>(nxt, g, k + DEPTH, tid);   // prefetch: lands during this/next chunk
 
         // ---- phase 1: y_row += M^T x_cam ; same-row edges of a lane pre-summed in registers,
         //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
@@ -537,6 +562,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
             return;
         }
 #endif
+        STAMP(5);                       // inter-chunk prologue: descriptors, dual loads, prefetch issue
         uint32_t cam[EPL], row[EPL];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -575,7 +601,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                 }
             }
         }
+        STAMP(0);                       // phase 1 (incl. waiting for this chunk's loads)
         __syncthreads();
+        STAMP(1);                       // barrier A
 
         // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
         //      rotated by the accumulator index => distinct banks), re-zero them, then
@@ -608,7 +636,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
             }
         }
         // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
+        STAMP(2);                       // phase 2
         __syncthreads();
+        STAMP(3);                       // barrier B
         if (MODE == 0) {
             // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
             S w[9];
@@ -640,15 +670,29 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
                     }
             }
         }
+        STAMP(4);                       // phase 3
         // (the barrier after the next chunk's phase 1 separates this chunk's phase 3 reads of wv
         //  from the next phase 2 writes; ys is already re-zeroed for the next phase 1)
     };
 
+    if (DEPTH == 1) {
 #pragma unroll 1
-    for (int k = k0; k < k1; k += 2) {
-        body(ra, rb, k);
-        if (k + 1 < k1) body(rb, ra, k + 1);
+        for (int k = k0; k < k1; k += 2) {
+            body(ra, rb, k);
+            if (k + 1 < k1) body(rb, ra, k + 1);
+        }
+    } else {
+#pragma unroll 1
+        for (int k = k0; k < k1; k += 3) {          // body(current, set to refill with chunk k + 2)
+            body(ra, rc, k);
+            if (k + 1 < k1) body(rb, ra, k + 1);
+            if (k + 2 < k1) body(rc, rb, k + 2);
+        }
     }
+#ifdef VICAN_STAMP
+    if (MODE == 0 && Rt_out && (tid == 0 || tid == BLOCK - 64))
+        for (int i = 0; i < 6; ++i) Rt_out[((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 6 + i] = (double)st_acc[i];
+#endif
     if (MODE == 0) {
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
@@ -721,7 +765,23 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
                               double* fx, void* stream) {
     if (int rc = vican_check_graph(g, "vican_block_op")) return rc;
     if (!lamT_inv || !x || !zpart || !fx) return set_err(VICAN_ERR_ARG, "vican_block_op: null pointer");
+#ifdef VICAN_STAMP
+    static double* stamp_buf = nullptr;                 // diagnostic builds only: per-workgroup phase cycles
+    if (!stamp_buf) hipMalloc(&stamp_buf, 4096 * 12 * sizeof(double));
+    if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, stamp_buf, nullptr, nullptr, fx, stream)) return rc;
+    if (getenv("VICAN_STAMP_DUMP")) {
+        hipStreamSynchronize((hipStream_t)stream);
+        static double host[4096 * 12];
+        hipMemcpy(host, stamp_buf, sizeof(double) * g->n_wg * 12, hipMemcpyDeviceToHost);
+        double sum[2][6] = {{0}};
+        for (int w = 0; w < g->n_wg; ++w) for (int h = 0; h < 2; ++h) for (int i = 0; i < 6; ++i) sum[h][i] += host[(w * 2 + h) * 6 + i];
+        for (int h = 0; h < 2; ++h)
+            fprintf(stderr, "STAMP wave%s: prologue %.0f phase1 %.0f barA %.0f phase2 %.0f barB %.0f phase3 %.0f  (mean cycles per workgroup)\n",
+                    h ? "-last" : "0", sum[h][5] / g->n_wg, sum[h][0] / g->n_wg, sum[h][1] / g->n_wg, sum[h][2] / g->n_wg, sum[h][3] / g->n_wg, sum[h][4] / g->n_wg);
+    }
+#else
     if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, nullptr, nullptr, nullptr, fx, stream)) return rc;
+#endif
     LAUNCH_CHECK("vican_block_op");
     return VICAN_OK;
 }
