@@ -203,9 +203,22 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
                                                        double n_add, vican_cg_state_t* st) {
     __shared__ double sh_beta;
     __shared__ int sh_go;
+    __shared__ double red[8];
     if (st->done) return;
+    // close the previous iteration: fixed-order block reduction of the partials (sum and max)
+    double ps = 0.0, pm = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) { ps += rr_part[i]; pm = fmax(pm, rr_part[CG_PARTS + i]); }
+    const double tsum = block_sum(ps, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pm = fmax(pm, __shfl_down(pm, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pm;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (n_part > 0) cg_close_iteration(rr_part, n_part, st);
+        if (n_part > 0) {
+            st->rr_time = tsum; st->rmax_time = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            st->iter += 1; st->rho_prev = st->rho; st->first = 0;
+        }
         const double rho = st->rr_cam + st->rr_time;
         if (st->iter == 0 && st->first) { st->bnorm2 = rho; st->atol2 = rtol * rtol * rho; }
         st->rho = rho;
@@ -455,6 +468,36 @@ extern "C" int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_stat
     return VICAN_OK;
 }
 
+// fold of one CG sweep in ONE launch: qcpq[0:3C] = qinv * sum_wg qc_part (planes [3][C] -> row-major
+// [C][3]) and qcpq[3C] = sum_wg pq_part (block 0).  Same fixed summation orders as
+// vican_slab_reduce_fx + vican_cg_reduce_pq.
+__global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
+                                                       const double* __restrict__ pq_part, double* __restrict__ qcpq,
+                                                       const vican_cg_state_t* __restrict__ st) {
+    __shared__ long long sh[1024];
+    if (st->done) return;
+    const long long n = 3LL * n_cam;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    long long s = 0;
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 16) s += part[(size_t)k * n + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        long long t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k * 64 + e];
+        const long long q = i / n_cam, cam = i % n_cam;
+        qcpq[cam * 3 + q] = (double)t * st->qinv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < n_slab; ++k) t += pq_part[k];
+        qcpq[n] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // composites: one CG iteration as two host calls (local half up to the point where a sharded
 // run all-reduces [q_c | p.q]; finishing half).  qcpq: [3C + 1] doubles.
@@ -466,8 +509,11 @@ extern "C" int vican_cg_iter_local(const vican_graph_t* g, const double* w, cons
     int rc;
     if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, stream)) < 0) return rc;
     if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
-    if ((rc = vican_slab_reduce_fx(qc_part, g->n_wg, g->n_cam, 3, 1.0, &st->qinv, nullptr, qcpq, stream)) < 0) return rc;
-    return vican_cg_reduce_pq(pq_part, g->n_wg, qcpq + 3 * g->n_cam, st, stream);
+    const long long n = 3LL * g->n_cam;
+    hipLaunchKernelGGL(cg_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                       (const long long*)qc_part, g->n_wg, g->n_cam, pq_part, qcpq, st);
+    LAUNCH_CHECK("vican_cg_iter_local");
+    return VICAN_OK;
 }
 extern "C" int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, const double* qcpq,
                                     const double* p_c, double* x_c, double* r_c, const double* p_t, const double* q_t,
