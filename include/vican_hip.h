@@ -68,7 +68,16 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);
+int vican_abi_version(void);            /* 3 */
+
+/* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
+ * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
+ * vican_slab_reduce_fx, vican_polar_dual, vican_dual_update and vican_fx_finish exit immediately
+ * unless *gate == 1 WHEN THEY EXECUTE: the host enqueues the continuation of the primal-dual
+ * iteration (bipgo.py:295-332) right behind vican_ritz without waiting for its verdict, and the
+ * device cancels it if the eigen-solve has not converged.  All other entry points ignore the gate.
+ * NULL (the default) disables gating.                                                        */
+int vican_set_gate(const int32_t* gate);
 
 /* ---- host-side planning (no GPU needed) ---------------------------------
  * Cut T rows (host row_ptr[T+1]) into chunks of whole rows with at most
@@ -214,6 +223,27 @@ int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_
 int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                            const double* z, double* R, double* H, double* G, double* Hcol,
                            double* beta, double* x_out, double pivot_floor, void* stream);
+
+/* Ritz step on the device (replaces the shift-invert ARPACK call of bipgo.py:288 together with the
+ * Lanczos steps).  HB[steps][row_stride]: row j = projected column V^T L Q_j ([hw/3][3] row-major,
+ * rows < 3(j+1) used) followed at offset hw by beta_j [3][3], as written by vican_lanczos_cam_step.
+ * A zero pivot in beta_j truncates the basis to eff = j+1 blocks.  The symmetric projected matrix
+ * (3 eff x 3 eff) is diagonalised by a parallel cyclic Jacobi iteration in LDS; Y[3 steps][3]
+ * receives the Ritz vectors of the three smallest values (zero rows beyond 3 eff).
+ * flags: bit 0 = first check of this Krylov run (no previous residual), bit 1 = the step budget
+ * is exhausted (forces stop).  With r = max_k |beta Y_k[last 3 rows]| / max|theta|:
+ *   floor_hit = (not first and r > r_prev/4 and r <= floor_tol) or (floor_level >= 0 and r <= 2 floor_level)
+ *   stop      = eff < steps or breakdown or r <= eig_tol or floor_hit or bit 1
+ *   converged = breakdown or floor_hit or r <= eig_tol           *gate = stop and converged
+ * status[VICAN_RITZ_STATUS_DOUBLES]: [0] r, [1] max|theta|, [2] stop, [3] converged, [4] floor_hit,
+ * [5] eff, [6] breakdown (all pivots of the last beta zero), [7..9] three smallest Ritz values,
+ * [10..11] the two largest (NaN when 3 eff < 5), [12] r (read back as r_prev by the next call),
+ * [13] Jacobi sweeps, [14] unscaled residual, [15] reserved.  steps <= VICAN_RITZ_MAX_STEPS.    */
+#define VICAN_RITZ_MAX_STEPS 32
+#define VICAN_RITZ_STATUS_DOUBLES 16
+int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags,
+               double eig_tol, double floor_tol, double floor_level, double* Y, double* status,
+               int32_t* gate, void* stream);
 
 /* ---- translation stage ---------------------------------------------------
  * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of

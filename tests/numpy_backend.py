@@ -40,6 +40,69 @@ class NumpyBackend:
         self.v = None if v is None else np.asarray(v, dtype=np.float64).reshape(-1, 3)
         self.rr_part_n = 1
         self._rr = 0.0
+        self._gate = None
+
+    # launch gate (vican_set_gate): the gated entry points do nothing unless gate[0] == 1
+    def gated(self, gate):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._gate = gate
+            try:
+                yield
+            finally:
+                self._gate = None
+        return cm()
+
+    def post_status(self, status):
+        return status
+
+    def wait_status(self, handle):
+        return handle.numpy()
+
+    def _closed(self):
+        return self._gate is not None and int(self._gate[0]) != 1
+
+    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate):
+        """Mirror of vican_ritz (include/vican_hip.h) with LAPACK instead of the Jacobi iteration."""
+        hb = HB[:steps].numpy()
+        Hh = hb[:, :hw].reshape(steps, -1, 3)
+        Bh = hb[:, hw:hw + 9].reshape(steps, 3, 3)
+        eff = steps
+        for j in range(steps):
+            if np.any(np.diag(Bh[j]) == 0.0):
+                eff = j + 1
+                break
+        ka = 3 * eff
+        Tm = np.zeros((ka, ka))
+        for j in range(eff):
+            kj = 3 * (j + 1)
+            Tm[:kj, 3 * j:3 * j + 3] = Hh[j, :kj, :]
+        Tm = np.triu(Tm)
+        Tm = Tm + Tm.T - np.diag(np.diag(Tm))
+        th, Yv = np.linalg.eigh(Tm)
+        beta = Bh[eff - 1]
+        resmax = float(np.linalg.norm(beta @ Yv[ka - 3:ka, :3], axis=0).max())
+        scale = max(abs(th[0]), abs(th[-1]), 1e-300)
+        r = resmax / scale
+        first, at_max = bool(flags & 1), bool(flags & 2)
+        breakdown = bool(np.all(np.diag(beta) == 0.0))
+        prev = float(status[12])
+        floor_hit = (not first) and r > 0.25 * prev and r <= floor_tol
+        if floor_level >= 0.0 and r <= 2.0 * floor_level:
+            floor_hit = True
+        stop = eff < steps or breakdown or r <= eig_tol or floor_hit or at_max
+        converged = breakdown or floor_hit or resmax <= eig_tol * scale
+        y = Y.numpy().reshape(-1, 3)
+        y[:3 * steps] = 0.0
+        y[:ka] = Yv[:, :3]
+        st = status.numpy()
+        st[:7] = [r, scale, float(stop), float(converged), float(floor_hit), eff, float(breakdown)]
+        st[7:10] = th[:3]
+        st[10:12] = th[-2:] if ka >= 5 else np.nan
+        st[12], st[13], st[14], st[15] = r, 0.0, resmax, 0.0
+        gate[0] = 1 if (stop and converged) else 0
 
     # allocation
     def empty(self, *shape, dtype=torch.float64):
@@ -71,6 +134,8 @@ class NumpyBackend:
         return y
 
     def block_op(self, lamT_inv, x, z_out):
+        if self._closed():
+            return
         y = self._y(x)
         w = lamT_inv.numpy().reshape(-1, 3, 3) @ y
         z = np.zeros((self.C, 3, 3))
@@ -78,6 +143,8 @@ class NumpyBackend:
         z_out.numpy()[:] = z.reshape(3 * self.C, 3)
 
     def dual_update(self, rc, Rt, lamT_inv):
+        if self._closed():
+            return
         if not self.T:
             return
         R, lam = svd_polar(self._y(rc)[: self.T], 2)
@@ -85,6 +152,8 @@ class NumpyBackend:
         lamT_inv.numpy()[: self.T] = lam.reshape(-1, 9)
 
     def polar_dual(self, mats, R_out, lam_out, mode):
+        if self._closed():
+            return
         R, lam = svd_polar(mats.numpy().reshape(-1, 3, 3), mode)
         if R_out is not None:
             R_out.numpy().reshape(-1, 9)[:] = R.reshape(-1, 9)
@@ -92,6 +161,8 @@ class NumpyBackend:
             lam_out.numpy().reshape(-1, 9)[:] = lam.reshape(-1, 9)
 
     def gauge_project(self, x_in, x_out):
+        if self._closed():
+            return
         X = x_in.numpy()
         Xg = X @ np.linalg.inv(X[:3, :])
         R, _ = svd_polar(Xg.reshape(self.C, 3, 3), 0)
@@ -142,6 +213,8 @@ class NumpyBackend:
             x_out.numpy()[:] = np.stack([q0, q1, q2], 1)
 
     def tall_combine(self, n, V, ld, ka, Y, X):
+        if self._closed():
+            return
         X.numpy()[:] = self._cols(V, ld, n, 0, ka).T @ Y.numpy().reshape(-1)[: ka * 3].reshape(ka, 3)
 
     def rows_to_cols(self, n, X, V, ld, col0):

@@ -227,3 +227,92 @@ def test_fused_lanczos_cam_step_matches_fine_grained():
         assert np.abs(a - b).max() < tol * max(1.0, np.abs(b).max())
     q = outs[0][3]
     assert np.abs(q.T @ q - np.eye(3)).max() < 1e-12 and np.abs(Q.T @ q).max() < 1e-12
+
+
+def _ritz_inputs(steps, m, seed, dead_at=None, gap=True):
+    """HB rows as vican_lanczos_cam_step writes them, for a random symmetric projected matrix."""
+    rng = np.random.default_rng(seed)
+    ka = 3 * steps
+    Q = np.linalg.qr(rng.standard_normal((ka, ka)))[0]
+    ev = np.sort(rng.uniform(1.0, 50.0, ka))
+    if gap and ka > 3:
+        ev[:3] = [0.011, 0.013, 0.02]                    # the cluster the solver is after
+    Tm = (Q * ev) @ Q.T
+    hw = 3 * (m + 1) * 3
+    HB = np.zeros((m, hw + 9))
+    for j in range(steps):
+        kj = 3 * (j + 1)
+        HB[j, : kj * 3] = Tm[:kj, 3 * j:3 * j + 3].reshape(-1)
+        HB[j, hw:] = np.triu(rng.standard_normal((3, 3)) * 1e-3 + np.eye(3) * 1e-2).reshape(-1)
+    if dead_at is not None:
+        HB[dead_at, hw + 8] = 0.0
+    return HB, hw
+
+
+@pytest.mark.parametrize("steps,dead_at", [(1, None), (2, None), (5, None), (6, None), (7, 4), (9, None), (16, None), (32, None), (3, 2)])
+def test_ritz_matches_lapack_and_gate_semantics(steps, dead_at):
+    H, N, g = make_backends(5, 40, 1, 3, 7, np.float64)
+    m = 32
+    HB, hw = _ritz_inputs(steps, m, 50 + steps, dead_at)
+    for flags, eig_tol, floor_tol, level, prev in [(1, 1e-10, 1e-7, -1.0, 0.0), (0, 1e-10, 1.0, -1.0, 1e-3), (2, 1e-10, 1e-7, -1.0, 0.0),
+                                                   (1, 1.0, 1e-7, -1.0, 0.0), (1, 1e-10, 1e-7, 10.0, 0.0)]:
+        HBd = H.from_numpy(HB)
+        Yd, std, gd = H.zeros(3 * (m + 1), 3), H.zeros(16), H.zeros(1, dtype=torch.int32)
+        Yn, stn, gn = N.zeros(3 * (m + 1), 3), N.zeros(16), N.zeros(1, dtype=torch.int32)
+        std[12] = prev; stn[12] = prev
+        Yd.fill_(7.0)                                        # rows beyond the basis must be overwritten with zeros
+        H.ritz(HBd, hw, steps, flags, eig_tol, floor_tol, level, Yd, std, gd)
+        N.ritz(torch.from_numpy(HB), hw, steps, flags, eig_tol, floor_tol, level, Yn, stn, gn)
+        sd, sn = std.cpu().numpy(), stn.numpy()
+        assert int(gd.item()) == int(gn[0]), (flags, sd, sn)
+        np.testing.assert_array_equal(sd[2:7], sn[2:7])      # stop, converged, floor_hit, eff, breakdown
+        np.testing.assert_allclose(sd[7:12], sn[7:12], rtol=1e-12, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(sd[[0, 1, 14]], sn[[0, 1, 14]], rtol=1e-7)
+        assert sd[12] == sd[0] and 1 <= sd[13] <= 20, sd[13]
+        eff = int(sn[5])
+        yd, yn = Yd.cpu().numpy(), Yn.numpy()
+        assert np.all(yd[3 * eff:3 * steps] == 0.0)
+        k = min(3, 3 * eff)
+        Pd, Pn = yd[:3 * eff, :k] @ yd[:3 * eff, :k].T, yn[:3 * eff, :k] @ yn[:3 * eff, :k].T
+        assert np.abs(Pd - Pn).max() < 1e-11                 # same invariant subspace (the gauge fix removes the mixing)
+        np.testing.assert_allclose(yd[:3 * eff, :k].T @ yd[:3 * eff, :k], np.eye(k), atol=1e-12)
+
+
+def test_gated_launches_are_cancelled_on_the_device():
+    """Everything enqueued under a closed gate leaves its outputs untouched; an open gate runs it."""
+    H, N, g = make_backends(37, 300, 1, 12, 3, np.float32)
+    C, T = 37, 300
+    rng = np.random.default_rng(2)
+    lamT, cd = H.empty(T, 9), H.empty(C)
+    H.init_duals(lamT, cd)
+    x = H.from_numpy(np.linalg.qr(rng.standard_normal((3 * C, 3)))[0])
+    z_ref = H.zeros(3 * C, 3)
+    H.block_op(lamT, x, z_ref)
+    gate = H.zeros(1, dtype=torch.int32)
+    fx_before = g.fx.clone()
+    for val in (0, 2, 1):
+        gate.fill_(val)
+        z, xp, rc, lamC = H.zeros(3 * C, 3), H.zeros(3 * C, 3), H.zeros(3 * C, 3), H.zeros(C, 9)
+        Rt, lamT2 = H.zeros(T, 9), lamT.clone()
+        X = H.zeros(3 * C, 3)
+        V, Y = H.from_numpy(rng.standard_normal(6 * 3 * C)), H.from_numpy(rng.standard_normal((6, 3)))
+        with H.gated(gate):
+            H.tall_combine(3 * C, V, 3 * C, 6, Y, X)
+            H.gauge_project(x, xp)
+            H.block_op(lamT, x, z)
+            H.polar_dual(z_ref, rc, lamC, 1)
+            H.dual_update(x, Rt, lamT2)
+        H.synchronize()
+        outs = [X, xp, z, rc, lamC, Rt]
+        if val != 1:
+            assert all(float(o.abs().max()) == 0.0 for o in outs)
+            assert torch.equal(lamT2, lamT) and torch.equal(g.fx, fx_before)
+        else:
+            assert all(float(o.abs().max()) > 0.0 for o in outs)
+            assert torch.equal(z, z_ref) and not torch.equal(lamT2, lamT)
+    # outside the context the gate is off again
+    gate.fill_(0)
+    z = H.zeros(3 * C, 3)
+    H.init_duals(lamT, cd)
+    H.block_op(lamT, x, z)
+    assert torch.equal(z, z_ref)

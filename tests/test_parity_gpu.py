@@ -31,9 +31,13 @@ def test_dropin_api_matches_reference(name, dt):
     rot, tr = pose_errors(res, exp)
     assert rot < ROT_TOL[dt] <= 1e-4, rot
     assert tr < translation_tol(exp, dt == "float64"), tr
-    # iteration count: exact (+-1) on the well-conditioned cases; on the heavy-tailed-weight case g4
-    # (the reference itself is 17 m from the converged solution there) only loosely comparable
-    slack = 1 if name != "g4_illcond" else max(2, int(exp["cg_iters"]) // 4)
+    # iteration count: exact (+-1) on the well-conditioned cases.  On the heavy-tailed-weight case g4 (the
+    # reference itself is 17 m from the converged solution there) CG has lost conjugacy after ~15 iterations
+    # and the relative residual jumps erratically between 4e-4 and 5e-6: it dips below rtol = 1e-5 at
+    # iterations 21 (9.0e-6, marginal), 25, 28 and 31/32, and which dip is caught first flips under 1e-14
+    # perturbations of the rotations (measured with the NumPy backend: 20 or 24 iterations) - so only the
+    # window of those dips is comparable there.
+    slack = 1 if name != "g4_illcond" else 12
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= slack
     first = next(iter(res.values()))
     assert first.R().dtype == dtype and first.t().dtype == np.float64       # bipgo.py:484-487 types

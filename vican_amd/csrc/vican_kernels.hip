@@ -6,8 +6,9 @@
 // ---------------------------------------------------------------------------
 // batched polar / gauge
 // ---------------------------------------------------------------------------
-__global__ void polar_dual_kernel(int n, const double* __restrict__ in, double* __restrict__ R_out,
+__global__ void polar_dual_kernel(const int32_t* __restrict__ gate, int n, const double* __restrict__ in, double* __restrict__ R_out,
                                   double* __restrict__ lam_out, int mode) {
+    GATE_RETURN(gate);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double A[9], R[9], lam[9];
@@ -25,13 +26,15 @@ extern "C" int vican_polar_dual(int32_t n, const double* in, double* R_out, doub
                                 void* stream) {
     if (n < 0 || !in || mode < 0 || mode > 2) return set_err(VICAN_ERR_ARG, "vican_polar_dual: bad argument");
     if (n == 0) return VICAN_OK;
-    hipLaunchKernelGGL(polar_dual_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, n, in, R_out,
+    hipLaunchKernelGGL(polar_dual_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate, n, in, R_out,
                        lam_out, mode);
     LAUNCH_CHECK("vican_polar_dual");
     return VICAN_OK;
 }
 
-__global__ void gauge_project_kernel(int n_cam, const double* __restrict__ xin, double* __restrict__ xout) {
+__global__ void gauge_project_kernel(const int32_t* __restrict__ gate, int n_cam, const double* __restrict__ xin,
+                                     double* __restrict__ xout) {
+    GATE_RETURN(gate);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cam) return;
     double g0[9], gi[9];
@@ -57,7 +60,7 @@ extern "C" int vican_gauge_project(int32_t n_cam, const double* x_in, double* x_
     // x_in may alias x_out: every thread reads block 0 before any thread of ANOTHER
     // workgroup may overwrite it only if they do not alias; require distinct buffers.
     if (x_in == x_out) return set_err(VICAN_ERR_ARG, "vican_gauge_project: in-place not supported");
-    hipLaunchKernelGGL(gauge_project_kernel, dim3((n_cam + 127) / 128), dim3(128), 0, (hipStream_t)stream, n_cam, x_in,
+    hipLaunchKernelGGL(gauge_project_kernel, dim3((n_cam + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate, n_cam, x_in,
                        x_out);
     LAUNCH_CHECK("vican_gauge_project");
     return VICAN_OK;
@@ -182,8 +185,9 @@ extern "C" int vican_chol_qr3(int32_t n, const double* R, const double* G, doubl
 }
 
 // X[n][3] (row-major) = V[:, :ka] Y[ka][3]
-__global__ __launch_bounds__(256) void tall_combine_kernel(int n, const double* __restrict__ V, int ld, int ka,
+__global__ __launch_bounds__(256) void tall_combine_kernel(const int32_t* __restrict__ gate, int n, const double* __restrict__ V, int ld, int ka,
                                                            const double* __restrict__ Y, double* __restrict__ X) {
+    GATE_RETURN(gate);
     __shared__ double y[KA_MAX * 3];
     for (int i = threadIdx.x; i < ka * 3; i += 256) y[i] = Y[i];
     __syncthreads();
@@ -200,7 +204,7 @@ extern "C" int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_
                                   void* stream) {
     if (n <= 0 || !V || !Y || !X || ka <= 0 || ka > KA_MAX || ld < n)
         return set_err(VICAN_ERR_ARG, "vican_tall_combine: bad argument");
-    hipLaunchKernelGGL(tall_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, V, ld, ka, Y, X);
+    hipLaunchKernelGGL(tall_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_vican_gate, n, V, ld, ka, Y, X);
     LAUNCH_CHECK("vican_tall_combine");
     return VICAN_OK;
 }
@@ -349,5 +353,217 @@ extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double*
     hipLaunchKernelGGL(lanczos_cam_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, R,
                        Hcol, beta, x_out, pivot_floor);
     LAUNCH_CHECK("vican_lanczos_cam_step");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Ritz step of the block Lanczos iteration, entirely on the device
+// ---------------------------------------------------------------------------
+// Assembles the projected matrix T = V^T L V (3 eff x 3 eff, eff <= VICAN_RITZ_MAX_STEPS) from the
+// columns recorded by the Lanczos steps, diagonalises it with a parallel two-sided Jacobi iteration
+// in LDS, forms the Ritz residuals of the three smallest pairs and takes the stop / converged
+// decision that the host used to take after a synchronous round trip (reference: the ARPACK call at
+// bipgo.py:288; tolerance semantics as in solver.RotationSolver).  `gate` receives 1 iff the
+// eigen-solve is finished AND converged: work enqueued behind this kernel under
+// vican_set_gate(gate) then runs, otherwise it cancels itself.
+//
+// Jacobi layout (Brent-Luk): round-robin pairing, N/2 disjoint pivots (p_k, q_k) per round, N-1
+// rounds per sweep.  Thread k computes the rotation of pair k from its three pivot entries; after a
+// barrier one thread per 2x2 block (pair k_i x pair k_j) applies B <- J_i^T B J_j in place - a block
+// is read and written by its owner only - and rotates the same 2x2 block of the eigenvector matrix
+// by J_j.  A round is bound by instruction issue and LDS latency of a few wavefronts (measured
+// ~0.45-0.9 us per round), so index arithmetic is recomputed instead of loaded and every LDS read of
+// a phase is independent of the others (one round trip per phase).
+// The rotation angle comes from a fast f32 evaluation (it only has to annihilate the pivot to a
+// relative 1e-7 per visit - the iteration converges quadratically anyway), but (c, s) are formed in
+// f64 from the half-angle tangent u as ((1-u^2), 2u) / (1+u^2), which is orthogonal to rounding for ANY
+// u, so the eigenvector matrix stays orthonormal.  Pivots below 2e-15 |T|_F (above the rounding noise
+// of the update, LAPACK-grade absolute accuracy) are skipped.
+__device__ __forceinline__ void ritz_pair(int k, int r, int N, int& p, int& q) {
+    int a = r + k, b = r - k + (N - 1);
+    if (a >= N - 1) a -= N - 1;
+    if (b >= N - 1) b -= N - 1;
+    if (k == 0) { a = N - 1; b = r; }
+    p = a < b ? a : b; q = a < b ? b : a;
+}
+
+// Jacobi rotation annihilating the pivot a_pq (to ~1e-7 relative): c, s exactly orthogonal.  Returns 1 if it rotates.
+__device__ __forceinline__ int ritz_rotation(double app, double aqq, double apq, bool live, double thr, double inv,
+                                             double& c, double& s) {
+    c = 1.0; s = 0.0;
+    if (!live || !(fabs(apq) > thr)) return 0;
+    const float df = (float)((aqq - app) * inv), hf = (float)(2.0 * apq * inv);
+    const float tau = df * __builtin_amdgcn_rcpf(hf);
+    const float at = fabsf(tau);
+    float t = __builtin_amdgcn_rcpf(at + __builtin_amdgcn_sqrtf(1.0f + at * at));      // tan(theta), |t| <= 1
+    t = tau < 0.0f ? -t : t;
+    const float uf = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + t * t));   // tan(theta/2)
+    const double u = (double)uf, u2 = u * u, x = 1.0 + u2;
+    double w = (double)__builtin_amdgcn_rcpf((float)x);
+    w = w * (2.0 - x * w); w = w * (2.0 - x * w);            // 1e-7 -> 1e-14 -> rounding
+    c = (1.0 - u2) * w; s = 2.0 * u * w;
+    return 1;
+}
+
+__global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ HB, int stride, int hw, int steps, int flags,
+                                                    double eig_tol, double floor_tol, double floor_level,
+                                                    double* __restrict__ Y, double* __restrict__ status,
+                                                    int32_t* __restrict__ gate) {
+    extern __shared__ double sm[];
+    __shared__ int s_eff, s_idx[5];
+    __shared__ double s_red[16];
+    const int tid = threadIdx.x, B = blockDim.x;
+    if (tid == 0) {
+        // a vanished pivot in beta_j: the Krylov space was exhausted at block j+1, the rest is zero padding
+        int eff = steps;
+        for (int j = 0; j < steps; ++j) {
+            const double* b = HB + (size_t)j * stride + hw;
+            if (b[0] == 0.0 || b[4] == 0.0 || b[8] == 0.0) { eff = j + 1; break; }
+        }
+        s_eff = eff;
+    }
+    __syncthreads();
+    const int eff = s_eff, n = 3 * eff, N = n + (n & 1), ld = N | 1, half = N / 2;
+    double* A = sm;                      // [N][ld]  (row/column n is a decoupled zero dummy when n is odd)
+    double* V = A + (size_t)N * ld;      // [N][ld]
+    double* cs = V + (size_t)N * ld;     // [half][2]
+
+    double nf = 0.0;
+    for (int idx = tid; idx < N * N; idx += B) {
+        const int i = idx / N, c = idx - i * N;
+        double v = 0.0;
+        if (i < n && c < n) {
+            const int lo = i < c ? i : c, hi = i < c ? c : i;         // symmetric completion of the upper triangle
+            v = HB[(size_t)(hi / 3) * stride + lo * 3 + (hi % 3)];
+        }
+        A[i * ld + c] = v;
+        V[i * ld + c] = (i == c) ? 1.0 : 0.0;
+        nf += v * v;
+    }
+    nf = block_sum(nf, s_red);
+    if (tid == 0) s_red[0] = nf;
+    __syncthreads();
+    const double normf = sqrt(s_red[0]);
+    const double thr = 2e-15 * normf;
+    // power-of-two normalisation for the f32 angle evaluation
+    int ex = 0;
+    if (normf > 0.0) frexp(normf, &ex);
+    const double inv = ldexp(1.0, -ex);
+    __syncthreads();
+
+    // Termination: a sweep without rotations, or - cheaper - a sweep whose largest pivot was already
+    // below 1e-8 |T|_F: Jacobi converges quadratically, so that sweep left the off-diagonal part at
+    // the 1e-16 |T|_F (|T|_F / gap) level and neither a polishing nor a verifying sweep is needed.
+    const double small = 1e-8 * normf;
+    int sweeps = 0;
+    for (; sweeps < 30; ++sweeps) {
+        int state = 0;                          // bit 0: rotated, bit 1: a pivot above `small` was seen
+        for (int r = 0; r < N - 1; ++r) {
+            if (tid < half) {                   // thread k: rotation of pair k from its three pivot entries
+                int p, q;
+                ritz_pair(tid, r, N, p, q);
+                const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];    // one LDS latency
+                double c, s;
+                if (ritz_rotation(app, aqq, apq, q < n, thr, inv, c, s)) state |= fabs(apq) > small ? 3 : 1;
+                cs[2 * tid] = c; cs[2 * tid + 1] = s;
+            }
+            __syncthreads();
+            for (int b = tid; b < half * half; b += B) {
+                const int ki = b / half, kj = b - ki * half;
+                int pi, qi, pj, qj;
+                ritz_pair(ki, r, N, pi, qi);                  // recomputed (ALU) so that every LDS read below
+                ritz_pair(kj, r, N, pj, qj);                  // is independent: one latency for all of them
+                double* a0 = A + pi * ld; double* a1 = A + qi * ld;
+                double* v0 = V + pi * ld; double* v1 = V + qi * ld;
+                const double ci = cs[2 * ki], si = cs[2 * ki + 1], cj = cs[2 * kj], sj = cs[2 * kj + 1];
+                const double b00 = a0[pj], b01 = a0[qj], b10 = a1[pj], b11 = a1[qj];
+                const double e00 = v0[pj], e01 = v0[qj], e10 = v1[pj], e11 = v1[qj];
+                // columns (J_j), then rows (J_i^T); identity rotations reproduce the entries exactly
+                const double t00 = cj * b00 - sj * b01, t01 = sj * b00 + cj * b01;
+                const double t10 = cj * b10 - sj * b11, t11 = sj * b10 + cj * b11;
+                double n00 = ci * t00 - si * t10, n01 = ci * t01 - si * t11;
+                double n10 = si * t00 + ci * t10, n11 = si * t01 + ci * t11;
+                if (ki == kj) { const double o = 0.5 * (n01 + n10); n01 = o; n10 = o; }
+                a0[pj] = n00; a0[qj] = n01; a1[pj] = n10; a1[qj] = n11;
+                v0[pj] = cj * e00 - sj * e01; v0[qj] = sj * e00 + cj * e01;
+                v1[pj] = cj * e10 - sj * e11; v1[qj] = sj * e10 + cj * e11;
+            }
+            __syncthreads();
+        }
+        const int any_rot = __syncthreads_or(state & 1), any_big = __syncthreads_or(state & 2);
+        if (!any_rot || !any_big) { ++sweeps; break; }
+    }
+
+    // ranks of the eigenvalues (ties broken by index): one thread per eigenvalue
+    if (tid < 5) s_idx[tid] = -1;
+    __syncthreads();
+    if (tid < n) {
+        const double d = A[tid * ld + tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double e = A[j * ld + j];
+            rank += (e < d || (e == d && j < tid)) ? 1 : 0;
+        }
+        if (rank < 3) s_idx[rank] = tid;                                    // three smallest
+        if (n >= 2 && rank >= n - 2) s_idx[3 + (rank - (n - 2))] = tid;     // second largest, largest
+        if (n == 1) s_idx[4] = tid;
+    }
+    __syncthreads();
+    // Ritz vectors of the three smallest values -> Y[3 steps][3] (zero rows beyond the effective basis)
+    for (int idx = tid; idx < 3 * steps * 3; idx += B) {
+        const int i = idx / 3, k = idx - 3 * i;
+        Y[idx] = (i < n && s_idx[k] >= 0) ? V[i * ld + s_idx[k]] : 0.0;
+    }
+    if (tid == 0) {
+        const double* beta = HB + (size_t)(eff - 1) * stride + hw;
+        double resmax = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            if (s_idx[k] < 0) continue;
+            double q = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                double v = 0.0;
+                for (int b = 0; b < 3; ++b) v += beta[a * 3 + b] * V[(n - 3 + b) * ld + s_idx[k]];
+                q += v * v;
+            }
+            resmax = fmax(resmax, sqrt(q));
+        }
+        const double th_min = A[s_idx[0] * ld + s_idx[0]], th_max = A[s_idx[4] * ld + s_idx[4]];
+        const double scale = fmax(fmax(fabs(th_min), fabs(th_max)), 1e-300);
+        const double r = resmax / scale;
+        const bool first = flags & 1, at_max = flags & 2;
+        const bool breakdown = beta[0] == 0.0 && beta[4] == 0.0 && beta[8] == 0.0;
+        const double prev = status[12];
+        bool floor_hit = !first && r > 0.25 * prev && r <= floor_tol;
+        if (floor_level >= 0.0 && r <= 2.0 * floor_level) floor_hit = true;
+        const bool stop = eff < steps || breakdown || r <= eig_tol || floor_hit || at_max;
+        const bool converged = breakdown || floor_hit || resmax <= eig_tol * scale;
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        status[0] = r; status[1] = scale; status[2] = stop; status[3] = converged; status[4] = floor_hit;
+        status[5] = eff; status[6] = breakdown;
+        for (int k = 0; k < 3; ++k) status[7 + k] = s_idx[k] >= 0 ? A[s_idx[k] * ld + s_idx[k]] : nan;
+        status[10] = n >= 5 ? A[s_idx[3] * ld + s_idx[3]] : nan;
+        status[11] = n >= 5 ? th_max : nan;
+        status[12] = r; status[13] = sweeps; status[14] = resmax; status[15] = 0.0;
+        *gate = (stop && converged) ? 1 : 0;
+    }
+}
+
+extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags, double eig_tol,
+                          double floor_tol, double floor_level, double* Y, double* status, int32_t* gate, void* stream) {
+    if (!HB || !Y || !status || !gate || steps < 1 || steps > VICAN_RITZ_MAX_STEPS || hw < 9 * steps || row_stride < hw + 9)
+        return set_err(VICAN_ERR_ARG, "vican_ritz: bad argument");
+    const int n = 3 * steps, N = n + (n & 1), ld = N | 1, half = N / 2;
+    const size_t lds = ((size_t)2 * N * ld + 2 * half) * sizeof(double) + (size_t)half * sizeof(int) + 16;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        if (hipFuncSetAttribute((const void*)ritz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "vican_ritz: cannot raise dynamic LDS limit");
+        configured = lds;
+    }
+    int threads = ((half * half + 63) / 64) * 64;            // one thread per 2x2 block, at most 1024
+    threads = threads > 1024 ? 1024 : threads;
+    hipLaunchKernelGGL(ritz_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, HB, row_stride, hw, steps,
+                       flags, eig_tol, floor_tol, floor_level, Y, status, gate);
+    LAUNCH_CHECK("vican_ritz");
     return VICAN_OK;
 }

@@ -17,7 +17,10 @@
 
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 2; }
+extern "C" int vican_abi_version(void) { return 3; }
+
+thread_local const int32_t* g_vican_gate = nullptr;
+extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
 
 // ---------------------------------------------------------------------------
 // host-side planning + LDS budget
@@ -373,7 +376,8 @@ extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out
 //   y contributions  |M^T x|      <= amax * xb          row totals <= rmax * xb
 //   z contributions  |M w|        <= amax * omega * xb  per-accumulator totals <= n_add * that
 // A single contribution must stay below 2^51 (magic-number conversion), a total below 2^62.
-__global__ void fx_finish_kernel(double* fx, double x_bound, double n_add, int bits) {
+__global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, double x_bound, double n_add, int bits) {
+    GATE_RETURN(gate);
     if (threadIdx.x || blockIdx.x) return;
     const double amax = fmax(fx[5], 1e-300), rmax = fmax(fx[6], 1e-300), om = fmax(fx[4], 1e-300);
     const double cy = amax * x_bound, ty = rmax * x_bound;
@@ -395,7 +399,7 @@ extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t
     const int bits = 47;
     (void)storage;
 #endif
-    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx, x_bound, n_add, bits);
+    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_vican_gate, fx, x_bound, n_add, bits);
     LAUNCH_CHECK("vican_fx_finish");
     return VICAN_OK;
 }
@@ -463,13 +467,15 @@ template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) 
 // row, no workgroup barrier inside]  barrier  ...   - two barriers per chunk; the register
 // set of the next chunk is loaded while the current one is processed (ping-pong, no copies).
 template <typename S, int BLOCK, int MODE, int CP>
-__global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, const double* __restrict__ lamT_inv,
+__global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
+                                                            const double* __restrict__ lamT_inv,
                                                             const double* __restrict__ x,
                                                             u64* __restrict__ zpart,
                                                             double* __restrict__ Rt_out,
                                                             double* __restrict__ lamT_out,
                                                             const double* __restrict__ rnorm,
                                                             double* __restrict__ fx) {
+    GATE_RETURN(gate);
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -508,6 +514,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
     const double up = ldexp(1.0, shift);
     const double y_scale = fx[0] * up, y_inv = fx[1] / up, z_scale = fx[2] * up;
     if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    if (MODE == 1 && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
     __syncthreads();
 
     for (int i = tid; i < 9 * C; i += BLOCK) xs[(i % 9) * CP + i / 9] = pre_scale<S>(x[i], y_scale);
@@ -701,8 +708,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(vican_graph_t g, con
 }
 
 // Rt[t], lamT_inv[t] from Z_t (stored in lamT_inv by the MODE 1 sweep), in place; omega bound.
-__global__ __launch_bounds__(128) void dual_svd_kernel(int n_time, double* __restrict__ Rt, double* __restrict__ lamT_inv,
-                                                       const double* __restrict__ rnorm, double* __restrict__ fx) {
+__global__ __launch_bounds__(128) void dual_svd_kernel(const int32_t* __restrict__ gate, int n_time, double* __restrict__ Rt,
+                                                       double* __restrict__ lamT_inv, const double* __restrict__ rnorm,
+                                                       double* __restrict__ fx) {
+    GATE_RETURN(gate);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double om = 0.0;
     if (t < n_time) {
@@ -732,7 +741,7 @@ static int launch_sweep1(const vican_graph_t* g, const double* lamT_inv, const d
             return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican sweep");
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
+    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
     return 0;
 }
 
@@ -790,12 +799,14 @@ extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, doub
                                  const double* rnorm, double* fx, void* stream) {
     if (int rc = vican_check_graph(g, "vican_dual_update")) return rc;
     if (!rc_ || !Rt || !lamT_inv || !rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_dual_update: null pointer");
-    if (hipMemsetAsync(fx + 4, 0, sizeof(double), (hipStream_t)stream) != hipSuccess)
-        return set_err(VICAN_ERR_LAUNCH, "vican_dual_update: memset failed");
-    if (g->n_chunk == 0) return VICAN_OK;
-    if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;
-    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g->n_time, Rt,
-                       lamT_inv, rnorm, fx);
+    if (g->n_chunk == 0) {                       // a rank without rows: omega bound 0 (memsets cannot be gated; nothing to cancel)
+        if (hipMemsetAsync(fx + 4, 0, sizeof(double), (hipStream_t)stream) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "vican_dual_update: memset failed");
+        return VICAN_OK;
+    }
+    if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
+    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate,
+                       g->n_time, Rt, lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update");
     return VICAN_OK;
 }
@@ -827,9 +838,10 @@ extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, 
 
 // slabs hold planes [ncomp][C]; the output is the row-major camera vector [C][ncomp].
 // 1024 threads = 64 elements x 16 slab groups (256 slabs -> 16 loads per thread in flight).
-__global__ __launch_bounds__(1024) void slab_reduce_fx_kernel(const long long* __restrict__ part, int n_slab, long long n,
+__global__ __launch_bounds__(1024) void slab_reduce_fx_kernel(const int32_t* __restrict__ gate, const long long* __restrict__ part, int n_slab, long long n,
                                                               int ncomp, double scale, const double* __restrict__ pa,
                                                               const double* __restrict__ pb, double* __restrict__ out) {
+    GATE_RETURN(gate);
     __shared__ long long sh[1024];
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
@@ -852,7 +864,7 @@ extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_
     if (!part || !out || n_slab <= 0 || n_cam <= 0 || ncomp <= 0) return set_err(VICAN_ERR_ARG, "vican_slab_reduce_fx: bad argument");
     const long long n = (long long)n_cam * ncomp;
     hipLaunchKernelGGL(slab_reduce_fx_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
-                       (const long long*)part, n_slab, n, ncomp, scale, pa, pb, out);
+                       g_vican_gate, (const long long*)part, n_slab, n, ncomp, scale, pa, pb, out);
     LAUNCH_CHECK("vican_slab_reduce_fx");
     return VICAN_OK;
 }

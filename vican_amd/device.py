@@ -9,6 +9,7 @@ hand-written HIP kernel.  No CPU fallback: without a GPU construction raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -169,6 +170,7 @@ class HipBackend:
         self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
         self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
+        self._status_host = {}
 
     # -- allocation helpers -------------------------------------------------
     def empty(self, *shape, dtype=torch.float64):
@@ -273,6 +275,33 @@ class HipBackend:
     def chol_qr3(self, n, R, G, V, ld, col0, beta_out, x_out, pivot_floor=0.0):
         self._ck(self.lib.vican_chol_qr3(n, _ptr(R), _ptr(G), _ptr(V), ld, col0, _ptr(beta_out), _ptr(x_out),
                                          float(pivot_floor), _stream()), "vican_chol_qr3")
+
+    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate):
+        """Device Ritz step over the first `steps` rows of HB (include/vican_hip.h: vican_ritz)."""
+        self._ck(self.lib.vican_ritz(_ptr(HB), HB.stride(0), hw, steps, flags, float(eig_tol), float(floor_tol),
+                                     float(floor_level), _ptr(Y), _ptr(status), _ptr(gate), _stream()), "vican_ritz")
+
+    @contextlib.contextmanager
+    def gated(self, gate):
+        """Launches of the gated entry points inside this block run only if gate[0] == 1 on the device."""
+        self.lib.vican_set_gate(_ptr(gate))
+        try:
+            yield
+        finally:
+            self.lib.vican_set_gate(None)
+
+    def post_status(self, status):
+        """Asynchronous device->host copy of a small status vector; returns a handle for wait_status."""
+        host = self._status_host.get(status.numel())
+        if host is None:
+            host = self._status_host[status.numel()] = (self.pinned(status.numel()), torch.cuda.Event())
+        host[0].copy_(status, non_blocking=True)
+        host[1].record()
+        return host
+
+    def wait_status(self, handle):
+        handle[1].synchronize()                     # only the copy, not the work enqueued behind it
+        return handle[0].numpy()
 
     def tall_combine(self, n, V, ld, ka, Y, X):
         self._ck(self.lib.vican_tall_combine(n, _ptr(V), ld, ka, _ptr(Y), _ptr(X), _stream()), "vican_tall_combine")
