@@ -61,7 +61,7 @@ extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_
     if (n_cam > 1024) return 0;
     int64_t a = (lim - 256 - 9LL * plane_stride(n_cam) * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
     int64_t b = (lim - 256 - 96LL * n_cam) / (24LL * n_copy + 72);   // rhs kernel (vican_trans.hip)
-    int64_t c = (lim - 256 - 48LL * n_cam) / (24LL * n_copy + 24);   // CG sweep
+    int64_t c = (lim - 256 - 48LL * n_cam) / (24LL * n_copy + 96);   // CG sweep (double-buffered row staging)
     int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
     return (int32_t)m;
 }
@@ -376,16 +376,15 @@ extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out
 //   y contributions  |M^T x|      <= amax * xb          row totals <= rmax * xb
 //   z contributions  |M w|        <= amax * omega * xb  per-accumulator totals <= n_add * that
 // A single contribution must stay below 2^51 (magic-number conversion), a total below 2^62.
-__global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, double x_bound, double n_add, int bits) {
+__global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, double x_bound, double n_add, int bits, int tot) {
     GATE_RETURN(gate);
     if (threadIdx.x || blockIdx.x) return;
     const double amax = fmax(fx[5], 1e-300), rmax = fmax(fx[6], 1e-300), om = fmax(fx[4], 1e-300);
     const double cy = amax * x_bound, ty = rmax * x_bound;
     const double cz = amax * om * x_bound, tz = cz * n_add;
-    // a lane pre-sums up to 4 contributions before converting: bits = 47 on the f64 path
-    // (4 * 2^47 < 2^51, magic-number conversion) and 28 on the f32 path (4 * 2^28 < 2^31, v_cvt_i32_f32)
-    int ey = min(bits - (int)ceil(log2(cy)), 61 - (int)ceil(log2(ty)));
-    int ez = min(bits - (int)ceil(log2(cz)), 61 - (int)ceil(log2(tz)));
+    // a lane pre-sums up to 4 contributions before converting: 4 * 2^47 < 2^51 (magic-number conversion)
+    int ey = min(bits - (int)ceil(log2(cy)), tot - (int)ceil(log2(ty)));
+    int ez = min(bits - (int)ceil(log2(cz)), tot - (int)ceil(log2(tz)));
     ey = max(min(ey, 100), -100); ez = max(min(ez, 100), -100);     // pre-scaled f32 tables stay finite
     fx[0] = ldexp(1.0, ey); fx[1] = ldexp(1.0, -ey);
     fx[2] = ldexp(1.0, ez); fx[3] = ldexp(1.0, -ez);
@@ -393,13 +392,10 @@ __global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, d
 }
 extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
     if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");
-#ifdef VICAN_F32_FIX28
-    const int bits = storage == VICAN_STORE_F32 ? 28 : 47;
-#else
-    const int bits = 47;
-    (void)storage;
-#endif
-    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_vican_gate, fx, x_bound, n_add, bits);
+    // f32 blocks: the accumulators hold raw magic-biased bit patterns and totals are recovered from the low
+    // 48 bits (fix_of<float>), so a total must stay below 2^46; f64 blocks: true 64-bit totals
+    const int bits = 47, tot = storage == VICAN_STORE_F32 ? 46 : 61;
+    hipLaunchKernelGGL(fx_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_vican_gate, fx, x_bound, n_add, bits, tot);
     LAUNCH_CHECK("vican_fx_finish");
     return VICAN_OK;
 }
@@ -435,29 +431,23 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
     else          { const uint2 t = *(const uint2*)ip; c.id[0] = t.x; c.id[1] = t.y; }
 }
 
-// Pre-scaling: on the f32 path the fixed-point scale is folded into the LDS tables (x is staged
-// as x*y_scale, w as w*z_scale: powers of two, exact), so a contribution converts with ONE
-// v_cvt_rpi_i32_f32 (floor(v + 0.5)) + sign extension; the f64 path scales inside the FMA of the
-// magic-number conversion.
 template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);
-#ifdef VICAN_F32_FIX28
-template <> __device__ __forceinline__ float pre_scale<float>(double v, double scale) { return (float)(v * scale); }
-#else
 template <> __device__ __forceinline__ float pre_scale<float>(double v, double) { return (float)v; }
-#endif
 template <> __device__ __forceinline__ double pre_scale<double>(double v, double) { return v; }
+// Contribution -> 64-bit fixed point.  f64 blocks: magic-number conversion (common.cuh to_fix).
+// f32 blocks: the raw bit pattern of fma(v, scale, 1.5*2^52) WITHOUT subtracting the bias - a sum of N
+// patterns is off by N * 0x4338'0000'0000'0000, which only touches bits 48..63, and the true total
+// (|.| < 2^46 by the choice of scale in fx_finish) is the sign-extended low 48 bits (fix_total).  One VALU
+// instruction less per contribution; a 24-bit f32 product is still represented without loss down to
+// 2^-46 of the TOTAL bound.
 template <typename S> __device__ __forceinline__ u64 fix_of(S v, double scale);
 template <> __device__ __forceinline__ u64 fix_of<double>(double v, double scale) { return to_fix(v, scale); }
-#ifdef VICAN_F32_FIX28
-template <> __device__ __forceinline__ u64 fix_of<float>(float v, double) {
-    int r;
-    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(v));
-    return (u64)(long long)r;
+template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) {
+    return (u64)__double_as_longlong(fma((double)v, scale, 6755399441055744.0));
 }
-#else
-// lossless: a 24-bit f32 product keeps all its bits down to 2^-23 of the contribution bound
-template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) { return to_fix((double)v, scale); }
-#endif
+template <typename S> __device__ __forceinline__ long long fix_total(long long s);
+template <> __device__ __forceinline__ long long fix_total<float>(long long s) { return (long long)((u64)s << 16) >> 16; }
+template <> __device__ __forceinline__ long long fix_total<double>(long long s) { return s; }
 
 // MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
 // MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
@@ -627,6 +617,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             }
             if (part_n > 1) s += __shfl_xor(s, 1, 64);
             if (part_n > 2) s += __shfl_xor(s, 2, 64);
+            s = fix_total<S>(s);
             const double y = (double)s * y_inv;                  // valid where lane == o * part_n
             if (MODE == 0) {
                 if (r != wave && o < 9) {
@@ -703,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     if (MODE == 0) {
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
-        for (int i = tid; i < 9 * C; i += BLOCK) zp[i] = zs[(i / C) * CP + i % C];
+        for (int i = tid; i < 9 * C; i += BLOCK) zp[i] = (u64)fix_total<S>((long long)zs[(i / C) * CP + i % C]);
     }
 }
 

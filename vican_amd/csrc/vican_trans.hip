@@ -248,8 +248,15 @@ extern "C" int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, dou
     return VICAN_OK;
 }
 
-// Timestep-major Laplacian sweep (12 algorithmic bytes per edge: weight + packed index)
-template <int BLOCK, int EPL>
+// Timestep-major Laplacian sweep (12 algorithmic bytes per edge: weight + packed index).
+// Software pipeline: while chunk k is processed, the edge words of chunk k+1 and the p_t / r_t / deg_t values
+// of its rows are already in flight (registers); they are committed to the second staging buffer in the fold
+// phase.  Two barriers per chunk and no global-memory latency on the critical path (the first version staged
+// each chunk's rows behind a barrier: ~3.6 us per chunk of pure latency, 117 us per launch on the stress graph).
+template <int EPL>
+struct CgRegs { double w[EPL]; uint32_t id[EPL]; };
+
+template <int BLOCK, int EPL, int NR>
 __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const double* __restrict__ w,
                                                          const double* __restrict__ deg_t,
                                                          const double* __restrict__ p_c, const double* __restrict__ r_t,
@@ -258,45 +265,80 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
                                                          const vican_cg_state_t* __restrict__ st) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if (st->done) return;
-    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
     u64* qc = (u64*)lds_raw;                               // [3][C] planes
     u64* qt = qc + 3 * C;                                  // [max_rows*3][ncopy]
-    double* pcs = (double*)(qt + (size_t)3 * g.max_rows * ncopy);   // [3][C] planes
-    double* pts = pcs + 3 * C;                             // [max_rows][3]
-    double* red = pts + 3 * g.max_rows;                    // [16]
+    double* pcs = (double*)(qt + (size_t)mr3 * ncopy);     // [3][C] planes
+    double* pts = pcs + 3 * C;                             // [2][max_rows*3]   p of the chunk's rows
+    double* dps = pts + 2 * mr3;                           // [2][max_rows*3]   deg * p
+    double* red = dps + 2 * mr3;                           // [16]
     const int tid = threadIdx.x, lane_copy = tid & cmask;
-    const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
+    const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero weight
     const bool upd = !st->first;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
     for (int i = tid; i < 3 * C; i += BLOCK) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; }
-    for (int i = tid; i < 3 * g.max_rows * ncopy; i += BLOCK) qt[i] = 0ull;
+    for (int i = tid; i < mr3 * ncopy; i += BLOCK) qt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
-    double pq = 0.0;
-    for (int k = k0; k < k1; ++k) {
-        const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        // edge data first: in flight across the barrier
-        double ww[EPL]; uint32_t id[EPL];
+
+    auto load_edges = [&](CgRegs<EPL>& e, int k) {
+        const size_t s = (size_t)k * g.slots + (size_t)tid * EPL;
+        if (EPL == 4) {
+            const uint4 t = *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
+            const double2 a = *(const double2*)(w + s), b = *(const double2*)(w + s + 2);
+            e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
+        } else {
+            const uint2 t = *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y;
+            const double2 a = *(const double2*)(w + s); e.w[0] = a.x; e.w[1] = a.y;
+        }
+    };
+    // rows of chunk k: p (updated p = r + beta p on all but the first iteration) and deg
+    struct RowRegs { double p[NR], d[NR]; };
+    auto load_rows = [&](RowRegs& rr, int k) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const size_t s = (size_t)k * g.slots + (size_t)tid * EPL + j;
-            id[j] = g.idx[s]; ww[j] = w[s];
+        for (int m = 0; m < NR; ++m) {
+            const int i = tid + m * BLOCK;
+            rr.p[m] = 0.0; rr.d[m] = 0.0;
+            if (i < n3) {
+                const size_t gi = (size_t)r0 * 3 + i;
+                double p = p_t[gi];
+                if (upd) p = r_t[gi] + beta * p;
+                rr.p[m] = p; rr.d[m] = deg_t[r0 + i / 3];
+            }
         }
-        __syncthreads();
-        for (int i = tid; i < 3 * nrows; i += BLOCK) {
-            const size_t gi = (size_t)r0 * 3 + i;
-            double p = p_t[gi];
-            if (upd) { p = r_t[gi] + beta * p; p_t[gi] = p; }
-            pts[i] = p;
+    };
+    auto commit_rows = [&](const RowRegs& rr, int k, int buf) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const int i = tid + m * BLOCK;
+            if (i < n3) {
+                pts[buf * mr3 + i] = rr.p[m]; dps[buf * mr3 + i] = rr.d[m] * rr.p[m];
+                if (upd) p_t[(size_t)r0 * 3 + i] = rr.p[m];
+            }
         }
-        __syncthreads();
+    };
+
+    // One chunk of edge words and row values is in flight ahead of the chunk being processed (a second one was
+    // measured: no gain on the stress graph, slower on sparse graphs).
+    CgRegs<EPL> ea, eb;
+    RowRegs rr;
+    double pq = 0.0;
+    if (k0 < k1) { load_edges(ea, k0); load_rows(rr, k0); commit_rows(rr, k0, 0); }
+    __syncthreads();
+
+    auto body = [&](CgRegs<EPL>& cur, CgRegs<EPL>& nxt, const int k, const int buf) {
+        const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
+        if (k + 1 < k1) { load_edges(nxt, k + 1); load_rows(rr, k + 1); }      // in flight during this chunk
+        const double* pt = pts + buf * mr3;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const bool pad = id[j] == VICAN_PAD_SLOT;
-            const uint32_t cam = pad ? pad_cam : (id[j] & 0xFFFFu), row = pad ? 0u : (id[j] >> 16);
-            const double wj = pad ? 0.0 : ww[j];
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
+            const double wj = pad ? 0.0 : cur.w[j];
             if (row != prow) {
                 if (prow != 0xFFFFFFFFu)
 #pragma unroll
@@ -306,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 acc[i] += wj * pcs[i * C + cam];
-                lds_add_fix(&qc[i * C + cam], to_fix(wj * pts[row * 3 + i], scale));
+                lds_add_fix(&qc[i * C + cam], to_fix(wj * pt[row * 3 + i], scale));
             }
         }
         if (prow != 0xFFFFFFFFu)
@@ -320,12 +362,18 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
                 sum += (long long)qt[a];
                 qt[a] = 0ull;
             }
-            const double q = deg_t[r0 + i / 3] * pts[i] - (double)sum * inv;
+            const double q = dps[buf * mr3 + i] - (double)sum * inv;
             q_t[(size_t)r0 * 3 + i] = q;
-            pq += pts[i] * q;
+            pq += pt[i] * q;
         }
+        if (k + 1 < k1) commit_rows(rr, k + 1, buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ea, eb, k, 0);
+        if (k + 1 < k1) body(eb, ea, k + 1, 1);
     }
-    __syncthreads();
     for (int i = tid; i < 3 * C; i += BLOCK) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
@@ -338,19 +386,26 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;
+    const int nr = (3 * g->max_rows + g->block_threads - 1) / g->block_threads;   // row values per thread (<= 3 EPL)
     hipStream_t s = (hipStream_t)stream;
-#define CG_LAUNCH(B, E)                                                                                          \
+#define CG_LAUNCH3(B, E, R)                                                                                      \
     do {                                                                                                         \
-        auto kern = cg_sweep_kernel<B, E>;                                                                       \
+        auto kern = cg_sweep_kernel<B, E, R>;                                                                    \
         static size_t conf = 0;                                                                                  \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
     } while (0)
+#define CG_LAUNCH(B, E)                                                                                          \
+    do {                                                                                                         \
+        if (nr <= 1) CG_LAUNCH3(B, E, 1); else if (nr <= 4) CG_LAUNCH3(B, E, 4); else CG_LAUNCH3(B, E, 12);      \
+    } while (0)
+    if (nr > 12) return set_err(VICAN_ERR_CAPACITY, "vican_cg_sweep: more than 4 rows per lane in a chunk");
     if (g->block_threads == 1024)     { if (epl == 4) CG_LAUNCH(1024, 4); else CG_LAUNCH(1024, 2); }
     else if (g->block_threads == 768) { if (epl == 4) CG_LAUNCH(768, 4);  else CG_LAUNCH(768, 2); }
     else if (g->block_threads == 512) { if (epl == 4) CG_LAUNCH(512, 4);  else CG_LAUNCH(512, 2); }
     else                              { if (epl == 4) CG_LAUNCH(256, 4);  else CG_LAUNCH(256, 2); }
 #undef CG_LAUNCH
+#undef CG_LAUNCH3
     LAUNCH_CHECK("vican_cg_sweep");
     return VICAN_OK;
 }
