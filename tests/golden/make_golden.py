@@ -160,6 +160,57 @@ def pickle_case():
     print("  ref_edges_pickle.pt  %d edges" % len(some))
 
 
+def eval_case():
+    """G7: dataset reader + evaluation harness.  A small cameras.json / object_pose file pair (own synthetic
+    data) is parsed by the REFERENCE's Dataset.read_cameras / read_object, and the notebook's cell-9 error
+    statistics are computed with the REFERENCE's optimize_gauge_SE3 / distance_SO3 / angle for a perturbed,
+    gauge-shifted estimate of the cameras.  The fixture holds the JSON text, the estimate and those outputs."""
+    import json
+    import tempfile
+    import vican.dataset as ref_dataset
+    rng = np.random.default_rng(77)
+    ids = ["0", "3", "10", "11", "25", "100", "7"]
+    R = synth.random_rotations(rng, len(ids)); t = rng.normal(0, 5.0, (len(ids), 3))
+    cams = {}
+    for i, c in enumerate(ids):
+        cams[c] = dict(fx=1000.0 + i, fy=990.0 - i, cx=640.5, cy=360.25, distortion=[0.01 * i] * 12, R=R[i].tolist(),
+                       t=t[i].tolist(), resolution_x=1280, resolution_y=720)
+    obj = {str(k): dict(R=synth.random_rotations(rng, 1)[0].tolist(), t=rng.normal(0, 1, 3).tolist()) for k in range(5)}
+    cam_text, obj_text = json.dumps(cams), json.dumps(obj)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "cameras.json"), "w").write(cam_text)
+        open(os.path.join(d, "object_pose_0.json"), "w").write(obj_text)
+        ds = ref_dataset.Dataset(root=d)
+    # estimate: ground truth moved by a global gauge, perturbed; camera "7" missing, one extra id
+    Gr = synth.random_rotations(rng, 1)[0]; Gt = rng.normal(0, 2.0, 3)
+    est = {}
+    for i, c in enumerate(ids[:-1]):
+        dR = synth.small_rotations(rng, 1, 0.02)[0] if hasattr(synth, "small_rotations") else ref_geometry.project_SO3(np.eye(3) + 0.02 * rng.standard_normal((3, 3)))
+        est[c] = ref_geometry.SE3(R=Gr @ R[i] @ dR, t=Gr @ t[i] + Gt + 0.03 * rng.standard_normal(3))
+    est["999"] = ref_geometry.SE3(R=np.eye(3), t=np.zeros(3))
+    valid = [c for c in ds.cams.keys() if c in est]
+    G = ref_geometry.optimize_gauge_SE3([ds.cams[c].extrinsics.inv() for c in valid], [est[c].inv() for c in valid])
+    r_err, t_err, xyz = [], [], []
+    for c in valid:
+        gt = ds.cams[c].extrinsics
+        e = G.inv() @ est[c]
+        t_err.append(np.linalg.norm(gt.t() - e.t(), ord=2) * 100)
+        r_err.append(ref_geometry.distance_SO3(gt.R(), e.R()))
+        xyz.append(np.abs(gt.t() - e.t()) * 100)
+    np.savez_compressed(os.path.join(HERE, "g7_eval.npz"), cameras_json=np.array(cam_text), object_json=np.array(obj_text),
+                        cam_ids=np.array(list(ds.cams.keys())),
+                        K=np.stack([ds.cams[c].intrinsics for c in ds.cams]), dist=np.stack([ds.cams[c].distortion for c in ds.cams]),
+                        ext_R=np.stack([ds.cams[c].extrinsics.R() for c in ds.cams]), ext_t=np.stack([ds.cams[c].extrinsics.t() for c in ds.cams]),
+                        obj_keys=np.array(list(ds.object.keys())), obj_R=np.stack([v.R() for v in ds.object.values()]),
+                        obj_t=np.stack([v.t() for v in ds.object.values()]),
+                        est_ids=np.array(list(est.keys())), est_R=np.stack([v.R() for v in est.values()]),
+                        est_t=np.stack([v.t() for v in est.values()]),
+                        valid=np.array(valid), gauge_R=np.asarray(G.R(), dtype=np.float64), gauge_t=np.asarray(G.t(), dtype=np.float64),
+                        r_err=np.array(r_err), t_err=np.array(t_err), xyz_err=np.stack(xyz),
+                        angle_deg=np.array([ref_geometry.angle(np.asarray(v.R())) for v in est.values()]))
+    print("  g7_eval      %d cameras" % len(ids))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -170,3 +221,5 @@ if __name__ == "__main__":
         polar_case()
     if not only or "pickle" in only:
         pickle_case()
+    if not only or "g7_eval" in only:
+        eval_case()
