@@ -172,6 +172,11 @@ def main():
     elapsed = float(el.item())
 
     kern_ms = np.array([a.elapsed_time(b) for a, b in K.events])
+    # a speculative launch that the Ritz gate cancelled on the device exits at its first instruction (a few
+    # microseconds): not a sweep, so not part of the average (none occur once the step prediction has settled)
+    n_cancelled = int((kern_ms < 0.1 * np.median(kern_ms)).sum()) if len(kern_ms) else 0
+    if n_cancelled:
+        kern_ms = kern_ms[kern_ms >= 0.1 * np.median(kern_ms)]
     op_bytes = g.op_bytes()
     achieved = op_bytes / (kern_ms.mean() * 1e-3) / 1e9 if len(kern_ms) else 0.0
     E_total = E_local * world
@@ -199,14 +204,13 @@ def main():
                    "parallelism": "timestep-sharded x%d, camera side replicated" % world},
         "roofline": {"bound": "hbm", "kernel": "block_sweep_kernel<MODE=0> (vican_block_op)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)),
+                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
                      "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
                      "padded_slots_over_edges": g.padded_slots() / max(E_local, 1)},
         "detail": {"rot_loop_ms_per_step": t_rot / args.steps * 1e3, "cg_ms_per_step": t_tr / args.steps * 1e3,
                    "sweeps_per_step": rot.stats["sweeps"], "lanczos_steps": rot.stats["lanczos_steps"],
                    "eig_resid": rot.stats["resid"], "cg_iters": tr.info.get("cg_iters"),
-                   "lanczos_checks": rot.stats.get("n_check"), "lanczos_sync_ms": 1e3 * rot.stats.get("t_sync", 0.0),
-                   "lanczos_host_ms": 1e3 * rot.stats.get("t_host", 0.0),
+                   "lanczos_checks": rot.stats.get("n_check"),
                    "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
                    "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
                    "rot_edges_per_s": E_total * args.maxiter * args.steps / t_rot if t_rot else None},

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/profile_<tag>/ (rocprofv3 csv) into profiles/<tag>_*.{csv,json,md}."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/profile_%s" % tag
@@ -32,7 +32,7 @@ def counters(sub):
     acc = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            if "block_sweep_kernel" in r["Kernel_Name"] and ", 0>" in r["Kernel_Name"]:
+            if re.search(r"block_sweep_kernel<\w+, \d+, 0[,>]", r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
