@@ -257,6 +257,19 @@ int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v,
                     const double* rc, const double* rt, double* rhs_t, void* rhs_c_part,
                     double gmax, double n_add, double* inv_out, void* stream);
 
+/* ---- Jacobi (diagonal) scaling for the tight translation solve ----------------------------
+ * The normal equations A = [[D_c, -W], [-W^T, D_t]] (x) I3 scaled symmetrically by S = D^-1/2 are again a
+ * weighted bipartite Laplacian system with unit degrees and weights w~_ct = w_ct s_c s_t <= 1, so the
+ * CG entry points below run Jacobi-preconditioned CG unchanged on (w~, deg = 1, S b); x = S x~.
+ * (Not in the reference - its CG stops at relres 1e-5, SURVEY.md section 7 - off by default.)       */
+/* s[i] = deg[i] > 0 ? deg[i]^-1/2 : 0 */
+int vican_jacobi_scale(int32_t n, const double* deg, double* s, void* stream);
+/* x[i][0..ncomp) *= s[i] */
+int vican_row_scale(int32_t n, int32_t ncomp, const double* s, double* x, void* stream);
+/* w_out[slot] = w[slot] * s_cam[camera(slot)] * s_row[row(slot)]   (chunk layout; padding slots -> 0) */
+int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s_cam,
+                        const double* s_row, double* w_out, void* stream);
+
 /* Device-resident CG state (one struct in device memory, initialised by vican_cg_init).
  * Mirrors scipy.sparse.linalg.cg (x0 = 0, no preconditioner, stop when |r| < rtol*|b| tested at
  * the top of every iteration).  The sweeps accumulate q = A p in 64-bit fixed point; its scale

@@ -226,6 +226,20 @@ class NumpyBackend:
         dc = np.zeros(self.C); np.add.at(dc, self.col, self.w)
         deg_t.numpy()[:] = d; deg_c.numpy()[:] = dc
 
+    def jacobi_scale(self, deg, s_out):
+        d = deg.numpy()
+        s_out.numpy()[:] = np.where(d > 0, 1.0 / np.sqrt(np.where(d > 0, d, 1.0)), 0.0)
+
+    def row_scale(self, s, x):
+        x.numpy()[:] = x.numpy() * s.numpy()[:, None]
+
+    def set_cg_scaling(self, s_c, s_t):
+        self._w_plain = self.w
+        self.w = self.w * s_c.numpy()[self.col] * s_t.numpy()[self.row]
+
+    def clear_cg_scaling(self):
+        self.w = self._w_plain
+
     def trans_rhs(self, rc, rt, rhs_t, rhs_c):
         A = rc.numpy().reshape(self.C, 3, 3)[self.col]
         B = rt.numpy().reshape(-1, 3, 3)[self.row]

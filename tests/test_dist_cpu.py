@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, dt, out_q):
+def _worker(rank, world, port, name, dt, out_q, tight=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, name, dt, out_q):
         K = NumpyBackend(prob.n_cam, prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], prob.col[e0:e1], prob.blk[e0:e1],
                          prob.a[e0:e1], prob.w[e0:e1], prob.u[e0:e1], prob.v[e0:e1], storage=np.dtype(dt).type)
         comm = Comm()
-        rc, Rt, x_c, x_t, stats = solve_on_backend(K, comm, gc.MAXITER, 3 * (prob.n_cam + T))
+        rc, Rt, x_c, x_t, stats = solve_on_backend(K, comm, gc.MAXITER, 3 * (prob.n_cam + T), tight=tight)
         full = torch.zeros(T, 12, dtype=torch.float64)
         full[r0:r1, :9] = Rt[: r1 - r0]
         full[r0:r1, 9:] = x_t[: r1 - r0]
@@ -81,6 +81,27 @@ def test_two_ranks_match_reference_and_single_rank(name, dt):
     # CG step (q_c | p.q fused, and r.r), plus O(1) setup messages and the final gather
     expected_msgs = (res["sweeps"] - gc.MAXITER) + 2 * (res["cg_iters"] + 1) + 16
     assert res["n_allreduce"] <= expected_msgs + 2 * 64          # CG runs in bursts; overshoot is bounded
+
+
+def test_two_ranks_tight_translations():
+    """Jacobi-scaled tight solve, sharded: reaches the converged solution of the reference's own system."""
+    name, dt = "g3_medium", "float64"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, dt, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    R, t = to_pose_arrays(prob, torch.from_numpy(res["rc"]), torch.from_numpy(res["Rt"]), torch.from_numpy(res["x_c"]),
+                          torch.from_numpy(res["x_t"]), exp["keys"], False)
+    assert float(np.linalg.norm(t - exp["t_tight"], axis=1).max()) < 1e-7
+    assert abs(t.sum(0)).max() < 1e-9                                  # the reference's gauge: translations sum to zero
 
 
 def test_shard_rows_cover_everything():

@@ -316,3 +316,39 @@ def test_gated_launches_are_cancelled_on_the_device():
     H.init_duals(lamT, cd)
     H.block_op(lamT, x, z)
     assert torch.equal(z, z_ref)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4]])
+def test_jacobi_scaling_kernels(cfg):
+    """vican_jacobi_scale / vican_row_scale / vican_scale_weights: the scaled weights have exactly the row and
+    camera sums of w s_c s_t (checked through vican_edge_sums on the chunk layout)."""
+    import ctypes as C
+    from vican_amd import _lib
+    from vican_amd.device import _ptr, _stream
+    Cn, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(Cn, T, lo, hi, 900 + Cn, np.float64, bt, nwg, er)
+    deg_t, deg_c = H.empty(T), H.empty(Cn)
+    H.trans_degrees(deg_t, deg_c)
+    s_t, s_c = H.empty(T), H.empty(Cn)
+    H.jacobi_scale(deg_t, s_t); H.jacobi_scale(deg_c, s_c)
+    dt, dc = deg_t.cpu().numpy(), deg_c.cpu().numpy()
+    np.testing.assert_allclose(s_t.cpu().numpy(), np.where(dt > 0, 1 / np.sqrt(np.where(dt > 0, dt, 1)), 0.0), rtol=1e-15)
+    np.testing.assert_allclose(s_c.cpu().numpy(), 1 / np.sqrt(dc), rtol=1e-15)
+    x = H.from_numpy(np.random.default_rng(0).standard_normal((T, 3)))
+    x0 = x.clone()
+    H.row_scale(s_t, x)
+    np.testing.assert_allclose(x.cpu().numpy(), x0.cpu().numpy() * s_t.cpu().numpy()[:, None], rtol=1e-15)
+    H.set_cg_scaling(s_c, s_t)
+    row_sum, cam_sum = H.zeros(T), H.zeros(Cn)
+    cam_ws = torch.empty(Cn, dtype=torch.int64, device=H.dev)
+    _lib.check(H.lib.vican_edge_sums(C.byref(g.desc), _ptr(H._w_scaled), 1, 1.0, _ptr(row_sum), _ptr(cam_sum), _ptr(cam_ws),
+                                     _stream()), "vican_edge_sums")
+    wt = N.w * s_c.cpu().numpy()[N.col] * s_t.cpu().numpy()[N.row]
+    assert wt.max() <= 1.0 + 1e-12
+    er_, ec_ = np.zeros(T), np.zeros(Cn)
+    np.add.at(er_, N.row, wt); np.add.at(ec_, N.col, wt)
+    np.testing.assert_allclose(row_sum.cpu().numpy(), er_, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(cam_sum.cpu().numpy(), ec_, rtol=1e-12, atol=1e-13)
+    assert H._cg_w is H._w_scaled and H._cg_wmax == 1.0
+    H.clear_cg_scaling()
+    assert H._cg_w is g.w

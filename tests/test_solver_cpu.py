@@ -60,6 +60,21 @@ def test_solver_logic_matches_reference(name, dt):
     assert np.abs(ev3 - evr[:, :3]).max() < (1e-7 if f64 else 1e-4) * np.abs(evr).max()
 
 
+@pytest.mark.parametrize("name,tol", [("g2_small", 1e-9), ("g3_medium", 1e-7), ("g4_illcond", 1e-5), ("g5_strings", 1e-9)])
+def test_tight_mode_reaches_the_converged_solution(name, tol):
+    """tight=True: Jacobi-scaled CG to relres 1e-10 lands on the converged solution of the
+    reference's own normal equations (golden `t_tight`: scipy cg run to 1e-14 on the reference's matrices), where
+    the reference's default answer is `dist_tight` away (0.15 mm ... 17 m)."""
+    g, case, prob = flatten_case(name, "float64")
+    exp = expected(g, "conjugate_gradient", "float64")
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.float64)
+    rc, Rt, x_c, x_t, stats = solve_on_backend(K, Comm(), gc.MAXITER, 3 * (prob.n_cam + prob.n_time), tight=True)
+    R, t = to_pose_arrays(prob, rc, Rt, x_c, x_t, exp["keys"], False)
+    assert stats["converged"] and stats["relres"] < 1e-9 and stats["cg_iters"] < 200
+    assert float(np.linalg.norm(t - exp["t_tight"], axis=1).max()) < tol
+    assert abs(t.sum(0)).max() < 1e-8 * max(1.0, np.abs(t).max())
+
+
 def lsqr_case(name, dt, backend_factory):
     """lsqr_solver="direct": LSQR on the merged system with the |b|^2 correction must reproduce the
     reference's scipy.lsqr answer on its un-merged 3E' x 3N system (same iterates, same stopping point)."""

@@ -14,6 +14,10 @@ Extra keyword-only arguments (defaults reproduce the reference):
     group     torch.distributed process group to shard timesteps over (default:
               the world group when torch.distributed is initialised)
     verbose   print phase timings
+    tight     converge the translations to relres 1e-10 with Jacobi-preconditioned CG instead of
+              reproducing the reference's loosely converged scipy answer (rtol 1e-5, up to metres away
+              from the solution of its own system on heavy-tailed weights); `lsqr_solver` is then only
+              validated.  Off by default: it deliberately breaks parity.
 """
 from __future__ import annotations
 
@@ -26,7 +30,7 @@ import torch
 from . import frontend
 from ._lib import VicanError
 from .geometry import SE3
-from .solver import Comm, LsqrTranslationSolver, RotationSolver, TranslationSolver
+from .solver import Comm, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
 
 __all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "solve_problem"]
 
@@ -36,7 +40,7 @@ def _shard_rows(T, world, rank):
 
 
 def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=np.float32,
-                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10):
+                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
     from .device import HipBackend, LocalGraph      # needs the GPU + extension
@@ -72,7 +76,13 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         return comm.allreduce(full)
 
     Rt_all = gather_rows(Rt_loc, 9)
-    if lsqr_solver == "direct":                                          # bipgo.py:479-480
+    if tight:                                                            # not in the reference (module docstring)
+        tr = TightTranslationSolver(K, comm)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+        if not tr.info["converged"]:
+            raise AssertionError("tight CG did not converge")
+    elif lsqr_solver == "direct":                                        # bipgo.py:479-480
         Rc_h = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()
         Rt_h = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()
         tr = LsqrTranslationSolver(K, comm)
@@ -100,14 +110,14 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
 
 def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callable, noise_model_t: Callable,
                       edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
-                      info: Optional[dict] = None, group=None, verbose: bool = False) -> dict:
+                      info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False) -> dict:
     """SE(3) synchronisation of static cameras and a moving marker object
     (reference bipgo.py:353-490).  See module docstring."""
     t0 = time.perf_counter()
     prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype)
     t1 = time.perf_counter()
     local = {} if info is None else info
-    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local)
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
     local["t_flatten"] = t1 - t0
     rot, pos = {}, {}
     for i, c in enumerate(prob.cam_names):
@@ -127,11 +137,11 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
 
 def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_model_t: Callable,
                              edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
-                             info: Optional[dict] = None, group=None, verbose: bool = False) -> dict:
+                             info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False) -> dict:
     """Object (marker cube) calibration from a moving camera (reference bipgo.py:493-545):
     markers take the camera role, frames the timestep role, every pose is inverted, the
     numerically smallest marker id is pinned to the identity; only marker poses are returned."""
     root, edges = frontend.invert_object_edges(src_edges)
     out = bipartite_se3sync(edges, {root: SE3(pose=np.eye(4))}, noise_model_r, noise_model_t, edge_filter,
-                            maxiter, lsqr_solver, dtype, info=info, group=group, verbose=verbose)
+                            maxiter, lsqr_solver, dtype, info=info, group=group, verbose=verbose, tight=tight)
     return {k: v for k, v in out.items() if "_" not in k}               # bipgo.py:543

@@ -131,6 +131,53 @@ extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const do
 // ---------------------------------------------------------------------------
 // conjugate gradients
 // ---------------------------------------------------------------------------
+// Jacobi scaling of the normal equations (tight translation solve, see vican_hip.h)
+// ---------------------------------------------------------------------------
+__global__ void jacobi_scale_kernel(int n, const double* __restrict__ deg, double* __restrict__ s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s[i] = deg[i] > 0.0 ? 1.0 / sqrt(deg[i]) : 0.0;
+}
+extern "C" int vican_jacobi_scale(int32_t n, const double* deg, double* s, void* stream) {
+    if (n < 0 || !deg || !s) return set_err(VICAN_ERR_ARG, "vican_jacobi_scale: bad argument");
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, deg, s);
+    LAUNCH_CHECK("vican_jacobi_scale");
+    return VICAN_OK;
+}
+__global__ void row_scale_kernel(long long n, int ncomp, const double* __restrict__ s, double* __restrict__ x) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * ncomp) x[i] *= s[i / ncomp];
+}
+extern "C" int vican_row_scale(int32_t n, int32_t ncomp, const double* s, double* x, void* stream) {
+    if (n < 0 || ncomp <= 0 || !s || !x) return set_err(VICAN_ERR_ARG, "vican_row_scale: bad argument");
+    if (n == 0) return VICAN_OK;
+    const long long tot = (long long)n * ncomp;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long)n,
+                       ncomp, s, x);
+    LAUNCH_CHECK("vican_row_scale");
+    return VICAN_OK;
+}
+__global__ void scale_weights_kernel(vican_graph_t g, const double* __restrict__ w, const double* __restrict__ s_cam,
+                                     const double* __restrict__ s_row, double* __restrict__ w_out) {
+    const int k = blockIdx.y;
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= g.slots) return;
+    const size_t i = (size_t)k * g.slots + sl;
+    const uint32_t id = g.idx[i];
+    w_out[i] = id == VICAN_PAD_SLOT ? 0.0 : w[i] * s_cam[id & 0xFFFFu] * s_row[g.chunk_row0[k] + (int)(id >> 16)];
+}
+extern "C" int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s_cam, const double* s_row,
+                                   double* w_out, void* stream) {
+    if (int r = vican_check_graph(g, "vican_scale_weights")) return r;
+    if (!w || !s_cam || !s_row || !w_out) return set_err(VICAN_ERR_ARG, "vican_scale_weights: null pointer");
+    if (g->n_chunk == 0) return VICAN_OK;
+    hipLaunchKernelGGL(scale_weights_kernel, dim3((g->slots + 255) / 256, g->n_chunk), dim3(256), 0, (hipStream_t)stream, *g, w,
+                       s_cam, s_row, w_out);
+    LAUNCH_CHECK("vican_scale_weights");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cg_init_kernel(int n_cam, int n_time, const double* __restrict__ b_c,
                                                       const double* __restrict__ b_t, double* x_c, double* x_t,
                                                       double* r_c, double* r_t, double* p_c, double* p_t,

@@ -171,6 +171,7 @@ class HipBackend:
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
         self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
         self._status_host = {}
+        self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, graph.wmax
 
     # -- allocation helpers -------------------------------------------------
     def empty(self, *shape, dtype=torch.float64):
@@ -233,7 +234,7 @@ class HipBackend:
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
         part = self.zpart[: self.g.n_wg * 3 * self.C]
-        self._ck(self.lib.vican_cg_iter_local(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
+        self._ck(self.lib.vican_cg_iter_local(self._gref, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
                                               _ptr(p_t), _ptr(q_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq), float(rtol),
                                               _ptr(self.rr_part), int(n_rr_part), self.n_add, _ptr(st), _stream()),
                  "vican_cg_iter_local")
@@ -324,9 +325,27 @@ class HipBackend:
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(rhs_c), _stream()),
                  "vican_slab_reduce_fx")
 
+    # Jacobi scaling (tight translation solve): the CG entry points then run on the scaled weights
+    def jacobi_scale(self, deg, s_out):
+        self._ck(self.lib.vican_jacobi_scale(deg.numel(), _ptr(deg), _ptr(s_out), _stream()), "vican_jacobi_scale")
+
+    def row_scale(self, s, x):
+        self._ck(self.lib.vican_row_scale(s.numel(), x.numel() // max(s.numel(), 1), _ptr(s), _ptr(x), _stream()), "vican_row_scale")
+
+    def set_cg_scaling(self, s_c, s_t):
+        """CG sweeps use w~ = w s_c s_t (<= 1) until clear_cg_scaling()."""
+        if self._w_scaled is None:
+            self._w_scaled = torch.empty_like(self.g.w)
+        self._ck(self.lib.vican_scale_weights(self._gref, _ptr(self.g.w), _ptr(s_c), _ptr(s_t), _ptr(self._w_scaled), _stream()),
+                 "vican_scale_weights")
+        self._cg_w, self._cg_wmax = self._w_scaled, 1.0
+
+    def clear_cg_scaling(self):
+        self._cg_w, self._cg_wmax = self.g.w, self.g.wmax
+
     def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
         self._ck(self.lib.vican_cg_init(self.C, self.T, _ptr(b_c), _ptr(b_t), _ptr(x_c), _ptr(x_t), _ptr(r_c), _ptr(r_t),
-                                        _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), self.g.wmax, _stream()), "vican_cg_init")
+                                        _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), self._cg_wmax, _stream()), "vican_cg_init")
 
     def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),
@@ -336,7 +355,7 @@ class HipBackend:
         """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
         nwg = self.g.n_wg
         part = self.zpart[: nwg * 3 * self.C]
-        self._ck(self.lib.vican_cg_sweep(self._gref, _ptr(self.g.w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
+        self._ck(self.lib.vican_cg_sweep(self._gref, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
                                          _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, 1.0, C.c_void_p(st.data_ptr() + 8 * _lib.CG_F["qinv"]),
                                                None, _ptr(qcpq), _stream()), "vican_slab_reduce_fx")

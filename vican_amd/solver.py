@@ -287,15 +287,56 @@ class TranslationSolver:
         return self.x_c, self.x_t
 
 
+class TightTranslationSolver(TranslationSolver):
+    """Translations converged to `rtol` (default 1e-10) instead of scipy's 1e-5 (NOT the
+    reference's behaviour - its loosely converged answer is up to metres from this one on heavy-tailed
+    weights).  Jacobi-preconditioned CG, realised as plain CG on the symmetrically scaled
+    system S A S (S = D^-1/2): that system is again a weighted bipartite Laplacian with unit degrees and weights
+    w s_c s_t, so the same device kernels run it.  Gauge as the reference: translations of all nodes sum to 0."""
+
+    def __init__(self, K, comm=None, rtol=1e-10, poll_every=16):
+        super().__init__(K, comm, rtol=rtol, poll_every=poll_every)
+        self.s_c, self.s_t = K.empty(K.C), K.empty(max(K.T, 1))
+
+    def solve(self, n_unknowns_total, maxiter=None):
+        K, comm = self.K, self.comm
+        K.jacobi_scale(self.deg_c, self.s_c)
+        K.jacobi_scale(self.deg_t, self.s_t)
+        K.row_scale(self.s_c, self.b_c)
+        K.row_scale(self.s_t, self.b_t)
+        deg_c, deg_t = self.deg_c, self.deg_t
+        self.deg_c, self.deg_t = torch.ones_like(deg_c), torch.ones_like(deg_t)       # unit diagonal of S A S
+        K.set_cg_scaling(self.s_c, self.s_t)
+        try:
+            super().solve(n_unknowns_total, maxiter)
+        finally:
+            K.clear_cg_scaling()
+            self.deg_c, self.deg_t = deg_c, deg_t
+        K.row_scale(self.s_c, self.x_c)
+        K.row_scale(self.s_t, self.x_t)
+        # CG from 0 on the scaled system leaves the null-space component (a common shift) D-weighted;
+        # move it to the reference's gauge: sum over all nodes = 0
+        tot = self.x_t[: K.T].sum(0)
+        comm.allreduce(tot)
+        shift = (tot + self.x_c.sum(0)) / (n_unknowns_total // 3)
+        self.x_c -= shift
+        self.x_t -= shift
+        return self.x_c, self.x_t
+
+
 def solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol=1e-10, rtol=1e-5, lsqr_solver="conjugate_gradient",
-                     bnorm2_fn=None):
+                     bnorm2_fn=None, tight=False):
     """Rotation stage then translation stage on one rank's backend ``K``.
     Returns (rc [3C,3] node<-world stacked, Rt_local [T,9], x_c [C,3], x_t [T,3], stats).
     ``bnorm2_fn(rc, Rt_local) -> |b|^2`` of the reference's un-merged system (LSQR stopping tests)."""
     rot = RotationSolver(K, comm, eig_tol=eig_tol)
     rc, Rt_loc = rot.run(maxiter)
     K.synchronize()
-    if lsqr_solver == "direct":
+    if tight:
+        tr = TightTranslationSolver(K, comm)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(n_unknowns_total)
+    elif lsqr_solver == "direct":
         tr = LsqrTranslationSolver(K, comm)
         x_c, x_t = tr.solve(rc, Rt_loc, n_unknowns_total, None if bnorm2_fn is None else bnorm2_fn(rc, Rt_loc))
     else:
