@@ -208,7 +208,28 @@ def eval_case():
                         valid=np.array(valid), gauge_R=np.asarray(G.R(), dtype=np.float64), gauge_t=np.asarray(G.t(), dtype=np.float64),
                         r_err=np.array(r_err), t_err=np.array(t_err), xyz_err=np.stack(xyz),
                         angle_deg=np.array([ref_geometry.angle(np.asarray(v.R())) for v in est.values()]))
-    print("  g7_eval      %d cameras" % len(ids))
+    # real-capture layout (DojoDataset, dataset.py:103-181), parsed by the reference
+    pose = lambda: np.block([[synth.random_rotations(rng, 1)[0], rng.normal(0, 2, (3, 1))], [np.zeros((1, 3)), np.ones((1, 1))]])
+    dj_intr = {c: dict(intrinsics=(np.eye(3) * (900 + i) + np.array([[0, 0, 640.0], [0, 0, 360.0], [0, 0, 0]])).tolist(),
+                       distortion=(0.001 * (i + 1) * np.arange(5)).tolist()) for i, c in enumerate(ids[:4])}
+    dj_extr = {c: pose().tolist() for c in ids[:4]}
+    dj_cube = {"to": {str(m): pose().tolist() for m in range(6)}}
+    with tempfile.TemporaryDirectory() as d:
+        json.dump(dj_intr, open(os.path.join(d, "cameras_intrinsics.json"), "w"))
+        json.dump(dj_extr, open(os.path.join(d, "cameras_transformations_to_origin_ground_truth.json"), "w"))
+        json.dump(dj_cube, open(os.path.join(d, "aruco_cube_transformations.json"), "w"))
+        os.makedirs(os.path.join(d, "aruco_images_samples", "5"))
+        open(os.path.join(d, "aruco_images_samples", "5", ids[1] + ".jpg"), "w").close()
+        dj = ref_dataset.DojoDataset(root=d)
+    np.savez_compressed(os.path.join(HERE, "g7_dojo.npz"), intr_json=np.array(json.dumps(dj_intr)), extr_json=np.array(json.dumps(dj_extr)),
+                        cube_json=np.array(json.dumps(dj_cube)), cam_ids=np.array(list(dj.cams.keys())),
+                        K=np.stack([dj.cams[c].intrinsics for c in dj.cams]), dist=np.stack([dj.cams[c].distortion for c in dj.cams]),
+                        ext_R=np.stack([dj.cams[c].extrinsics.R() for c in dj.cams]), ext_t=np.stack([dj.cams[c].extrinsics.t() for c in dj.cams]),
+                        con_ids=np.array(list(dj.object_constraints.keys())),
+                        con_R=np.stack([v.R() for v in dj.object_constraints.values()]),
+                        con_t=np.stack([v.t() for v in dj.object_constraints.values()]),
+                        im_cam_id=np.array(dj.im_data["cam_id"]), im_timestamp=np.array(dj.im_data["timestamp"]))
+    print("  g7_eval      %d cameras (+ g7_dojo)" % len(ids))
 
 
 if __name__ == "__main__":

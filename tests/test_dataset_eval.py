@@ -83,3 +83,27 @@ def test_edge_cache_roundtrip(tmp_path):
     for a, b in zip(again.values(), ref.values()):
         np.testing.assert_array_equal(a["pose"].R(), b["pose"].R())
         np.testing.assert_array_equal(a["pose"].t(), b["pose"].t())
+
+
+def test_dojo_dataset_reader_matches_reference(tmp_path):
+    """Real-capture layout (reference DojoDataset, dataset.py:103-181): constraints are the INVERSE marker poses."""
+    from vican.dataset import DojoDataset
+    g = np.load(os.path.join(GOLDEN_DIR, "g7_dojo.npz"))
+    (tmp_path / "cameras_intrinsics.json").write_text(str(g["intr_json"]))
+    (tmp_path / "cameras_transformations_to_origin_ground_truth.json").write_text(str(g["extr_json"]))
+    (tmp_path / "aruco_cube_transformations.json").write_text(str(g["cube_json"]))
+    (tmp_path / "aruco_images_samples" / "5").mkdir(parents=True)
+    (tmp_path / "aruco_images_samples" / "5" / (str(g["im_cam_id"][0]) + ".jpg")).write_bytes(b"")
+    ds = DojoDataset(root=str(tmp_path))
+    assert list(ds.cams) == [str(c) for c in g["cam_ids"]]
+    for i, c in enumerate(ds.cams):
+        np.testing.assert_array_equal(ds.cams[c].intrinsics, g["K"][i])
+        np.testing.assert_array_equal(ds.cams[c].distortion, g["dist"][i])
+        np.testing.assert_allclose(ds.cams[c].extrinsics.R(), g["ext_R"][i], atol=1e-7)     # 4x4 poses are float32 (geometry.py:214)
+        np.testing.assert_allclose(ds.cams[c].extrinsics.t(), g["ext_t"][i], atol=1e-6)
+        assert ds.cams[c].resolution_x is None
+    assert list(ds.object_constraints) == [str(c) for c in g["con_ids"]]
+    for i, v in enumerate(ds.object_constraints.values()):
+        np.testing.assert_allclose(v.R(), g["con_R"][i], atol=1e-6)
+        np.testing.assert_allclose(v.t(), g["con_t"][i], atol=1e-5)
+    assert ds.im_data["cam_id"] == [str(c) for c in g["im_cam_id"]] and ds.im_data["timestamp"] == ["5"]

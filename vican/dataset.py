@@ -1,1 +1,2 @@
-from vican_amd.dataset import Camera, Dataset, load_edges, read_cameras, read_object_poses, save_edges  # noqa: F401
+from vican_amd.dataset import (Camera, Dataset, DojoDataset, load_edges, read_cameras,  # noqa: F401
+                               read_object_poses, save_edges)

@@ -16,7 +16,7 @@ import numpy as np
 
 from .geometry import SE3
 
-__all__ = ["Camera", "Dataset", "read_cameras", "read_object_poses", "load_edges", "save_edges"]
+__all__ = ["Camera", "Dataset", "DojoDataset", "read_cameras", "read_object_poses", "load_edges", "save_edges"]
 
 
 class Camera:
@@ -84,6 +84,52 @@ class Dataset:
         self.im_data = {"filename": [], "timestamp": [], "cam": [], "cam_id": []}
         for t in os.listdir(self.root):
             d = os.path.join(self.root, t)
+            if not (t.isnumeric() and os.path.isdir(d)):
+                continue
+            for fn in os.listdir(d):
+                if fn.endswith(".jpg"):
+                    cam_id = fn.split(".")[0]
+                    self.im_data["cam_id"].append(cam_id)
+                    self.im_data["filename"].append(os.path.join(d, fn))
+                    self.im_data["timestamp"].append(t)
+                    self.im_data["cam"].append(self.cams[cam_id])
+
+
+class DojoDataset:
+    """Real-capture layout (reference dataset.py:103-181): ``cameras_intrinsics.json`` (per camera
+    ``intrinsics`` 3x3 + ``distortion``), ``cameras_transformations_to_origin_ground_truth.json`` (4x4 per
+    camera), ``aruco_cube_transformations.json`` (``{"to": {marker: 4x4}}`` -> ``object_constraints``
+    holding the INVERSE of each, ready to be passed as ``constraints=``), images under
+    ``aruco_images_samples/<timestamp>/<camera_id>.jpg``."""
+
+    def __init__(self, root: str):
+        self.root = root
+        self.read_cameras()
+        self.read_im_data()
+        self.read_object_constraints()
+
+    def read_cameras(self):
+        with open(os.path.join(self.root, "cameras_intrinsics.json")) as f:
+            intr = json.load(f)
+        with open(os.path.join(self.root, "cameras_transformations_to_origin_ground_truth.json")) as f:
+            extr = json.load(f)
+        self.cams = {}
+        for c in extr.keys():
+            self.cams[c] = Camera(id=c, intrinsics=np.array(intr[c]["intrinsics"]), distortion=np.array(intr[c]["distortion"]),
+                                  extrinsics=SE3(pose=np.array(extr[c])), resolution_x=None, resolution_y=None)
+
+    def read_object_constraints(self):
+        with open(os.path.join(self.root, "aruco_cube_transformations.json")) as f:
+            data = json.load(f)
+        self.object_constraints = {m: SE3(pose=np.array(v)).inv() for m, v in data["to"].items()}
+
+    def read_im_data(self):
+        path = os.path.join(self.root, "aruco_images_samples")
+        self.im_data = {"filename": [], "timestamp": [], "cam": [], "cam_id": []}
+        if not os.path.isdir(path):
+            raise FileNotFoundError(path)
+        for t in os.listdir(path):
+            d = os.path.join(path, t)
             if not (t.isnumeric() and os.path.isdir(d)):
                 continue
             for fn in os.listdir(d):
