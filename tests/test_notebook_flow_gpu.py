@@ -1,0 +1,89 @@
+"""The reference notebook's flow (main.ipynb cells 1-9) end to end through the import shim on the GPU:
+dataset folders -> cached edge dictionaries -> object calibration -> camera calibration with the calibrated
+cube as constraints -> ground-truth error table.  Synthetic renders (no images: the OpenCV pose-estimation
+cell is replaced by the cached `cam_marker_edges.pt`, as the notebook itself offers)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from vican_amd import synth      # noqa: E402
+
+
+def _write_dataset(root, scene, flat):
+    from vican.geometry import SE3
+    from vican.dataset import save_edges
+    os.makedirs(root, exist_ok=True)
+    cams = {str(c): dict(fx=1000.0, fy=1000.0, cx=640.0, cy=360.0, distortion=[0.0] * 12, R=scene["R_cam"][i].tolist(),
+                         t=scene["p_cam"][i].tolist(), resolution_x=1280, resolution_y=720)
+            for i, c in enumerate(scene["cam_ids"])}
+    json.dump(cams, open(os.path.join(root, "cameras.json"), "w"))
+    save_edges(synth.edges_to_dict(flat, SE3), os.path.join(root, "cam_marker_edges.pt"))
+
+
+def test_notebook_flow(tmp_path):
+    import torch                                                          # cell 1 imports
+    from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync
+    from vican.geometry import optimize_gauge_SE3, distance_SO3, angle   # noqa: F401
+    from vican.dataset import Dataset
+    from vican_amd.evaluate import calibration_errors, format_error_table
+    # stands in for shapely Polygon(...).area; the synthetic marker squares are tiny (6-12 px), so an offset keeps the
+    # area**6 weights of cell 3 within a factor ~2 of each other as on real renders (heavy-tailed weights are the
+    # regime where the reference's loose CG breaks down - covered by golden g4 and by tight=True below)
+    area = lambda edge: 900.0 + synth.shoelace_area(edge["corners"])
+
+    scene = synth.make_scene(12, 400, 8, seed=5)
+    obj_scene = dict(scene)                                               # cube calibration: one moving camera, 600 frames
+    rng = np.random.default_rng(6)
+    obj_scene["R_obj"], obj_scene["p_obj"] = synth.random_rotations(rng, 600), rng.normal(0, 1.0, (600, 3)) + np.array([0, 0, 4.0])
+    obj_scene["time_ids"] = np.array([str(i) for i in range(600)])
+    DATASET_PATH, OBJ_DATASET_PATH = str(tmp_path / "small_room"), str(tmp_path / "cube_calib")
+    _write_dataset(DATASET_PATH, scene, synth.make_camera_edges(scene, cpt=4, mpv=3, sigma_r=1e-3, sigma_t=1e-3, seed=7))
+    _write_dataset(OBJ_DATASET_PATH, scene, synth.make_object_edges(obj_scene, mpv=4, sigma_r=1e-4, sigma_t=1e-4, seed=8))
+
+    dataset, obj_dataset = Dataset(root=DATASET_PATH), Dataset(root=OBJ_DATASET_PATH)
+    assert len(dataset.cams) == 12 and len(obj_dataset.cams) == 12
+
+    # cell 3: 1. object calibration from the cached edges
+    aux = torch.load(os.path.join(OBJ_DATASET_PATH, "cam_marker_edges.pt"), weights_only=False)
+    obj_pose_est = object_bipartite_se3sync(aux,
+                                            noise_model_r=lambda edge: 0.01 * area(edge) ** 2,
+                                            noise_model_t=lambda edge: 0.001 * area(edge) ** 6,
+                                            edge_filter=lambda edge: edge["reprojected_err"] < 0.1,
+                                            maxiter=4, lsqr_solver="conjugate_gradient", dtype=np.float64)
+    assert sorted(obj_pose_est, key=int) == [str(i) for i in range(8)]
+    # the cube geometry is recovered (gauge of the output: root marker at the identity rotation, translations of
+    # all nodes sum to zero - so marker positions are compared relative to the root marker)
+    t0 = np.asarray(obj_pose_est["0"].t(), dtype=np.float64)
+    for i, m in enumerate(scene["marker_ids"]):
+        assert distance_SO3(np.asarray(obj_pose_est[m].R(), dtype=np.float64), scene["R_mk"][i]) < 0.05
+        assert np.linalg.norm(np.asarray(obj_pose_est[m].t()) - t0 - scene["q_mk"][i]) < 5e-3     # loose CG (rtol 1e-5)
+    # tight=True converges the same system: sub-millimetre marker positions at 0.1 mm measurement noise
+    obj_tight = object_bipartite_se3sync(aux, noise_model_r=lambda edge: 0.01 * area(edge) ** 2,
+                                         noise_model_t=lambda edge: 0.001 * area(edge) ** 6,
+                                         edge_filter=lambda edge: edge["reprojected_err"] < 0.1,
+                                         maxiter=4, lsqr_solver="conjugate_gradient", dtype=np.float64, tight=True)
+    tt0 = np.asarray(obj_tight["0"].t(), dtype=np.float64)
+    for i, m in enumerate(scene["marker_ids"]):
+        assert np.linalg.norm(np.asarray(obj_tight[m].t()) - tt0 - scene["q_mk"][i]) < 1e-3
+
+    # cells 5-7: 3. camera calibration with the calibrated cube as constraints
+    cam_marker_edges = torch.load(os.path.join(DATASET_PATH, "cam_marker_edges.pt"), weights_only=False)
+    tmax = 300
+    edges = {k: v for k, v in cam_marker_edges.items() if int(k[1].split("_")[0]) < tmax}
+    pose_est = bipartite_se3sync(edges, constraints=obj_pose_est,
+                                 noise_model_r=lambda edge: 0.001 * area(edge) ** 1.0,
+                                 noise_model_t=lambda edge: 0.001 * area(edge) ** 2.0,
+                                 edge_filter=lambda edge: edge["reprojected_err"] < 0.05,
+                                 maxiter=4, lsqr_solver="conjugate_gradient", dtype=np.float32)
+    assert all(c in pose_est for c in dataset.cams) and "0_0" in pose_est and pose_est["0"].R().dtype == np.float32
+
+    # cell 9: 4. comparison with ground truth
+    res = calibration_errors(dataset.cams, pose_est)
+    print(format_error_table(res))
+    assert res["missing"] == []
+    assert res["table"]["SO(3)"]["max"] < 0.1          # degrees  (measurement noise 1e-3 rad = 0.06 deg per edge)
+    assert res["table"]["E(3)"]["max"] < 1.0           # centimetres (1 mm per edge, ~100 edges per camera)
