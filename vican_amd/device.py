@@ -291,6 +291,17 @@ class HipBackend:
         finally:
             self.lib.vican_set_gate(None)
 
+    def capture(self, fn):
+        """Record the launches of fn() into a HIP graph (nothing executes); returns an object with .replay().
+        fn must only enqueue kernels on the current stream with arguments that stay valid (device-resident
+        state, preallocated buffers) - used for launch-bound inner loops on small graphs."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        return g
+
     def post_status(self, status):
         """Asynchronous device->host copy of a small status vector; returns a handle for wait_status."""
         host = self._status_host.get(status.numel())

@@ -244,6 +244,9 @@ class TranslationSolver:
         self.qcpq = K.zeros(3 * C + 1)
         self.st = K.zeros(CG_STATE_DOUBLES)
         self.info = {}
+        n_edges = getattr(getattr(K, "g", None), "n_edges", None)
+        self.small_graph = n_edges is not None and n_edges < 2_000_000
+        self._graph, self._graph_key = None, None
 
     def _state(self):
         h = self.st.cpu()
@@ -265,18 +268,34 @@ class TranslationSolver:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
         maxiter = 10 * n_unknowns_total if maxiter is None else maxiter       # scipy default
         n_part, it_launched, s = 0, 0, None
+
+        def one_iteration(n_part):
+            K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
+            if multi:
+                comm.allreduce(self.qcpq)
+            n_part = K.cg_iter_finish(self.deg_c, self.qcpq, self.p_c, self.x_c, self.r_c, self.p_t, self.q_t,
+                                      self.x_t, self.r_t, st)
+            if multi:
+                K.cg_end(n_part, st)
+                comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
+                n_part = 0
+            return n_part
+
+        # On small graphs an iteration is five kernels of a few microseconds each - launch-bound from Python.
+        # All per-iteration quantities (alpha, beta, norms, the done flag) live in the device state struct, so
+        # every iteration after the first is the SAME sequence of launches: recorded once into a HIP graph and
+        # replayed (single rank only; the graph is kept while the buffers it names stay alive).
+        use_graph = self.small_graph and not multi and hasattr(K, "capture")
         while True:
             burst = min(self.poll_every, maxiter + 1 - it_launched)
             for _ in range(burst):
-                K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
-                if multi:
-                    comm.allreduce(self.qcpq)
-                n_part = K.cg_iter_finish(self.deg_c, self.qcpq, self.p_c, self.x_c, self.r_c, self.p_t, self.q_t,
-                                          self.x_t, self.r_t, st)
-                if multi:
-                    K.cg_end(n_part, st)
-                    comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
-                    n_part = 0
+                if use_graph and it_launched >= 1:
+                    key = (n_part, float(self.rtol), self.deg_t.data_ptr(), self.deg_c.data_ptr())
+                    if self._graph_key != key:
+                        self._graph, self._graph_key = K.capture(lambda: one_iteration(n_part)), key
+                    self._graph.replay()
+                else:
+                    n_part = one_iteration(n_part)
                 it_launched += 1
             s = self._state()
             if s["done"] or it_launched > maxiter:
