@@ -197,10 +197,11 @@ def main():
         "metric": "edges/sec through bipartite_se3sync primal-dual iter",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "%s products, 64-bit fixed-point accumulation, f64 camera side" % args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s: %d cameras x %d timesteps/GPU x %d cams/timestep, %d merged edges/GPU, "
                                "maxiter=%d + CG translation solve, blocks stored %s" % (
                                    args.workload, C, Tl, cpt, E_local, args.maxiter, args.dtype),
+                   "arithmetic": "%s block products, exact 64-bit fixed-point accumulation, f64 camera side and CG" % args.dtype,
                    "parallelism": "timestep-sharded x%d, camera side replicated" % world},
         "roofline": {"bound": "hbm", "kernel": "block_sweep_kernel<MODE=0> (vican_block_op)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
