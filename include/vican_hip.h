@@ -61,14 +61,15 @@ typedef struct vican_graph {
     int32_t block_threads;    /* 256, 512, 768 or 1024 */
     int32_t n_wg;             /* persistent workgroups per sweep (= number of partial slabs) */
     int32_t n_copy;           /* lane-striped copies of the per-row accumulators (power of 2, <= 32) */
-    int32_t reserved;
+    int32_t wg_chunk_cap;     /* most chunks one workgroup of a block sweep may take (dynamic tickets, see
+                                 vican_block_op); >= ceil(n_chunk / n_wg); 0 = unlimited */
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 3 */
+int vican_abi_version(void);            /* 4 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -127,7 +128,8 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
  * VICAN_FX_DOUBLES doubles: [0] y scale, [1] its inverse, [2] z scale, [3] its inverse,
  * [4] omega = max_t |lamT_inv[t]|_F * rnorm[t], [5] max block norm, [6] max_t rnorm[t],
  * [7] 2^-shift of the last vican_block_op (its scales are raised by 2^shift when the actual
- * max_c |x_c|_F is below x_bound), [8] x_bound, [9..11] spare.
+ * max_c |x_c|_F is below x_bound), [8] x_bound, [9] spare, [10] two 32-bit counters of the block sweeps'
+ * chunk scheduler (zero between launches), [11] spare.
  * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
  * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
  * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup;
@@ -153,7 +155,9 @@ int vican_scaled_identity(int32_t n, const double* scale, double* out /*[n][9]*/
  * bipgo.py:273,334 and the SpMM at bipgo.py:300).  x: [3C][3] double with |x_c|_F <= the
  * x_bound given to vican_fx_finish; zpart: [n_wg][9][C] planes of 64-bit fixed point (scale fx[2]),
  * to be folded by vican_slab_reduce_fx.  Each block is read from HBM exactly once; products
- * are formed in the storage type (f32 for f32 blocks), sums are exact integers.       */
+ * are formed in the storage type (f32 for f32 blocks), sums are exact integers.
+ * Chunks are handed to the workgroups through a ticket counter in fx[10] (exact integer sums: the
+ * assignment cannot change the result), so launches on ONE graph must be serialised on one stream. */
 int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x,
                    void* zpart, double* fx, void* stream);
 /* Composite: vican_block_op + vican_slab_reduce_fx -> z [3C][3] (this rank's partial of P x). */

@@ -17,7 +17,7 @@
 
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 3; }
+extern "C" int vican_abi_version(void) { return 4; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
@@ -466,6 +466,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                                                             const double* __restrict__ rnorm,
                                                             double* __restrict__ fx) {
     GATE_RETURN(gate);
+#ifdef VICAN_STAMP
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
+    unsigned long long rt_loop0 = 0, rt_loop1 = 0;
+#endif
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -480,18 +484,40 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
     const int part_n = ncopy < 4 ? ncopy : 4, per = ncopy / part_n;   // phase 2: part_n lanes per accumulator
 
+    // Chunks are handed out dynamically: DEPTH+1 per workgroup up front (chunk = workgroup + i * grid), then one
+    // ticket per processed chunk from a device counter (fx[10]), fetched one body ahead of the prefetch that
+    // needs it.  Measured with static ranges: workgroups finished between 192 and 212 us of a 214 us launch
+    // (32 vs 33 chunks each, and CU-to-CU speed differences) - with tickets all finish within one chunk time.
+    // Sums are exact integers, so WHICH workgroup accumulates a chunk cannot change the result; the
+    // per-workgroup cap keeps the number of adds into one accumulator within the bound fx_finish assumed.
+    constexpr int DEPTH = (BLOCK <= 512) ? 2 : 1;
+    __shared__ int s_knext;
+    unsigned int* sched = (unsigned int*)(fx + 10);            // [0] next ticket, [1] workgroups finished
+    const int nchunk = g.n_chunk, nwg = (int)gridDim.x;
+    const int cap = g.wg_chunk_cap > DEPTH ? g.wg_chunk_cap : 0x7fffffff;
+    int kc = (int)blockIdx.x, kn1 = kc + nwg, kn2 = kc + 2 * nwg, taken = DEPTH + 1;
+    ChunkRegs<S, EPL> ra, rb, rc;
+    // the first chunk(s) are requested before anything else: their HBM latency overlaps the table staging
+    if (kc < nchunk) load_chunk<S, EPL>(ra, g, kc, tid);
+    if (DEPTH == 2 && kn1 < nchunk) load_chunk<S, EPL>(rb, g, kn1, tid);
+
     // The scales in fx assume |x_c|_F <= x_bound (sqrt 3).  Krylov vectors are far smaller
     // (~sqrt(3/C)), so every workgroup measures max_c |x_c|_F of THIS input (all find the same
     // value) and shifts both scales up by the power of two that still keeps it below the bound:
     // 4-5 more bits of fixed-point resolution for free.  Workgroup 0 records 2^-shift in fx[7]
-    // for vican_slab_reduce_fx.
+    // for vican_slab_reduce_fx.  x is read once (registers), measured, then staged as planes.
+    constexpr int XC = (CP + BLOCK - 1) / BLOCK;                // cameras per thread
+    double xv[XC][9];
     double xm2 = 0.0;
-    for (int c = tid; c < C; c += BLOCK) {
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        const int c = tid + m * BLOCK;
         double q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { const double v = x[(size_t)c * 9 + i]; q += v * v; }
+        for (int i = 0; i < 9; ++i) { xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0; q += xv[m][i] * xv[m][i]; }
         xm2 = fmax(xm2, q);
     }
+    const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8];
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) xm2 = fmax(xm2, __shfl_xor(xm2, o2, 64));
     if (lane == 0) ysum[wave] = xm2;                     // scratch: ysum is not used before phase 2
@@ -499,20 +525,26 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     xm2 = 0.0;
     for (int i = 0; i < NWAVE; ++i) xm2 = fmax(xm2, ysum[i]);
     int shift = 0;
-    if (xm2 > 0.0) shift = (int)floor(log2(fx[8] / sqrt(xm2)));     // fx[8] = x_bound
+    // floor(log2(x_bound / sqrt(xm2))) = floor(log2(x_bound^2 / xm2) / 2): one division + exponent extraction
+    if (xm2 > 0.0) { const double r2 = fx8 * fx8 / xm2; shift = r2 >= 1.0 ? (ilogb(r2) >> 1) : 0; }     // fx[8] = x_bound
     shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
     const double up = ldexp(1.0, shift);
-    const double y_scale = fx[0] * up, y_inv = fx[1] / up, z_scale = fx[2] * up;
+    const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = fx2 * up;
     if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if (MODE == 1 && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
     __syncthreads();
 
-    for (int i = tid; i < 9 * C; i += BLOCK) xs[(i % 9) * CP + i / 9] = pre_scale<S>(x[i], y_scale);
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        const int c = tid + m * BLOCK;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], y_scale);
+        }
+    }
     if (MODE == 0) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
     for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
 
-    const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
-    const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 #ifdef VICAN_STAMP
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t;
 #define STAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -524,14 +556,17 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     // Register ring: DEPTH chunks in flight ahead of the one being processed.  512-thread workgroups
     // have 256 VGPRs per lane and keep two chunks in flight (the memory system then always has work
     // from this CU); 768/1024-thread workgroups only have room for one.
-    constexpr int DEPTH = (BLOCK <= 512) ? 2 : 1;
-    ChunkRegs<S, EPL> ra, rb, rc;
-    if (k0 < k1) load_chunk<S, EPL>(ra, g, k0, tid);
-    if (DEPTH == 2 && k0 + 1 < k1) load_chunk<S, EPL>(rb, g, k0 + 1, tid);
     __syncthreads();
 
     STAMP0();
-    auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int k) {
+#ifdef VICAN_STAMP
+    rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // body: process chunk k (registers `cur`), prefetch chunk kpref into `nxt`, draw the ticket for the chunk
+    // the NEXT body will prefetch; returns that chunk index (>= nchunk: nothing left / cap reached)
+    auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int k, const int kpref) -> int {
+        unsigned int ticket = 0;
+        if (tid == 0 && taken < cap) ticket = atomicAdd(&sched[0], 1u);     // oldest vector-memory op of this body
         const int r0 = g.chunk_row0[k];
         const int nrows = g.chunk_row0[k + 1] - r0;
         // duals of the row this wavefront will fold in phase 2 (lane -> accumulator o = lane / part_n).
@@ -544,7 +579,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             L0 = L[0]; L1 = L[1]; L2 = L[2];
         }
         __builtin_amdgcn_sched_barrier(0);                              // keep these loads ahead of the prefetch
-        if (k + DEPTH < k1) load_chunk<S, EPL>(nxt, g, k + DEPTH, tid);   // prefetch: lands during this/next chunk
+        if (kpref < nchunk) load_chunk<S, EPL>(nxt, g, kpref, tid);      // prefetch: lands during this/next chunk
 
         // ---- phase 1: y_row += M^T x_cam ; same-row edges of a lane pre-summed in registers,
         //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
@@ -556,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #pragma unroll
             for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
             if (keep == 123.456f && cur.id[0] == 77u) zs[0] = 1ull;
-            return;
+            return 0x7fffffff;
         }
 #endif
         STAMP(5);                       // inter-chunk prologue: descriptors, dual loads, prefetch issue
@@ -599,7 +634,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             }
         }
         STAMP(0);                       // phase 1 (incl. waiting for this chunk's loads)
+        if (tid == 0) s_knext = taken < cap ? (DEPTH + 1) * nwg + (int)ticket : 0x7fffffff;
         __syncthreads();
+        const int knew = s_knext;       // read between the two barriers of this body; rewritten after the second
         STAMP(1);                       // barrier A
 
         // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
@@ -671,23 +708,38 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         STAMP(4);                       // phase 3
         // (the barrier after the next chunk's phase 1 separates this chunk's phase 3 reads of wv
         //  from the next phase 2 writes; ys is already re-zeroed for the next phase 1)
+        return knew;
     };
 
+#define VICAN_ADVANCE1(knew_) do { const int kn_ = (knew_); kc = kn1; kn1 = kn_; taken += kn_ < nchunk ? 1 : 0; } while (0)
+#define VICAN_ADVANCE2(knew_) do { const int kn_ = (knew_); kc = kn1; kn1 = kn2; kn2 = kn_; taken += kn_ < nchunk ? 1 : 0; } while (0)
     if (DEPTH == 1) {
 #pragma unroll 1
-        for (int k = k0; k < k1; k += 2) {
-            body(ra, rb, k);
-            if (k + 1 < k1) body(rb, ra, k + 1);
+        while (kc < nchunk) {
+            VICAN_ADVANCE1(body(ra, rb, kc, kn1));
+            if (kc >= nchunk) break;
+            VICAN_ADVANCE1(body(rb, ra, kc, kn1));
         }
     } else {
 #pragma unroll 1
-        for (int k = k0; k < k1; k += 3) {          // body(current, set to refill with chunk k + 2)
-            body(ra, rc, k);
-            if (k + 1 < k1) body(rb, ra, k + 1);
-            if (k + 2 < k1) body(rc, rb, k + 2);
+        while (kc < nchunk) {                       // body(current, set to refill with the chunk two ahead)
+            VICAN_ADVANCE2(body(ra, rc, kc, kn2));
+            if (kc >= nchunk) break;
+            VICAN_ADVANCE2(body(rb, ra, kc, kn2));
+            if (kc >= nchunk) break;
+            VICAN_ADVANCE2(body(rc, rb, kc, kn2));
         }
     }
+#undef VICAN_ADVANCE1
+#undef VICAN_ADVANCE2
+    // the last workgroup to get here re-arms the ticket counter for the next launch (every ticket of every
+    // workgroup has been drawn by then)
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&sched[1], 1u) == (unsigned)nwg - 1u) { __threadfence(); sched[0] = 0u; sched[1] = 0u; }
+    }
 #ifdef VICAN_STAMP
+    rt_loop1 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0 && Rt_out && (tid == 0 || tid == BLOCK - 64))
         for (int i = 0; i < 6; ++i) Rt_out[((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 6 + i] = (double)st_acc[i];
 #endif
@@ -696,6 +748,12 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
         for (int i = tid; i < 9 * C; i += BLOCK) zp[i] = (u64)fix_total<S>((long long)zs[(i / C) * CP + i % C]);
     }
+#ifdef VICAN_STAMP
+    if (MODE == 0 && Rt_out && tid == 0) {                 // wall-clock structure of the launch, per workgroup
+        double* w = Rt_out + 4096 * 12 + (size_t)blockIdx.x * 4;
+        w[0] = (double)rt_begin; w[1] = (double)rt_loop0; w[2] = (double)rt_loop1; w[3] = (double)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // Rt[t], lamT_inv[t] from Z_t (stored in lamT_inv by the MODE 1 sweep), in place; omega bound.
@@ -767,7 +825,7 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
     if (!lamT_inv || !x || !zpart || !fx) return set_err(VICAN_ERR_ARG, "vican_block_op: null pointer");
 #ifdef VICAN_STAMP
     static double* stamp_buf = nullptr;                 // diagnostic builds only: per-workgroup phase cycles
-    if (!stamp_buf) hipMalloc(&stamp_buf, 4096 * 12 * sizeof(double));
+    if (!stamp_buf) hipMalloc(&stamp_buf, 4096 * 16 * sizeof(double));
     if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, stamp_buf, nullptr, nullptr, fx, stream)) return rc;
     if (getenv("VICAN_STAMP_DUMP")) {
         hipStreamSynchronize((hipStream_t)stream);
@@ -775,6 +833,20 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
         hipMemcpy(host, stamp_buf, sizeof(double) * g->n_wg * 12, hipMemcpyDeviceToHost);
         double sum[2][6] = {{0}};
         for (int w = 0; w < g->n_wg; ++w) for (int h = 0; h < 2; ++h) for (int i = 0; i < 6; ++i) sum[h][i] += host[(w * 2 + h) * 6 + i];
+        {   // wall-clock structure of the launch (100 MHz ticks -> us), over workgroups
+            static double rt[4096 * 4];
+            hipMemcpy(rt, stamp_buf + 4096 * 12, sizeof(double) * g->n_wg * 4, hipMemcpyDeviceToHost);
+            double b0 = 1e300, b1 = 0, l0min = 1e300, l0max = 0, l1min = 1e300, l1max = 0, emax = 0, pro = 0, loop = 0, epi = 0;
+            for (int w = 0; w < g->n_wg; ++w) {
+                const double* r = rt + w * 4;
+                b0 = fmin(b0, r[0]); b1 = fmax(b1, r[0]); l0min = fmin(l0min, r[1]); l0max = fmax(l0max, r[1]);
+                l1min = fmin(l1min, r[2]); l1max = fmax(l1max, r[2]); emax = fmax(emax, r[3]);
+                pro += r[1] - r[0]; loop += r[2] - r[1]; epi += r[3] - r[2];
+            }
+            fprintf(stderr, "WALL us: first start 0, last start %.2f | loop start %.2f..%.2f | loop end %.2f..%.2f | last end %.2f | mean prologue %.2f loop %.2f epilogue %.2f\n",
+                    (b1 - b0) / 100, (l0min - b0) / 100, (l0max - b0) / 100, (l1min - b0) / 100, (l1max - b0) / 100, (emax - b0) / 100,
+                    pro / g->n_wg / 100, loop / g->n_wg / 100, epi / g->n_wg / 100);
+        }
         for (int h = 0; h < 2; ++h)
             fprintf(stderr, "STAMP wave%s: prologue %.0f phase1 %.0f barA %.0f phase2 %.0f barB %.0f phase3 %.0f  (mean cycles per workgroup)\n",
                     h ? "-last" : "0", sum[h][5] / g->n_wg, sum[h][0] / g->n_wg, sum[h][1] / g->n_wg, sum[h][2] / g->n_wg, sum[h][3] / g->n_wg, sum[h][4] / g->n_wg);

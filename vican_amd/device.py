@@ -103,6 +103,11 @@ class LocalGraph:
         # max timestep rows one workgroup handles (bounds the adds into one z accumulator)
         bounds = (np.arange(self.n_wg + 1, dtype=np.int64) * self.n_chunk) // self.n_wg
         self.rows_per_wg_max = int(np.diff(self.chunk_row0_host[bounds]).max()) if nchunk else 1
+        # the block sweeps hand chunks out dynamically (tickets); a workgroup takes at most `cap` of them, which
+        # bounds the adds into one of its z accumulators
+        per = -(-self.n_chunk // self.n_wg) if nchunk else 1
+        self.wg_chunk_cap = per + max(2, -(-per // 8))
+        self.rows_per_wg_sweep = max(self.rows_per_wg_max, min(self.n_time, self.wg_chunk_cap * self.max_rows), 1)
         self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
         nslot = max(1, self.n_chunk) * slots
         self.blk = torch.empty(9 * nslot, dtype=blk.dtype, device=dev)
@@ -113,7 +118,7 @@ class LocalGraph:
         self.u = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
         self.v = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
         self.desc = _lib.Graph(self.n_cam, self.n_time, self.n_chunk, slots, self.max_rows, storage, block_threads,
-                               self.n_wg, self.n_copy, 0, self.blk.data_ptr(), self.idx.data_ptr(),
+                               self.n_wg, self.n_copy, self.wg_chunk_cap, self.blk.data_ptr(), self.idx.data_ptr(),
                                self.chunk_row0.data_ptr())
         gref = C.byref(self.desc)
         row_ptr = row_ptr.to(dev, torch.int32).contiguous()
@@ -194,7 +199,7 @@ class HipBackend:
         return _lib.check(rc, what)
 
     def _fx_finish(self):
-        self._ck(self.lib.vican_fx_finish(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_max + 1),
+        self._ck(self.lib.vican_fx_finish(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_sweep + 1),
                                           self.g.desc.storage, _stream()),
                  "vican_fx_finish")
 
