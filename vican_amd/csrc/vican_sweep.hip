@@ -497,9 +497,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     const int cap = g.wg_chunk_cap > DEPTH ? g.wg_chunk_cap : 0x7fffffff;
     int kc = (int)blockIdx.x, kn1 = kc + nwg, kn2 = kc + 2 * nwg, taken = DEPTH + 1;
     ChunkRegs<S, EPL> ra, rb, rc;
-    // the first chunk(s) are requested before anything else: their HBM latency overlaps the table staging
-    if (kc < nchunk) load_chunk<S, EPL>(ra, g, kc, tid);
-    if (DEPTH == 2 && kn1 < nchunk) load_chunk<S, EPL>(rb, g, kn1, tid);
 
     // The scales in fx assume |x_c|_F <= x_bound (sqrt 3).  Krylov vectors are far smaller
     // (~sqrt(3/C)), so every workgroup measures max_c |x_c|_F of THIS input (all find the same
@@ -508,20 +505,32 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     // for vican_slab_reduce_fx.  x is read once (registers), measured, then staged as planes.
     constexpr int XC = (CP + BLOCK - 1) / BLOCK;                // cameras per thread
     double xv[XC][9];
-    double xm2 = 0.0;
 #pragma unroll
     for (int m = 0; m < XC; ++m) {
         const int c = tid + m * BLOCK;
-        double q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0; q += xv[m][i] * xv[m][i]; }
-        xm2 = fmax(xm2, q);
+        for (int i = 0; i < 9; ++i) xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0;
     }
     const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8];
+    // The first chunk(s) are requested right behind the x loads (vector-memory results retire in issue
+    // order, so x - an L2 hit - must be the older request): their HBM latency overlaps the table staging.
+    __builtin_amdgcn_sched_barrier(0);
+    if (kc < nchunk) load_chunk<S, EPL>(ra, g, kc, tid);
+    if (DEPTH == 2 && kn1 < nchunk) load_chunk<S, EPL>(rb, g, kn1, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    double xm2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q += xv[m][i] * xv[m][i];
+        xm2 = fmax(xm2, q);
+    }
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) xm2 = fmax(xm2, __shfl_xor(xm2, o2, 64));
     if (lane == 0) ysum[wave] = xm2;                     // scratch: ysum is not used before phase 2
     __syncthreads();
+
     xm2 = 0.0;
     for (int i = 0; i < NWAVE; ++i) xm2 = fmax(xm2, ysum[i]);
     int shift = 0;
