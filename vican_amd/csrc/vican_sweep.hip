@@ -89,9 +89,15 @@ int vican_check_graph(const vican_graph_t* g, const char* who) {
 // With the camera-side LDS tables stored as planes [component][camera], every gather of
 // x_cam, every fixed-point atomic on z_cam and every striped atomic on y_row then hits 32
 // distinct banks per 32-lane group - the conflict-free rate instead of the 4x slower
-// "random" one (PMC: 75 % of LDS cycles were bank conflicts before this).  Within a class
-// the edges keep CSR order (row-major), so a lane's EPL edges mostly share a row.  Classes
-// that overflow their lanes spill into the free slots of the others.
+// "random" one (PMC: 75 % of LDS cycles were bank conflicts before this).
+// It is also ROW-AWARE: of the n edges a row has in a class, the first EPL*floor(n/EPL) fill
+// whole lanes ("pure" lanes: one row per lane), allocated from the first lane group of the class
+// upwards; the n mod EPL leftovers of all rows are packed continuously into lanes allocated from the
+// last lane group downwards.  The sweep flushes a lane's row sum whenever the row changes inside the
+// lane (masked, but at full instruction cost); with this order the lanes that change row sit in the
+// last few wavefronts and all others skip those flushes (execz branches): 12 x 36 -> about
+// 10 x 9 + 2 x 36 row-accumulator atomics per chunk.  Classes that overflow their lanes spill into the
+// free slots of the others.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr,
                                                         const int32_t* __restrict__ col, int32_t* __restrict__ perm,
@@ -99,42 +105,63 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
     extern __shared__ int32_t sh[];                 // overflow list [slots]
     const int k = blockIdx.x, lane = threadIdx.x;
     int novf = 0;                                   // wave-uniform
-    const int e0 = row_ptr[g.chunk_row0[k]], e1 = row_ptr[g.chunk_row0[k + 1]];
+    const int r_first = g.chunk_row0[k], r_last = g.chunk_row0[k + 1];
     int32_t* pm = perm + (size_t)k * g.slots;
     for (int s = lane; s < g.slots; s += 64) pm[s] = -1;
     __syncthreads();
-    const int cap = (g.block_threads / 32) * epl;   // slots per camera class
-    int cnt = 0;                                    // lane c (< 32) holds the running count of class c
+    const int G = g.block_threads / 32;             // lane groups (of 32 lanes) = lanes per camera class
+    int pure_lanes = 0, left_cnt = 0;               // lane c (< 32): state of class c
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = e0; base < e1; base += 64) {
-        const int e = base + lane;
-        const bool valid = e < e1;
-        const int c = valid ? (col[e] & 31) : -1;
-        int rank = 0;
-        for (int kk = 0; kk < 32; ++kk) {
-            const unsigned long long m = __ballot(c == kk);
-            const int before = __shfl(cnt, kk, 64);
-            if (c == kk) rank = before + __popcll(m & lt);
-            if (lane == kk) cnt += __popcll(m);
+    for (int r = r_first; r < r_last; ++r) {
+        const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+        if (e0 == e1) continue;
+        int n_c = 0;                                // lane kk: edges of this row in class kk
+        for (int base = e0; base < e1; base += 64) {
+            const int e = base + lane;
+            const int c = e < e1 ? (col[e] & 31) : -1;
+            for (int kk = 0; kk < 32; ++kk) {
+                const unsigned long long m = __ballot(c == kk);
+                if (lane == kk) n_c += __popcll(m);
+            }
         }
-        const bool spill = valid && rank >= cap;
-        const unsigned long long sm = __ballot(spill);      // ordered compaction: deterministic layout
-        if (valid && !spill) {
-            // lane group of this rank, rotated by the class and interleaved over the wavefronts: the
-            // partially filled tail groups of the 32 classes (and the spill slots that fill them) end up
-            // spread over all wavefronts instead of piling irregular work onto the last one
-            const int G = g.block_threads / 32, W = G / 2 > 0 ? G / 2 : 1;
-            const int pos = (rank / epl + c) % G;
-            const int grp = (G > 1) ? (pos % W) * 2 + pos / W : 0;
-            pm[(c + 32 * grp) * epl + (rank % epl)] = e;
+        int seen = 0;
+        for (int base = e0; base < e1; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < e1;
+            const int c = valid ? (col[e] & 31) : -1;
+            int pos = 0, ncls = 0, pl = 0, lc = 0;
+            for (int kk = 0; kk < 32; ++kk) {
+                const unsigned long long m = __ballot(c == kk);
+                const int before = __shfl(seen, kk, 64), nk = __shfl(n_c, kk, 64);
+                const int plk = __shfl(pure_lanes, kk, 64), lck = __shfl(left_cnt, kk, 64);
+                if (c == kk) { pos = before + __popcll(m & lt); ncls = nk; pl = plk; lc = lck; }
+                if (lane == kk) seen += __popcll(m);
+            }
+            bool spill = false;
+            int grp = 0, slot = 0;
+            if (valid) {
+                const int full = (ncls / epl) * epl, rem = ncls - full;
+                const int back_groups = (lc + rem + epl - 1) / epl;         // leftover lane groups in use after this row
+                if (pos < full) {                   // pure lane, from the front
+                    grp = pl + pos / epl; slot = pos % epl;
+                    spill = grp >= G - back_groups;
+                } else {                            // leftover stream, from the back
+                    const int lr = lc + (pos - full);
+                    grp = G - 1 - lr / epl; slot = lr % epl;
+                    spill = grp < pl + ncls / epl;
+                }
+            }
+            const unsigned long long sm = __ballot(spill);      // ordered compaction: deterministic layout
+            if (valid && !spill) pm[(c + 32 * grp) * epl + slot] = e;
+            if (spill) sh[novf + __popcll(sm & lt)] = e;
+            novf += __popcll(sm);
         }
-        if (spill) sh[novf + __popcll(sm & lt)] = e;
-        novf += __popcll(sm);
+        if (lane < 32) { pure_lanes += n_c / epl; left_cnt += n_c % epl; }
     }
     __syncthreads();
-    if (lane == 0 && novf > 0) {                    // spill: few edges, any free slot will do
-        int o = 0;
-        for (int s = 0; s < g.slots && o < novf; ++s)
+    if (lane == 0 && novf > 0) {                    // spill: few edges; fill free slots from the back (the
+        int o = 0;                                  // wavefronts that change rows anyway)
+        for (int s = g.slots - 1; s >= 0 && o < novf; --s)
             if (pm[s] < 0) pm[s] = sh[o++];
     }
 }
