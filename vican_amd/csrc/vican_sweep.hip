@@ -782,7 +782,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     if (MODE == 0) {
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
-        for (int i = tid; i < 9 * C; i += BLOCK) zp[i] = (u64)fix_total<S>((long long)zs[(i / C) * CP + i % C]);
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            for (int c = tid; c < C; c += BLOCK) zp[q * C + c] = (u64)fix_total<S>((long long)zs[q * CP + c]);
     }
 #ifdef VICAN_STAMP
     if (MODE == 0 && Rt_out && tid == 0) {                 // wall-clock structure of the launch, per workgroup

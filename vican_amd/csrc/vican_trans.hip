@@ -593,10 +593,21 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
         const long long q = i / n_cam, cam = i % n_cam;
         qcpq[cam * 3 + q] = (double)t * st->qinv;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < n_slab; ++k) t += pq_part[k];
-        qcpq[n] = t;
+    if (blockIdx.x == 0) {                   // p.q partials: loaded in parallel, summed in a fixed order
+        __shared__ double pq[1024];
+        __syncthreads();
+        for (int k0 = 0; k0 < n_slab; k0 += 1024) {
+            const int k = k0 + threadIdx.x;
+            pq[threadIdx.x] = k < n_slab ? pq_part[k] : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = k0 ? qcpq[n] : 0.0;
+                const int m = n_slab - k0 < 1024 ? n_slab - k0 : 1024;
+                for (int j = 0; j < m; ++j) t += pq[j];
+                qcpq[n] = t;
+            }
+            __syncthreads();
+        }
     }
 }
 
