@@ -29,17 +29,22 @@ __device__ __host__ inline double fix_scale(double c, double n_add, double* inv)
 // ---------------------------------------------------------------------------
 // right-hand side:  g_ct = Rc_c^T u_ct + Rt_t^T v_ct ;  rhs_t = sum_c g_ct ; rhs_c = -sum_t g_ct
 // ---------------------------------------------------------------------------
-template <int BLOCK, int EPL>
+// Software pipeline as in cg_sweep_kernel: the edge words of chunk k+1 (packed index + u + v: 52 B per edge)
+// and the R_t blocks of its rows are in flight while chunk k is processed; two barriers per chunk.
+template <int EPL>
+struct RhsRegs { double u[3][EPL], v[3][EPL]; uint32_t id[EPL]; };
+
+template <int BLOCK, int EPL, int NR>
 __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const double* __restrict__ u,
                                                           const double* __restrict__ v, const double* __restrict__ rc,
                                                           const double* __restrict__ rt, double* __restrict__ rhs_t,
                                                           u64* __restrict__ rhs_c_part, double scale, double inv) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr9 = 9 * g.max_rows;
     u64* gc = (u64*)lds_raw;                          // [3][C] planes
     u64* gt = gc + 3 * C;                             // [max_rows*3][ncopy]
     double* rcs = (double*)(gt + (size_t)3 * g.max_rows * ncopy);   // [9][C] planes
-    double* rts = rcs + 9 * C;                        // [max_rows][9]
+    double* rts = rcs + 9 * C;                        // [2][max_rows][9]
     const int tid = threadIdx.x, lane_copy = tid & cmask;
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
     for (int i = tid; i < 9 * C; i += BLOCK) rcs[(i % 9) * C + i / 9] = rc[i];
@@ -47,37 +52,59 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
     for (int i = tid; i < 3 * g.max_rows * ncopy; i += BLOCK) gt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
-    for (int k = k0; k < k1; ++k) {
+
+    auto load_edges = [&](RhsRegs<EPL>& e, int k) {
+        const size_t s = (size_t)k * g.slots + (size_t)tid * EPL;
+        if (EPL == 4) { const uint4 t = *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
+        else          { const uint2 t = *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const size_t o = ((size_t)k * 3 + p) * g.slots + (size_t)tid * EPL;
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2) {
+                const double2 a = *(const double2*)(u + o + j), b = *(const double2*)(v + o + j);
+                e.u[p][j] = a.x; e.u[p][j + 1] = a.y; e.v[p][j] = b.x; e.v[p][j + 1] = b.y;
+            }
+        }
+    };
+    double rv[NR];
+    auto load_rows = [&](int k) {
+        const int r0 = g.chunk_row0[k], n9 = 9 * (g.chunk_row0[k + 1] - r0);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; rv[m] = i < n9 ? rt[(size_t)r0 * 9 + i] : 0.0; }
+    };
+    auto commit_rows = [&](int k, int buf) {
+        const int n9 = 9 * (g.chunk_row0[k + 1] - g.chunk_row0[k]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; if (i < n9) rts[buf * mr9 + i] = rv[m]; }
+    };
+
+    RhsRegs<EPL> ea, eb;
+    if (k0 < k1) { load_edges(ea, k0); load_rows(k0); commit_rows(k0, 0); }
+    __syncthreads();
+
+    auto body = [&](RhsRegs<EPL>& cur, RhsRegs<EPL>& nxt, const int k, const int buf) {
         const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        __syncthreads();
-        for (int i = tid; i < 9 * nrows; i += BLOCK) rts[i] = rt[(size_t)r0 * 9 + i];
-        __syncthreads();
+        if (k + 1 < k1) { load_edges(nxt, k + 1); load_rows(k + 1); }          // in flight during this chunk
+        const double* rtb = rts + buf * mr9;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const int s = tid * EPL + j;
-            const uint32_t id = g.idx[(size_t)k * g.slots + s];
-            const bool pad = id == VICAN_PAD_SLOT;
-            const uint32_t cam = pad ? pad_cam : (id & 0xFFFFu), row = pad ? 0u : (id >> 16);
-            double uu[3], vv[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                uu[p] = u[((size_t)k * 3 + p) * g.slots + s];
-                vv[p] = v[((size_t)k * 3 + p) * g.slots + s];
-            }
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
             if (row != prow) {
                 if (prow != 0xFFFFFFFFu)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) lds_add_fix(&gt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
                 prow = row; acc[0] = acc[1] = acc[2] = 0.0;
             }
-            const double* B = rts + row * 9;
+            const double* B = rtb + row * 9;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {       // world<-node = transpose of the stored blocks
-                const double gi = rcs[(0 * 3 + i) * C + cam] * uu[0] + rcs[(1 * 3 + i) * C + cam] * uu[1] +
-                                  rcs[(2 * 3 + i) * C + cam] * uu[2] + B[0 * 3 + i] * vv[0] + B[1 * 3 + i] * vv[1] +
-                                  B[2 * 3 + i] * vv[2];
+                const double gi = rcs[(0 * 3 + i) * C + cam] * cur.u[0][j] + rcs[(1 * 3 + i) * C + cam] * cur.u[1][j] +
+                                  rcs[(2 * 3 + i) * C + cam] * cur.u[2][j] + B[0 * 3 + i] * cur.v[0][j] +
+                                  B[1 * 3 + i] * cur.v[1][j] + B[2 * 3 + i] * cur.v[2][j];
                 acc[i] += gi;
                 lds_add_fix(&gc[i * C + cam], to_fix(-gi, scale));
             }
@@ -95,8 +122,14 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
             }
             rhs_t[(size_t)r0 * 3 + i] = (double)sum * inv;
         }
+        if (k + 1 < k1) commit_rows(k + 1, buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ea, eb, k, 0);
+        if (k + 1 < k1) body(eb, ea, k + 1, 1);
     }
-    __syncthreads();
     for (int i = tid; i < 3 * C; i += BLOCK) rhs_c_part[(size_t)blockIdx.x * 3 * C + i] = gc[i];
 }
 
@@ -112,17 +145,24 @@ extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const do
     const size_t lds = (size_t)rhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;
     hipStream_t st = (hipStream_t)stream;
-#define RHS_LAUNCH(B, E)                                                                                         \
+const int nr = (9 * g->max_rows + g->block_threads - 1) / g->block_threads;        // R_t values per thread (<= 9 EPL)
+#define RHS_LAUNCH3(B, E, R)                                                                                     \
     do {                                                                                                         \
-        auto kern = trans_rhs_kernel<B, E>;                                                                      \
+        auto kern = trans_rhs_kernel<B, E, R>;                                                                   \
         static size_t conf = 0;                                                                                  \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, st, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv); \
+    } while (0)
+#define RHS_LAUNCH(B, E)                                                                                         \
+    do {                                                                                                         \
+        if (nr <= 1) RHS_LAUNCH3(B, E, 1); else if (nr <= 4) RHS_LAUNCH3(B, E, 4); else if (nr <= 12) RHS_LAUNCH3(B, E, 12); \
+        else RHS_LAUNCH3(B, E, 36);                                                                              \
     } while (0)
     if (g->block_threads == 1024)     { if (epl == 4) RHS_LAUNCH(1024, 4); else RHS_LAUNCH(1024, 2); }
     else if (g->block_threads == 768) { if (epl == 4) RHS_LAUNCH(768, 4);  else RHS_LAUNCH(768, 2); }
     else if (g->block_threads == 512) { if (epl == 4) RHS_LAUNCH(512, 4);  else RHS_LAUNCH(512, 2); }
     else                              { if (epl == 4) RHS_LAUNCH(256, 4);  else RHS_LAUNCH(256, 2); }
+#undef RHS_LAUNCH3
 #undef RHS_LAUNCH
     LAUNCH_CHECK("vican_trans_rhs");
     return VICAN_OK;
