@@ -69,7 +69,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 4 */
+int vican_abi_version(void);            /* 5 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -227,6 +227,16 @@ int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_
 int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                            const double* z, double* R, double* H, double* G, double* Hcol,
                            double* beta, double* x_out, double pivot_floor, void* stream);
+
+/* The same step as ONE cooperative kernel: <= 32 workgroups (32 cameras each, all resident) that meet at
+ * three device-side grid barriers instead of seven dependent launches.  ws: scratch of
+ * vican_lanczos_coop_ws_doubles(n_cam) doubles; sync_ws: two 32-bit words, zero before the first call
+ * (the kernel leaves them zero).  n_cam <= 1024.  Results equal vican_lanczos_cam_step up to the order
+ * of the (fixed-order, deterministic) partial sums.                                              */
+int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam);
+int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
+                           const double* z, double* ws, double* Hcol, double* beta, double* x_out,
+                           double pivot_floor, uint32_t* sync_ws, void* stream);
 
 /* Ritz step on the device (replaces the shift-invert ARPACK call of bipgo.py:288 together with the
  * Lanczos steps).  HB[steps][row_stride]: row j = projected column V^T L Q_j ([hw/3][3] row-major,

@@ -208,23 +208,33 @@ def test_lsqr_kernels(cfg):
     assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
 
 
-def test_fused_lanczos_cam_step_matches_fine_grained():
-    C = 60
-    H, N, _ = make_backends(C, 80, 2, 6, 9, np.float64)
+@pytest.mark.parametrize("C,j", [(5, 0), (60, 3), (333, 7), (1000, 5), (1024, 20)])
+def test_lanczos_cam_step_variants_agree(C, j):
+    """Camera-side Lanczos step: the cooperative single-kernel variant (grid barriers), the launch sequence /
+    single-workgroup kernel behind vican_lanczos_cam_step and the NumPy restatement give the same block."""
+    H, N, _ = make_backends(C, 40, 1, min(C, 6), 9, np.float64)
     rng = np.random.default_rng(11)
-    n, m, j = 3 * C, 6, 3
+    n, m = 3 * C, 24
+    ka = min(3 * (j + 1), n - 3)
+    j = ka // 3 - 1
     Q, _ = np.linalg.qr(rng.standard_normal((n, 3 * (j + 1))))
     Vn = np.zeros((3 * (m + 1), n)); Vn[: 3 * (j + 1)] = Q.T
     lam = rng.standard_normal((C, 3, 3)); lam = (lam @ np.swapaxes(lam, 1, 2) + np.eye(3)).reshape(C, 9)
     z = rng.standard_normal((n, 3))
     outs = []
-    for K in (H, N):
+    for K, coop in ((H, True), (H, True), (H, False), (N, None)):          # the cooperative kernel twice: re-armed barrier
+        if coop is not None:
+            K.coop_cam_step = coop
         V = K.from_numpy(Vn.reshape(-1).copy())
         R, Hs, G, Hcol, beta, x = K.zeros(3 * n), K.zeros(3 * (m + 1) * 3), K.zeros(9), K.zeros(3 * (m + 1) * 3), K.zeros(9), K.zeros(n, 3)
         K.lanczos_cam_step(K.from_numpy(lam), V, n, j, K.from_numpy(z), R, Hs, G, Hcol, beta, x, 0.0)
         outs.append([t.cpu().numpy() for t in (V, Hcol, beta, x)])
-    for a, b, tol in zip(outs[0], outs[1], (1e-10, 1e-10, 1e-10, 1e-10)):
-        assert np.abs(a - b).max() < tol * max(1.0, np.abs(b).max())
+    H.coop_cam_step = True
+    for o in outs[:3]:
+        for a, b in zip(o, outs[3]):
+            assert np.abs(a - b).max() < 1e-10 * max(1.0, np.abs(b).max())
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)                                 # deterministic
     q = outs[0][3]
     assert np.abs(q.T @ q - np.eye(3)).max() < 1e-12 and np.abs(Q.T @ q).max() < 1e-12
 

@@ -332,6 +332,220 @@ __global__ __launch_bounds__(1024) void lanczos_cam_fused_kernel(int n_cam, cons
     }
 }
 
+// ---------------------------------------------------------------------------
+// Cooperative camera-side Lanczos step: the seven launches of the fine-grained sequence (each a few
+// microseconds of work behind ~5 us of launch latency) as ONE kernel of <= 32 co-resident workgroups that
+// meet at three grid barriers (device counter + spin; the grid is far smaller than the chip, so all
+// workgroups are resident).  Each workgroup owns a slice of <= 32 cameras (96 rows of the 3C x 3 block):
+// its rows of R live in LDS for the whole step; only the Gram partials (3 ka doubles per workgroup and pass)
+// and the 3x3 Gram of R cross workgroups, summed in a fixed order => deterministic.
+// ---------------------------------------------------------------------------
+#define COOP_CAMS 32
+#define COOP_ROWS (3 * COOP_CAMS)
+// Everything that crosses workgroups (the partial sums) is written and read with device-scope atomics, which
+// go through to the memory-side coherence point by themselves; a device-scope FENCE would instead write back the
+// whole L2 of the XCD - which still holds the megabytes of slabs of the sweep that ran just before (measured:
+// ~10 us per fence, 33 us for an otherwise empty step).  __syncthreads() waits for the workgroup's own stores.
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void coop_grid_sync(unsigned int* counter, unsigned int target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+// partial H = V[:, :ka]^T R over this workgroup's rows (wave per basis vector), to part[ka*3];
+// vs: this workgroup's rows of the basis, staged in LDS as [ka][COOP_ROWS]
+__device__ __forceinline__ void coop_gram(const double* __restrict__ vs, int ka, int nsl,
+                                          const double (*rs)[COOP_ROWS], double* __restrict__ part, int nwg, int wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wave; k < ka; k += nw) {
+        const double* v = vs + k * COOP_ROWS;
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = lane; i < nsl; i += 64) { const double vi = v[i]; s0 += vi * rs[0][i]; s1 += vi * rs[1][i]; s2 += vi * rs[2][i]; }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {                                   // layout [3 ka][nwg]: one element's partials are contiguous
+            st_agent(part + (size_t)(k * 3) * nwg + wg, s0); st_agent(part + (size_t)(k * 3 + 1) * nwg + wg, s1);
+            st_agent(part + (size_t)(k * 3 + 2) * nwg + wg, s2);
+        }
+    }
+}
+// out[t] = sum_w part[t][w] (fixed order).  The device-scope loads cost ~150 ns each when one thread issues them
+// back to back, so all threads fetch a window of COOP_STAGE values at once (coalesced) and the sums run from LDS.
+#define COOP_STAGE 2048
+__device__ __forceinline__ void coop_reduce(const double* __restrict__ part, int hs, int nwg, double* __restrict__ stage,
+                                            double* __restrict__ out) {
+    const int per = COOP_STAGE / nwg;                      // elements per window
+    for (int t0 = 0; t0 < hs; t0 += per) {
+        const int nt = hs - t0 < per ? hs - t0 : per, cnt = nt * nwg;
+        double v[COOP_STAGE / 256];
+#pragma unroll
+        for (int m = 0; m < COOP_STAGE / 256; ++m) {
+            const int e = threadIdx.x + m * 256;
+            v[m] = e < cnt ? ld_agent(part + (size_t)t0 * nwg + e) : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < COOP_STAGE / 256; ++m) stage[threadIdx.x + m * 256] = v[m];
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            double a = 0.0;
+            for (int w = 0; w < nwg; ++w) a += stage[t * nwg + w];
+            out[t0 + t] = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const double* __restrict__ lamC, double* V, int ld,
+                                                               int j, const double* __restrict__ z, double* ws,
+                                                               double* __restrict__ Hcol, double* __restrict__ beta_out,
+                                                               double* __restrict__ x_out, double pivot_floor,
+                                                               unsigned int* sync) {
+    extern __shared__ double vs[];                       // [ka][COOP_ROWS]: this workgroup's rows of the basis,
+    __shared__ double rs[3][COOP_ROWS];                  // read from global memory ONCE for all four uses
+    __shared__ double h[KA_MAX * 3], h2[KA_MAX * 3];
+    __shared__ double g6[4][6], G6s[6];
+    __shared__ double stage[COOP_STAGE];
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x, tid = threadIdx.x;
+#ifdef COOP_STAMP
+    unsigned long long ts[12]; int nts = 0;
+#define CSTAMP() do { if (nts < 12) ts[nts++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSTAMP() do {} while (0)
+#endif
+    CSTAMP();
+    const int ka = 3 * (j + 1), hs = 3 * ka;
+    const int c0 = (int)(((long long)wg * n_cam) / nwg), c1 = (int)(((long long)(wg + 1) * n_cam) / nwg);
+    const int row0 = 3 * c0, nsl = 3 * (c1 - c0);
+    double* part1 = ws;                                  // [nwg][hs]
+    double* part2 = ws + (size_t)nwg * hs;               // [nwg][hs]
+    double* partG = ws + (size_t)2 * nwg * hs;           // [nwg][8]
+    for (int t = tid; t < ka * COOP_ROWS; t += blockDim.x) {
+        const int k = t / COOP_ROWS, i = t - k * COOP_ROWS;
+        vs[t] = i < nsl ? V[(size_t)k * ld + row0 + i] : 0.0;
+    }
+    // A Q_j = Lambda_C Q_j - z on this slice
+    if (tid < c1 - c0) {
+        const int c = c0 + tid;
+        double L[9], q[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L[k] = lamC[(size_t)c * 9 + k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) q[i * 3 + b] = V[(size_t)(3 * j + b) * ld + 3 * c + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                rs[b][3 * tid + i] = L[i * 3] * q[b] + L[i * 3 + 1] * q[3 + b] + L[i * 3 + 2] * q[6 + b] -
+                                     z[(size_t)(3 * c + i) * 3 + b];
+    }
+    __syncthreads();
+    // two Gram-Schmidt passes against the whole basis
+    for (int pass = 0; pass < 2; ++pass) {
+        double* part = pass ? part2 : part1;
+        double* hh = pass ? h2 : h;
+        CSTAMP();
+        coop_gram(vs, ka, nsl, rs, part, nwg, wg);
+        CSTAMP();
+        coop_grid_sync(&sync[0], (unsigned)((pass + 1) * nwg));
+        CSTAMP();
+        coop_reduce(part, hs, nwg, stage, hh);
+        if (tid < nsl) {
+            double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
+            for (int k = 0; k < ka; ++k) {
+                const double v = vs[k * COOP_ROWS + tid];
+                r0 -= v * hh[k * 3]; r1 -= v * hh[k * 3 + 1]; r2 -= v * hh[k * 3 + 2];
+            }
+            rs[0][tid] = r0; rs[1][tid] = r1; rs[2][tid] = r2;
+        }
+        __syncthreads();
+    }
+    if (wg == 0) for (int t = tid; t < hs; t += blockDim.x) Hcol[t] = h[t] + h2[t];
+    // G = R^T R: slice partial -> all workgroups
+    {
+        double g[6] = {0, 0, 0, 0, 0, 0};
+        if (tid < nsl) {
+            const double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
+            g[0] = r0 * r0; g[1] = r0 * r1; g[2] = r0 * r2; g[3] = r1 * r1; g[4] = r1 * r2; g[5] = r2 * r2;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) g6[tid >> 6][q] = g[q];
+        __syncthreads();
+        if (tid < 6) st_agent(partG + (size_t)tid * nwg + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
+    }
+    CSTAMP();
+    coop_grid_sync(&sync[0], (unsigned)(3 * nwg));
+    CSTAMP();
+    coop_reduce(partG, 6, nwg, stage, G6s);
+    // upper Cholesky G = beta^T beta, Q = R beta^-1  (same pivot rule as chol_qr3_kernel)
+    const double g00 = G6s[0], g01 = G6s[1], g02 = G6s[2], g11 = G6s[3], g12 = G6s[4], g22 = G6s[5];
+    const double tr = g00 + g11 + g22, floor_ = fmax(1e-28 * tr, pivot_floor);
+    double b00 = 0, b01 = 0, b02 = 0, b11 = 0, b12 = 0, b22 = 0, i00 = 0, i11 = 0, i22 = 0;
+    if (g00 > floor_) { b00 = sqrt(g00); i00 = 1.0 / b00; b01 = g01 * i00; b02 = g02 * i00; }
+    const double d11 = g11 - b01 * b01;
+    if (d11 > floor_) { b11 = sqrt(d11); i11 = 1.0 / b11; b12 = (g12 - b01 * b02) * i11; }
+    const double d22 = g22 - b02 * b02 - b12 * b12;
+    if (d22 > floor_) { b22 = sqrt(d22); i22 = 1.0 / b22; }
+    if (wg == 0 && tid == 0) {
+        beta_out[0] = b00; beta_out[1] = b01; beta_out[2] = b02; beta_out[3] = 0; beta_out[4] = b11; beta_out[5] = b12;
+        beta_out[6] = 0; beta_out[7] = 0; beta_out[8] = b22;
+    }
+    if (tid < nsl) {
+        const int col0 = 3 * (j + 1), i = row0 + tid;
+        const double q0 = rs[0][tid] * i00;
+        const double q1 = (rs[1][tid] - q0 * b01) * i11;
+        const double q2 = (rs[2][tid] - q0 * b02 - q1 * b12) * i22;
+        V[(size_t)col0 * ld + i] = q0; V[(size_t)(col0 + 1) * ld + i] = q1; V[(size_t)(col0 + 2) * ld + i] = q2;
+        x_out[(size_t)i * 3] = q0; x_out[(size_t)i * 3 + 1] = q1; x_out[(size_t)i * 3 + 2] = q2;
+    }
+#ifdef COOP_STAMP
+    CSTAMP();
+    if (wg == 3 && tid == 0) {
+        printf("COOP j=%d ticks(10ns):", j);
+        for (int i = 1; i < nts; ++i) printf(" %llu", ts[i] - ts[i - 1]);
+        printf("\n");
+    }
+#endif
+    // the last workgroup out re-arms the barrier counter for the next launch
+    if (tid == 0 && __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1u) {
+        __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+extern "C" int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam) {
+    const int64_t nwg = (n_cam + COOP_CAMS - 1) / COOP_CAMS;
+    return nwg * (2LL * 3 * KA_MAX + 8);
+}
+extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j, const double* z,
+                                      double* ws, double* Hcol, double* beta, double* x_out, double pivot_floor,
+                                      uint32_t* sync_ws, void* stream) {
+    if (n_cam <= 0 || n_cam > 32 * COOP_CAMS || !lamC || !V || !z || !ws || !Hcol || !beta || !x_out || !sync_ws || j < 0 ||
+        3 * (j + 1) > 128 || ld < 3 * n_cam)                 // basis slice in LDS: 128 x 96 doubles = 96 KB
+        return set_err(VICAN_ERR_ARG, "vican_lanczos_cam_coop: bad argument");
+    const int nwg = (n_cam + COOP_CAMS - 1) / COOP_CAMS;                    // <= 32 workgroups: always co-resident
+    const size_t lds = (size_t)3 * (j + 1) * COOP_ROWS * sizeof(double);
+    static size_t configured = 0;
+    if (lds > 32 * 1024 && lds > configured) {
+        if (hipFuncSetAttribute((const void*)lanczos_cam_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * COOP_ROWS * 8) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "vican_lanczos_cam_coop: cannot raise dynamic LDS limit");
+        configured = 128 * COOP_ROWS * 8;
+    }
+    hipLaunchKernelGGL(lanczos_cam_coop_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, ws, Hcol,
+                       beta, x_out, pivot_floor, sync_ws);
+    LAUNCH_CHECK("vican_lanczos_cam_coop");
+    return VICAN_OK;
+}
+
 extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                                       const double* z, double* R, double* H, double* G, double* Hcol, double* beta,
                                       double* x_out, double pivot_floor, void* stream) {

@@ -176,6 +176,8 @@ class HipBackend:
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
         self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
         self._status_host = {}
+        self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
+        self._coop_ws, self._coop_sync = None, None
         self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, graph.wmax
 
     # -- allocation helpers -------------------------------------------------
@@ -233,6 +235,14 @@ class HipBackend:
                                            _ptr(z_out), _stream()), "vican_block_op_z")
 
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
+        if self.coop_cam_step:
+            if self._coop_ws is None:
+                self._coop_ws = torch.zeros(int(self.lib.vican_lanczos_coop_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
+                self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            self._ck(self.lib.vican_lanczos_cam_coop(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(self._coop_ws), _ptr(Hcol),
+                                                     _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), _stream()),
+                     "vican_lanczos_cam_coop")
+            return
         self._ck(self.lib.vican_lanczos_cam_step(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
                                                  _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _stream()),
                  "vican_lanczos_cam_step")
