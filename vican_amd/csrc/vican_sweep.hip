@@ -770,9 +770,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #undef VICAN_ADVANCE2
     // the last workgroup to get here re-arms the ticket counter for the next launch (every ticket of every
     // workgroup has been drawn by then)
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&sched[1], 1u) == (unsigned)nwg - 1u) { __threadfence(); sched[0] = 0u; sched[1] = 0u; }
+    // (device-scope atomics only - a device-scope fence would write back this XCD's whole L2, slabs included)
+    if (tid == 0 && __hip_atomic_fetch_add(&sched[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1u) {
+        __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef VICAN_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
