@@ -53,7 +53,7 @@ class Comm:
 
 
 class RotationSolver:
-    def __init__(self, K, comm=None, m_max=32, eig_tol=1e-10, floor_tol=1e-7, min_steps=6, check_every=2, warm_min_steps=2,
+    def __init__(self, K, comm=None, m_max=32, eig_tol=1e-10, floor_tol=1e-7, min_steps=4, check_every=2, warm_min_steps=2,
                  max_restarts=20, seed=1234):
         self.K, self.comm = K, comm or Comm()
         self.C = K.C
@@ -65,7 +65,8 @@ class RotationSolver:
         # on cache-resident graphs an edge sweep costs tens of microseconds - less than one projection
         # check (host sync + small eigh) - so check less often there
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
-        if n_edges is not None and n_edges * max(self.comm.world, 1) < 2_000_000:
+        self.small_graph = n_edges is not None and n_edges * max(self.comm.world, 1) < 2_000_000
+        if self.small_graph:
             self.min_steps, self.warm_min_steps, self.check_every = max(min_steps, 8), max(warm_min_steps, 4), max(check_every, 4)
         self.max_restarts, self.seed = max_restarts, seed
         n, m = self.n, self.m_max
@@ -170,7 +171,9 @@ class RotationSolver:
                     prev_res, prev_steps = r, steps
                     if stop:
                         break
-                    next_check = min(steps + self.check_every, self.m_max)
+                    # a failed check costs less than one edge sweep on large graphs (device Ritz step, cancelled
+                    # speculative launches), so the first few steps are checked one by one
+                    next_check = min(steps + (1 if steps < 8 and not self.small_graph else self.check_every), self.m_max)
             th = st[7:12].copy()
             if conv:
                 self.tail_done = tail is not None
