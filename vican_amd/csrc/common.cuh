@@ -34,7 +34,7 @@ int vican_check_graph(const vican_graph_t* g, const char* who);   // vican_sweep
 extern thread_local const int32_t* g_vican_gate;
 #define GATE_RETURN(gate) do { if ((gate) != nullptr && *(gate) != 1) return; } while (0)
 static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 96LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 144) + 256; }
-static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 48LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 96) + 256; }
+static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 48LL * n_cam + (int64_t)max_rows * (48LL * n_copy + 96) + 256; }
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------

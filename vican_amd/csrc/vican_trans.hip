@@ -354,8 +354,8 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     if (st->done) return;
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
     u64* qc = (u64*)lds_raw;                               // [3][C] planes
-    u64* qt = qc + 3 * C;                                  // [max_rows*3][ncopy]
-    double* pcs = (double*)(qt + (size_t)mr3 * ncopy);     // [3][C] planes
+    u64* qt = qc + 3 * C;                                  // [2][max_rows*3][ncopy]
+    double* pcs = (double*)(qt + (size_t)2 * mr3 * ncopy); // [3][C] planes
     double* pts = pcs + 3 * C;                             // [2][max_rows*3]   p of the chunk's rows
     double* dps = pts + 2 * mr3;                           // [2][max_rows*3]   deg * p
     double* red = dps + 2 * mr3;                           // [16]
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     const bool upd = !st->first;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
     for (int i = tid; i < 3 * C; i += BLOCK) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; }
-    for (int i = tid; i < mr3 * ncopy; i += BLOCK) qt[i] = 0ull;
+    for (int i = tid; i < 2 * mr3 * ncopy; i += BLOCK) qt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 
@@ -408,17 +408,40 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     };
 
     // One chunk of edge words and row values is in flight ahead of the chunk being processed (a second one was
-    // measured: no gain on the stress graph, slower on sparse graphs).
+    // measured: no gain on the stress graph, slower on sparse graphs).  The fold of a chunk's row accumulators
+    // (a few threads, a chain of LDS reads and a global store - nothing in the chunk depends on it) is deferred
+    // into the next chunk's body, where it overlaps with everybody's edge work: ONE barrier per chunk; the row
+    // accumulators are double-buffered for that.
+    // The row values are requested TWO bodies ahead: with one barrier per chunk a body lasts about as long as a
+    // global-memory round trip, and the commit at its end would wait for loads issued at its start.
     CgRegs<EPL> ea, eb;
-    RowRegs rr;
+    RowRegs ra, rb;
     double pq = 0.0;
-    if (k0 < k1) { load_edges(ea, k0); load_rows(rr, k0); commit_rows(rr, k0, 0); }
+    if (k0 < k1) { load_edges(ea, k0); load_rows(ra, k0); commit_rows(ra, k0, 0); }
+    if (k0 + 1 < k1) load_rows(ra, k0 + 1);
     __syncthreads();
 
-    auto body = [&](CgRegs<EPL>& cur, CgRegs<EPL>& nxt, const int k, const int buf) {
+    auto fold = [&](const int k, const int buf) {
         const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        if (k + 1 < k1) { load_edges(nxt, k + 1); load_rows(rr, k + 1); }      // in flight during this chunk
+        u64* q = qt + (size_t)buf * mr3 * ncopy;
+        for (int i = tid; i < 3 * nrows; i += BLOCK) {
+            long long sum = 0;
+            for (int c = 0; c < ncopy; ++c) {
+                const int a = i * ncopy + ((c + i) & cmask);
+                sum += (long long)q[a];
+                q[a] = 0ull;
+            }
+            const double qv = dps[buf * mr3 + i] - (double)sum * inv;
+            q_t[(size_t)r0 * 3 + i] = qv;
+            pq += pts[buf * mr3 + i] * qv;
+        }
+    };
+    // body(k): edges `cur`; `rx` holds the rows of chunk k+1 (committed at the end), `ry` receives those of k+2
+    auto body = [&](CgRegs<EPL>& cur, CgRegs<EPL>& nxt, RowRegs& rx, RowRegs& ry, const int k, const int buf) {
+        if (k + 1 < k1) load_edges(nxt, k + 1);                                // in flight during this chunk
+        if (k + 2 < k1) load_rows(ry, k + 2);
         const double* pt = pts + buf * mr3;
+        u64* qtb = qt + (size_t)buf * mr3 * ncopy;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
@@ -429,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
             if (row != prow) {
                 if (prow != 0xFFFFFFFFu)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+                    for (int i = 0; i < 3; ++i) lds_add_fix(&qtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
                 prow = row; acc[0] = acc[1] = acc[2] = 0.0;
             }
 #pragma unroll
@@ -440,27 +463,20 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
         }
         if (prow != 0xFFFFFFFFu)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
-        __syncthreads();
-        for (int i = tid; i < 3 * nrows; i += BLOCK) {
-            long long sum = 0;
-            for (int c = 0; c < ncopy; ++c) {
-                const int a = i * ncopy + ((c + i) & cmask);
-                sum += (long long)qt[a];
-                qt[a] = 0ull;
-            }
-            const double q = dps[buf * mr3 + i] - (double)sum * inv;
-            q_t[(size_t)r0 * 3 + i] = q;
-            pq += pt[i] * q;
-        }
-        if (k + 1 < k1) commit_rows(rr, k + 1, buf ^ 1);
+            for (int i = 0; i < 3; ++i) lds_add_fix(&qtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+        // previous chunk's fold, then the next chunk's rows into the staging buffer the fold has just read
+        // (same index -> same thread in both loops, so no cross-thread hazard on that buffer)
+        if (k > k0) fold(k - 1, buf ^ 1);
+        if (k + 1 < k1) commit_rows(rx, k + 1, buf ^ 1);
         __syncthreads();
     };
 #pragma unroll 1
     for (int k = k0; k < k1; k += 2) {
-        body(ea, eb, k, 0);
-        if (k + 1 < k1) body(eb, ea, k + 1, 1);
+        body(ea, eb, ra, rb, k, 0);
+        if (k + 1 < k1) body(eb, ea, rb, ra, k + 1, 1);
     }
+    if (k0 < k1) fold(k1 - 1, (k1 - 1 - k0) & 1);
+    __syncthreads();
     for (int i = tid; i < 3 * C; i += BLOCK) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
