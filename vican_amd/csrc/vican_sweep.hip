@@ -556,6 +556,18 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) xm2 = fmax(xm2, __shfl_xor(xm2, o2, 64));
     if (lane == 0) ysum[wave] = xm2;                     // scratch: ysum is not used before phase 2
+    // tables staged BEFORE the (single) prologue barrier: they do not depend on the measured norm
+    // (the wavefronts of a 768-thread workgroup start up to ~3 us apart: every barrier here costs that skew)
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        const int c = tid + m * BLOCK;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], 1.0);
+        }
+    }
+    if (MODE == 0) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
+    for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
     __syncthreads();
 
     xm2 = 0.0;
@@ -568,18 +580,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = fx2 * up;
     if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if (MODE == 1 && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
-    __syncthreads();
-
-#pragma unroll
-    for (int m = 0; m < XC; ++m) {
-        const int c = tid + m * BLOCK;
-        if (c < C) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], y_scale);
-        }
-    }
-    if (MODE == 0) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
-    for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
 
 #ifdef VICAN_STAMP
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t;
@@ -592,7 +592,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     // Register ring: DEPTH chunks in flight ahead of the one being processed.  512-thread workgroups
     // have 256 VGPRs per lane and keep two chunks in flight (the memory system then always has work
     // from this CU); 768/1024-thread workgroups only have room for one.
-    __syncthreads();
 
     STAMP0();
 #ifdef VICAN_STAMP
