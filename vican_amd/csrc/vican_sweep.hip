@@ -236,25 +236,34 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
 //   the fixed-point scales.
 // ---------------------------------------------------------------------------
 // Deterministic (order-independent) sums: 64-bit fixed point relative to vmax >= max|val|.
+// Persistent workgroups: camera sums are collected in an LDS table over all the chunks a workgroup handles and
+// flushed once (the first version issued one global atomic per edge onto n_cam addresses: 2.9 ms for 25 M edges).
 template <typename S>
-__global__ void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double scale, double inv,
-                                 double* __restrict__ row_out, u64* __restrict__ cam_acc) {
+__global__ __launch_bounds__(256) void edge_sums_kernel(vican_graph_t g, const S* __restrict__ val, double scale, double inv,
+                                                        double* __restrict__ row_out, u64* __restrict__ cam_acc) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    u64* rows = (u64*)lds_raw;
-    const int k = blockIdx.x;
-    const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) rows[r] = 0ull;
-    __syncthreads();
-    const size_t base = (size_t)k * g.slots;
-    for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
-        const uint32_t id = g.idx[base + s];
-        if (id == VICAN_PAD_SLOT) continue;
-        const u64 f = to_fix((double)val[base + s], scale);
-        lds_add_fix(&rows[id >> 16], f);
-        atomicAdd(&cam_acc[id & 0xFFFFu], f);
+    u64* cams = (u64*)lds_raw;                        // [n_cam]
+    u64* rows = cams + g.n_cam;                       // [max_rows]
+    for (int c = threadIdx.x; c < g.n_cam; c += blockDim.x) cams[c] = 0ull;
+    for (int k = blockIdx.x; k < g.n_chunk; k += gridDim.x) {
+        const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
+        for (int r = threadIdx.x; r < nrows; r += blockDim.x) rows[r] = 0ull;
+        __syncthreads();
+        const size_t base = (size_t)k * g.slots;
+        for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
+            const uint32_t id = g.idx[base + s];
+            if (id == VICAN_PAD_SLOT) continue;
+            const u64 f = to_fix((double)val[base + s], scale);
+            lds_add_fix(&rows[id >> 16], f);
+            lds_add_fix(&cams[id & 0xFFFFu], f);
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < nrows; r += blockDim.x) row_out[r0 + r] = (double)(long long)rows[r] * inv;
+        __syncthreads();
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < nrows; r += blockDim.x) row_out[r0 + r] = (double)(long long)rows[r] * inv;
+    for (int c = threadIdx.x; c < g.n_cam; c += blockDim.x)
+        if (cams[c] != 0ull) atomicAdd(&cam_acc[c], cams[c]);
 }
 __global__ void fix_to_double_kernel(int n, const u64* __restrict__ in, double inv, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,12 +283,13 @@ extern "C" int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t 
     if (e2 < e) e = e2;
     const double scale = ldexp(1.0, e), inv = ldexp(1.0, -e);
     if (g->n_chunk > 0) {
-        const size_t lds = (size_t)g->max_rows * 8;
+        const size_t lds = ((size_t)g->max_rows + g->n_cam) * 8;
+        const int grid = g->n_chunk < 2048 ? g->n_chunk : 2048;
         if (val_is_f64)
-            hipLaunchKernelGGL(edge_sums_kernel<double>, dim3(g->n_chunk), dim3(256), lds, st, *g, (const double*)val, scale, inv,
+            hipLaunchKernelGGL(edge_sums_kernel<double>, dim3(grid), dim3(256), lds, st, *g, (const double*)val, scale, inv,
                                row_sum, (u64*)cam_ws);
         else
-            hipLaunchKernelGGL(edge_sums_kernel<float>, dim3(g->n_chunk), dim3(256), lds, st, *g, (const float*)val, scale, inv,
+            hipLaunchKernelGGL(edge_sums_kernel<float>, dim3(grid), dim3(256), lds, st, *g, (const float*)val, scale, inv,
                                row_sum, (u64*)cam_ws);
     }
     hipLaunchKernelGGL(fix_to_double_kernel, dim3((g->n_cam + 255) / 256), dim3(256), 0, st, g->n_cam, (const u64*)cam_ws, inv, cam_sum);
