@@ -108,6 +108,51 @@ def test_roundtrip_property_at_scale():
     assert np.abs((pc - pc.mean(0)) - (pgt - pgt.mean(0))).max() < 1e-6
 
 
+def test_full_size_stress_graph_properties():
+    """BASELINE.json's stress configuration at FULL size (1000 cameras x 100 000 timesteps x 250 cameras per
+    timestep = 25 M merged edges, 1 GB of f32 blocks - far beyond what the oracle can run), checked through
+    size-independent properties: (1) noise-free measurements -> the ground truth up to gauge, to f32 accuracy;
+    (2) the operator sweep is bit-reproducible although chunks are handed to workgroups dynamically;
+    (3) the result does not depend on the workgroup count / chunk assignment."""
+    import torch
+    from vican_amd import synth
+    from vican_amd.device import HipBackend, LocalGraph
+    from vican_amd.geometry import geodesic
+    from vican_amd.solver import Comm, solve_on_backend
+    C, T = 1000, 100000
+    dev = torch.device("cuda:0")
+    gr = synth.make_merged_graph_torch(C, T, 250, dev, torch.float32, seed=9, sigma_r=0.0, sigma_t=0.0)
+    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+    assert g.n_edges == 25_000_000
+    K = HipBackend(g)
+    rc, Rt, x_c, x_t, st = solve_on_backend(K, Comm(), 4, 3 * (C + T))
+    Rc = rc.reshape(C, 3, 3).transpose(1, 2).cpu().numpy()
+    Rgt = gr["R_cam"].cpu().numpy()
+    G = Rgt[0]
+    assert geodesic(G @ Rc, Rgt).max() < 2e-6                       # f32 blocks: 6e-8 relative rounding per entry
+    Rtt = Rt.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()
+    assert geodesic(G @ Rtt, gr["R_obj"].cpu().numpy()).max() < 2e-6
+    pc, pgt = x_c.cpu().numpy() @ G.T, gr["p_cam"].cpu().numpy()
+    assert np.abs((pc - pc.mean(0)) - (pgt - pgt.mean(0))).max() < 5e-4   # scipy-style CG at rtol 1e-5
+    assert st["sweeps"] <= 24 and st["converged"]
+    # (2) same sweep twice: identical bits
+    lamT, cd = K.empty(T, 9), K.empty(C)
+    K.init_duals(lamT, cd)
+    x = torch.linalg.qr(torch.randn(3 * C, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))[0].contiguous()
+    z1, z2 = K.zeros(3 * C, 3), K.zeros(3 * C, 3)
+    K.block_op(lamT, x, z1); K.block_op(lamT, x, z2)
+    assert torch.equal(z1, z2)
+    # (3) a different workgroup count (other chunk-to-workgroup assignment, other slab count): exact integer sums ->
+    # identical up to the fixed-point scale (n_add differs), i.e. to ~2^-40 of the bound
+    g2 = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"], n_wg=97)
+    K2 = HipBackend(g2)
+    lam2, cd2 = K2.empty(T, 9), K2.empty(C)
+    K2.init_duals(lam2, cd2)
+    z3 = K2.zeros(3 * C, 3)
+    K2.block_op(lam2, x, z3)
+    assert float((z3 - z1).abs().max()) < 1e-9 * float(z1.abs().max())
+
+
 def test_solve_is_bit_reproducible():
     """All edge-side sums are 64-bit fixed point (integer atomics) and all camera-side reductions
     have a fixed order, so two solves of the same problem - including a fresh pack of the graph -
