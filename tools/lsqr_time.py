@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Time the translation stage with lsqr_solver="direct" (GPU LSQR) vs CG on synthetic graphs (GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from vican_amd import synth
+from vican_amd.device import HipBackend, LocalGraph
+from vican_amd.solver import Comm, RotationSolver, TranslationSolver, LsqrTranslationSolver
+dev = torch.device("cuda:0")
+for (C, T, k) in ((340, 10000, 4), (1000, 100000, 250)):
+    gr = synth.make_merged_graph_torch(C, T, k, dev, torch.float32, seed=0)
+    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+    K = HipBackend(g)
+    rot = RotationSolver(K, Comm()); rc, Rt = rot.run(4)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr = TranslationSolver(K, Comm()); tr.setup(rc, Rt); tr.solve(3 * (C + T))
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        ls = LsqrTranslationSolver(K, Comm()); ls.solve(rc, Rt, 3 * (C + T), None)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        print("C=%d T=%d E=%d: CG %.2f ms (%d it)   LSQR %.2f ms (%s it, istop %s)" % (C, T, g.n_edges, (t1 - t0) * 1e3, tr.info["cg_iters"], (t2 - t1) * 1e3, ls.info.get("lsqr_iters"), ls.info.get("istop")))

@@ -249,7 +249,7 @@ class TranslationSolver:
         self.info = {}
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges < 2_000_000
-        self._graph, self._graph_key = None, None
+        self._graph, self._graph_key, self._n_solves = None, None, 0
 
     def _state(self):
         h = self.st.cpu()
@@ -287,8 +287,10 @@ class TranslationSolver:
         # On small graphs an iteration is five kernels of a few microseconds each - launch-bound from Python.
         # All per-iteration quantities (alpha, beta, norms, the done flag) live in the device state struct, so
         # every iteration after the first is the SAME sequence of launches: recorded once into a HIP graph and
-        # replayed (single rank only; the graph is kept while the buffers it names stay alive).
-        use_graph = self.small_graph and not multi and hasattr(K, "capture")
+        # replayed (single rank only; the graph is kept while the buffers it names stay alive).  Recording costs a
+        # few milliseconds, so only a solver object that is used again (time series, benchmark loop) does it.
+        use_graph = self.small_graph and not multi and hasattr(K, "capture") and self._n_solves >= 1
+        self._n_solves += 1
         while True:
             burst = min(self.poll_every, maxiter + 1 - it_launched)
             for _ in range(burst):
