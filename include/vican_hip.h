@@ -69,7 +69,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 5 */
+int vican_abi_version(void);            /* 6 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -370,17 +370,18 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
  * |b|^2 - |b~|^2, added back by the host driver).  The Golub-Kahan scalars stay on the host.
  * u: per-edge 3-vectors in slot order [n_chunk][3][slots]; part: >= max(n_wg, 1024) doubles of
  * scratch; the *_out scalars are single device doubles (all-reduce them when sharded).        */
-/* u <- b~ (unnormalised);  *nrm2_out = |u|^2 over this rank's edges */
+/* u <- b~ (unnormalised);  *nrm2_out = |u|^2 over this rank's edges;  sw[slot] = s_e = sqrt(w_e) (slot order,
+ * 0 on padding) for the step kernels */
 int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
-                      const double* rc, const double* rt, double* u, double* part, double* nrm2_out,
-                      void* stream);
+                      const double* rc, const double* rt, double* u, double* sw, double* part,
+                      double* nrm2_out, void* stream);
 /* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
-int vican_lsqr_u_step(const vican_graph_t* g, const double* w, const double* v_c, const double* v_t,
+int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,
                       double coef, double* u, double* part, double* nrm2_out, void* stream);
 /* v_t <- sum_c s u inv_beta - beta v_t (in place), *nrm2_t_out = |v_t|^2; camera side as
  * fixed-point slabs vc_part[n_wg][3][C] of -sum_t s u inv_beta (fold with
  * vican_slab_reduce_fx, scale = *inv_out, then vican_lsqr_cam_v).  smax >= max sqrt(w_e).      */
-int vican_lsqr_v_step(const vican_graph_t* g, const double* w, const double* u, double inv_beta,
+int vican_lsqr_v_step(const vican_graph_t* g, const double* sw, const double* u, double inv_beta,
                       double beta, double* v_t, void* vc_part, double* part, double* nrm2_t_out,
                       double smax, double n_add, double* inv_out, void* stream);
 /* v_c <- acc - beta v_c ; *nrm2_out = |v_c|^2 */

@@ -91,7 +91,7 @@ PROTOTYPES = {
     "vican_cg_cam_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_time_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vican_cg_end": (C.c_int, [_vp, _i32, _vp, _vp]),
-    "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
     "vican_lsqr_cam_v": (C.c_int, [_i32, _vp, _f64, _vp, _vp, _vp]),

@@ -10,6 +10,7 @@
 //   u-step   u <- s (v_t - v_c) - coef * u          (12 + 2*24 algorithmic bytes / edge)
 //   v-step   v <- J~^T (u / beta) - beta v           (12 + 24 bytes / edge, fixed-point sums)
 #include "common.cuh"
+#include <type_traits>
 
 #define LSQR_PARTS 1024
 
@@ -20,7 +21,8 @@ template <int BLOCK, int EPL>
 __global__ __launch_bounds__(BLOCK) void lsqr_init_u_kernel(vican_graph_t g, const double* __restrict__ w,
                                                             const double* __restrict__ ue, const double* __restrict__ ve,
                                                             const double* __restrict__ rc, const double* __restrict__ rt,
-                                                            double* __restrict__ u, double* __restrict__ part) {
+                                                            double* __restrict__ u, double* __restrict__ sw,
+                                                            double* __restrict__ part) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int C = g.n_cam;
     double* rcs = (double*)lds_raw;                 // [9][C] planes
@@ -41,10 +43,11 @@ __global__ __launch_bounds__(BLOCK) void lsqr_init_u_kernel(vican_graph_t g, con
             const int s = tid * EPL + j;
             const size_t e = (size_t)k * g.slots + s;
             const uint32_t id = g.idx[e];
-            double out[3] = {0, 0, 0};
+            double out[3] = {0, 0, 0}, sq = 0.0;
             if (id != VICAN_PAD_SLOT) {
                 const uint32_t cam = id & 0xFFFFu, row = id >> 16;
-                const double inv_s = 1.0 / sqrt(w[e]);
+                sq = sqrt(w[e]);
+                const double inv_s = 1.0 / sq;
                 double uu[3], vv[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) { uu[p] = ue[((size_t)k * 3 + p) * g.slots + s]; vv[p] = ve[((size_t)k * 3 + p) * g.slots + s]; }
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(BLOCK) void lsqr_init_u_kernel(vican_graph_t g, con
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p) u[((size_t)k * 3 + p) * g.slots + s] = out[p];
+            sw[e] = sq;                               // s_e = sqrt(w_e) (0 on padding): the steps below never take a root
         }
     }
     const double t = block_sum(nrm, red);
@@ -67,41 +71,84 @@ __global__ __launch_bounds__(BLOCK) void lsqr_init_u_kernel(vican_graph_t g, con
 }
 
 // u <- s (v_t - v_c) - coef * u ; partial |u|^2
-template <int BLOCK, int EPL>
-__global__ __launch_bounds__(BLOCK) void lsqr_u_step_kernel(vican_graph_t g, const double* __restrict__ w,
+// Both per-iteration kernels are software pipelines like cg_sweep_kernel (vican_trans.hip): the edge words of
+// chunk k+1 (16-byte loads) and the row values of the following chunk are in flight while chunk k is processed,
+// one barrier per chunk; sw = sqrt(w) is precomputed by vican_lsqr_init_u.
+template <int EPL>
+struct LsqrRegs { double u[3][EPL], s[EPL]; uint32_t id[EPL]; };
+
+template <int EPL>
+__device__ __forceinline__ void lsqr_load_edges(LsqrRegs<EPL>& e, const vican_graph_t& g, const double* __restrict__ sw,
+                                                const double* __restrict__ u, int k, int tid) {
+    const size_t s = (size_t)k * g.slots + (size_t)tid * EPL;
+    if (EPL == 4) { const uint4 t = *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
+    else          { const uint2 t = *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+#pragma unroll
+    for (int j = 0; j < EPL; j += 2) { const double2 a = *(const double2*)(sw + s + j); e.s[j] = a.x; e.s[j + 1] = a.y; }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const size_t o = ((size_t)k * 3 + p) * g.slots + (size_t)tid * EPL;
+#pragma unroll
+        for (int j = 0; j < EPL; j += 2) { const double2 a = *(const double2*)(u + o + j); e.u[p][j] = a.x; e.u[p][j + 1] = a.y; }
+    }
+}
+
+template <int BLOCK, int EPL, int NR>
+__global__ __launch_bounds__(BLOCK) void lsqr_u_step_kernel(vican_graph_t g, const double* __restrict__ sw,
                                                             const double* __restrict__ v_c, const double* __restrict__ v_t,
                                                             double coef, double* __restrict__ u, double* __restrict__ part) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int C = g.n_cam;
+    const int C = g.n_cam, mr3 = 3 * g.max_rows;
     double* vcs = (double*)lds_raw;                 // [3][C] planes
-    double* vts = vcs + 3 * C;                      // [max_rows][3]
-    double* red = vts + 3 * g.max_rows;
+    double* vts = vcs + 3 * C;                      // [2][max_rows][3]
+    double* red = vts + 2 * mr3;
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * C; i += BLOCK) vcs[(i % 3) * C + i / 3] = v_c[i];
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    double rv[NR];
+    auto load_rows = [&](int k) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; rv[m] = i < n3 ? v_t[(size_t)r0 * 3 + i] : 0.0; }
+    };
+    auto commit_rows = [&](int k, int buf) {
+        const int n3 = 3 * (g.chunk_row0[k + 1] - g.chunk_row0[k]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; if (i < n3) vts[buf * mr3 + i] = rv[m]; }
+    };
+    LsqrRegs<EPL> ea, eb;
     double nrm = 0.0;
-    for (int k = k0; k < k1; ++k) {
-        const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        __syncthreads();
-        for (int i = tid; i < 3 * nrows; i += BLOCK) vts[i] = v_t[(size_t)r0 * 3 + i];
-        __syncthreads();
+    if (k0 < k1) { lsqr_load_edges<EPL>(ea, g, sw, u, k0, tid); load_rows(k0); commit_rows(k0, 0); }
+    __syncthreads();
+    auto body = [&](LsqrRegs<EPL>& cur, LsqrRegs<EPL>& nxt, const int k, const int buf) {
+        if (k + 1 < k1) { lsqr_load_edges<EPL>(nxt, g, sw, u, k + 1, tid); load_rows(k + 1); }
+        const double* vt = vts + buf * mr3;
+        double un[3][EPL];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const int s = tid * EPL + j;
-            const size_t e = (size_t)k * g.slots + s;
-            const uint32_t id = g.idx[e];
-            if (id == VICAN_PAD_SLOT) continue;
-            const uint32_t cam = id & 0xFFFFu, row = id >> 16;
-            const double sq = sqrt(w[e]);
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? 0u : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                const size_t a = ((size_t)k * 3 + p) * g.slots + s;
-                const double un = sq * (vts[row * 3 + p] - vcs[p * C + cam]) - coef * u[a];
-                u[a] = un;
-                nrm += un * un;
+                const double v = pad ? 0.0 : cur.s[j] * (vt[row * 3 + p] - vcs[p * C + cam]) - coef * cur.u[p][j];
+                un[p][j] = v;
+                nrm += v * v;
             }
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            double* o = u + ((size_t)k * 3 + p) * g.slots + (size_t)tid * EPL;
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2) *(double2*)(o + j) = make_double2(un[p][j], un[p][j + 1]);
+        }
+        if (k + 1 < k1) commit_rows(k + 1, buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ea, eb, k, 0);
+        if (k + 1 < k1) body(eb, ea, k + 1, 1);
     }
     const double t = block_sum(nrm, red);
     if (tid == 0) part[blockIdx.x] = t;
@@ -109,66 +156,92 @@ __global__ __launch_bounds__(BLOCK) void lsqr_u_step_kernel(vican_graph_t g, con
 
 // v_raw = J~^T (u * inv_beta) - beta * v : rows finished here (v_t in place, partial |v_t|^2),
 // camera side as fixed-point slabs of  -sum_t s u inv_beta.   Bound: |u inv_beta| <= 1, |s| <= smax.
-template <int BLOCK, int EPL>
-__global__ __launch_bounds__(BLOCK) void lsqr_v_step_kernel(vican_graph_t g, const double* __restrict__ w,
+template <int BLOCK, int EPL, int NR>
+__global__ __launch_bounds__(BLOCK) void lsqr_v_step_kernel(vican_graph_t g, const double* __restrict__ sw,
                                                             const double* __restrict__ u, double inv_beta, double beta,
                                                             double* __restrict__ v_t, u64* __restrict__ vc_part,
                                                             double* __restrict__ part, double scale, double inv) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
     u64* vc = (u64*)lds_raw;                          // [3][C] planes
-    u64* vt = vc + 3 * C;                             // [max_rows*3][ncopy]
-    double* red = (double*)(vt + (size_t)3 * g.max_rows * ncopy);
+    u64* vt = vc + 3 * C;                             // [2][max_rows*3][ncopy]
+    double* red = (double*)(vt + (size_t)2 * mr3 * ncopy);
     const int tid = threadIdx.x, lane_copy = tid & cmask;
+    const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);
     for (int i = tid; i < 3 * C; i += BLOCK) vc[i] = 0ull;
-    for (int i = tid; i < 3 * g.max_rows * ncopy; i += BLOCK) vt[i] = 0ull;
+    for (int i = tid; i < 2 * mr3 * ncopy; i += BLOCK) vt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    struct RowRegs { double v[NR]; };
+    auto load_rows = [&](RowRegs& rr, int k) {          // old v_t of the chunk's rows, consumed by its (deferred) fold
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; rr.v[m] = i < n3 ? v_t[(size_t)r0 * 3 + i] : 0.0; }
+    };
     double nrm = 0.0;
+    auto fold = [&](const RowRegs& rr, const int k, const int buf) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+        u64* q = vt + (size_t)buf * mr3 * ncopy;
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+            const int i = tid + m * BLOCK;
+            if (i < n3) {
+                long long sum = 0;
+                for (int c = 0; c < ncopy; ++c) {
+                    const int a = i * ncopy + ((c + i) & cmask);
+                    sum += (long long)q[a];
+                    q[a] = 0ull;
+                }
+                const double vn = (double)sum * inv - beta * rr.v[m];
+                v_t[(size_t)r0 * 3 + i] = vn;
+                nrm += vn * vn;
+            }
+        }
+    };
+    LsqrRegs<EPL> ea, eb;
+    RowRegs ra, rb;
+    if (k0 < k1) { lsqr_load_edges<EPL>(ea, g, sw, u, k0, tid); load_rows(ra, k0); }
     __syncthreads();
-    for (int k = k0; k < k1; ++k) {
-        const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
+    // body(k): edges `cur`; `rs` holds the old v_t of chunk k-1 (folded here) and is then refilled with those of
+    // chunk k+1 (consumed one body later, by the fold in body k+2)
+    auto body = [&](LsqrRegs<EPL>& cur, LsqrRegs<EPL>& nxt, RowRegs& rs, const int k, const int buf) {
+        if (k + 1 < k1) lsqr_load_edges<EPL>(nxt, g, sw, u, k + 1, tid);
+        u64* vtb = vt + (size_t)buf * mr3 * ncopy;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const int s = tid * EPL + j;
-            const size_t e = (size_t)k * g.slots + s;
-            const uint32_t id = g.idx[e];
-            if (id == VICAN_PAD_SLOT) continue;
-            const uint32_t cam = id & 0xFFFFu, row = id >> 16;
-            const double sq = sqrt(w[e]) * inv_beta;
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
+            const double sq = pad ? 0.0 : cur.s[j] * inv_beta;
             if (row != prow) {
                 if (prow != 0xFFFFFFFFu)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&vt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+                    for (int i = 0; i < 3; ++i) lds_add_fix(&vtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
                 prow = row; acc[0] = acc[1] = acc[2] = 0.0;
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                const double a = sq * u[((size_t)k * 3 + p) * g.slots + s];
+                const double a = sq * cur.u[p][j];
                 acc[p] += a;
                 lds_add_fix(&vc[p * C + cam], to_fix(-a, scale));
             }
         }
         if (prow != 0xFFFFFFFFu)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) lds_add_fix(&vt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+            for (int i = 0; i < 3; ++i) lds_add_fix(&vtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+        if (k > k0) fold(rs, k - 1, buf ^ 1);             // deferred: overlaps with everybody's edge work
+        if (k + 1 < k1) load_rows(rs, k + 1);
         __syncthreads();
-        for (int i = tid; i < 3 * nrows; i += BLOCK) {
-            long long sum = 0;
-            for (int c = 0; c < ncopy; ++c) {
-                const int a = i * ncopy + ((c + i) & cmask);
-                sum += (long long)vt[a];
-                vt[a] = 0ull;
-            }
-            const size_t gi = (size_t)r0 * 3 + i;
-            const double vn = (double)sum * inv - beta * v_t[gi];
-            v_t[gi] = vn;
-            nrm += vn * vn;
-        }
-        __syncthreads();
+    };
+    // register sets: chunk k's old rows live in ra for even (k-k0), rb for odd
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ea, eb, rb, k, 0);
+        if (k + 1 < k1) body(eb, ea, ra, k + 1, 1);
     }
+    if (k0 < k1) { if ((k1 - 1 - k0) & 1) fold(rb, k1 - 1, 1); else fold(ra, k1 - 1, 0); }
+    __syncthreads();
     for (int i = tid; i < 3 * C; i += BLOCK) vc_part[(size_t)blockIdx.x * 3 * C + i] = vc[i];
     const double t = block_sum(nrm, red);
     if (tid == 0) part[blockIdx.x] = t;
@@ -186,6 +259,25 @@ __global__ __launch_bounds__(BLOCK) void lsqr_v_step_kernel(vican_graph_t g, con
         else if (g->block_threads == 512) { if (epl_ == 4) launch_(KERN<512, 4>, 512);   else launch_(KERN<512, 2>, 512); }   \
         else                              { if (epl_ == 4) launch_(KERN<256, 4>, 256);   else launch_(KERN<256, 2>, 256); }   \
     } while (0)
+// the pipelined step kernels additionally carry NR = row values per thread (3 max_rows / block, <= 3 EPL)
+#define LSQR_DISPATCH_NR(KERN, LDS, ...)                                                                         \
+    do {                                                                                                         \
+        const int epl_ = g->slots / g->block_threads;                                                            \
+        const int nr_ = (3 * g->max_rows + g->block_threads - 1) / g->block_threads;                             \
+        auto launch_ = [&](auto kern, int B) {                                                                   \
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));      \
+            hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), (LDS), st, __VA_ARGS__);                            \
+        };                                                                                                       \
+        auto pick_ = [&](auto b_, auto e_) {                                                                     \
+            constexpr int B = decltype(b_)::value, E = decltype(e_)::value;                                      \
+            if (nr_ <= 1) launch_(KERN<B, E, 1>, B); else if (nr_ <= 4) launch_(KERN<B, E, 4>, B); else launch_(KERN<B, E, 12>, B); \
+        };                                                                                                       \
+        using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;                    \
+        if (g->block_threads == 1024)     { if (epl_ == 4) pick_(std::integral_constant<int, 1024>{}, I4{}); else pick_(std::integral_constant<int, 1024>{}, I2{}); } \
+        else if (g->block_threads == 768) { if (epl_ == 4) pick_(std::integral_constant<int, 768>{}, I4{});  else pick_(std::integral_constant<int, 768>{}, I2{}); }  \
+        else if (g->block_threads == 512) { if (epl_ == 4) pick_(std::integral_constant<int, 512>{}, I4{});  else pick_(std::integral_constant<int, 512>{}, I2{}); }  \
+        else                              { if (epl_ == 4) pick_(std::integral_constant<int, 256>{}, I4{});  else pick_(std::integral_constant<int, 256>{}, I2{}); }  \
+    } while (0)
 
 // out[0] = sum part[0..n)   (fixed order)
 __global__ void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
@@ -197,35 +289,37 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int n, doub
 }
 
 extern "C" int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
-                                 const double* rc, const double* rt, double* u, double* part, double* nrm2_out,
+                                 const double* rc, const double* rt, double* u, double* sw, double* part, double* nrm2_out,
                                  void* stream) {
     if (int r = vican_check_graph(g, "vican_lsqr_init_u")) return r;
-    if (!w || !ue || !ve || !rc || !rt || !u || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_init_u: null pointer");
+    if (!w || !ue || !ve || !rc || !rt || !u || !sw || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_init_u: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)8 * (9 * g->n_cam + 9 * g->max_rows + 16);
-    LSQR_DISPATCH(lsqr_init_u_kernel, lds, *g, w, ue, ve, rc, rt, u, part);
+    LSQR_DISPATCH(lsqr_init_u_kernel, lds, *g, w, ue, ve, rc, rt, u, sw, part);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, g->n_wg, nrm2_out);
     LAUNCH_CHECK("vican_lsqr_init_u");
     return VICAN_OK;
 }
 
-extern "C" int vican_lsqr_u_step(const vican_graph_t* g, const double* w, const double* v_c, const double* v_t,
+extern "C" int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,
                                  double coef, double* u, double* part, double* nrm2_out, void* stream) {
     if (int r = vican_check_graph(g, "vican_lsqr_u_step")) return r;
-    if (!w || !v_c || !v_t || !u || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_u_step: null pointer");
+    if (!sw || !v_c || !v_t || !u || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_u_step: null pointer");
+    if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_u_step: more than 4 rows per lane in a chunk");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)8 * (3 * g->n_cam + 3 * g->max_rows + 16);
-    LSQR_DISPATCH(lsqr_u_step_kernel, lds, *g, w, v_c, v_t, coef, u, part);
+    const size_t lds = (size_t)8 * (3 * g->n_cam + 6 * g->max_rows + 16);
+    LSQR_DISPATCH_NR(lsqr_u_step_kernel, lds, *g, sw, v_c, v_t, coef, u, part);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, g->n_wg, nrm2_out);
     LAUNCH_CHECK("vican_lsqr_u_step");
     return VICAN_OK;
 }
 
-extern "C" int vican_lsqr_v_step(const vican_graph_t* g, const double* w, const double* u, double inv_beta, double beta,
+extern "C" int vican_lsqr_v_step(const vican_graph_t* g, const double* sw, const double* u, double inv_beta, double beta,
                                  double* v_t, void* vc_part, double* part, double* nrm2_t_out, double smax, double n_add,
                                  double* inv_out, void* stream) {
     if (int r = vican_check_graph(g, "vican_lsqr_v_step")) return r;
-    if (!w || !u || !v_t || !vc_part || !part || !nrm2_t_out || !inv_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_v_step: null pointer");
+    if (!sw || !u || !v_t || !vc_part || !part || !nrm2_t_out || !inv_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_v_step: null pointer");
+    if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_v_step: more than 4 rows per lane in a chunk");
     hipStream_t st = (hipStream_t)stream;
     double c = smax > 1e-300 ? smax : 1e-300;
     int e = 47 - (int)ceil(log2(c));
@@ -234,7 +328,7 @@ extern "C" int vican_lsqr_v_step(const vican_graph_t* g, const double* w, const 
     const double scale = ldexp(1.0, e), inv = ldexp(1.0, -e);
     *inv_out = inv;
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
-    LSQR_DISPATCH(lsqr_v_step_kernel, lds, *g, w, u, inv_beta, beta, v_t, (u64*)vc_part, part, scale, inv);
+    LSQR_DISPATCH_NR(lsqr_v_step_kernel, lds, *g, sw, u, inv_beta, beta, v_t, (u64*)vc_part, part, scale, inv);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, g->n_wg, nrm2_t_out);
     LAUNCH_CHECK("vican_lsqr_v_step");
     return VICAN_OK;

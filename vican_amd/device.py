@@ -405,17 +405,19 @@ def _lsqr_alloc(self):
     if not hasattr(self, "_lsqr_u"):
         nslot = max(1, self.g.n_chunk) * self.g.slots
         self._lsqr_u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
+        self._lsqr_sw = torch.zeros(nslot, dtype=torch.float64, device=self.dev)       # sqrt(w), written by lsqr_init_u
         self._lsqr_part = torch.zeros(max(self.g.n_wg, 1024), dtype=torch.float64, device=self.dev)
 
 
 def _lsqr_init_u(self, rc, rt, nrm2_out):
     _lsqr_alloc(self)
     self._ck(self.lib.vican_lsqr_init_u(self._gref, _ptr(self.g.w), _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt),
-                                        _ptr(self._lsqr_u), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_init_u")
+                                        _ptr(self._lsqr_u), _ptr(self._lsqr_sw), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()),
+             "vican_lsqr_init_u")
 
 
 def _lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
-    self._ck(self.lib.vican_lsqr_u_step(self._gref, _ptr(self.g.w), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
+    self._ck(self.lib.vican_lsqr_u_step(self._gref, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
                                         _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
 
 
@@ -424,7 +426,7 @@ def _lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
     nwg = self.g.n_wg
     part = self.zpart[: nwg * 3 * self.C]
     inv = C.c_double(0.0)
-    self._ck(self.lib.vican_lsqr_v_step(self._gref, _ptr(self.g.w), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
+    self._ck(self.lib.vican_lsqr_v_step(self._gref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
                                         _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self.n_add,
                                         C.byref(inv), _stream()), "vican_lsqr_v_step")
     self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
