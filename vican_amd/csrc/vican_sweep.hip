@@ -91,11 +91,11 @@ int vican_check_graph(const vican_graph_t* g, const char* who) {
 // distinct banks per 32-lane group - the conflict-free rate instead of the 4x slower
 // "random" one (PMC: 75 % of LDS cycles were bank conflicts before this).
 // It is also ROW-AWARE: of the n edges a row has in a class, the first EPL*floor(n/EPL) fill
-// whole lanes ("pure" lanes: one row per lane), allocated from the first lane group of the class
-// upwards; the n mod EPL leftovers of all rows are packed continuously into lanes allocated from the
-// last lane group downwards.  The sweep flushes a lane's row sum whenever the row changes inside the
-// lane (masked, but at full instruction cost); with this order the lanes that change row sit in the
-// last few wavefronts and all others skip those flushes (execz branches): 12 x 36 -> about
+// whole lanes ("pure" lanes: one row per lane), allocated from one end of the class's lane groups;
+// the n mod EPL leftovers of all rows are packed continuously into lanes allocated from the other end
+// (mirrored at the end so that the leftovers sit in the first, i.e. oldest, wavefronts).  The sweep flushes
+// a lane's row sum whenever the row changes inside the lane (masked, but at full instruction cost); with this
+// order the lanes that change row sit in few wavefronts and all others skip those flushes (execz branches): 12 x 36 -> about
 // 10 x 9 + 2 x 36 row-accumulator atomics per chunk.  Classes that overflow their lanes spill into the
 // free slots of the others.
 // ---------------------------------------------------------------------------
@@ -152,16 +152,18 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
                 }
             }
             const unsigned long long sm = __ballot(spill);      // ordered compaction: deterministic layout
-            if (valid && !spill) pm[(c + 32 * grp) * epl + slot] = e;
+            // lane groups are mirrored: the leftover lanes end up in the FIRST wavefronts - the oldest ones, which
+            // the SIMD arbiter favours, so the wavefronts with the extra flush work finish first (-3 % vs last)
+            if (valid && !spill) pm[(c + 32 * (G - 1 - grp)) * epl + slot] = e;
             if (spill) sh[novf + __popcll(sm & lt)] = e;
             novf += __popcll(sm);
         }
         if (lane < 32) { pure_lanes += n_c / epl; left_cnt += n_c % epl; }
     }
     __syncthreads();
-    if (lane == 0 && novf > 0) {                    // spill: few edges; fill free slots from the back (the
+    if (lane == 0 && novf > 0) {                    // spill: few edges; fill free slots from the front (the
         int o = 0;                                  // wavefronts that change rows anyway)
-        for (int s = g.slots - 1; s >= 0 && o < novf; --s)
+        for (int s = 0; s < g.slots && o < novf; ++s)
             if (pm[s] < 0) pm[s] = sh[o++];
     }
 }
