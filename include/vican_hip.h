@@ -133,7 +133,8 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
  * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
  * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
  * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup;
- * one contribution gets 47 bits on the f64 path, 28 on the f32 path (single v_cvt_i32_f32). */
+ * a contribution gets up to 47 bits; totals stay below 2^61 (f64 blocks) or 2^46 (f32 blocks, whose
+ * accumulators hold raw magic-number bit patterns that are sign-extended from 48 bits at the end). */
 #define VICAN_FX_DOUBLES 12
 int vican_block_norms(const vican_graph_t* g, double* rnorm /*[T]*/, double* fx, void* stream);
 int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream);

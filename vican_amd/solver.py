@@ -63,7 +63,7 @@ class RotationSolver:
         self.warm_min_steps = warm_min_steps
         self.floor_tol = floor_tol
         # on cache-resident graphs an edge sweep costs tens of microseconds - less than one projection
-        # check (host sync + small eigh) - so check less often there
+        # check (device Ritz kernel + cancelled speculative launches) - so check less often there
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges * max(self.comm.world, 1) < 2_000_000
         if self.small_graph:
