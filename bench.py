@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cams-per-t", type=int, default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage type of the 3x3 blocks")
     ap.add_argument("--maxiter", type=int, default=4)
+    ap.add_argument("--no-large-shop", action="store_true", help="skip the large_shop wall-clock measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
     ap.add_argument("--n-copy", type=int, default=None)
@@ -216,6 +217,37 @@ def main():
                    "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
                    "rot_edges_per_s": E_total * args.maxiter * args.steps / t_rot if t_rot else None},
     }
+    if rank == 0 and world == 1 and args.workload == "stress" and not args.no_large_shop:
+        # second half of BASELINE.json's metric: wall-clock of a full solve of a large_shop-sized graph
+        # (340 cameras x 10 000 timesteps x 4 cameras per timestep: cache-resident, latency-bound)
+        try:
+            del K, g, rot, tr
+            torch.cuda.empty_cache()
+            Cl, Tl2, cl = 340, 10000, 4
+            gr = synth.make_merged_graph_torch(Cl, Tl2, cl, dev, tdt, seed=0)
+            g2 = LocalGraph(Cl, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+            K2 = HipBackend(g2)
+            rot2, tr2 = RotationSolver(K2, comm), TranslationSolver(K2, comm)
+
+            def solve2():
+                rot2.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+                tr2.poll_every = 8
+                rc, Rt = rot2.run(args.maxiter)
+                tr2.setup(rc, Rt)
+                tr2.solve(3 * (Cl + Tl2))
+                K2.synchronize()
+            for _ in range(2):
+                solve2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                solve2()
+            torch.cuda.synchronize()
+            out["detail"]["large_shop_wall_clock"] = {
+                "ms_per_solve": (time.perf_counter() - t0) / 5 * 1e3, "cameras": Cl, "timesteps": Tl2, "merged_edges": g2.n_edges,
+                "lanczos_steps": rot2.stats["lanczos_steps"], "cg_iters": tr2.info.get("cg_iters"), "solves_timed": 5}
+        except Exception as exc:
+            out["detail"]["large_shop_wall_clock"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Ts = args.cpu_sample_timesteps or (300 if args.workload == "stress" else 10000)
         try:
