@@ -615,6 +615,66 @@ extern "C" int vican_cg_time_step(int32_t n_time, const double* p_t, const doubl
     return nb;
 }
 
+// cg_cam_step + cg_time_step in ONE launch: every block derives alpha itself (the camera-side dot product is
+// 3C elements: cheaper to recompute per block than to wait for another kernel), block 0 also updates the camera
+// vectors and the state.  Same thread mappings and summation orders as the two separate kernels => same bits.
+__global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, const double* __restrict__ deg_c,
+                                                      const double* __restrict__ qc_sum, const double* __restrict__ pq_time,
+                                                      const double* __restrict__ p_c, double* x_c, double* r_c,
+                                                      const double* __restrict__ p_t, const double* __restrict__ q_t,
+                                                      double* x_t, double* r_t, double* __restrict__ rr_part,
+                                                      vican_cg_state_t* st) {
+    __shared__ double red[8];
+    __shared__ double sh_alpha;
+    if (st->done) return;
+    const int nc = 3 * n_cam;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const double q = deg_c[i / 3] * p_c[i] - qc_sum[i];
+        s += p_c[i] * q;
+    }
+    const double pqc = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const double pq = *pq_time + pqc;
+        sh_alpha = st->rho / pq;
+        if (blockIdx.x == 0) { st->pq_time = *pq_time; st->pq = pq; st->alpha = sh_alpha; }
+    }
+    __syncthreads();
+    const double alpha = sh_alpha;
+    double rr = 0.0, m = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        x_t[i] += alpha * p_t[i];
+        const double r = r_t[i] - alpha * q_t[i];
+        r_t[i] = r;
+        rr += r * r; m = fmax(m, fabs(r));
+    }
+    const double t = block_sum(rr, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); }
+    if (blockIdx.x != 0) return;
+    __syncthreads();
+    double rc2 = 0.0, mc = 0.0;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const double p = p_c[i];
+        const double q = deg_c[i / 3] * p - qc_sum[i];
+        x_c[i] += alpha * p;
+        const double r = r_c[i] - alpha * q;
+        r_c[i] = r;
+        rc2 += r * r; mc = fmax(mc, fabs(r));
+    }
+    const double tc = block_sum(rc2, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mc;
+    __syncthreads();
+    if (threadIdx.x == 0) { st->rr_cam = tc; st->rmax_cam = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); }
+}
+
 __global__ void cg_end_kernel(const double* __restrict__ rr_part, int n_part, vican_cg_state_t* st) {
     if (st->done) return;
     if (threadIdx.x == 0) cg_close_iteration(rr_part, n_part, st);
@@ -688,7 +748,13 @@ extern "C" int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double*
                                     const double* p_c, double* x_c, double* r_c, const double* p_t, const double* q_t,
                                     double* x_t, double* r_t, double* rr_part, int32_t part_cap, vican_cg_state_t* st,
                                     void* stream) {
-    int rc = vican_cg_cam_step(n_cam, deg_c, qcpq, qcpq + 3 * n_cam, p_c, x_c, r_c, st, stream);
-    if (rc < 0) return rc;
-    return vican_cg_time_step(n_time, p_t, q_t, x_t, r_t, rr_part, part_cap, st, stream);
+    if (n_cam <= 0 || n_time < 0 || !deg_c || !qcpq || !p_c || !x_c || !r_c || !p_t || !q_t || !x_t || !r_t || !rr_part ||
+        part_cap < 2 * CG_PARTS || !st)
+        return set_err(VICAN_ERR_ARG, "vican_cg_iter_finish: bad argument");
+    const long long n = 3LL * n_time;
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
+    hipLaunchKernelGGL(cg_step_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_cam, n, deg_c, qcpq, qcpq + 3 * n_cam,
+                       p_c, x_c, r_c, p_t, q_t, x_t, r_t, rr_part, st);
+    LAUNCH_CHECK("vican_cg_iter_finish");
+    return nb;
 }
