@@ -638,7 +638,11 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #pragma unroll
             for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
             if (keep == 123.456f && cur.id[0] == 77u) zs[0] = 1ull;
-            return 0x7fffffff;
+            if (tid == 0) s_knext = taken < cap ? (DEPTH + 1) * nwg + (int)ticket : 0x7fffffff;
+            __syncthreads();
+            const int kn_ = __builtin_amdgcn_readfirstlane(s_knext);
+            __syncthreads();
+            return kn_;
         }
 #endif
         STAMP(5);                       // inter-chunk prologue: descriptors, dual loads, prefetch issue
@@ -683,7 +687,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         STAMP(0);                       // phase 1 (incl. waiting for this chunk's loads)
         if (tid == 0) s_knext = taken < cap ? (DEPTH + 1) * nwg + (int)ticket : 0x7fffffff;
         __syncthreads();
-        const int knew = s_knext;       // read between the two barriers of this body; rewritten after the second
+        // read between the two barriers of this body (rewritten after the second); wave-uniform -> scalar register,
+        // so that the chunk addresses derived from it are scalar arithmetic
+        const int knew = __builtin_amdgcn_readfirstlane(s_knext);
         STAMP(1);                       // barrier A
 
         // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
