@@ -249,7 +249,7 @@ class TranslationSolver:
         self.info = {}
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges < 2_000_000
-        self._graph, self._graph_key, self._n_solves = None, None, 0
+        self._graphs, self._n_solves = {}, 0
 
     def _state(self):
         h = self.st.cpu()
@@ -293,15 +293,27 @@ class TranslationSolver:
         self._n_solves += 1
         while True:
             burst = min(self.poll_every, maxiter + 1 - it_launched)
-            for _ in range(burst):
-                if use_graph and it_launched >= 1:
-                    key = (n_part, float(self.rtol), self.deg_t.data_ptr(), self.deg_c.data_ptr())
-                    if self._graph_key != key:
-                        self._graph, self._graph_key = K.capture(lambda: one_iteration(n_part)), key
-                    self._graph.replay()
-                else:
-                    n_part = one_iteration(n_part)
+            left = burst
+            if it_launched == 0:                                  # the first iteration passes other arguments
+                n_part = one_iteration(n_part)
                 it_launched += 1
+                left -= 1
+            if use_graph and left > 0:
+                # the rest of the burst as ONE graph launch (iterations past convergence cancel themselves)
+                key = (n_part, left, float(self.rtol), self.deg_t.data_ptr(), self.deg_c.data_ptr())
+                if key not in self._graphs:
+                    npart = n_part
+
+                    def burst_fn(npart=npart, left=left):
+                        for _ in range(left):
+                            one_iteration(npart)
+                    self._graphs[key] = K.capture(burst_fn)
+                self._graphs[key].replay()
+                it_launched += left
+            else:
+                for _ in range(left):
+                    n_part = one_iteration(n_part)
+                    it_launched += 1
             s = self._state()
             if s["done"] or it_launched > maxiter:
                 break
