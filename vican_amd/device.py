@@ -321,9 +321,16 @@ class HipBackend:
         """Asynchronous device->host copy of a small status vector; returns a handle for wait_status."""
         host = self._status_host.get(status.numel())
         if host is None:
-            host = self._status_host[status.numel()] = (self.pinned(status.numel()), torch.cuda.Event())
-        host[0].copy_(status, non_blocking=True)
-        host[1].record()
+            host = self._status_host[status.numel()] = (self.pinned(status.numel()), torch.cuda.Event(), torch.cuda.Event(),
+                                                        torch.cuda.Stream())
+        # the copy runs on a side stream: in the launch stream it would sit between the Ritz kernel and the
+        # speculative continuation and cost ~20 us of copy-engine latency per primal-dual iteration
+        buf, done, ready, side = host
+        ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            buf.copy_(status, non_blocking=True)
+            done.record()
         return host
 
     def wait_status(self, handle):
