@@ -51,7 +51,7 @@ static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32
 // y sums (f64) + w (storage type) + n_copy striped u64 accumulators
 // camera planes are padded to a compile-time stride CP (256 or 1024 entries) so that the nine
 // component planes are reached with LDS immediate offsets instead of per-access address math
-static inline int64_t plane_stride(int32_t n_cam) { return n_cam <= 256 ? 256 : 1024; }
+static inline int64_t plane_stride(int32_t n_cam) { return n_cam <= 256 ? 256 : (n_cam <= 512 ? 512 : 1024); }
 extern "C" int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy) {
     const int64_t s = ssize(storage), cp = plane_stride(n_cam);
     return 9LL * cp * (s + 8) + (int64_t)max_rows * (72 + 9 * s + 72LL * n_copy) + 256;
@@ -495,7 +495,7 @@ template <> __device__ __forceinline__ long long fix_total<double>(long long s) 
 // Per chunk:  [phase 3 of the previous chunk | phase 1]  barrier  [phase 2: one wavefront per
 // row, no workgroup barrier inside]  barrier  ...   - two barriers per chunk; the register
 // set of the next chunk is loaded while the current one is processed (ping-pong, no copies).
-template <typename S, int BLOCK, int MODE, int CP>
+template <typename S, int BLOCK, int MODE, int CP, bool ROWPAR>
 __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
                                                             const double* __restrict__ lamT_inv,
                                                             const double* __restrict__ x,
@@ -695,6 +695,31 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
         //      rotated by the accumulator index => distinct banks), re-zero them, then
         //      w = lamT_inv * y (or the SVD) with wave shuffles only - no workgroup barrier inside
+        if constexpr (ROWPAR) {
+            // many short rows (sparse graphs; chosen at launch when max_rows > 2 wavefronts' worth): a wavefront per
+            // row would run nrows / NWAVE rounds back to back; instead one thread per (row, accumulator):
+            // fold -> barrier -> w = lamT_inv * y, all rows at once
+            for (int i = tid; i < nrows * 9; i += BLOCK) {
+                const int oo = i % 9;
+                long long s = 0;
+                for (int c = 0; c < ncopy; ++c) {
+                    const int a = i * ncopy + ((c + oo) & cmask);
+                    s += (long long)ys[a];
+                    ys[a] = 0ull;
+                }
+                ysum[i] = (double)fix_total<S>(s) * y_inv;
+            }
+            __syncthreads();
+            for (int i = tid; i < nrows * 9; i += BLOCK) {
+                if (MODE == 0) {
+                    const int r = i / 9, oo = i - 9 * r, a3 = oo / 3, b3 = oo - 3 * a3;
+                    const double* L = lamT_inv + (size_t)(r0 + r) * 9 + a3 * 3;
+                    wv[i] = pre_scale<S>(L[0] * ysum[r * 9 + b3] + L[1] * ysum[r * 9 + 3 + b3] + L[2] * ysum[r * 9 + 6 + b3], z_scale);
+                } else {
+                    lamT_out[(size_t)r0 * 9 + i] = ysum[i];
+                }
+            }
+        } else
         for (int r = wave; r < nrows; r += NWAVE) {
             long long s = 0;
             if (o < 9) {
@@ -835,11 +860,11 @@ __global__ __launch_bounds__(128) void dual_svd_kernel(const int32_t* __restrict
     if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
 }
 
-template <typename S, int BLOCK, int MODE, int CP>
-static int launch_sweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
-                        double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
+template <typename S, int BLOCK, int MODE, int CP, bool ROWPAR>
+static int launch_sweep2(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+                         double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
     const size_t lds = (size_t)vican_sweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy);
-    auto kern = block_sweep_kernel<S, BLOCK, MODE, CP>;
+    auto kern = block_sweep_kernel<S, BLOCK, MODE, CP, ROWPAR>;
     static size_t configured = 0;       // per instantiation
     if (lds > configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -850,10 +875,17 @@ static int launch_sweep1(const vican_graph_t* g, const double* lamT_inv, const d
     return 0;
 }
 
+template <typename S, int BLOCK, int MODE, int CP>
+static int launch_sweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
+                        double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
+    if (g->max_rows > 2 * (BLOCK / 64)) return launch_sweep2<S, BLOCK, MODE, CP, true>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
+    return launch_sweep2<S, BLOCK, MODE, CP, false>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
+}
 template <typename S, int BLOCK, int MODE>
 static int launch_sweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
                         double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
     if (g->n_cam <= 256) return launch_sweep1<S, BLOCK, MODE, 256>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
+    if (g->n_cam <= 512) return launch_sweep1<S, BLOCK, MODE, 512>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
     return launch_sweep1<S, BLOCK, MODE, 1024>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, st);
 }
 
