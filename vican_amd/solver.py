@@ -249,7 +249,7 @@ class TranslationSolver:
         self.info = {}
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges < 2_000_000
-        self._graphs, self._n_solves = {}, 0
+        self._graphs, self._n_solves, self._last_iters = {}, 0, None
 
     def _state(self):
         h = self.st.cpu()
@@ -291,8 +291,14 @@ class TranslationSolver:
         # few milliseconds, so only a solver object that is used again (time series, benchmark loop) does it.
         use_graph = self.small_graph and not multi and hasattr(K, "capture") and self._n_solves >= 1
         self._n_solves += 1
+        first_burst = True
         while True:
             burst = min(self.poll_every, maxiter + 1 - it_launched)
+            if first_burst and self._last_iters is not None:
+                # the same system was solved before (time series, benchmark loop): launch exactly as many iterations
+                # as it took then, plus the one that detects convergence, before the first poll
+                burst = min(max(self._last_iters + 1, 1), 64, maxiter + 1 - it_launched)
+            first_burst = False
             left = burst
             if it_launched == 0:                                  # the first iteration passes other arguments
                 n_part = one_iteration(n_part)
@@ -318,6 +324,7 @@ class TranslationSolver:
             if s["done"] or it_launched > maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
+        self._last_iters = int(s["iter"]) if s["done"] else None
         self.info = dict(cg_iters=s["iter"], converged=bool(s["done"]),
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
         return self.x_c, self.x_t
