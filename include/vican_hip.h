@@ -69,7 +69,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 6 */
+int vican_abi_version(void);            /* 7 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -165,6 +165,16 @@ int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double*
 int vican_block_op_z(const vican_graph_t* g, const double* lamT_inv, const double* x,
                      void* zpart, double* fx, double* z, void* stream);
 
+/* Non-eliminated solver (bipartite_so3sync, bipgo.py:91,119: `pairwise_r @ r` on all C+T nodes).
+ * The symmetric operator R~ = [[0, M], [M^T, 0]] applied to [x_cam; x_time] in ONE pass over the blocks:
+ *   y_time[t] = sum_c M_ct^T x_cam[c]   ([T][9] doubles, exact fixed-point row sums)
+ *   z_cam[c]  = sum_t M_ct x_time[t]    ([C][9] doubles, slabs folded as in vican_block_op_z)
+ * |x_cam[c]|_F, |x_time[t]|_F <= the x_bound given to vican_bip_scales, which prepares fx for this
+ * entry point (phase-3 operand bounded by x_bound itself, i.e. omega = 1). */
+int vican_bip_scales(double* fx, double x_bound, double n_add, int32_t storage, void* stream);
+int vican_bip_apply(const vican_graph_t* g, const double* x_cam, const double* x_time, void* zpart,
+                    double* fx, double* z_cam, double* y_time, void* stream);
+
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,
  * lamT_inv[t] = U S^-1 U^T.  rc: [3C][3]; Rt, lamT_inv: [T][9].  Refreshes fx[4]
@@ -183,7 +193,8 @@ int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_
 
 /* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
  * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),
- * lam_out [n][9] (may be NULL): mode 1 = U S U^T, mode 2 = U S^-1 U^T.       */
+ * lam_out [n][9] (may be NULL): mode & 3 = 1: U S U^T, 2: U S^-1 U^T;
+ * mode & 4: R_out = U V^T WITHOUT the det fix (bipgo.py:126-127).              */
 int vican_polar_dual(int32_t n, const double* in, double* R_out, double* lam_out,
                      int32_t mode, void* stream);
 
@@ -253,7 +264,7 @@ int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t
  * status[VICAN_RITZ_STATUS_DOUBLES]: [0] r, [1] max|theta|, [2] stop, [3] converged, [4] floor_hit,
  * [5] eff, [6] breakdown (all pivots of the last beta zero), [7..9] three smallest Ritz values,
  * [10..11] the two largest (NaN when 3 eff < 5), [12] r (read back as r_prev by the next call),
- * [13] Jacobi sweeps, [14] unscaled residual, [15] reserved.  steps <= VICAN_RITZ_MAX_STEPS.    */
+ * [13] Jacobi sweeps, [14] unscaled residual, [15] 4th smallest Ritz value (NaN if none).  steps <= VICAN_RITZ_MAX_STEPS.    */
 #define VICAN_RITZ_MAX_STEPS 32
 #define VICAN_RITZ_STATUS_DOUBLES 16
 int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags,

@@ -10,6 +10,7 @@ What it restates (own NumPy/SciPy code, same third-party calls the reference mak
   ``large_bipartite_so3sync``    reference vican/bipgo.py:145-350
   ``bipartite_se3sync``          reference vican/bipgo.py:353-490
   ``object_bipartite_se3sync``   reference vican/bipgo.py:493-545
+  ``bipartite_so3sync``          reference vican/bipgo.py:18-142 (non-eliminated variant; dead code upstream)
 
 Parity status: PINNED.  ``tests/golden/*.npz`` hold outputs of the REAL reference
 run in the build container (``tests/golden/make_golden.py``, numpy 2.2.6 /
@@ -29,8 +30,8 @@ import numpy as np
 from scipy.sparse import csr_matrix, diags
 from scipy.sparse.linalg import cg, eigs, lsqr
 
-__all__ = ["flatten_edges", "so3sync_arrays", "translation_arrays",
-           "bipartite_se3sync", "object_bipartite_se3sync", "polar_dual", "Pose"]
+__all__ = ["flatten_edges", "so3sync_arrays", "translation_arrays", "so3sync_general_arrays",
+           "bipartite_se3sync", "object_bipartite_se3sync", "bipartite_so3sync", "polar_dual", "Pose"]
 
 
 class Pose:
@@ -289,3 +290,78 @@ def object_bipartite_se3sync(src_edges, noise_model_r, noise_model_t, edge_filte
     out = bipartite_se3sync(edges, {root: ident}, noise_model_r, noise_model_t, edge_filter,
                             maxiter, lsqr_solver, dtype, loop, info)
     return {k: v for k, v in out.items() if "_" not in k}                                       # :543
+
+
+# ---------------------------------------------------------------------------
+# the non-eliminated variant (bipgo.py:18-142)
+# ---------------------------------------------------------------------------
+
+def so3sync_general_arrays(C, T, cam, time, blocks, a, maxiter, dtype=np.float32, info=None):
+    """Primal-dual iteration on all N = C+T nodes (cameras first; bipgo.py:54-133).
+
+    blocks: (E,3,3) = sum k_r R~ R_m R_0^T per merged edge (bipgo.py:45-49), a: (E,) summed weights.
+    Returns r (N,3,3): the blocks of the reference's final ``r`` as they are (u @ vt WITHOUT det fix,
+    not transposed - bipgo.py:127,139-141)."""
+    N = C + T
+    i, j = np.asarray(cam), C + np.asarray(time)
+    off_r = np.repeat(np.arange(3), 3)[None, :]
+    off_c = np.tile(np.arange(3), 3)[None, :]
+    bi = np.concatenate([(3 * i[:, None] + off_r), (3 * j[:, None] + off_r)], axis=1).reshape(-1)        # :81-84
+    bj = np.concatenate([(3 * j[:, None] + off_c), (3 * i[:, None] + off_c)], axis=1).reshape(-1)
+    bd = np.concatenate([blocks.reshape(-1, 9), np.swapaxes(blocks, 1, 2).reshape(-1, 9)], axis=1).reshape(-1)
+    pr = csr_matrix((bd.astype(dtype), (bi, bj)), shape=(3 * N, 3 * N))                                   # :91
+    adj = csr_matrix((np.repeat(a, 2).astype(dtype), (np.stack([i, j], 1).reshape(-1), np.stack([j, i], 1).reshape(-1))),
+                     shape=(N, N))                                                                         # :92
+    deg = np.asarray(adj.sum(axis=1)).squeeze()
+    lbd = diags(np.repeat(deg, 3).astype(dtype), 0)                                                        # :95-99
+    rows = (3 * np.arange(N)[:, None] + off_r).reshape(-1)
+    cols = (3 * np.arange(N)[:, None] + off_c).reshape(-1)
+    hist = []
+    r = None
+    for _ in range(maxiter):
+        L = lbd - pr
+        L = 0.5 * (L.T + L)                                                                                # :102-103
+        ev, evec = eigs(L, k=5, sigma=-1e-6)                                                               # :106
+        ev, evec = np.real(ev), np.real(evec)
+        hist.append(ev.astype(np.float64))
+        # the reference takes columns 0..2 of ARPACK's output, which for shift-invert are the eigenvalues
+        # CLOSEST TO sigma first; the restatement selects them explicitly
+        sel = np.argsort(np.abs(ev + 1e-6), kind="stable")[:3]
+        v3 = evec[:, sel]
+        r = v3 @ np.linalg.inv(v3[:3, :])                                                                  # :113
+        r = polar_dual(r.reshape(N, 3, 3))[0].reshape(3 * N, 3).astype(r.dtype)                            # :115-116
+        y = np.asarray(pr @ r).reshape(N, 3, 3)                                                            # :119
+        u, sv, vt = np.linalg.svd(y)
+        r = (u @ vt).reshape(3 * N, 3)                                                                     # :126-127 (no det fix)
+        lam = (u * sv[:, None, :]) @ np.swapaxes(u, 1, 2)                                                  # :131
+        lbd = csr_matrix((lam.reshape(-1), (rows, cols)), shape=(3 * N, 3 * N))                            # :133 (float64)
+    if info is not None:
+        info["evals"] = np.array(hist)
+    return np.asarray(r, dtype=np.float64).reshape(N, 3, 3)
+
+
+def bipartite_so3sync(src_edges, constraints, noise_model, edge_filter, maxiter, dtype=np.float32, info=None):
+    """bipgo.py:18-142: {camera id: r, '<t>_0': r} with r the raw 3x3 blocks of the final iterate."""
+    root = str(min(list(constraints.keys())))                                                              # :33
+    r_0 = np.asarray(constraints[root].R())
+    cam_s, time_s, blks, kr = [], [], [], []
+    for key, val in src_edges.items():
+        if not edge_filter(val):
+            continue
+        ts, mid = key[1].split("_")
+        k_r = noise_model(val)
+        blks.append(np.asarray(k_r * np.asarray(val["pose"].R()) @ np.asarray(constraints[mid].R()) @ r_0.T,
+                               dtype=np.float64))                                                          # :44-45
+        cam_s.append(key[0]); time_s.append(ts); kr.append(float(k_r))
+    cam_nodes, ci = np.unique(np.char.add("c", np.array(cam_s, dtype=str)), return_inverse=True)           # :54
+    time_nodes, ti = np.unique(np.char.add("t", np.array(time_s, dtype=str)), return_inverse=True)
+    flat = dict(cam_names=cam_nodes, time_names=time_nodes, cam_idx=ci.astype(np.int64), time_idx=ti.astype(np.int64),
+                wR=np.array(blks).reshape(-1, 3, 3), k_r=np.array(kr))
+    mg = merge_edges(flat)                                                                                 # :47-52
+    r = so3sync_general_arrays(mg["C"], mg["T"], mg["cam"], mg["time"], mg["blocks"], mg["a"], maxiter, dtype, info)
+    out = {}
+    for k, c in enumerate(cam_nodes):                                                                      # :135-141
+        out[c[1:]] = r[k]
+    for k, t in enumerate(time_nodes):
+        out[t[1:] + "_0"] = r[mg["C"] + k]
+    return out

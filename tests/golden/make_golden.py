@@ -232,6 +232,36 @@ def eval_case():
     print("  g7_eval      %d cameras (+ g7_dojo)" % len(ids))
 
 
+SO3_CASES = ("g2_small", "g3_medium", "g5_strings")
+
+
+def so3_case():
+    """G8: the non-eliminated variant `bipartite_so3sync` (bipgo.py:18-142) on the inputs of the camera
+    cases above (their fixtures hold the inputs); outputs only: rotation dict + the eigs values."""
+    out = {}
+    for name in SO3_CASES:
+        case = gc.CASES[name]
+        scene, flat = gc.build_flat(case)
+        src = synth.edges_to_dict(flat, ref_geometry.SE3)
+        cons = synth.constraints_from_scene(scene, ref_geometry.SE3)
+        nr, ff = gc.CALLABLES[case["noise_r"]], gc.CALLABLES[case["filt"]]
+        for dt in ("float64", "float32"):
+            _rec["evals"] = []
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                res = ref_bipgo.bipartite_so3sync(src, constraints=cons, noise_model=nr, edge_filter=ff,
+                                                  maxiter=gc.MAXITER, dtype=np.dtype(dt).type)
+            tag = "%s_%s_" % (name, dt)
+            keys = list(res.keys())
+            out[tag + "keys"] = np.array([str(k) for k in keys])
+            out[tag + "R"] = np.stack([np.asarray(res[k], dtype=np.float64) for k in keys])
+            out[tag + "evals"] = np.stack(_rec["evals"])
+            print("  g8_so3sync   %-12s %-8s nodes=%d evals[-1]=%s" % (
+                name, dt, len(keys), np.array2string(out[tag + "evals"][-1], precision=3)))
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__,
+                                "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, "g8_so3sync.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -244,3 +274,5 @@ if __name__ == "__main__":
         pickle_case()
     if not only or "g7_eval" in only:
         eval_case()
+    if not only or "g8_so3sync" in only:
+        so3_case()

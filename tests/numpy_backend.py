@@ -19,6 +19,9 @@ def svd_polar(mats, mode):
     fix = np.ones((len(mats), 3)); fix[:, 2] = d
     R = (u * fix[:, None, :]) @ vt
     lam = None
+    if mode & 4:                      # no det fix (bipgo.py:126-127)
+        R = u @ vt
+        mode &= 3
     if mode == 1:
         lam = (u * s[:, None, :]) @ np.swapaxes(u, 1, 2)
     elif mode == 2:
@@ -29,6 +32,7 @@ def svd_polar(mats, mode):
 class NumpyBackend:
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64):
         self.C = int(n_cam)
+        self.storage_f64 = np.dtype(storage) == np.float64
         self.T = len(row_ptr) - 1
         self.row_ptr = np.asarray(row_ptr, dtype=np.int64)
         self.col = np.asarray(col, dtype=np.int64)
@@ -101,7 +105,7 @@ class NumpyBackend:
         st[:7] = [r, scale, float(stop), float(converged), float(floor_hit), eff, float(breakdown)]
         st[7:10] = th[:3]
         st[10:12] = th[-2:] if ka >= 5 else np.nan
-        st[12], st[13], st[14], st[15] = r, 0.0, resmax, 0.0
+        st[12], st[13], st[14], st[15] = r, 0.0, resmax, (th[3] if ka >= 4 else np.nan)
         gate[0] = 1 if (stop and converged) else 0
 
     # allocation
@@ -142,6 +146,25 @@ class NumpyBackend:
         np.add.at(z, self.col, self.M @ w[self.row])
         z_out.numpy()[:] = z.reshape(3 * self.C, 3)
 
+    # non-eliminated solver: both halves of R~ [x_cam; x_time]  (x, z: [3(C+T), 3], cameras first)
+    def node_degrees(self, out):
+        o = out.numpy(); o[:] = 0.0
+        np.add.at(o, self.col, self.a)
+        np.add.at(o, self.C + self.row, self.a)
+
+    def bip_scales(self):
+        pass
+
+    def bip_apply(self, x, z_out):
+        if self._closed():
+            return
+        C, T = self.C, self.T
+        X = x.numpy().reshape(C + T, 3, 3)
+        z = np.zeros((C + T, 3, 3))
+        np.add.at(z, self.col, self.M @ X[C + self.row])
+        np.add.at(z, C + self.row, np.swapaxes(self.M, 1, 2) @ X[self.col])
+        z_out.numpy()[:] = z.reshape(3 * (C + T), 3)
+
     def dual_update(self, rc, Rt, lamT_inv):
         if self._closed():
             return
@@ -157,7 +180,7 @@ class NumpyBackend:
         R, lam = svd_polar(mats.numpy().reshape(-1, 3, 3), mode)
         if R_out is not None:
             R_out.numpy().reshape(-1, 9)[:] = R.reshape(-1, 9)
-        if lam_out is not None and mode:
+        if lam_out is not None and (mode & 3):
             lam_out.numpy().reshape(-1, 9)[:] = lam.reshape(-1, 9)
 
     def gauge_project(self, x_in, x_out):
@@ -165,7 +188,7 @@ class NumpyBackend:
             return
         X = x_in.numpy()
         Xg = X @ np.linalg.inv(X[:3, :])
-        R, _ = svd_polar(Xg.reshape(self.C, 3, 3), 0)
+        R, _ = svd_polar(Xg.reshape(-1, 3, 3), 0)
         x_out.numpy()[:] = R.reshape(-1, 3)
 
     # Lanczos helpers (V column-major: column k = V[k*ld : k*ld+n])
@@ -174,9 +197,10 @@ class NumpyBackend:
         return V.numpy().reshape(-1)[k0 * ld: k1 * ld].reshape(k1 - k0, ld)[:, :n]
 
     def lap_apply(self, lamC, V, ld, col0, z, aq):
-        n = 3 * self.C
-        q = self._cols(V, ld, n, col0, col0 + 3).T.reshape(self.C, 3, 3)          # rows 3c+i, cols b
-        r = lamC.numpy().reshape(self.C, 3, 3) @ q - z.numpy().reshape(self.C, 3, 3)
+        nn = lamC.numel() // 9
+        n = 3 * nn
+        q = self._cols(V, ld, n, col0, col0 + 3).T.reshape(nn, 3, 3)          # rows 3c+i, cols b
+        r = lamC.numpy().reshape(nn, 3, 3) @ q - z.numpy().reshape(nn, 3, 3)
         aq.numpy().reshape(3, n)[:] = r.reshape(n, 3).T
 
     def tall_gram(self, n, V, ld, ka, R, H):
@@ -358,7 +382,7 @@ class NumpyBackend:
 
     # composites (same call surface as HipBackend)
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
-        n, ka = 3 * self.C, 3 * (j + 1)
+        n, ka = 3 * (lamC.numel() // 9), 3 * (j + 1)
         self.lap_apply(lamC, V, ld, 3 * j, z, R)
         self.tall_gram(n, V, ld, ka, R, H); self.tall_update(n, V, ld, ka, H, R, Hcol, 0)
         self.tall_gram(n, V, ld, ka, R, H); self.tall_update(n, V, ld, ka, H, R, Hcol, 1)

@@ -1,0 +1,91 @@
+"""SURVEY 8(f) row 4 - the non-eliminated variant `bipartite_so3sync` (reference bipgo.py:18-142) on CPU:
+oracle pinned against outputs of the REAL reference (tests/golden/g8_so3sync.npz), then the product's front-end +
+host orchestration (GeneralRotationSolver) through the NumPy stand-in backend against the same goldens."""
+import numpy as np
+import pytest
+
+import golden_cases as gc
+from numpy_backend import NumpyBackend
+from oracle import bipgo_oracle as orc
+from util import load_golden, rebuild_inputs
+from vican_amd import frontend
+from vican_amd.solver import Comm, GeneralRotationSolver
+
+G8 = load_golden("g8_so3sync")
+CASES = [("g2_small", "float64"), ("g2_small", "float32"), ("g5_strings", "float64"), ("g5_strings", "float32")]
+
+
+def inputs(name):
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    return src, cons, nr, ff
+
+
+def golden(name, dt):
+    tag = "%s_%s_" % (name, dt)
+    return [str(k) for k in G8[tag + "keys"]], G8[tag + "R"], G8[tag + "evals"]
+
+
+@pytest.mark.parametrize("name,dt", CASES + [("g3_medium", "float64")])
+def test_oracle_matches_reference(name, dt):
+    src, cons, nr, ff = inputs(name)
+    keys, R, evals = golden(name, dt)
+    info = {}
+    res = orc.bipartite_so3sync(src, cons, nr, ff, gc.MAXITER, np.dtype(dt).type, info=info)
+    assert list(res.keys()) == keys                                   # node naming + dict order (bipgo.py:135-141)
+    err = max(np.abs(res[k] - R[i]).max() for i, k in enumerate(keys))
+    # g3: the iteration is chaotic there (~100 negative eigenvalues, interior eigenvectors) - still reproduced in
+    # float64 because the restatement makes the same LAPACK/ARPACK calls on the same data
+    assert err < (1e-7 if dt == "float64" else 2e-6), err
+    assert np.abs(np.sort(info["evals"], 1) - np.sort(evals, 1)).max() < (1e-9 if dt == "float64" else 1e-4)
+
+
+def run_numpy(name, dt, maxiter=gc.MAXITER):
+    src, cons, nr, ff = inputs(name)
+    prob = frontend.flatten_so3(src, cons, nr, ff)
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, storage=np.dtype(dt).type)
+    rot = GeneralRotationSolver(K, Comm.single())
+    r = rot.run(maxiter).numpy().reshape(-1, 3, 3)
+    names = [str(c) for c in prob.cam_names] + [str(s) + "_0" for s in prob.time_names]
+    return names, r, rot
+
+
+@pytest.mark.parametrize("name,dt", CASES)
+def test_solver_logic_matches_reference(name, dt):
+    keys, R, evals = golden(name, dt)
+    names, r, rot = run_numpy(name, dt)
+    assert names == keys
+    # entries of (possibly improper) orthogonal blocks: compare element-wise
+    assert np.abs(r - R).max() < (1e-7 if dt == "float64" else 5e-6)
+    ev = np.sort(np.array(rot.stats["evals"])[:, :3], axis=1)
+    evr = np.sort(np.sort(evals, axis=1)[:, :3], axis=1)
+    assert np.abs(ev - evr).max() < (1e-7 if dt == "float64" else 1e-4) * np.abs(evals).max()
+
+
+def test_indefinite_regime_fails_loudly():
+    """g3 (noisy multi-marker edges): after one dual update the connection Laplacian has ~90 negative eigenvalues
+    and the reference's eigs(sigma=-1e-6) returns interior eigenvectors; the product refuses instead."""
+    with pytest.raises(ArithmeticError, match="indefinite"):
+        run_numpy("g3_medium", "float64")
+
+
+def test_front_end_matches_oracle_blocks():
+    src, cons, nr, ff = inputs("g2_small")
+    prob = frontend.flatten_so3(src, cons, nr, ff)
+    # dense R~ from the product's CSR against the reference convention k_r R~ R_m R_0^T (bipgo.py:45)
+    C, T = prob.n_cam, prob.n_time
+    dense = np.zeros((C, T, 3, 3)); deg = np.zeros((C, T))
+    root = str(min(list(cons.keys())))
+    cam_pos = {c: i for i, c in enumerate(prob.cam_names)}
+    time_pos = {s: i for i, s in enumerate(prob.time_names)}
+    for (c, tm), v in src.items():
+        if not ff(v):
+            continue
+        ts, mid = tm.split("_")
+        k = nr(v)
+        dense[cam_pos[c], time_pos[ts]] += k * v["pose"].R() @ cons[mid].R() @ cons[root].R().T
+        deg[cam_pos[c], time_pos[ts]] += k
+    rows = np.repeat(np.arange(T), np.diff(prob.row_ptr))
+    assert np.abs(dense[prob.col, rows] - prob.blk.reshape(-1, 3, 3)).max() < 1e-12
+    assert np.abs(deg[prob.col, rows] - prob.a).max() < 1e-12
+    assert np.count_nonzero(deg) == prob.n_edges

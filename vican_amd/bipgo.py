@@ -30,9 +30,9 @@ import torch
 from . import frontend
 from ._lib import VicanError
 from .geometry import SE3
-from .solver import Comm, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
+from .solver import Comm, GeneralRotationSolver, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
 
-__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "solve_problem"]
+__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem"]
 
 
 def _shard_rows(T, world, rank):
@@ -146,3 +146,55 @@ def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_mod
     out = bipartite_se3sync(edges, {root: SE3(pose=np.eye(4))}, noise_model_r, noise_model_t, edge_filter,
                             maxiter, lsqr_solver, dtype, info=info, group=group, verbose=verbose, tight=tight)
     return {k: v for k, v in out.items() if "_" not in k}               # bipgo.py:543
+
+
+def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable, edge_filter: Callable, maxiter: int,
+                      dtype=np.float32, *, info: Optional[dict] = None, verbose: bool = False, eig_tol: float = 1e-10) -> dict:
+    """SO(3) synchronisation on the bipartite graph WITHOUT eliminating the timestep nodes - drop-in for the
+    reference's older variant (vican/bipgo.py:18-142; not called by its notebook).
+
+    Returns ``{camera id: r, '<t>_0': r}`` with r the raw 3x3 blocks of the final iterate: U V^T of the last
+    per-node SVD, NOT det-fixed and NOT transposed (bipgo.py:126-127,135-141).  The gauge is the first node in
+    np.unique order of the 'c<id>' / 't<timestamp>' names.  Single GPU.
+
+    Differences from the reference, both loud: ``maxiter=0`` raises the reference's UnboundLocalError; and an
+    ArithmeticError is raised when the dual iterate makes the connection Laplacian strongly indefinite - the
+    reference's shift-invert ``eigs(sigma=-1e-6)`` then returns INTERIOR eigenvectors (and a meaningless answer),
+    which the matrix-free eigen-solver does not reproduce."""
+    from .device import HipBackend, LocalGraph
+
+    if not torch.cuda.is_available():
+        raise VicanError("no GPU visible: vican_amd has no CPU fallback")
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if torch.distributed.get_rank() != 0 and verbose:
+            print("bipartite_so3sync: replicated on every rank (the non-eliminated variant is not sharded)")
+    t0 = time.perf_counter()
+    prob = frontend.flatten_so3(src_edges, constraints, noise_model, edge_filter)
+    if maxiter < 1:
+        raise UnboundLocalError("local variable 'r' referenced before assignment")      # bipgo.py:139
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt))
+    K = HipBackend(g)
+    t1 = time.perf_counter()
+    rot = GeneralRotationSolver(K, Comm.single(), eig_tol=eig_tol)
+    r = rot.run(maxiter).reshape(prob.n_cam + prob.n_time, 3, 3).cpu().numpy()
+    t2 = time.perf_counter()
+    # the reference's `r` stays in the dtype of its first eigs call unless a later iteration rebuilds it in float64
+    out_dt = np.float32 if (maxiter == 1 and np.dtype(dtype) == np.float32) else np.float64
+    r = r.astype(out_dt)
+    out = {}
+    for i, c in enumerate(prob.cam_names):                                              # bipgo.py:135-141
+        out[str(c)] = r[i]
+    for i, s in enumerate(prob.time_names):
+        out[str(s) + "_0"] = r[prob.n_cam + i]
+    if info is not None:
+        info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
+                    eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
+                    n_cam=prob.n_cam, n_time=prob.n_time, n_edges=prob.n_edges, n_src=prob.n_src,
+                    t_pack=t1 - t0, t_rot=t2 - t1)
+    if verbose:
+        print("bipartite_so3sync: C=%d T=%d E=%d  pack %.1f ms  solve %.1f ms" % (
+            prob.n_cam, prob.n_time, prob.n_edges, 1e3 * (t1 - t0), 1e3 * (t2 - t1)))
+    return out

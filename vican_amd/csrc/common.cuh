@@ -152,11 +152,12 @@ __device__ __forceinline__ double det3(const double* m) {
 }
 
 // Polar rotation with det fix and dual block from one SVD.
-// mode: 0 none, 1 lam = U S U^T, 2 lam = U S^-1 U^T   (S NOT sign corrected: bipgo.py:312,329)
+// mode & 3: 0 none, 1 lam = U S U^T, 2 lam = U S^-1 U^T   (S NOT sign corrected: bipgo.py:312,329)
+// mode & 4: R = U V^T without the det fix (the non-eliminated solver, bipgo.py:126-127)
 __device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
     double U[9], s[3], V[9];
     svd3(A, U, s, V);
-    const double d = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
+    const double d = (!(mode & 4) && det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
     if (R) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -165,10 +166,10 @@ __device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
                 R[i * 3 + j] = U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1] +
                                d * U[i * 3 + 2] * V[j * 3 + 2];
     }
-    if (lam && mode) {
+    if (lam && (mode & 3)) {
         double f[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) f[k] = (mode == 1) ? s[k] : 1.0 / s[k];
+        for (int k = 0; k < 3; ++k) f[k] = ((mode & 3) == 1) ? s[k] : 1.0 / s[k];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll

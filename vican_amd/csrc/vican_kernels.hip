@@ -18,13 +18,13 @@ __global__ void polar_dual_kernel(const int32_t* __restrict__ gate, int n, const
     if (R_out)
 #pragma unroll
         for (int q = 0; q < 9; ++q) R_out[(size_t)i * 9 + q] = R[q];
-    if (lam_out && mode)
+    if (lam_out && (mode & 3))
 #pragma unroll
         for (int q = 0; q < 9; ++q) lam_out[(size_t)i * 9 + q] = lam[q];
 }
 extern "C" int vican_polar_dual(int32_t n, const double* in, double* R_out, double* lam_out, int32_t mode,
                                 void* stream) {
-    if (n < 0 || !in || mode < 0 || mode > 2) return set_err(VICAN_ERR_ARG, "vican_polar_dual: bad argument");
+    if (n < 0 || !in || mode < 0 || mode > 6 || (mode & 3) == 3) return set_err(VICAN_ERR_ARG, "vican_polar_dual: bad argument");
     if (n == 0) return VICAN_OK;
     hipLaunchKernelGGL(polar_dual_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate, n, in, R_out,
                        lam_out, mode);
@@ -625,6 +625,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
                                                     int32_t* __restrict__ gate) {
     extern __shared__ double sm[];
     __shared__ int s_eff, s_idx[5];
+    __shared__ double s_th4;
     __shared__ double s_red[16];
     const int tid = threadIdx.x, B = blockDim.x;
     if (tid == 0) {
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
 
     // ranks of the eigenvalues (ties broken by index): one thread per eigenvalue
     if (tid < 5) s_idx[tid] = -1;
+    if (tid == 0) s_th4 = __longlong_as_double(0x7ff8000000000000LL);
     __syncthreads();
     if (tid < n) {
         const double d = A[tid * ld + tid];
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
             rank += (e < d || (e == d && j < tid)) ? 1 : 0;
         }
         if (rank < 3) s_idx[rank] = tid;                                    // three smallest
+        if (rank == 3) s_th4 = d;                                           // fourth smallest (reported only)
         if (n >= 2 && rank >= n - 2) s_idx[3 + (rank - (n - 2))] = tid;     // second largest, largest
         if (n == 1) s_idx[4] = tid;
     }
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         for (int k = 0; k < 3; ++k) status[7 + k] = s_idx[k] >= 0 ? A[s_idx[k] * ld + s_idx[k]] : nan;
         status[10] = n >= 5 ? A[s_idx[3] * ld + s_idx[3]] : nan;
         status[11] = n >= 5 ? th_max : nan;
-        status[12] = r; status[13] = sweeps; status[14] = resmax; status[15] = 0.0;
+        status[12] = r; status[13] = sweeps; status[14] = resmax; status[15] = s_th4;
         *gate = (stop && converged) ? 1 : 0;
     }
 }

@@ -17,7 +17,7 @@
 
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 6; }
+extern "C" int vican_abi_version(void) { return 7; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
@@ -490,6 +490,9 @@ template <> __device__ __forceinline__ long long fix_total<double>(long long s) 
 
 // MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
 // MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
+// MODE 2: y_row = sum M^T x_cam -> lamT_out,  zpart[wg] = sum M * xt_row    (both halves of the symmetric
+//         (C+T)-node operator R~ [x_cam; x_time] of the non-eliminated solver in ONE pass over the blocks;
+//         `lamT_inv` carries x_time [T][9])
 // Arithmetic in the storage type S (f32 products for f32 blocks), accumulation in 64-bit fixed point.
 //
 // Per chunk:  [phase 3 of the previous chunk | phase 1]  barrier  [phase 2: one wavefront per
@@ -512,10 +515,11 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr bool HAS_Z = (MODE == 0 || MODE == 2);            // camera-side accumulators + phase 3
     const int C = g.n_cam, nx = 9 * CP, ncopy = g.n_copy, cmask = ncopy - 1;
     // 8-byte arrays first, then the storage-type tables
     u64* zs = (u64*)lds_raw;                                   // [9][CP] planes (MODE 0)
-    double* ysum = (double*)(zs + (MODE == 0 ? nx : 0));       // [max_rows][9] (MODE 1)
+    double* ysum = (double*)(zs + (HAS_Z ? nx : 0));       // [max_rows][9] (MODE 1)
     u64* ys = (u64*)(ysum + 9 * g.max_rows);                   // [max_rows*9][ncopy]
     S* xs = (S*)(ys + (size_t)9 * g.max_rows * ncopy);         // [9][CP] planes
     S* wv = xs + nx;                                           // [max_rows][9] (MODE 0; pre-scaled likewise)
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], 1.0);
         }
     }
-    if (MODE == 0) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
+    if (HAS_Z) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
     for (int i = tid; i < 9 * g.max_rows * ncopy; i += BLOCK) ys[i] = 0ull;
     __syncthreads();
 
@@ -588,9 +592,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     // floor(log2(x_bound / sqrt(xm2))) = floor(log2(x_bound^2 / xm2) / 2): one division + exponent extraction
     if (xm2 > 0.0) { const double r2 = fx8 * fx8 / xm2; shift = r2 >= 1.0 ? (ilogb(r2) >> 1) : 0; }     // fx[8] = x_bound
     shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
+    if (MODE == 2) shift = 0;                   // x_time is not measured here: both scales stay at the x_bound ones
     const double up = ldexp(1.0, shift);
     const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = fx2 * up;
-    if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    if (HAS_Z && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if (MODE == 1 && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
 
 #ifdef VICAN_STAMP
@@ -625,6 +630,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             const double* L = lamT_inv + (size_t)(r0 + wave) * 9 + oa * 3;
             L0 = L[0]; L1 = L[1]; L2 = L[2];
         }
+        if (MODE == 2 && wave < nrows && o < 9) L0 = lamT_inv[(size_t)(r0 + wave) * 9 + o];     // x_time entry o of the row
         __builtin_amdgcn_sched_barrier(0);                              // keep these loads ahead of the prefetch
         if (kpref < nchunk) load_chunk<S, EPL>(nxt, g, kpref, tid);      // prefetch: lands during this/next chunk
 
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                     wv[i] = pre_scale<S>(L[0] * ysum[r * 9 + b3] + L[1] * ysum[r * 9 + 3 + b3] + L[2] * ysum[r * 9 + 6 + b3], z_scale);
                 } else {
                     lamT_out[(size_t)r0 * 9 + i] = ysum[i];
+                    if (MODE == 2) wv[i] = pre_scale<S>(lamT_inv[(size_t)r0 * 9 + i], z_scale);
                 }
             }
         } else
@@ -746,13 +753,17 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 // Z_t goes to global memory; the per-row SVDs run afterwards in a fully parallel
                 // kernel (one thread per row) instead of serialising this streaming sweep
                 if (o < 9 && lane == o * part_n) lamT_out[(size_t)(r0 + r) * 9 + o] = y;
+                if (MODE == 2) {
+                    if (r != wave && o < 9) L0 = lamT_inv[(size_t)(r0 + r) * 9 + o];
+                    if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0, z_scale);
+                }
             }
         }
         // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
         STAMP(2);                       // phase 2
         __syncthreads();
         STAMP(3);                       // barrier B
-        if (MODE == 0) {
+        if (HAS_Z) {
             // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
             S w[9];
             uint32_t prow = 0xFFFFFFFFu;
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     if (MODE == 0 && Rt_out && (tid == 0 || tid == BLOCK - 64))
         for (int i = 0; i < 6; ++i) Rt_out[((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 6 + i] = (double)st_acc[i];
 #endif
-    if (MODE == 0) {
+    if (HAS_Z) {
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
 #pragma unroll
@@ -944,6 +955,26 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
 #endif
     LAUNCH_CHECK("vican_block_op");
     return VICAN_OK;
+}
+
+// Both halves of R~ [x_cam; x_time] (non-eliminated solver): y_time[t] = sum_c M_ct^T x_cam[c] (exact fixed-point
+// row sums -> f64), z_cam = slab-reduced sum_t M_ct x_time[t].  fx must hold the scales of vican_bip_scales.
+extern "C" int vican_bip_apply(const vican_graph_t* g, const double* x_cam, const double* x_time, void* zpart,
+                               double* fx, double* z_cam, double* y_time, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_bip_apply")) return rc;
+    if (!x_cam || !x_time || !zpart || !fx || !z_cam || !y_time) return set_err(VICAN_ERR_ARG, "vican_bip_apply: null pointer");
+    if (g->n_chunk == 0) return set_err(VICAN_ERR_ARG, "vican_bip_apply: graph without edges");
+    if (int rc = dispatch_sweep<2>(g, x_time, x_cam, (u64*)zpart, nullptr, y_time, nullptr, fx, stream)) return rc;
+    LAUNCH_CHECK("vican_bip_apply");
+    return vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 3, fx + 7, z_cam, stream);
+}
+
+__global__ void set_double_kernel(double* p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+// Fixed-point scales for vican_bip_apply: the phase-3 operand is x_time itself (|x_t|_F <= x_bound), i.e. omega = 1.
+extern "C" int vican_bip_scales(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
+    if (!fx) return set_err(VICAN_ERR_ARG, "vican_bip_scales: null pointer");
+    hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, fx + 4, 1.0);
+    return vican_fx_finish(fx, x_bound, n_add, storage, stream);
 }
 
 extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, double* Rt, double* lamT_inv,

@@ -167,6 +167,7 @@ class HipBackend:
         self.g = graph
         self.dev = graph.device
         self.C, self.T = graph.n_cam, graph.n_time
+        self.storage_f64 = graph.storage_dtype == torch.float64
         self._gref = C.byref(graph.desc)
         nwg = graph.n_wg
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
@@ -178,7 +179,7 @@ class HipBackend:
         self._status_host = {}
         self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
         self._coop_ws, self._coop_sync = None, None
-        self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, graph.wmax
+        self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, getattr(graph, "wmax", None)
 
     # -- allocation helpers -------------------------------------------------
     def empty(self, *shape, dtype=torch.float64):
@@ -234,8 +235,25 @@ class HipBackend:
         self._ck(self.lib.vican_block_op_z(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx),
                                            _ptr(z_out), _stream()), "vican_block_op_z")
 
+    def node_degrees(self, out):
+        """Weighted degrees of all C+T nodes (cameras first) - bipgo.py:95."""
+        out[: self.C].copy_(self.g.cam_sum_a)
+        out[self.C:].copy_(self.g.row_sum_a[: self.T])
+
+    def bip_scales(self):
+        """Fixed-point scales for bip_apply (instead of init_duals / set_duals)."""
+        self._ck(self.lib.vican_bip_scales(_ptr(self.g.fx), X_BOUND, float(self.g.rows_per_wg_sweep + 1), self.g.desc.storage,
+                                           _stream()), "vican_bip_scales")
+
+    def bip_apply(self, x, z_out):
+        """z_out = R~ x on all C+T nodes (x, z_out: [3(C+T), 3], cameras first) - one pass over the blocks."""
+        off = 8 * 9 * self.C
+        self._ck(self.lib.vican_bip_apply(self._gref, _ptr(x), C.c_void_p(x.data_ptr() + off), _ptr(self.zpart), _ptr(self.g.fx),
+                                          _ptr(z_out), C.c_void_p(z_out.data_ptr() + off), _stream()), "vican_bip_apply")
+
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
-        if self.coop_cam_step:
+        n_nodes = lamC.numel() // 9             # C for the eliminated solver, C + T for the general one
+        if self.coop_cam_step and n_nodes == self.C:
             if self._coop_ws is None:
                 self._coop_ws = torch.zeros(int(self.lib.vican_lanczos_coop_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
                 self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
@@ -243,7 +261,7 @@ class HipBackend:
                                                      _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), _stream()),
                      "vican_lanczos_cam_coop")
             return
-        self._ck(self.lib.vican_lanczos_cam_step(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
+        self._ck(self.lib.vican_lanczos_cam_step(n_nodes, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
                                                  _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _stream()),
                  "vican_lanczos_cam_step")
 
@@ -275,11 +293,11 @@ class HipBackend:
                  "vican_polar_dual")
 
     def gauge_project(self, x_in, x_out):
-        self._ck(self.lib.vican_gauge_project(self.C, _ptr(x_in), _ptr(x_out), _stream()), "vican_gauge_project")
+        self._ck(self.lib.vican_gauge_project(x_in.numel() // 9, _ptr(x_in), _ptr(x_out), _stream()), "vican_gauge_project")
 
     # -- Lanczos helpers ----------------------------------------------------
     def lap_apply(self, lamC, V, ld, col0, z, aq):
-        self._ck(self.lib.vican_lap_apply(self.C, _ptr(lamC), _ptr(V), ld, col0, _ptr(z), _ptr(aq), _stream()), "vican_lap_apply")
+        self._ck(self.lib.vican_lap_apply(lamC.numel() // 9, _ptr(lamC), _ptr(V), ld, col0, _ptr(z), _ptr(aq), _stream()), "vican_lap_apply")
 
     def tall_gram(self, n, V, ld, ka, R, H):
         self._ck(self.lib.vican_tall_gram(n, _ptr(V), ld, ka, _ptr(R), _ptr(H), _stream()), "vican_tall_gram")

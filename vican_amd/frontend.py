@@ -107,6 +107,47 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     return p
 
 
+def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
+    """Rotation-only flattening of the non-eliminated variant ``bipartite_so3sync`` (bipgo.py:33-52):
+        M_ct += k_r * R~_e R_m R_root^T,   a_ct += k_r
+    (note R_m R_root^T here against R_m^T R_root in ``flatten`` - the reference's two variants use different
+    constraint conventions, bipgo.py:45 vs :213).  Only the rotation-stage fields of Problem are filled."""
+    root = str(min(list(constraints.keys())))                      # bipgo.py:33
+    r_root = np.asarray(constraints[root].R(), dtype=np.float64)
+    cams, times, marks, poses, kr = [], [], [], [], []
+    for key, val in src_edges.items():
+        if not edge_filter(val):
+            continue
+        ts, mid = key[1].split("_")[:2]
+        cams.append(key[0]); times.append(ts); marks.append(mid)
+        poses.append(val["pose"]); kr.append(noise_model(val))
+    n = len(cams)
+    if n == 0:
+        raise ValueError("no edge passes edge_filter")
+    mk_names, mk_idx = np.unique(np.array(marks, dtype=str), return_inverse=True)
+    Cm = np.stack([np.asarray(constraints[str(m)].R(), dtype=np.float64) @ r_root.T for m in mk_names])   # KeyError as bipgo.py:41
+    R = np.stack([np.asarray(p.R(), dtype=np.float64) for p in poses])
+    kr = np.asarray(kr, dtype=np.float64)
+    wR = (kr[:, None, None] * R) @ Cm[mk_idx]
+    cam_nodes, ci = np.unique(np.char.add("c", np.array(cams, dtype=str)), return_inverse=True)           # bipgo.py:54
+    time_nodes, ti = np.unique(np.char.add("t", np.array(times, dtype=str)), return_inverse=True)
+    C, T = len(cam_nodes), len(time_nodes)
+    key = ti.astype(np.int64) * C + ci
+    ukey, inv = np.unique(key, return_inverse=True)
+    order = np.argsort(inv, kind="stable")
+    starts = np.searchsorted(inv[order], np.arange(len(ukey)))
+    p = Problem()
+    p.root, p.n_src = root, n
+    p.cam_names = np.array([c[1:] for c in cam_nodes])
+    p.time_names = np.array([s[1:] for s in time_nodes])
+    p.col = (ukey % C).astype(np.int32)
+    p.row_ptr = np.zeros(T + 1, dtype=np.int32)
+    np.cumsum(np.bincount((ukey // C).astype(np.int64), minlength=T), out=p.row_ptr[1:])
+    p.blk = np.add.reduceat(wR[order], starts, axis=0).reshape(len(ukey), 9)
+    p.a = np.add.reduceat(kr[order], starts, axis=0)
+    return p
+
+
 def bnorm2(prob: Problem, Rc: np.ndarray, Rt: np.ndarray) -> float:
     """|b|^2 of the reference's stacked measurement vector (bipgo.py:454-461) for world<-node
     rotations Rc [C,3,3], Rt [T,3,3]:  b_e = k_t (R_c t~_e + R_t R_root^T R_m tau_m)."""

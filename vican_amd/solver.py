@@ -45,6 +45,13 @@ class Comm:
             self.rank = torch.distributed.get_rank(group)
         self.n_allreduce = 0
 
+    @classmethod
+    def single(cls):
+        """A one-rank communicator even inside an initialised process group (replicated computations)."""
+        c = cls.__new__(cls)
+        c.group, c.world, c.rank, c.n_allreduce = None, 1, 0, 0
+        return c
+
     def allreduce(self, t):
         if self.world > 1:
             torch.distributed.all_reduce(t, group=self.group)
@@ -54,14 +61,17 @@ class Comm:
 
 class RotationSolver:
     def __init__(self, K, comm=None, m_max=32, eig_tol=1e-10, floor_tol=1e-7, min_steps=4, check_every=2, warm_min_steps=2,
-                 max_restarts=20, seed=1234):
+                 max_restarts=20, seed=1234, n_nodes=None):
         self.K, self.comm = K, comm or Comm()
         self.C = K.C
-        self.n = 3 * K.C
+        self.N = K.C if n_nodes is None else n_nodes          # nodes of the eigenproblem (cameras; C+T for the general solver)
+        self.n = 3 * self.N
         self.m_max = max(1, min(m_max, 32, self.n // 3))       # VICAN_RITZ_MAX_STEPS
         self.eig_tol, self.min_steps, self.check_every = eig_tol, min_steps, check_every
         self.warm_min_steps = warm_min_steps
-        self.floor_tol = floor_tol
+        # the stalled-residual rule below exists for the rounding floor of f32 blocks (~6e-8); f64 blocks have none
+        # above 1e-13, and a slowly converging iteration (< 4x per check) must not be mistaken for a floor
+        self.floor_tol = floor_tol if not getattr(K, "storage_f64", False) else min(floor_tol, 1e-13)
         # on cache-resident graphs an edge sweep costs tens of microseconds - less than one projection
         # check (device Ritz kernel + cancelled speculative launches) - so check less often there
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
@@ -93,8 +103,8 @@ class RotationSolver:
         self.X = K.empty(n, 3)
         self.Xp = K.empty(n, 3)
         self.rc = K.empty(n, 3)                     # r_c of the reference (node<-world), stacked
-        self.lamC = K.empty(self.C, 9)
-        self.cam_deg = K.empty(self.C)
+        self.lamC = K.empty(self.N, 9)
+        self.cam_deg = K.empty(self.N)
         self.lamT = K.empty(max(K.T, 1), 9)
         self.Rt = K.empty(max(K.T, 1), 9)
         self.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
@@ -175,6 +185,7 @@ class RotationSolver:
                     # speculative launches), so the first few steps are checked one by one
                     next_check = min(steps + (1 if steps < 8 and not self.small_graph else self.check_every), self.m_max)
             th = st[7:12].copy()
+            self.th4 = float(st[15])                    # fourth smallest Ritz value (NaN if the basis is too small)
             if conv:
                 self.tail_done = tail is not None
                 break
@@ -231,6 +242,65 @@ class RotationSolver:
             self.iterate(it == 0, it)
         self.eig_tol = tol_final
         return self.rc, self.Rt
+
+
+class GeneralRotationSolver(RotationSolver):
+    """The reference's non-eliminated variant ``bipartite_so3sync`` (bipgo.py:94-133): primal-dual iteration on
+    ALL C+T nodes (cameras first, then timesteps - np.unique order of 'c..'/'t..' names, bipgo.py:54), full 3x3
+    dual blocks Lambda_i = U S U^T on every node, no det fix in the final polar step (bipgo.py:126-127).
+
+    Same machinery as RotationSolver - block Lanczos on L = Lambda - R~ with the device Ritz step and the gated
+    speculative tail - with the operator  R~ [x_c; x_t] = [sum_t M_ct x_t ; sum_c M_ct^T x_c]  evaluated in one pass
+    over the blocks (``bip_apply``).  Single rank: the timestep-side vectors are as large as the camera side here,
+    so there is no cheap sharding."""
+
+    def __init__(self, K, comm=None, **kw):
+        comm = comm or Comm()
+        if comm.world != 1:
+            raise ValueError("bipartite_so3sync runs on a single rank (no timestep sharding in the non-eliminated variant)")
+        super().__init__(K, comm, n_nodes=K.C + K.T, **kw)
+
+    def apply_P(self, x, z):
+        self.K.bip_apply(x, z)
+        self.stats["sweeps"] += 1
+
+    def init(self):
+        K = self.K
+        K.node_degrees(self.cam_deg)                            # bipgo.py:95-99
+        K.scaled_identity(self.cam_deg, self.lamC)
+        K.bip_scales()
+        if self.x0 is None:
+            lscale = float(self.cam_deg.max())
+            self.pivot_floor = (1e-12 * lscale) ** 2
+            g = torch.Generator(device="cpu"); g.manual_seed(self.seed)
+            self.x0 = torch.randn(self.n, 3, generator=g, dtype=torch.float64).to(self.X.device)
+
+    def _tail(self):
+        K = self.K
+        K.gauge_project(self.X, self.Xp)                        # bipgo.py:113-116
+        K.bip_apply(self.Xp, self.z)                            # bipgo.py:119
+        K.polar_dual(self.z, self.rc, self.lamC, 5)             # bipgo.py:125-131 (U V^T without det fix, U S U^T)
+
+    def iterate(self, first, it=None):
+        th = self.spectral(self.x0 if first else self.rc, warm=not first, it=it, tail=self._tail)
+        self.stats["sweeps"] += 1
+        # The reference asks ARPACK for the eigenvalues CLOSEST TO -1e-6 (shift-invert, bipgo.py:106); that is the
+        # bottom of the spectrum - what the Lanczos iteration delivers - only while no eigenvalue lies further
+        # below zero than the fourth one lies above it.  Once the dual iterate makes L strongly indefinite (noisy
+        # multi-marker graphs: ~100 negative eigenvalues, see DESIGN.md) the reference picks interior eigenvectors,
+        # which a matrix-free solver cannot reproduce: fail loudly instead of returning something else.
+        if self.th4 == self.th4 and th[0] < 0.0 and -th[0] > self.th4:
+            raise ArithmeticError("bipartite_so3sync: the connection Laplacian became indefinite (smallest eigenvalue "
+                                  "%.3e, fourth %.3e); the reference's eigs(sigma=-1e-6) selects interior eigenvalues here, "
+                                  "which this solver does not reproduce" % (th[0], self.th4))
+
+    def run(self, maxiter):
+        # no relaxed early tolerances here: this iteration contracts the error of an earlier spectral step only
+        # ~5-10x per iteration (checked on the goldens), so every step is solved to the full tolerance
+        self.init()
+        for it in range(maxiter):
+            self.iterate(it == 0, it)
+        return self.rc
 
 
 class TranslationSolver:
