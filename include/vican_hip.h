@@ -212,10 +212,13 @@ int vican_gauge_project(int32_t n_cam, const double* x_in, double* x_out, void* 
  * aq column-major [3][3C].                                                    */
 int vican_lap_apply(int32_t n_cam, const double* lamC, const double* V, int32_t ld,
                     int32_t col0, const double* z, double* aq, void* stream);
-/* H[k][c] = V[:,k] . R[:,c]  for k < ka, c < 3  (R column-major [3][n]); one
- * workgroup per basis column, fixed summation order.                          */
+/* H[k][c] = V[:,k] . R[:,c]  for k < ka, c < 3  (R column-major [3][n]); fixed summation order.
+ * One workgroup per basis column; with a scratch buffer ws of ws_doubles >= 128 * ka * 3 doubles
+ * (VICAN_GRAM_WS_DOUBLES covers every ka) vectors of n >= 16384 rows are summed in row slices
+ * by the whole chip and folded in slice order.  ws may be NULL.                          */
+#define VICAN_GRAM_WS_DOUBLES (128 * 192 * 3)
 int vican_tall_gram(int32_t n, const double* V, int32_t ld, int32_t ka, const double* R,
-                    double* H, void* stream);
+                    double* H, double* ws, int64_t ws_doubles, void* stream);
 /* R -= V[:, :ka] H ; if H_out: H_out[ka][3] = H (accumulate=0) or += H (accumulate=1) */
 int vican_tall_update(int32_t n, const double* V, int32_t ld, int32_t ka, const double* H,
                       double* R, double* H_out, int32_t accumulate, void* stream);
@@ -235,10 +238,11 @@ int vican_rows_to_cols(int32_t n, const double* X, double* V, int32_t ld, int32_
 /* Composite = the camera-side half of block-Lanczos step j as one host call: vican_lap_apply,
  * two Gram-Schmidt passes (vican_tall_gram + vican_tall_update, coefficients summed into
  * Hcol[3(j+1)][3]), R^T R, vican_chol_qr3 into basis block j+1 / beta / x_out.  R [3][3C],
- * H [>= 3(j+1)*3], G [9] are scratch.                                              */
+ * H [>= 3(j+1)*3], G [9] are scratch; ws / ws_doubles as in vican_tall_gram (may be NULL / 0). */
 int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                            const double* z, double* R, double* H, double* G, double* Hcol,
-                           double* beta, double* x_out, double pivot_floor, void* stream);
+                           double* beta, double* x_out, double pivot_floor,
+                           double* ws, int64_t ws_doubles, void* stream);
 
 /* The same step as ONE cooperative kernel: <= 32 workgroups (32 cameras each, all resident) that meet at
  * three device-side grid barriers instead of seven dependent launches.  ws: scratch of

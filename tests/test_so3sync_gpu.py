@@ -119,3 +119,43 @@ def test_so3sync_larger_synthetic_consistent_graph():
         lhs = v["pose"].R() @ cons[tm.split("_")[1]].R() @ cons[str(min(cons.keys()))].R().T @ res[ts + "_0"]
         worst = max(worst, np.abs(lhs - res[c]).max())
     assert worst < 1e-8, worst
+
+
+@pytest.mark.parametrize("n,ka", [(16384, 3), (50001, 7), (303000, 48), (600000, 96)])
+def test_sliced_tall_gram_for_long_vectors(n, ka):
+    """vican_tall_gram with a workspace: row-sliced partial sums folded in slice order (long vectors of the
+    non-eliminated solver) against NumPy, bit-identical on repeats; without workspace: the column kernel."""
+    H, N, g = make_backends(5, 40, 1, 3, 7, np.float64)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(n + ka)
+    V = torch.randn(ka * n, generator=gen, dtype=torch.float64, device="cuda")
+    R = torch.randn(3 * n, generator=gen, dtype=torch.float64, device="cuda")
+    out, out2 = H.zeros(ka * 3), H.zeros(ka * 3)
+    H.tall_gram(n, V, n, ka, R, out)
+    ref = (V.view(ka, n) @ R.view(3, n).T).cpu().numpy().reshape(-1)
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-10 * np.sqrt(n)
+    H.tall_gram(n, V, n, ka, R, out2)
+    assert torch.equal(out, out2)
+    H._gram_workspace = lambda n_: None                     # no workspace -> one workgroup per column
+    H.tall_gram(n, V, n, ka, R, out2)
+    assert np.abs(out2.cpu().numpy() - ref).max() < 1e-10 * np.sqrt(n)
+
+
+def test_general_lanczos_step_long_vectors_matches_numpy():
+    C, T = 300, 6000
+    H, N, g = make_backends(C, T, 3, 8, 11, np.float64)
+    nn = C + T
+    n, j, m = 3 * nn, 2, 6
+    rng = np.random.default_rng(4)
+    Q = np.linalg.qr(rng.standard_normal((n, 3 * (j + 1))))[0]
+    V0 = np.zeros((3 * (m + 1), n)); V0[: 3 * (j + 1)] = Q.T
+    lam = rng.standard_normal((nn, 3, 3)); lam = lam + np.swapaxes(lam, 1, 2) + 6 * np.eye(3)
+    z = rng.standard_normal((n, 3))
+    outs = []
+    for K in (H, N):
+        V = K.from_numpy(V0.reshape(-1).copy())
+        R, Hs, G = K.empty(3 * n), K.empty(3 * (m + 1) * 3), K.empty(9)
+        Hcol, beta, x = K.zeros(3 * (m + 1) * 3), K.zeros(9), K.empty(n, 3)
+        K.lanczos_cam_step(K.from_numpy(lam.reshape(nn, 9)), V, n, j, K.from_numpy(z), R, Hs, G, Hcol, beta, x, 0.0)
+        outs.append([t.cpu().numpy() for t in (Hcol, beta, x)])
+    for a, b in zip(*outs):
+        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(b).max())

@@ -19,6 +19,7 @@ SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kern
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip")]
 HEADERS = [os.path.join(CSRC, "common.cuh")]
 FX_DOUBLES = 12
+GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 INCLUDE = os.path.join(ROOT, "include")
 
 STORE_F32, STORE_F64 = 0, 1
@@ -74,12 +75,12 @@ PROTOTYPES = {
     "vican_polar_dual": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp]),
     "vican_gauge_project": (C.c_int, [_i32, _vp, _vp, _vp]),
     "vican_lap_apply": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "vican_tall_gram": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "vican_tall_gram": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, C.c_int64, _vp]),
     "vican_tall_update": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "vican_chol_qr3": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp]),
     "vican_tall_combine": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vican_rows_to_cols": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp]),
-    "vican_lanczos_cam_step": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
+    "vican_lanczos_cam_step": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, C.c_int64, _vp]),
     "vican_block_op_z": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -112,9 +112,67 @@ __global__ __launch_bounds__(256) void tall_gram_kernel(int n, const double* __r
     const double t0 = block_sum(s0, red), t1 = block_sum(s1, red), t2 = block_sum(s2, red);
     if (threadIdx.x == 0) { H[k * 3] = t0; H[k * 3 + 1] = t1; H[k * 3 + 2] = t2; }
 }
+// Long vectors (the non-eliminated solver: n = 3(C+T) ~ 1e5..1e6): one workgroup per (group of GRAM_COLS basis
+// columns, slice of rows) so that the whole chip streams V once and R GRAM_COLS times less often than above
+// (measured at n = 303000, ka = 48: 400 us with one workgroup per column); partial sums per slice are folded in
+// slice order by tall_gram_fold_kernel - deterministic.
+#define GRAM_COLS 4
+__global__ __launch_bounds__(256) void tall_gram_slice_kernel(int n, const double* __restrict__ V, int ld, int ka,
+                                                              const double* __restrict__ R, int rows_per_slice,
+                                                              double* __restrict__ part) {
+    __shared__ double red[4][GRAM_COLS * 3];
+    const int k0 = blockIdx.x * GRAM_COLS, s = blockIdx.y;
+    const int i0 = s * rows_per_slice, i1 = min(n, i0 + rows_per_slice);
+    double acc[GRAM_COLS][3];
+#pragma unroll
+    for (int c = 0; c < GRAM_COLS; ++c) acc[c][0] = acc[c][1] = acc[c][2] = 0.0;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) {
+        const double r0 = R[i], r1 = R[(size_t)n + i], r2 = R[(size_t)2 * n + i];
+#pragma unroll
+        for (int c = 0; c < GRAM_COLS; ++c) {
+            const double v = (k0 + c < ka) ? V[(size_t)(k0 + c) * ld + i] : 0.0;
+            acc[c][0] += v * r0; acc[c][1] += v * r1; acc[c][2] += v * r2;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < GRAM_COLS; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double t = wave_sum(acc[c][q]);
+            if (lane == 0) red[wave][c * 3 + q] = t;
+        }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < GRAM_COLS * 3 && k0 + t / 3 < ka)
+        part[((size_t)s * ka + k0) * 3 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+__global__ void tall_gram_fold_kernel(const double* __restrict__ part, int n_slice, int m, double* __restrict__ H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double s = 0.0;
+    for (int k = 0; k < n_slice; ++k) s += part[(size_t)k * m + i];
+    H[i] = s;
+}
+#define GRAM_SLICE_MIN_N 16384
+#define GRAM_MAX_SLICES 128
+
 extern "C" int vican_tall_gram(int32_t n, const double* V, int32_t ld, int32_t ka, const double* R, double* H,
-                               void* stream) {
+                               double* ws, int64_t ws_doubles, void* stream) {
     if (n <= 0 || !V || !R || !H || ka <= 0 || ld < n) return set_err(VICAN_ERR_ARG, "vican_tall_gram: bad argument");
+    if (ws && n >= GRAM_SLICE_MIN_N) {
+        int rows = 4096;
+        while ((n + rows - 1) / rows > GRAM_MAX_SLICES) rows *= 2;
+        const int n_slice = (n + rows - 1) / rows;
+        if ((int64_t)n_slice * ka * 3 <= ws_doubles) {
+            hipLaunchKernelGGL(tall_gram_slice_kernel, dim3((ka + GRAM_COLS - 1) / GRAM_COLS, n_slice), dim3(256), 0,
+                               (hipStream_t)stream, n, V, ld, ka, R, rows, ws);
+            hipLaunchKernelGGL(tall_gram_fold_kernel, dim3((ka * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, n_slice,
+                               ka * 3, H);
+            LAUNCH_CHECK("vican_tall_gram");
+            return VICAN_OK;
+        }
+    }
     hipLaunchKernelGGL(tall_gram_kernel, dim3(ka), dim3(256), 0, (hipStream_t)stream, n, V, ld, R, H);
     LAUNCH_CHECK("vican_tall_gram");
     return VICAN_OK;
@@ -548,7 +606,7 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
 
 extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                                       const double* z, double* R, double* H, double* G, double* Hcol, double* beta,
-                                      double* x_out, double pivot_floor, void* stream) {
+                                      double* x_out, double pivot_floor, double* ws, int64_t ws_doubles, void* stream) {
     if (n_cam <= 0 || !lamC || !V || !z || !R || !H || !G || !Hcol || !beta || !x_out || j < 0 || 3 * (j + 1) > KA_MAX ||
         ld < 3 * n_cam)
         return set_err(VICAN_ERR_ARG, "vican_lanczos_cam_step: bad argument");
@@ -557,11 +615,11 @@ extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double*
         const int n = 3 * n_cam, ka = 3 * (j + 1);
         int rc;
         if ((rc = vican_lap_apply(n_cam, lamC, V, ld, 3 * j, z, R, stream)) < 0) return rc;
-        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;
+        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, ws, ws_doubles, stream)) < 0) return rc;
         if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 0, stream)) < 0) return rc;
-        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, stream)) < 0) return rc;          // second Gram-Schmidt pass
+        if ((rc = vican_tall_gram(n, V, ld, ka, R, H, ws, ws_doubles, stream)) < 0) return rc;          // second Gram-Schmidt pass
         if ((rc = vican_tall_update(n, V, ld, ka, H, R, Hcol, 1, stream)) < 0) return rc;
-        if ((rc = vican_tall_gram(n, R, n, 3, R, G, stream)) < 0) return rc;
+        if ((rc = vican_tall_gram(n, R, n, 3, R, G, ws, ws_doubles, stream)) < 0) return rc;
         return vican_chol_qr3(n, R, G, V, ld, 3 * (j + 1), beta, x_out, pivot_floor, stream);
     }
     hipLaunchKernelGGL(lanczos_cam_fused_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, R,

@@ -178,7 +178,7 @@ class HipBackend:
         self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
         self._status_host = {}
         self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
-        self._coop_ws, self._coop_sync = None, None
+        self._coop_ws, self._coop_sync, self._gram_ws = None, None, None
         self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, getattr(graph, "wmax", None)
 
     # -- allocation helpers -------------------------------------------------
@@ -251,6 +251,14 @@ class HipBackend:
         self._ck(self.lib.vican_bip_apply(self._gref, _ptr(x), C.c_void_p(x.data_ptr() + off), _ptr(self.zpart), _ptr(self.g.fx),
                                           _ptr(z_out), C.c_void_p(z_out.data_ptr() + off), _stream()), "vican_bip_apply")
 
+    def _gram_workspace(self, n):
+        """Slice partials of vican_tall_gram for long vectors (the non-eliminated solver); None for short ones."""
+        if n < 16384:
+            return None
+        if self._gram_ws is None:
+            self._gram_ws = torch.empty(_lib.GRAM_WS_DOUBLES, dtype=torch.float64, device=self.dev)
+        return self._gram_ws
+
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
         n_nodes = lamC.numel() // 9             # C for the eliminated solver, C + T for the general one
         if self.coop_cam_step and n_nodes == self.C:
@@ -261,8 +269,10 @@ class HipBackend:
                                                      _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), _stream()),
                      "vican_lanczos_cam_coop")
             return
+        ws = self._gram_workspace(3 * n_nodes)
         self._ck(self.lib.vican_lanczos_cam_step(n_nodes, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
-                                                 _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _stream()),
+                                                 _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(ws),
+                                                 0 if ws is None else ws.numel(), _stream()),
                  "vican_lanczos_cam_step")
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
@@ -300,7 +310,9 @@ class HipBackend:
         self._ck(self.lib.vican_lap_apply(lamC.numel() // 9, _ptr(lamC), _ptr(V), ld, col0, _ptr(z), _ptr(aq), _stream()), "vican_lap_apply")
 
     def tall_gram(self, n, V, ld, ka, R, H):
-        self._ck(self.lib.vican_tall_gram(n, _ptr(V), ld, ka, _ptr(R), _ptr(H), _stream()), "vican_tall_gram")
+        ws = self._gram_workspace(n)
+        self._ck(self.lib.vican_tall_gram(n, _ptr(V), ld, ka, _ptr(R), _ptr(H), _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
+                 "vican_tall_gram")
 
     def tall_update(self, n, V, ld, ka, H, R, H_out, accumulate):
         self._ck(self.lib.vican_tall_update(n, _ptr(V), ld, ka, _ptr(H), _ptr(R), _ptr(H_out), int(accumulate), _stream()),
