@@ -81,3 +81,27 @@ def test_api_error_paths():
         bipartite_se3sync(src, cons, one, one, lambda e: False, 4, "conjugate_gradient", np.float64)
     out = bipartite_se3sync(src, cons, one, one, lambda e: True, 1, "direct", np.float32)     # maxiter 1, LSQR, f32
     assert len(out) == 4 + 10 and next(iter(out.values())).R().dtype == np.float32
+
+
+def test_disconnected_graph_warns_and_still_returns():
+    """Two unrelated rigs in one edge dict: the reference returns an arbitrary null-space mixture silently
+    (SURVEY.md section 5); the drop-in warns, solves, and each component is still internally consistent."""
+    import golden_cases as gc
+    from util import load_golden, rebuild_inputs
+    from vican.bipgo import bipartite_se3sync
+    from vican_amd.bipgo import DisconnectedGraphWarning
+    from vican_amd.geometry import geodesic
+    g = load_golden("g2_small")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", g)
+    both = dict(src)
+    both.update({("x" + c, "9" + tm): v for (c, tm), v in src.items()})
+    with pytest.warns(DisconnectedGraphWarning, match="2 connected components"):
+        res = bipartite_se3sync(both, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+    assert len(res) == 2 * (len(g["gt_R_cam"]) + len(g["gt_R_obj"]))
+    assert all(np.isfinite(p.R()).all() and np.isfinite(p.t()).all() for p in res.values())
+    # inside the component of the gauge camera relative rotations equal those of the single-rig solve
+    one = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+    keys = [k for k in one if "_" not in k]
+    ra = np.stack([res[k].R() @ res[keys[0]].R().T for k in keys])
+    rb = np.stack([one[k].R() @ one[keys[0]].R().T for k in keys])
+    assert float(geodesic(ra, rb).max()) < 1e-6

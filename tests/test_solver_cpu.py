@@ -103,3 +103,29 @@ def test_lsqr_direct_matches_reference(name, dt):
     # scipy's lsqr stops at atol = btol = 1e-6: like the CG path the answer is only loosely converged,
     # but the iterates coincide, so agreement is at the 1e-6 m level
     assert float(np.linalg.norm(t - exp["t"], axis=1).max()) < (2e-6 if f64 else 5e-4)
+
+
+def test_component_count_and_warning():
+    import warnings
+    from vican_amd.bipgo import DisconnectedGraphWarning, _warn_if_disconnected
+    g, case, prob = flatten_case("g3_medium", "float64")
+    assert frontend.count_components(prob) == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert _warn_if_disconnected(prob) == 1
+    gl = load_golden("g2_small")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", gl)
+    three = dict(src)
+    three.update({("x" + c, "8" + tm): v for (c, tm), v in src.items()})
+    three.update({("y" + c, "9" + tm): v for (c, tm), v in src.items()})
+    p3 = frontend.flatten(three, cons, nr, nt, ff, np.float64)
+    assert frontend.count_components(p3) == 3
+    with pytest.warns(DisconnectedGraphWarning, match="3 connected components"):
+        _warn_if_disconnected(p3)
+    # a chain graph (diameter = number of nodes): propagation still terminates with one component
+    chain = frontend.Problem()
+    n = 257
+    chain.cam_names, chain.time_names = np.arange(n), np.arange(n - 1)
+    chain.row_ptr = 2 * np.arange(n, dtype=np.int32)
+    chain.col = np.stack([np.arange(n - 1), np.arange(1, n)], 1).reshape(-1).astype(np.int32)
+    assert frontend.count_components(chain) == 1

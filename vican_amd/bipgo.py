@@ -22,6 +22,7 @@ Extra keyword-only arguments (defaults reproduce the reference):
 from __future__ import annotations
 
 import time
+import warnings
 from typing import Callable, Optional
 
 import numpy as np
@@ -32,7 +33,20 @@ from ._lib import VicanError
 from .geometry import SE3
 from .solver import Comm, GeneralRotationSolver, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
 
-__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem"]
+__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem", "DisconnectedGraphWarning"]
+
+
+class DisconnectedGraphWarning(UserWarning):
+    """The kept edges do not connect all cameras and timesteps: poses of different components are unrelated."""
+
+
+def _warn_if_disconnected(prob):
+    n = frontend.count_components(prob)
+    if n > 1:
+        warnings.warn("the pose graph has %d connected components after filtering: the eigen-problem has %d near-null "
+                      "vectors and the poses of different components are in unrelated gauges (the reference returns "
+                      "such a result silently)" % (n, 3 * n), DisconnectedGraphWarning, stacklevel=3)
+    return n
 
 
 def _shard_rows(T, world, rank):
@@ -116,6 +130,7 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
     (reference bipgo.py:353-490).  See module docstring."""
     t0 = time.perf_counter()
     prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype)
+    _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
     Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
@@ -170,6 +185,7 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
             print("bipartite_so3sync: replicated on every rank (the non-eliminated variant is not sharded)")
     t0 = time.perf_counter()
     prob = frontend.flatten_so3(src_edges, constraints, noise_model, edge_filter)
+    _warn_if_disconnected(prob)
     if maxiter < 1:
         raise UnboundLocalError("local variable 'r' referenced before assignment")      # bipgo.py:139
     dev = torch.device("cuda", torch.cuda.current_device())

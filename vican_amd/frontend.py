@@ -148,6 +148,27 @@ def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
     return p
 
 
+def count_components(prob: Problem) -> int:
+    """Connected components of the merged camera x timestep graph (vectorised min-label propagation with
+    pointer jumping).  More than one means more than three near-null eigenvectors: the reference then returns an
+    arbitrary mixture of the components' gauges without any diagnostic ('disconnected graph
+    silently yields garbage'); the drop-in API warns."""
+    C, col, row_ptr = prob.n_cam, prob.col.astype(np.int64), prob.row_ptr.astype(np.int64)
+    rows = np.repeat(np.arange(prob.n_time), np.diff(row_ptr))
+    order = np.argsort(col, kind="stable")                          # edges grouped by camera
+    rows_by_cam = rows[order]
+    cam_start = np.searchsorted(col[order], np.arange(C))
+    lab = np.arange(C)
+    while True:
+        lab_t = np.minimum.reduceat(lab[col], row_ptr[:-1])         # every timestep row has >= 1 edge
+        new = np.minimum(lab, np.minimum.reduceat(lab_t[rows_by_cam], cam_start))
+        new = new[new]
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    return int(len(np.unique(lab)))
+
+
 def bnorm2(prob: Problem, Rc: np.ndarray, Rt: np.ndarray) -> float:
     """|b|^2 of the reference's stacked measurement vector (bipgo.py:454-461) for world<-node
     rotations Rc [C,3,3], Rt [T,3,3]:  b_e = k_t (R_c t~_e + R_t R_root^T R_m tau_m)."""
