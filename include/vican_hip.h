@@ -73,7 +73,7 @@ int vican_abi_version(void);            /* 7 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
- * vican_slab_reduce_fx, vican_polar_dual, vican_dual_update and vican_fx_finish exit immediately
+ * vican_slab_reduce_fx, vican_polar_dual, vican_dual_update(_op) and vican_fx_finish exit immediately
  * unless *gate == 1 WHEN THEY EXECUTE: the host enqueues the continuation of the primal-dual
  * iteration (bipgo.py:295-332) right behind vican_ritz without waiting for its verdict, and the
  * device cancels it if the eigen-solve has not converged.  All other entry points ignore the gate.
@@ -128,8 +128,9 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
  * VICAN_FX_DOUBLES doubles: [0] y scale, [1] its inverse, [2] z scale, [3] its inverse,
  * [4] omega = max_t |lamT_inv[t]|_F * rnorm[t], [5] max block norm, [6] max_t rnorm[t],
  * [7] 2^-shift of the last vican_block_op (its scales are raised by 2^shift when the actual
- * max_c |x_c|_F is below x_bound), [8] x_bound, [9] spare, [10] two 32-bit counters of the block sweeps'
- * chunk scheduler (zero between launches), [11] spare.
+ * max_c |x_c|_F is below x_bound), [8] x_bound, [9] z scale for a phase-3 operand bounded by x_bound itself
+ * (vican_dual_update_op), [10] two 32-bit counters of the block sweeps' chunk scheduler (zero between
+ * launches), [11] inverse of [9].
  * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
  * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
  * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup;
@@ -190,6 +191,17 @@ int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out
  * vican_cg_sweep slabs: ncomp 3, pa = &state->qinv; vican_trans_rhs slabs: ncomp 3, scale = *inv_out. */
 int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_t ncomp, double scale,
                          const double* pa, const double* pb, double* out, void* stream);
+
+/* vican_dual_update fused with the first operator application of the NEXT eigen-solve: the same outputs, and
+ * z_raw [3C][3] = this rank's partial of  sum_t M_ct polar(Z_t)  (Z_t = sum_c M_ct^T R_c as above) - with the new
+ * duals lamT_inv[t] = U S^-1 U^T the product lamT_inv[t] Z_t IS the polar factor U V^T, so z_raw = P_new R_c for the
+ * warm-start block R_c of the next iteration (bipgo.py:285-292 after :318-334), obtained in the same pass over the
+ * blocks.  The polar factors are formed inside the sweep by a Newton iteration (SVD fallback for singular rows).
+ * vican_right_solve3 then applies the 3x3 normalisation beta^-1 of the start block (vican_chol_qr3). */
+int vican_dual_update_op(const vican_graph_t* g, const double* Rc, double* Rt, double* lamT_inv,
+                         const double* rnorm, double* fx, void* zpart, double* z_raw, void* stream);
+/* Z[n][3] = X[n][3] * beta^-1, beta upper triangular [3][3] (zero pivot -> zero column); X may equal Z. */
+int vican_right_solve3(int32_t n, const double* X, const double* beta, double* Z, void* stream);
 
 /* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
  * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),

@@ -174,6 +174,28 @@ class NumpyBackend:
         Rt.numpy()[: self.T] = R.reshape(-1, 9)
         lamT_inv.numpy()[: self.T] = lam.reshape(-1, 9)
 
+    def dual_update_op(self, rc, Rt, lamT_inv, z_raw):
+        if self._closed():
+            return
+        z = np.zeros((self.C, 3, 3))
+        if self.T:
+            u, _, vt = np.linalg.svd(self._y(rc)[: self.T])
+            np.add.at(z, self.col, self.M @ (u @ vt)[self.row])            # lamT_new Z_t = U V^T
+        z_raw.numpy()[:] = z.reshape(3 * self.C, 3)
+        self.dual_update(rc, Rt, lamT_inv)
+
+    def right_solve3(self, X, beta, Z):
+        b = beta.numpy().reshape(-1)[:9].reshape(3, 3)
+        x = X.numpy().reshape(-1, 3)
+        z = np.zeros_like(x)
+        if b[0, 0] != 0.0:
+            z[:, 0] = x[:, 0] / b[0, 0]
+        if b[1, 1] != 0.0:
+            z[:, 1] = (x[:, 1] - z[:, 0] * b[0, 1]) / b[1, 1]
+        if b[2, 2] != 0.0:
+            z[:, 2] = (x[:, 2] - z[:, 0] * b[0, 2] - z[:, 1] * b[1, 2]) / b[2, 2]
+        Z.numpy().reshape(-1, 3)[:] = z
+
     def polar_dual(self, mats, R_out, lam_out, mode):
         if self._closed():
             return

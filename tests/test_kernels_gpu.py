@@ -362,3 +362,82 @@ def test_jacobi_scaling_kernels(cfg):
     assert H._cg_w is H._w_scaled and H._cg_wmax == 1.0
     H.clear_cg_scaling()
     assert H._cg_w is g.w
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_fused_dual_update_op(cfg, dt):
+    """vican_dual_update_op: the outputs of vican_dual_update, and z_raw = P_new rc from the same pass (Newton polar
+    factors inside the sweep) - against the unfused path on the same device and the NumPy mirror."""
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 500 + C, dt, bt, nwg, er)
+    rng = np.random.default_rng(6)
+    lam0, cd = H.empty(T, 9), H.empty(C)
+    H.init_duals(lam0, cd)
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    Rt1, L1, Rt2, L2 = H.zeros(T, 9), H.zeros(T, 9), H.zeros(T, 9), H.zeros(T, 9)
+    zraw, zref = H.empty(3 * C, 3), H.empty(3 * C, 3)
+    H.dual_update_op(H.from_numpy(rc), Rt1, L1, zraw)
+    H.dual_update(H.from_numpy(rc), Rt2, L2)
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0, posinf=-8.0, neginf=-9.0)      # rows without edges carry inf/nan duals
+    assert torch.equal(nn(Rt1), nn(Rt2)) and torch.equal(nn(L1), nn(L2))      # same exact row sums, same SVD kernel
+    nz = np.diff(N.row_ptr) > 0
+    well = nz & (np.diff(N.row_ptr) >= 2)
+    # unfused reference on the device: block_op with the new duals (rows without edges carry inf/nan duals: mask them)
+    Lc = L2.clone(); Lc[torch.from_numpy(~nz).to(Lc.device)] = 0.0
+    H.set_duals(Lc); H.block_op(Lc, H.from_numpy(rc), zref)
+    Rn, Ln, zn = N.zeros(T, 9), N.zeros(T, 9), N.empty(3 * C, 3)
+    N.dual_update_op(N.from_numpy(rc), Rn, Ln, zn)
+    scale = np.abs(zn.numpy()).max()
+    tol = 1e-9 if dt == np.float64 else 3e-6
+    assert np.abs(zraw.cpu().numpy() - zn.numpy()).max() <= tol * scale
+    # (the unfused product lamT_new (Z_t beta) loses cond(Z_t) digits on rows with one or two noisy blocks: sanity level only)
+    assert np.abs(zraw.cpu().numpy() - zref.cpu().numpy()).max() <= (1e-6 if dt == np.float64 else 1e-4) * scale
+    assert np.abs(Rt1.cpu().numpy()[well] - Rn.numpy()[well]).max() < (1e-9 if dt == np.float64 else 2e-3)
+    # bit-identical on repeats (exact integer sums, deterministic Newton iteration)
+    z2 = H.empty(3 * C, 3)
+    H.dual_update_op(H.from_numpy(rc), Rt2, L2, z2)
+    assert torch.equal(zraw, z2)
+    # start-block normalisation: z_raw beta^-1
+    beta = np.triu(rng.standard_normal((3, 3))) + 3 * np.eye(3)
+    zs = H.empty(3 * C, 3)
+    H.right_solve3(zraw, H.from_numpy(beta.reshape(-1)), zs)
+    assert np.abs(zs.cpu().numpy() - zraw.cpu().numpy() @ np.linalg.inv(beta)).max() <= 1e-12 * scale
+    beta[1, 1] = 0.0                                                  # dropped column
+    H.right_solve3(zraw, H.from_numpy(beta.reshape(-1)), zs)
+    assert not zs.cpu().numpy()[:, 1].any()
+
+
+def test_newton_polar_inside_the_sweep_handles_reflections_and_singular_rows():
+    """Rows whose block sum Z_t has a negative determinant (polar factor = reflection, as U V^T of the reference's
+    SVD) or is singular (SVD fallback) - through a graph with one edge per row and hand-made blocks."""
+    from vican_amd.device import HipBackend, LocalGraph
+    rng = np.random.default_rng(8)
+    C, T = 4, 64
+    rp = np.arange(T + 1, dtype=np.int32)
+    col = (np.arange(T) % C).astype(np.int32)
+    blk = rng.standard_normal((T, 3, 3))
+    blk[::3] *= -np.sign(np.linalg.det(blk[::3]))[:, None, None]     # det < 0
+    blk[5] = np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0])             # rank 1
+    blk[7] = 0.0                                                     # zero block
+    blk[9] = np.diag([1.0, 1e-11, 1.0])                              # cond 1e11
+    a = np.ones(T)
+    dev = torch.device("cuda:0")
+    g = LocalGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(blk.reshape(T, 9)).to(dev),
+                   torch.from_numpy(a).to(dev))
+    H = HipBackend(g)
+    lam0, cd = H.empty(T, 9), H.empty(C)
+    H.init_duals(lam0, cd)
+    rc = np.tile(np.eye(3), (C, 1))                                   # Z_t = M_t^T
+    Rt, L, zraw = H.zeros(T, 9), H.zeros(T, 9), H.empty(3 * C, 3)
+    H.dual_update_op(H.from_numpy(rc), Rt, L, zraw)
+    u, s, vt = np.linalg.svd(np.swapaxes(blk, 1, 2))
+    w = u @ vt
+    good = np.ones(T, bool); good[[5, 7]] = False                     # polar factor not unique there: only finiteness
+    z = np.zeros((C, 3, 3))
+    np.add.at(z, col[good], blk[good] @ w[good])
+    zb = np.zeros((C, 3, 3))
+    np.add.at(zb, col[~good], np.abs(blk[~good]).sum(axis=(1, 2))[:, None, None] * np.ones((3, 3)))
+    got = zraw.cpu().numpy().reshape(C, 3, 3)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - z) <= 1e-9 * np.abs(z).max() + 2.0 * zb).all()

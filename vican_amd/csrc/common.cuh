@@ -179,6 +179,50 @@ __device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
     }
 }
 
+// out of line on purpose: the (never taken in practice) SVD path must not raise the register pressure of the caller
+__device__ __attribute__((noinline)) void polar_svd_fallback(const double* A, double* R) { polar_dual3(A, R, nullptr, 4); }
+
+// Orthogonal polar factor U V^T of A (NO det fix: a reflection for det A < 0) by the Newton iteration
+// X <- (X + X^-T) / 2 started from A scaled to |A|_F = sqrt 3.  Timestep sums Z_t = sum_c M_ct^T R_c are close to a
+// scaled rotation, where it converges quadratically in 3-4 steps of ~80 flops - cheap enough to run inside the
+// streaming sweep (the Jacobi SVD is ~20x that).  Falls back to the SVD for (nearly) singular blocks.
+__device__ inline void polar_newton3(const double* A, double* R) {
+    double X[9], n2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) n2 += A[q] * A[q];
+    bool ok = n2 > 0.0 && n2 < 1e300;
+    const double sc = ok ? sqrt(3.0 / n2) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) X[q] = A[q] * sc;
+    if (ok) {
+        ok = false;
+        for (int it = 0; it < 40; ++it) {
+            double Cf[9];
+            Cf[0] = X[4] * X[8] - X[5] * X[7]; Cf[1] = X[5] * X[6] - X[3] * X[8]; Cf[2] = X[3] * X[7] - X[4] * X[6];
+            Cf[3] = X[2] * X[7] - X[1] * X[8]; Cf[4] = X[0] * X[8] - X[2] * X[6]; Cf[5] = X[1] * X[6] - X[0] * X[7];
+            Cf[6] = X[1] * X[5] - X[2] * X[4]; Cf[7] = X[2] * X[3] - X[0] * X[5]; Cf[8] = X[0] * X[4] - X[1] * X[3];
+            const double det = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
+            if (!(fabs(det) > 1e-9)) break;                 // |X|_F ~ sqrt 3: relative singularity (cond > ~1e9) -> SVD
+            const double h = 0.5 / det;
+            double delta = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const double nx = 0.5 * X[q] + h * Cf[q];
+                const double d = nx - X[q];
+                delta += d * d;
+                X[q] = nx;
+            }
+            if (delta <= 1e-22) { ok = true; break; }       // |step| <= 1e-11: the new iterate is converged to rounding
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = X[q];
+    } else {
+        polar_svd_fallback(A, R);
+    }
+}
+
 // --- 64-bit fixed-point accumulation helpers (see vican_sweep.hip header) -----
 typedef unsigned long long u64;
 

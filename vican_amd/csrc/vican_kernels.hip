@@ -66,6 +66,26 @@ extern "C" int vican_gauge_project(int32_t n_cam, const double* x_in, double* x_
     return VICAN_OK;
 }
 
+// Z[i][:] = X[i][:] * beta^-1 for the upper-triangular 3x3 beta of vican_chol_qr3 (row-major [n][3]): turns
+// A (R beta^-1) = (A R) beta^-1 around, so that an operator application computed for the un-normalised start block R
+// (vican_dual_update_op) serves the orthonormalised one.  A zero pivot (dropped column) gives a zero column.
+__global__ void right_solve3_kernel(int n, const double* __restrict__ X, const double* __restrict__ beta, double* __restrict__ Z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double b00 = beta[0], b01 = beta[1], b02 = beta[2], b11 = beta[4], b12 = beta[5], b22 = beta[8];
+    const double x0 = X[(size_t)i * 3], x1 = X[(size_t)i * 3 + 1], x2 = X[(size_t)i * 3 + 2];
+    const double z0 = b00 != 0.0 ? x0 / b00 : 0.0;
+    const double z1 = b11 != 0.0 ? (x1 - z0 * b01) / b11 : 0.0;
+    const double z2 = b22 != 0.0 ? (x2 - z0 * b02 - z1 * b12) / b22 : 0.0;
+    Z[(size_t)i * 3] = z0; Z[(size_t)i * 3 + 1] = z1; Z[(size_t)i * 3 + 2] = z2;
+}
+extern "C" int vican_right_solve3(int32_t n, const double* X, const double* beta, double* Z, void* stream) {
+    if (n <= 0 || !X || !beta || !Z) return set_err(VICAN_ERR_ARG, "vican_right_solve3: bad argument");
+    hipLaunchKernelGGL(right_solve3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, X, beta, Z);
+    LAUNCH_CHECK("vican_right_solve3");
+    return VICAN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // camera-side dense helpers for block Lanczos.  V: column-major basis, column k
 // at V + k*ld (ld >= n).  R (work block) is column-major [3][n]; x/z are row-major [n][3].

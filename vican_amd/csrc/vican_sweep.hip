@@ -428,6 +428,11 @@ __global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, d
     fx[0] = ldexp(1.0, ey); fx[1] = ldexp(1.0, -ey);
     fx[2] = ldexp(1.0, ez); fx[3] = ldexp(1.0, -ez);
     fx[7] = 1.0; fx[8] = x_bound;
+    // the same for a phase-3 operand bounded by x_bound itself (omega = 1): MODE 3 sweeps (vican_dual_update_op)
+    const double cz1 = amax * x_bound, tz1 = cz1 * n_add;
+    int e1 = min(bits - (int)ceil(log2(cz1)), tot - (int)ceil(log2(tz1)));
+    e1 = max(min(e1, 100), -100);
+    fx[9] = ldexp(1.0, e1); fx[11] = ldexp(1.0, -e1);
 }
 extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
     if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");
@@ -488,11 +493,28 @@ template <typename S> __device__ __forceinline__ long long fix_total(long long s
 template <> __device__ __forceinline__ long long fix_total<float>(long long s) { return (long long)((u64)s << 16) >> 16; }
 template <> __device__ __forceinline__ long long fix_total<double>(long long s) { return s; }
 
+// a0 b0 + a1 b1 + a2 b2 with the roundings spelled out (one product, two fused multiply-adds).  The chunk body
+// below is instantiated once per register set of the ping-pong ring, and WHICH instance processes a given chunk
+// depends on the order the tickets are drawn; left to -ffp-contract=fast the two instances were compiled to
+// different mixes of (packed) mul/add/fma for one pair of outputs in one instantiation (<float,768,0,512>), i.e.
+// launches differed in the last f32 bit of z components (1,1),(1,2) about once in 30 - found by repetition.
+template <typename S>
+__device__ __forceinline__ S dot3(S a0, S b0, S a1, S b1, S a2, S b2) {
+#pragma clang fp contract(off)
+    S t = a0 * b0;
+    t = __builtin_elementwise_fma(a1, b1, t);
+    return __builtin_elementwise_fma(a2, b2, t);
+}
+
 // MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
 // MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
 // MODE 2: y_row = sum M^T x_cam -> lamT_out,  zpart[wg] = sum M * xt_row    (both halves of the symmetric
 //         (C+T)-node operator R~ [x_cam; x_time] of the non-eliminated solver in ONE pass over the blocks;
 //         `lamT_inv` carries x_time [T][9])
+// MODE 3: MODE 1 (Z_t = sum M^T R_c -> lamT_out, for dual_svd_kernel) AND zpart[wg] = sum M * polar(Z_t) in the same
+//         pass: with the new duals Lambda_t = U S^-1 U^T (Z_t = U S V^T) the product Lambda_t Z_t is the polar
+//         factor U V^T, so this IS the first operator application P_new R_c of the next eigen-solve (up to the 3x3
+//         normalisation of the start block, applied afterwards) - one pass over the blocks instead of two
 // Arithmetic in the storage type S (f32 products for f32 blocks), accumulation in 64-bit fixed point.
 //
 // Per chunk:  [phase 3 of the previous chunk | phase 1]  barrier  [phase 2: one wavefront per
@@ -515,7 +537,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    constexpr bool HAS_Z = (MODE == 0 || MODE == 2);            // camera-side accumulators + phase 3
+    constexpr bool HAS_Z = (MODE == 0 || MODE == 2 || MODE == 3);            // camera-side accumulators + phase 3
     const int C = g.n_cam, nx = 9 * CP, ncopy = g.n_copy, cmask = ncopy - 1;
     // 8-byte arrays first, then the storage-type tables
     u64* zs = (u64*)lds_raw;                                   // [9][CP] planes (MODE 0)
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #pragma unroll
         for (int i = 0; i < 9; ++i) xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0;
     }
-    const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8];
+    const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8], fx9 = (MODE == 3) ? fx[9] : 0.0;
     // The first chunk(s) are requested right behind the x loads (vector-memory results retire in issue
     // order, so x - an L2 hit - must be the older request): their HBM latency overlaps the table staging.
     __builtin_amdgcn_sched_barrier(0);
@@ -592,11 +614,11 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     // floor(log2(x_bound / sqrt(xm2))) = floor(log2(x_bound^2 / xm2) / 2): one division + exponent extraction
     if (xm2 > 0.0) { const double r2 = fx8 * fx8 / xm2; shift = r2 >= 1.0 ? (ilogb(r2) >> 1) : 0; }     // fx[8] = x_bound
     shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
-    if (MODE == 2) shift = 0;                   // x_time is not measured here: both scales stay at the x_bound ones
+    if (MODE == 2 || MODE == 3) shift = 0;      // phase-3 operand not measured here (x_time / polar factors, |.|_F = x_bound)
     const double up = ldexp(1.0, shift);
-    const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = fx2 * up;
-    if (HAS_Z && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
-    if (MODE == 1 && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
+    const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = (MODE == 3) ? fx9 : fx2 * up;     // fx[9]: scale for omega = 1
+    if ((MODE == 0 || MODE == 2) && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
 
 #ifdef VICAN_STAMP
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t;
@@ -674,8 +696,8 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
-                        const S c = vget<S>(cur.m[0 + a], j) * xc[b] + vget<S>(cur.m[3 + a], j) * xc[3 + b] +
-                                    vget<S>(cur.m[6 + a], j) * xc[6 + b];
+                        const S c = dot3<S>(vget<S>(cur.m[0 + a], j), xc[b], vget<S>(cur.m[3 + a], j), xc[3 + b],
+                                            vget<S>(cur.m[6 + a], j), xc[6 + b]);
                         acc[a * 3 + b] = cont ? acc[a * 3 + b] + c : c;
                     }
                 const bool last = (j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j];
@@ -720,10 +742,18 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 if (MODE == 0) {
                     const int r = i / 9, oo = i - 9 * r, a3 = oo / 3, b3 = oo - 3 * a3;
                     const double* L = lamT_inv + (size_t)(r0 + r) * 9 + a3 * 3;
-                    wv[i] = pre_scale<S>(L[0] * ysum[r * 9 + b3] + L[1] * ysum[r * 9 + 3 + b3] + L[2] * ysum[r * 9 + 6 + b3], z_scale);
+                    wv[i] = pre_scale<S>(dot3<double>(L[0], ysum[r * 9 + b3], L[1], ysum[r * 9 + 3 + b3], L[2], ysum[r * 9 + 6 + b3]), z_scale);
                 } else {
                     lamT_out[(size_t)r0 * 9 + i] = ysum[i];
                     if (MODE == 2) wv[i] = pre_scale<S>(lamT_inv[(size_t)r0 * 9 + i], z_scale);
+                }
+            }
+            if (MODE == 3) {                            // one thread per row: polar factor of Z_t -> phase-3 operand
+                for (int r = tid; r < nrows; r += BLOCK) {
+                    double R[9];
+                    polar_newton3(ysum + r * 9, R);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) wv[r * 9 + q] = pre_scale<S>(R[q], z_scale);
                 }
             }
         } else
@@ -748,15 +778,25 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 }
                 const double y0 = __shfl(y, (0 + ob) * part_n, 64), y1 = __shfl(y, (3 + ob) * part_n, 64),
                              y2 = __shfl(y, (6 + ob) * part_n, 64);
-                if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0 * y0 + L1 * y1 + L2 * y2, z_scale);
+                if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(dot3<double>(L0, y0, L1, y1, L2, y2), z_scale);
             } else {
                 // Z_t goes to global memory; the per-row SVDs run afterwards in a fully parallel
                 // kernel (one thread per row) instead of serialising this streaming sweep
                 if (o < 9 && lane == o * part_n) lamT_out[(size_t)(r0 + r) * 9 + o] = y;
+                if (MODE == 3 && o < 9 && lane == o * part_n) ysum[r * 9 + o] = y;
                 if (MODE == 2) {
                     if (r != wave && o < 9) L0 = lamT_inv[(size_t)(r0 + r) * 9 + o];
                     if (o < 9 && lane == o * part_n) wv[r * 9 + o] = pre_scale<S>(L0, z_scale);
                 }
+            }
+        }
+        if (MODE == 3 && !ROWPAR) {                     // rows of the chunk side by side in one wavefront: polar factors
+            __syncthreads();
+            if (tid < nrows) {
+                double R[9];
+                polar_newton3(ysum + tid * 9, R);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) wv[tid * 9 + q] = pre_scale<S>(R[q], z_scale);
             }
         }
         // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
@@ -782,8 +822,8 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int b = 0; b < 3; ++b) {
-                        const S v = vget<S>(cur.m[i * 3 + 0], j) * w[b] + vget<S>(cur.m[i * 3 + 1], j) * w[3 + b] +
-                                    vget<S>(cur.m[i * 3 + 2], j) * w[6 + b];
+                        const S v = dot3<S>(vget<S>(cur.m[i * 3 + 0], j), w[b], vget<S>(cur.m[i * 3 + 1], j), w[3 + b],
+                                            vget<S>(cur.m[i * 3 + 2], j), w[6 + b]);
 #if defined(VICAN_ABLATE) && VICAN_ABLATE == 1      /* no phase-3 atomics */
                         asm volatile("" :: "v"(v));
 #elif defined(VICAN_ABLATE) && VICAN_ABLATE == 2    /* phase-3 atomics without the products */
@@ -990,6 +1030,27 @@ extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, doub
     hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate,
                        g->n_time, Rt, lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update");
+    return VICAN_OK;
+}
+
+// Dual update fused with the first operator application of the next eigen-solve (MODE 3): as vican_dual_update,
+// and z_raw[3C][3] = this rank's partial of  sum_t M_ct polar(Z_t)  =  P_new R_c  for the NEW duals.
+extern "C" int vican_dual_update_op(const vican_graph_t* g, const double* rc_, double* Rt, double* lamT_inv,
+                                    const double* rnorm, double* fx, void* zpart, double* z_raw, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_dual_update_op")) return rc;
+    if (!rc_ || !Rt || !lamT_inv || !rnorm || !fx || !zpart || !z_raw) return set_err(VICAN_ERR_ARG, "vican_dual_update_op: null pointer");
+    if (g->n_chunk == 0) {                       // a rank without rows (memsets cannot be gated; z_raw is only read after a converged gate)
+        if (hipMemsetAsync(fx + 4, 0, sizeof(double), (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(z_raw, 0, sizeof(double) * 9 * g->n_cam, (hipStream_t)stream) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "vican_dual_update_op: memset failed");
+        return VICAN_OK;
+    }
+    if (int rc = dispatch_sweep<3>(g, nullptr, rc_, (u64*)zpart, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
+    LAUNCH_CHECK("vican_dual_update_op");
+    if (int rc = vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 11, nullptr, z_raw, stream)) return rc;
+    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate,
+                       g->n_time, Rt, lamT_inv, rnorm, fx);
+    LAUNCH_CHECK("vican_dual_update_op");
     return VICAN_OK;
 }
 

@@ -298,6 +298,16 @@ class HipBackend:
                                             _ptr(self.g.fx), _stream()), "vican_dual_update")
         self._fx_finish()
 
+    def dual_update_op(self, rc, Rt, lamT_inv, z_raw):
+        """dual_update + z_raw[3C,3] = local partial of P_new rc (the next eigen-solve's first operator application)
+        in ONE pass over the blocks (include/vican_hip.h: vican_dual_update_op)."""
+        self._ck(self.lib.vican_dual_update_op(self._gref, _ptr(rc), _ptr(Rt), _ptr(lamT_inv), _ptr(self.g.rnorm),
+                                               _ptr(self.g.fx), _ptr(self.zpart), _ptr(z_raw), _stream()), "vican_dual_update_op")
+        self._fx_finish()
+
+    def right_solve3(self, X, beta, Z):
+        self._ck(self.lib.vican_right_solve3(X.numel() // 3, _ptr(X), _ptr(beta), _ptr(Z), _stream()), "vican_right_solve3")
+
     def polar_dual(self, mats, R_out, lam_out, mode):
         self._ck(self.lib.vican_polar_dual(mats.numel() // 9, _ptr(mats), _ptr(R_out), _ptr(lam_out), mode, _stream()),
                  "vican_polar_dual")

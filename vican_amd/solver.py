@@ -107,6 +107,9 @@ class RotationSolver:
         self.cam_deg = K.empty(self.N)
         self.lamT = K.empty(max(K.T, 1), 9)
         self.Rt = K.empty(max(K.T, 1), 9)
+        self.zraw = K.empty(n, 3)                   # P_new rc from the fused dual update (see _tail)
+        self.z_ready = False
+        self.fuse_dual_op = True
         self.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
 
     # -- operator ------------------------------------------------------------
@@ -155,7 +158,13 @@ class RotationSolver:
             prev_res, floor_hit, prev_steps, first = None, False, 0, True
             while True:
                 j = steps
-                self.apply_P(self.xrow, self.z)
+                if j == 0 and restart == 0 and self.z_ready:
+                    # warm start from rc: P rc was formed by the fused dual update of the previous primal-dual
+                    # iteration (one pass over the blocks instead of two); the start block is rc beta0^-1
+                    K.right_solve3(self.zraw, self.beta0, self.z)
+                else:
+                    self.apply_P(self.xrow, self.z)
+                self.z_ready = False
                 # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
                 # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
                 K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
@@ -216,17 +225,26 @@ class RotationSolver:
             g = torch.Generator(device="cpu"); g.manual_seed(self.seed)
             self.x0 = torch.randn(self.n, 3, generator=g, dtype=torch.float64).to(self.X.device)
 
-    def _tail(self):
-        """Everything of a primal-dual iteration after the eigen-solve (enqueued under the Ritz gate)."""
+    def _tail(self, fuse=False):
+        """Everything of a primal-dual iteration after the eigen-solve (enqueued under the Ritz gate).
+        fuse: another iteration follows - its eigen-solve starts from rc, and P_new rc comes out of the dual
+        update's own pass over the blocks (lamT_new Z_t is the polar factor of Z_t)."""
         K = self.K
         K.gauge_project(self.X, self.Xp)                        # bipgo.py:295-297
         K.block_op(self.lamT, self.Xp, self.z)                  # bipgo.py:300
         self.comm.allreduce(self.z)
         K.polar_dual(self.z, self.rc, self.lamC, 1)             # bipgo.py:306-315
-        K.dual_update(self.rc, self.Rt, self.lamT)              # bipgo.py:318-332
+        if fuse:
+            K.dual_update_op(self.rc, self.Rt, self.lamT, self.zraw)   # bipgo.py:318-332 (+ :285-288 of the next iteration)
+            self.comm.allreduce(self.zraw)
+        else:
+            K.dual_update(self.rc, self.Rt, self.lamT)          # bipgo.py:318-332
 
-    def iterate(self, first, it=None):
-        self.spectral(self.x0 if first else self.rc, warm=not first, it=it, tail=self._tail)
+    def iterate(self, first, it=None, last=True):
+        fuse = self.fuse_dual_op and not last
+        self.z_ready = self.z_ready and not first
+        self.spectral(self.x0 if first else self.rc, warm=not first, it=it, tail=lambda: self._tail(fuse))
+        self.z_ready = fuse
         self.stats["sweeps"] += 2
 
     def run(self, maxiter):
@@ -239,7 +257,7 @@ class RotationSolver:
             # steps are solved to the full tolerance; each earlier one is relaxed by 100x, at most to 1e-4.
             relax = max(0, (maxiter - 2) - it)
             self.eig_tol = min(max(tol_final * 100.0 ** relax, tol_final), 1e-4)
-            self.iterate(it == 0, it)
+            self.iterate(it == 0, it, last=(it == maxiter - 1))
         self.eig_tol = tol_final
         return self.rc, self.Rt
 
