@@ -7,11 +7,11 @@ src = "gpurun_out/profile_%s" % tag
 os.makedirs("profiles", exist_ok=True)
 OURS = ("block_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs",
         "dual_svd", "edge_sums", "block_norms", "pack_edges", "plan_slots", "init_duals", "fx_finish", "duals_bound",
-        "scaled_identity", "rows_to_cols")
+        "scaled_identity", "rows_to_cols", "lanczos_", "ritz_", "right_solve3", "lsqr_", "jacobi", "row_scale")
 
 def first(pat):
-    f = glob.glob(os.path.join(src, pat), recursive=True)
-    return f[0] if f else None
+    f = glob.glob(os.path.join(src, pat), recursive=True)       # gpurun merges into existing directories: newest wins
+    return max(f, key=os.path.getmtime) if f else None
 
 # 1. kernel stats of the default bench command (only this project's kernels + total)
 out = []
@@ -53,6 +53,14 @@ if os.path.exists(bj):
     if lines:
         bench = json.loads(lines[-1])
         json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
+tl = []
+for name, title in (("timeline_stress.txt", "stress workload (bench.py default), second-to-last solve of a rocprofv3 --kernel-trace run"),
+                    ("timeline_large_shop.txt", "large_shop workload (340 cameras x 10000 timesteps x 4 cams/timestep), second-to-last solve")):
+    fn = os.path.join(src, name)
+    if os.path.exists(fn):
+        tl.append("# %s  (tools/timeline.py)\n%s" % (title, open(fn).read()))
+if tl:
+    open("profiles/%s_timeline.txt" % tag, "w").write("\n".join(tl))
 summary = dict(tag=tag, kernel="block_sweep_kernel<.,.,0> (vican_block_op)", counters_mean_per_dispatch=pm, traffic=traffic,
                workload=bench["config"]["workload"] if bench else None,
                bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None)
