@@ -179,47 +179,82 @@ __device__ void polar_dual3(const double* A, double* R, double* lam, int mode) {
     }
 }
 
+// Orthogonal polar factor U V^T of A (NO det fix: a reflection for det A < 0) by the Newton iteration
+// X <- (X + X^-T) / 2 started from A scaled to |A|_F = sqrt 3.  Timestep sums Z_t = sum_c M_ct^T R_c and the
+// camera-side products are close to a scaled rotation, where it converges quadratically in 3-4 steps of ~80 flops -
+// cheap enough to run inside the streaming sweep (the Jacobi SVD is ~20x that).  Only used for well-conditioned
+// blocks (normalised determinant > 1e-3, i.e. cond <~ 1e3: the early iterates invert X, and their rounding errors
+// (~cond eps) perturb the matrix whose polar factor the iteration converges to); returns false otherwise.
+__device__ inline bool polar_newton_core(const double* A, double* X) {
+    double n2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) n2 += A[q] * A[q];
+    if (!(n2 > 0.0 && n2 < 1e300)) return false;
+    const double sc = sqrt(3.0 / n2);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) X[q] = A[q] * sc;
+    for (int it = 0; it < 24; ++it) {
+        double Cf[9];
+        Cf[0] = X[4] * X[8] - X[5] * X[7]; Cf[1] = X[5] * X[6] - X[3] * X[8]; Cf[2] = X[3] * X[7] - X[4] * X[6];
+        Cf[3] = X[2] * X[7] - X[1] * X[8]; Cf[4] = X[0] * X[8] - X[2] * X[6]; Cf[5] = X[1] * X[6] - X[0] * X[7];
+        Cf[6] = X[1] * X[5] - X[2] * X[4]; Cf[7] = X[2] * X[3] - X[0] * X[5]; Cf[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
+        if (!(fabs(det) > 1e-3)) return false;          // |det| only grows towards 1 along the iteration: decided at it = 0
+        const double h = 0.5 / det;
+        double delta = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double nx = 0.5 * X[q] + h * Cf[q];
+            const double d = nx - X[q];
+            delta += d * d;
+            X[q] = nx;
+        }
+        if (delta <= 1e-22) return true;                // |step| <= 1e-11: the new iterate is converged to rounding
+    }
+    return false;
+}
+
 // out of line on purpose: the (never taken in practice) SVD path must not raise the register pressure of the caller
 __device__ __attribute__((noinline)) void polar_svd_fallback(const double* A, double* R) { polar_dual3(A, R, nullptr, 4); }
 
-// Orthogonal polar factor U V^T of A (NO det fix: a reflection for det A < 0) by the Newton iteration
-// X <- (X + X^-T) / 2 started from A scaled to |A|_F = sqrt 3.  Timestep sums Z_t = sum_c M_ct^T R_c are close to a
-// scaled rotation, where it converges quadratically in 3-4 steps of ~80 flops - cheap enough to run inside the
-// streaming sweep (the Jacobi SVD is ~20x that).  Falls back to the SVD for (nearly) singular blocks.
 __device__ inline void polar_newton3(const double* A, double* R) {
-    double X[9], n2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) n2 += A[q] * A[q];
-    bool ok = n2 > 0.0 && n2 < 1e300;
-    const double sc = ok ? sqrt(3.0 / n2) : 0.0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) X[q] = A[q] * sc;
-    if (ok) {
-        ok = false;
-        for (int it = 0; it < 40; ++it) {
-            double Cf[9];
-            Cf[0] = X[4] * X[8] - X[5] * X[7]; Cf[1] = X[5] * X[6] - X[3] * X[8]; Cf[2] = X[3] * X[7] - X[4] * X[6];
-            Cf[3] = X[2] * X[7] - X[1] * X[8]; Cf[4] = X[0] * X[8] - X[2] * X[6]; Cf[5] = X[1] * X[6] - X[0] * X[7];
-            Cf[6] = X[1] * X[5] - X[2] * X[4]; Cf[7] = X[2] * X[3] - X[0] * X[5]; Cf[8] = X[0] * X[4] - X[1] * X[3];
-            const double det = X[0] * Cf[0] + X[1] * Cf[1] + X[2] * Cf[2];
-            if (!(fabs(det) > 1e-9)) break;                 // |X|_F ~ sqrt 3: relative singularity (cond > ~1e9) -> SVD
-            const double h = 0.5 / det;
-            double delta = 0.0;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const double nx = 0.5 * X[q] + h * Cf[q];
-                const double d = nx - X[q];
-                delta += d * d;
-                X[q] = nx;
-            }
-            if (delta <= 1e-22) { ok = true; break; }       // |step| <= 1e-11: the new iterate is converged to rounding
-        }
-    }
-    if (ok) {
+    double X[9];
+    if (polar_newton_core(A, X)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) R[q] = X[q];
     } else {
         polar_svd_fallback(A, R);
+    }
+}
+
+// polar_dual3 without the SVD where the block allows it: Q = U V^T from the Newton iteration; for det A > 0 that is
+// the det-fixed rotation, A Q^T = U S U^T is the dual block (mode 1) and its inverse U S^-1 U^T (mode 2).
+// Reflections (det A < 0 with the det fix requested: needs the third singular pair) and ill-conditioned blocks
+// take the SVD path.
+__device__ inline void polar_dual3_fast(const double* A, double* R, double* lam, int mode) {
+    double Q[9];
+    const bool ok = polar_newton_core(A, Q);
+    if (!ok || (!(mode & 4) && det3(Q) < 0.0)) { polar_dual3(A, R, lam, mode); return; }
+    if (R) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = Q[q];
+    }
+    if (lam && (mode & 3)) {
+        double H[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) H[i * 3 + j] = A[i * 3] * Q[j * 3] + A[i * 3 + 1] * Q[j * 3 + 1] + A[i * 3 + 2] * Q[j * 3 + 2];
+        const double h01 = 0.5 * (H[1] + H[3]), h02 = 0.5 * (H[2] + H[6]), h12 = 0.5 * (H[5] + H[7]);
+        if ((mode & 3) == 1) {
+            lam[0] = H[0]; lam[1] = h01; lam[2] = h02; lam[3] = h01; lam[4] = H[4]; lam[5] = h12; lam[6] = h02; lam[7] = h12; lam[8] = H[8];
+        } else {                                        // inverse of the symmetric positive definite H by cofactors
+            const double c00 = H[4] * H[8] - h12 * h12, c01 = h02 * h12 - h01 * H[8], c02 = h01 * h12 - h02 * H[4];
+            const double c11 = H[0] * H[8] - h02 * h02, c12 = h01 * h02 - H[0] * h12, c22 = H[0] * H[4] - h01 * h01;
+            const double id = 1.0 / (H[0] * c00 + h01 * c01 + h02 * c02);
+            lam[0] = c00 * id; lam[1] = c01 * id; lam[2] = c02 * id; lam[3] = c01 * id; lam[4] = c11 * id; lam[5] = c12 * id;
+            lam[6] = c02 * id; lam[7] = c12 * id; lam[8] = c22 * id;
+        }
     }
 }
 

@@ -14,7 +14,7 @@ __global__ void polar_dual_kernel(const int32_t* __restrict__ gate, int n, const
     double A[9], R[9], lam[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) A[q] = in[(size_t)i * 9 + q];
-    polar_dual3(A, R, lam, mode);
+    polar_dual3_fast(A, R, lam, mode);
     if (R_out)
 #pragma unroll
         for (int q = 0; q < 9; ++q) R_out[(size_t)i * 9 + q] = R[q];
@@ -51,7 +51,7 @@ __global__ void gauge_project_kernel(const int32_t* __restrict__ gate, int n_cam
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) A[i * 3 + j] = xc[i * 3] * gi[j] + xc[i * 3 + 1] * gi[3 + j] + xc[i * 3 + 2] * gi[6 + j];
-    polar_dual3(A, R, nullptr, 0);
+    polar_dual3_fast(A, R, nullptr, 0);
 #pragma unroll
     for (int q = 0; q < 9; ++q) xout[(size_t)c * 9 + q] = R[q];
 }

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(128) void dual_svd_kernel(const int32_t* __restrict
         double Z[9], R[9], lam[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) Z[q] = lamT_inv[(size_t)t * 9 + q];
-        polar_dual3(Z, R, lam, 2);
+        polar_dual3_fast(Z, R, lam, 2);
         double fro = 0.0;
 #pragma unroll
         for (int q = 0; q < 9; ++q) { Rt[(size_t)t * 9 + q] = R[q]; lamT_inv[(size_t)t * 9 + q] = lam[q]; fro += lam[q] * lam[q]; }
