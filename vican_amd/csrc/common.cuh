@@ -209,7 +209,7 @@ __device__ inline bool polar_newton_core(const double* A, double* X) {
             delta += d * d;
             X[q] = nx;
         }
-        if (delta <= 1e-22) return true;                // |step| <= 1e-11: the new iterate is converged to rounding
+        if (delta <= 1e-16) return true;                // |step| <= 1e-8: quadratic convergence leaves the new iterate at ~step^2/2
     }
     return false;
 }

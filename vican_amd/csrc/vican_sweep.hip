@@ -343,21 +343,35 @@ extern "C" int vican_block_norms(const vican_graph_t* g, double* rnorm, double* 
     return VICAN_OK;
 }
 
+// Raise fx[4] to the workgroup's maximum with ONE atomic: same-address device-scope atomics are serialised at the memory
+// side (~10 ns each; measured: 1600 per-wavefront atomics = most of a 20 us kernel at T = 100000).
+__device__ __forceinline__ void wg_raise_bound(double om, double* target) {
+    __shared__ double sh_max[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = om;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) m = fmax(m, sh_max[i]);
+        if (m > 0.0) atomic_max_pos(target, m);
+    }
+}
+
 // Initial duals from the stored row sums d_t (bipgo.py:271-276): lamT_inv[t] = I/d_t, and the
 // fixed-point bound omega = max_t |lamT_inv[t]|_F * rnorm[t].
 __global__ void init_duals_kernel(int n_time, const double* __restrict__ d, const double* __restrict__ rnorm,
                                   double* __restrict__ lamT_inv, double* __restrict__ fx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     double om = 0.0;
-    if (t < n_time) {
-        const double inv = 1.0 / d[t];
-        double* o = lamT_inv + (size_t)t * 9;
-        o[0] = inv; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = inv; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = inv;
-        if (d[t] > 0.0) om = 1.7320508075688772 * inv * rnorm[t];
+    if (t < n_time && d[t] > 0.0) om = 1.7320508075688772 / d[t] * rnorm[t];
+    // contiguous stores: element i of the [T][9] array belongs to row i / 9 (diagonal entries i % 9 in {0, 4, 8})
+    const int r0 = blockIdx.x * blockDim.x, nloc = min((int)blockDim.x, n_time - r0) * 9;       // 32-bit index arithmetic
+    for (int i = threadIdx.x; i < nloc; i += blockDim.x) {
+        const int r = i / 9, q = i - 9 * r;
+        lamT_inv[(size_t)r0 * 9 + i] = (q == 0 || q == 4 || q == 8) ? 1.0 / d[r0 + r] : 0.0;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
-    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
+    wg_raise_bound(om, &fx[4]);
 }
 
 extern "C" int vican_init_duals(int32_t n_time, const double* row_sum_a, const double* rnorm, double* lamT_inv,
@@ -382,9 +396,7 @@ __global__ void duals_bound_kernel(int n_time, const double* __restrict__ lamT_i
         om = sqrt(q) * rnorm[t];
         if (!(om >= 0.0) || om > 1e300) om = 0.0;          // rows without edges carry inf/nan duals
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
-    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
+    wg_raise_bound(om, &fx[4]);
 }
 extern "C" int vican_duals_bound(int32_t n_time, const double* lamT_inv, const double* rnorm, double* fx, void* stream) {
     if (n_time < 0 || !lamT_inv || !rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_duals_bound: bad argument");
@@ -889,26 +901,33 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 }
 
 // Rt[t], lamT_inv[t] from Z_t (stored in lamT_inv by the MODE 1 sweep), in place; omega bound.
-__global__ __launch_bounds__(128) void dual_svd_kernel(const int32_t* __restrict__ gate, int n_time, double* __restrict__ Rt,
+__global__ __launch_bounds__(256) void dual_svd_kernel(const int32_t* __restrict__ gate, int n_time, double* __restrict__ Rt,
                                                        double* __restrict__ lamT_inv, const double* __restrict__ rnorm,
                                                        double* __restrict__ fx) {
     GATE_RETURN(gate);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // rows are 72-byte records: per-thread loads/stores of one record each run at ~0.3 TB/s (8-byte accesses 72 bytes
+    // apart; measured 21 us for 100000 rows, arithmetic ~2 us) - the workgroup's 256 records go through LDS instead,
+    // read and written as contiguous words
+    __shared__ double sh[2][256 * 9];
+    const int t0 = blockIdx.x * 256, t = t0 + threadIdx.x;
+    const int nloc = min(256, n_time - t0) * 9;
+    for (int i = threadIdx.x; i < nloc; i += 256) sh[0][i] = lamT_inv[(size_t)t0 * 9 + i];
+    __syncthreads();
     double om = 0.0;
     if (t < n_time) {
         double Z[9], R[9], lam[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) Z[q] = lamT_inv[(size_t)t * 9 + q];
+        for (int q = 0; q < 9; ++q) Z[q] = sh[0][threadIdx.x * 9 + q];
         polar_dual3_fast(Z, R, lam, 2);
         double fro = 0.0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { Rt[(size_t)t * 9 + q] = R[q]; lamT_inv[(size_t)t * 9 + q] = lam[q]; fro += lam[q] * lam[q]; }
+        for (int q = 0; q < 9; ++q) { sh[1][threadIdx.x * 9 + q] = R[q]; sh[0][threadIdx.x * 9 + q] = lam[q]; fro += lam[q] * lam[q]; }
         om = sqrt(fro) * rnorm[t];
         if (!(om >= 0.0) || om > 1e300) om = 0.0;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
-    if ((threadIdx.x & 63) == 0 && om > 0.0) atomic_max_pos(&fx[4], om);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nloc; i += 256) { Rt[(size_t)t0 * 9 + i] = sh[1][i]; lamT_inv[(size_t)t0 * 9 + i] = sh[0][i]; }
+    wg_raise_bound(om, &fx[4]);
 }
 
 template <typename S, int BLOCK, int MODE, int CP, bool ROWPAR>
@@ -1027,7 +1046,7 @@ extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, doub
         return VICAN_OK;
     }
     if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
-    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate,
+    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_vican_gate,
                        g->n_time, Rt, lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update");
     return VICAN_OK;
@@ -1048,7 +1067,7 @@ extern "C" int vican_dual_update_op(const vican_graph_t* g, const double* rc_, d
     if (int rc = dispatch_sweep<3>(g, nullptr, rc_, (u64*)zpart, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
     LAUNCH_CHECK("vican_dual_update_op");
     if (int rc = vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 11, nullptr, z_raw, stream)) return rc;
-    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 127) / 128), dim3(128), 0, (hipStream_t)stream, g_vican_gate,
+    hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_vican_gate,
                        g->n_time, Rt, lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update_op");
     return VICAN_OK;
