@@ -512,6 +512,9 @@ template <> __device__ __forceinline__ long long fix_total<double>(long long s) 
 // launches differed in the last f32 bit of z components (1,1),(1,2) about once in 30 - found by repetition.
 template <typename S>
 __device__ __forceinline__ S dot3(S a0, S b0, S a1, S b1, S a2, S b2) {
+#ifdef VICAN_DOT3_PLAIN          /* A/B only: lets the compiler contract (and reproduces the nondeterminism) */
+    return a0 * b0 + a1 * b1 + a2 * b2;
+#endif
 #pragma clang fp contract(off)
     S t = a0 * b0;
     t = __builtin_elementwise_fma(a1, b1, t);
