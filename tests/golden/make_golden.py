@@ -262,6 +262,45 @@ def so3_case():
     np.savez_compressed(os.path.join(HERE, "g8_so3sync.npz"), **out)
 
 
+def input_digest(flat):
+    """Order-sensitive digest of the generated source edges (so a test knows it regenerated the same inputs)."""
+    return np.array([float(np.sum(flat["R"] * np.arange(1, flat["R"].size + 1).reshape(flat["R"].shape) % 7)),
+                     float(np.sum(flat["t"])), float(np.sum(flat["corners"])), float(len(flat["cam_key"]))])
+
+
+def large_shop_case():
+    """G9: the reference at BASELINE configs[2] scale (see golden_cases.LARGE_SHOP); outputs + input digest only."""
+    import time
+    case = gc.LARGE_SHOP
+    scene, flat = gc.build_flat(case)
+    src = synth.edges_to_dict(flat, ref_geometry.SE3)
+    cons = synth.constraints_from_scene(scene, ref_geometry.SE3)
+    nr, nt, ff = (gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
+    out = {"digest": input_digest(flat)}
+    for solver, dt in case["runs"]:
+        _rec["evals"], _rec["cg_iters"], _rec["cg_relres"], _rec["t_tight"] = [], None, None, None
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            res = ref_bipgo.bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff,
+                                              maxiter=gc.MAXITER, lsqr_solver=solver, dtype=np.dtype(dt).type)
+        wall = time.time() - t0
+        tag = "out_%s_%s_" % (solver, dt)
+        keys = list(res.keys())
+        out[tag + "keys"] = np.array([str(k) for k in keys])
+        out[tag + "R"] = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in keys]).astype(np.float32)   # f32 run: exact
+        out[tag + "t"] = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in keys])
+        out[tag + "evals"] = np.stack(_rec["evals"])
+        out[tag + "cg_iters"] = np.int64(_rec["cg_iters"])
+        out[tag + "cg_relres"] = np.float64(_rec["cg_relres"])
+        tt = _rec["t_tight"]
+        out[tag + "dist_tight"] = np.float64(np.linalg.norm(out[tag + "t"] - tt[:len(keys)], axis=1).max())
+        out[tag + "ref_wall_s"] = np.float64(wall)
+        print("  g9_large_shop %-20s %-8s nodes=%d src_edges=%d cg_iters=%s dist_tight=%.3e reference wall %.1f s" % (
+            solver, dt, len(keys), len(src), _rec["cg_iters"], out[tag + "dist_tight"], wall))
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__, "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, "g9_large_shop.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -276,3 +315,5 @@ if __name__ == "__main__":
         eval_case()
     if not only or "g8_so3sync" in only:
         so3_case()
+    if "g9_large_shop" in only:               # minutes of reference time: only on request
+        large_shop_case()

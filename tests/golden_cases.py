@@ -86,6 +86,14 @@ CASES = {
 
 MAXITER = 4
 
+# G9: BASELINE.json configs[2] scale ("large_shop (10k timesteps)"): 340 cameras x 10000 timesteps, 4 cameras per
+# timestep, 2 markers per view = 80000 source edges.  The fixture holds the reference's OUTPUTS only (plus a digest of
+# the inputs): the inputs are regenerated from this seeded description (tests/golden/make_golden.py: large_shop_case).
+LARGE_SHOP = dict(mode="camera", scene=dict(n_cam=340, n_time=10000, n_marker=12, seed=91),
+                  edges=dict(cpt=4, mpv=2, sigma_r=1e-2, sigma_t=1e-2, seed=92),
+                  noise_r="w_area_mild", noise_t="w_area_mild_t", filt="f_all",
+                  runs=[("conjugate_gradient", "float32")])
+
 
 def build_flat(case: dict):
     """Scene + flat source-edge arrays of a case (deterministic)."""
