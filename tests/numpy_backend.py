@@ -184,6 +184,16 @@ class NumpyBackend:
         z_raw.numpy()[:] = z.reshape(3 * self.C, 3)
         self.dual_update(rc, Rt, lamT_inv)
 
+    def lanczos_seed(self, x0, V, ld, beta0, xrow, zraw=None, z=None):
+        n = x0.numel() // 3
+        R, G = torch.zeros(3 * n, dtype=torch.float64), torch.zeros(9, dtype=torch.float64)
+        self.rows_to_cols(n, x0, R, n, 0)
+        self.tall_gram(n, R, n, 3, R, G)
+        self.chol_qr3(n, R, G, V, ld, 0, beta0, xrow, 0.0)
+        if zraw is not None:
+            self.right_solve3(zraw, beta0, z)
+        return True
+
     def right_solve3(self, X, beta, Z):
         b = beta.numpy().reshape(-1)[:9].reshape(3, 3)
         x = X.numpy().reshape(-1, 3)

@@ -441,3 +441,39 @@ def test_newton_polar_inside_the_sweep_handles_reflections_and_singular_rows():
     got = zraw.cpu().numpy().reshape(C, 3, 3)
     assert np.isfinite(got).all()
     assert (np.abs(got - z) <= 1e-9 * np.abs(z).max() + 2.0 * zb).all()
+
+
+@pytest.mark.parametrize("n", [3, 15, 1020, 3000, 16384])
+def test_lanczos_seed_matches_the_launch_sequence(n):
+    """vican_lanczos_seed (one launch) against rows_to_cols + tall_gram + chol_qr3 + right_solve3 and NumPy."""
+    H, N, g = make_backends(5, 40, 1, 3, 7, np.float64)
+    rng = np.random.default_rng(n)
+    x0 = rng.standard_normal((n, 3)) @ np.array([[2.0, 0.3, -0.1], [0.0, 1.5, 0.4], [0.0, 0.0, 0.7]])
+    zraw = rng.standard_normal((n, 3))
+    m = 2
+    outs = []
+    for K, fused in ((H, True), (H, False), (N, True)):
+        V, beta, xrow, z = K.zeros(3 * (m + 1) * n), K.zeros(9), K.zeros(n, 3), K.zeros(n, 3)
+        if fused:
+            assert K.lanczos_seed(K.from_numpy(x0), V, n, beta, xrow, K.from_numpy(zraw), z)
+        else:
+            R, G = K.zeros(3 * n), K.zeros(9)
+            K.rows_to_cols(n, K.from_numpy(x0), R, n, 0)
+            K.tall_gram(n, R, n, 3, R, G)
+            K.chol_qr3(n, R, G, V, n, 0, beta, xrow, 0.0)
+            K.right_solve3(K.from_numpy(zraw), beta, z)
+        outs.append([t.cpu().numpy().copy() for t in (V, beta, xrow, z)])
+    q, r = np.linalg.qr(x0)
+    sgn = np.sign(np.diag(r))
+    for o in outs:
+        assert np.abs(o[1].reshape(3, 3) - r * sgn[:, None]).max() < 1e-10 * np.abs(r).max()       # beta = R factor with positive diagonal
+        assert np.abs(o[2] - q * sgn[None, :]).max() < 1e-10
+        assert np.abs(o[0][: 3 * n].reshape(3, n).T - o[2]).max() == 0.0                           # basis columns = the same block
+        assert np.abs(o[3] - zraw @ np.linalg.inv(r * sgn[:, None])).max() < 1e-9 * np.abs(o[3]).max()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.abs(a - b).max() < 1e-12 * max(1.0, np.abs(b).max())
+    # a zero column of the start block: zero pivot -> zero column (pivot rule of vican_chol_qr3 with pivot_floor 0)
+    x1 = x0.copy(); x1[:, 2] = 0.0
+    V, beta, xrow = H.zeros(3 * (m + 1) * n), H.zeros(9), H.zeros(n, 3)
+    H.lanczos_seed(H.from_numpy(x1), V, n, beta, xrow)
+    assert beta.cpu().numpy()[8] == 0.0 and not xrow.cpu().numpy()[:, 2].any() and np.isfinite(xrow.cpu().numpy()).all()

@@ -20,6 +20,7 @@ SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kern
 HEADERS = [os.path.join(CSRC, "common.cuh")]
 FX_DOUBLES = 12
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
+SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
 INCLUDE = os.path.join(ROOT, "include")
 
 STORE_F32, STORE_F64 = 0, 1
@@ -83,6 +84,7 @@ PROTOTYPES = {
     "vican_lanczos_cam_step": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, C.c_int64, _vp]),
     "vican_block_op_z": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_dual_update_op": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lanczos_seed": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vican_right_solve3": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

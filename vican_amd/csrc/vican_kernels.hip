@@ -262,6 +262,69 @@ extern "C" int vican_chol_qr3(int32_t n, const double* R, const double* G, doubl
     return VICAN_OK;
 }
 
+// Start block of an eigen-solve in ONE launch (n <= VICAN_SEED_MAX_N): G = X0^T X0, upper Cholesky G = beta^T beta,
+// Q0 = X0 beta^-1 -> basis columns 0..2 and the row-major sweep input, beta0; optionally also Z = Zraw beta^-1
+// (vican_right_solve3).  Replaces vican_rows_to_cols + vican_tall_gram + vican_chol_qr3 (+ vican_right_solve3): four
+// dependent launches of 5-8 us each at the head of every primal-dual iteration.  One workgroup; the six Gram entries
+// are reduced in a fixed order.
+#define VICAN_SEED_THREADS 1024
+__global__ __launch_bounds__(VICAN_SEED_THREADS) void lanczos_seed_kernel(int n, const double* __restrict__ X0, double* __restrict__ V,
+                                                                            int ld, double* __restrict__ beta_out,
+                                                                            double* __restrict__ x_out, const double* __restrict__ Zraw,
+                                                                            double* __restrict__ Z) {
+    __shared__ double red[16][6];
+    __shared__ double sb[9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += VICAN_SEED_THREADS) {
+        const double a = X0[(size_t)i * 3], b = X0[(size_t)i * 3 + 1], c = X0[(size_t)i * 3 + 2];
+        g[0] += a * a; g[1] += a * b; g[2] += a * c; g[3] += b * b; g[4] += b * c; g[5] += c * c;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double t = wave_sum(g[k]);
+        if (lane == 0) red[wave][k] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double G6[6];
+        for (int k = 0; k < 6; ++k) { double t = 0.0; for (int w = 0; w < VICAN_SEED_THREADS / 64; ++w) t += red[w][k]; G6[k] = t; }
+        const double g00 = G6[0], g01 = G6[1], g02 = G6[2], g11 = G6[3], g12 = G6[4], g22 = G6[5];
+        const double floor_ = 1e-28 * (g00 + g11 + g22);                // same pivot rule as chol_qr3_kernel
+        double b00 = 0, b01 = 0, b02 = 0, b11 = 0, b12 = 0, b22 = 0;
+        if (g00 > floor_) { b00 = sqrt(g00); b01 = g01 / b00; b02 = g02 / b00; }
+        const double d11 = g11 - b01 * b01;
+        if (d11 > floor_) { b11 = sqrt(d11); b12 = (g12 - b01 * b02) / b11; }
+        const double d22 = g22 - b02 * b02 - b12 * b12;
+        if (d22 > floor_) b22 = sqrt(d22);
+        sb[0] = b00; sb[1] = b01; sb[2] = b02; sb[3] = 0; sb[4] = b11; sb[5] = b12; sb[6] = 0; sb[7] = 0; sb[8] = b22;
+        for (int k = 0; k < 9; ++k) beta_out[k] = sb[k];
+    }
+    __syncthreads();
+    const double b00 = sb[0], b01 = sb[1], b02 = sb[2], b11 = sb[4], b12 = sb[5], b22 = sb[8];
+    const double i00 = b00 != 0.0 ? 1.0 / b00 : 0.0, i11 = b11 != 0.0 ? 1.0 / b11 : 0.0, i22 = b22 != 0.0 ? 1.0 / b22 : 0.0;
+    for (int i = tid; i < n; i += VICAN_SEED_THREADS) {
+        const double r0 = X0[(size_t)i * 3], r1 = X0[(size_t)i * 3 + 1], r2 = X0[(size_t)i * 3 + 2];
+        const double q0 = r0 * i00, q1 = (r1 - q0 * b01) * i11, q2 = (r2 - q0 * b02 - q1 * b12) * i22;
+        V[i] = q0; V[(size_t)ld + i] = q1; V[(size_t)2 * ld + i] = q2;
+        x_out[(size_t)i * 3] = q0; x_out[(size_t)i * 3 + 1] = q1; x_out[(size_t)i * 3 + 2] = q2;
+        if (Zraw) {
+            const double x0 = Zraw[(size_t)i * 3], x1 = Zraw[(size_t)i * 3 + 1], x2 = Zraw[(size_t)i * 3 + 2];
+            const double z0 = x0 * i00, z1 = (x1 - z0 * b01) * i11, z2 = (x2 - z0 * b02 - z1 * b12) * i22;
+            Z[(size_t)i * 3] = z0; Z[(size_t)i * 3 + 1] = z1; Z[(size_t)i * 3 + 2] = z2;
+        }
+    }
+}
+extern "C" int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, double* beta_out, double* x_out,
+                                  const double* Zraw, double* Z, void* stream) {
+    if (n <= 0 || n > VICAN_SEED_MAX_N || !X0 || !V || !beta_out || !x_out || ld < n || (Zraw && !Z) || X0 == x_out)
+        return set_err(VICAN_ERR_ARG, "vican_lanczos_seed: bad argument");
+    hipLaunchKernelGGL(lanczos_seed_kernel, dim3(1), dim3(VICAN_SEED_THREADS), 0, (hipStream_t)stream, n, X0, V, ld, beta_out,
+                       x_out, Zraw, Z);
+    LAUNCH_CHECK("vican_lanczos_seed");
+    return VICAN_OK;
+}
+
 // X[n][3] (row-major) = V[:, :ka] Y[ka][3]
 __global__ __launch_bounds__(256) void tall_combine_kernel(const int32_t* __restrict__ gate, int n, const double* __restrict__ V, int ld, int ka,
                                                            const double* __restrict__ Y, double* __restrict__ X) {

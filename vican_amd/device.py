@@ -305,6 +305,15 @@ class HipBackend:
                                                _ptr(self.g.fx), _ptr(self.zpart), _ptr(z_raw), _stream()), "vican_dual_update_op")
         self._fx_finish()
 
+    def lanczos_seed(self, x0, V, ld, beta0, xrow, zraw=None, z=None):
+        """Start block in one launch (include/vican_hip.h: vican_lanczos_seed); False if the vectors are too long."""
+        n = x0.numel() // 3
+        if n > _lib.SEED_MAX_N:
+            return False
+        self._ck(self.lib.vican_lanczos_seed(n, _ptr(x0), _ptr(V), ld, _ptr(beta0), _ptr(xrow), _ptr(zraw), _ptr(z), _stream()),
+                 "vican_lanczos_seed")
+        return True
+
     def right_solve3(self, X, beta, Z):
         self._ck(self.lib.vican_right_solve3(X.numel() // 3, _ptr(X), _ptr(beta), _ptr(Z), _stream()), "vican_right_solve3")
 

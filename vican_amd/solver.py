@@ -119,11 +119,16 @@ class RotationSolver:
         self.stats["sweeps"] += 1
 
     # -- spectral step ---------------------------------------------------------
-    def _seed_block(self, x0):
+    def _seed_block(self, x0, with_z=False):
+        """Orthonormal start block from x0 (and, with_z: z = zraw beta0^-1, the operator applied to it - see _tail)."""
         K, n = self.K, self.n
+        if K.lanczos_seed(x0, self.V, self.ld, self.beta0, self.xrow, self.zraw if with_z else None, self.z if with_z else None):
+            return
         K.rows_to_cols(n, x0, self.R, n, 0)
         K.tall_gram(n, self.R, n, 3, self.R, self.G)
         K.chol_qr3(n, self.R, self.G, self.V, self.ld, 0, self.beta0, self.xrow, 0.0)
+        if with_z:
+            K.right_solve3(self.zraw, self.beta0, self.z)
 
     def _ritz(self, steps, first, floor_level):
         """Enqueue the device Ritz step for the first `steps` blocks and the asynchronous read-back of its
@@ -144,7 +149,9 @@ class RotationSolver:
         K, n, ld = self.K, self.n, self.ld
         total_steps, floor_at = 0, 0
         for restart in range(self.max_restarts + 1):
-            self._seed_block(x0)
+            have_z = restart == 0 and self.z_ready
+            self._seed_block(x0, with_z=have_z)
+            self.z_ready = False
             steps = 0
             # a failed projection check costs a pipeline bubble (host round trip) against >= one edge sweep
             # per extra step, so warm-started iterations (previous R_c: already ~1e-3 from the answer) are
@@ -158,13 +165,10 @@ class RotationSolver:
             prev_res, floor_hit, prev_steps, first = None, False, 0, True
             while True:
                 j = steps
-                if j == 0 and restart == 0 and self.z_ready:
-                    # warm start from rc: P rc was formed by the fused dual update of the previous primal-dual
-                    # iteration (one pass over the blocks instead of two); the start block is rc beta0^-1
-                    K.right_solve3(self.zraw, self.beta0, self.z)
-                else:
+                if not (j == 0 and have_z):
+                    # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
+                    #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
                     self.apply_P(self.xrow, self.z)
-                self.z_ready = False
                 # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
                 # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
                 K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
