@@ -125,14 +125,31 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")])
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC, *os.environ.get("VICAN_CFLAGS", "").split(), *SOURCES,
-           "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
+    # one hipcc per translation unit, in parallel (the sweep file alone instantiates ~190 kernels), then a link step
+    import concurrent.futures
+    import tempfile
+    flags = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC,
+             *os.environ.get("VICAN_CFLAGS", "").split()]
+    with tempfile.TemporaryDirectory(prefix="_build_", dir=CSRC) as tmp:        # objects stay inside the tree
+        objs = [os.path.join(tmp, os.path.basename(src) + ".o") for src in SOURCES]
+
+        def compile_one(job):
+            src, obj = job
+            cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            return subprocess.run(cmd, capture_output=True, text=True)
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
+            for res in pool.map(compile_one, zip(SOURCES, objs)):
+                if res.returncode != 0:
+                    raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise VicanError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 
