@@ -281,7 +281,8 @@ int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t
  * receives the Ritz vectors of the three smallest values (zero rows beyond 3 eff).
  * flags: bit 0 = first check of this Krylov run (no previous residual), bit 1 = the step budget
  * is exhausted (forces stop).  With r = max_k |beta Y_k[last 3 rows]| / max|theta|:
- *   floor_hit = (not first and r > r_prev/4 and r <= floor_tol) or (floor_level >= 0 and r <= 2 floor_level)
+ *   floor_hit = (not first and r > stall_ratio r_prev and r <= floor_tol) or (floor_level >= 0 and r <= 2 floor_level)
+ *               (stall_ratio in (0,1): 1/4 for checks several steps apart, 1/2 for consecutive steps)
  *   stop      = eff < steps or breakdown or r <= eig_tol or floor_hit or bit 1
  *   converged = breakdown or floor_hit or r <= eig_tol           *gate = stop and converged
  * status[VICAN_RITZ_STATUS_DOUBLES]: [0] r, [1] max|theta|, [2] stop, [3] converged, [4] floor_hit,
@@ -291,8 +292,8 @@ int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t
 #define VICAN_RITZ_MAX_STEPS 32
 #define VICAN_RITZ_STATUS_DOUBLES 16
 int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags,
-               double eig_tol, double floor_tol, double floor_level, double* Y, double* status,
-               int32_t* gate, void* stream);
+               double eig_tol, double floor_tol, double floor_level, double stall_ratio, double* Y,
+               double* status, int32_t* gate, void* stream);
 
 /* ---- translation stage ---------------------------------------------------
  * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of

@@ -68,7 +68,7 @@ class NumpyBackend:
     def _closed(self):
         return self._gate is not None and int(self._gate[0]) != 1
 
-    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate):
+    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate, stall_ratio=0.25):
         """Mirror of vican_ritz (include/vican_hip.h) with LAPACK instead of the Jacobi iteration."""
         hb = HB[:steps].numpy()
         Hh = hb[:, :hw].reshape(steps, -1, 3)
@@ -93,7 +93,7 @@ class NumpyBackend:
         first, at_max = bool(flags & 1), bool(flags & 2)
         breakdown = bool(np.all(np.diag(beta) == 0.0))
         prev = float(status[12])
-        floor_hit = (not first) and r > 0.25 * prev and r <= floor_tol
+        floor_hit = (not first) and r > stall_ratio * prev and r <= floor_tol
         if floor_level >= 0.0 and r <= 2.0 * floor_level:
             floor_hit = True
         stop = eff < steps or breakdown or r <= eig_tol or floor_hit or at_max

@@ -57,7 +57,7 @@ PROTOTYPES = {
     "vican_jacobi_scale": (C.c_int, [_i32, _vp, _vp, _vp]),
     "vican_row_scale": (C.c_int, [_i32, _i32, _vp, _vp, _vp]),
     "vican_scale_weights": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
-    "vican_ritz": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "vican_ritz": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "vican_plan_chunks": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32]),
     "vican_sweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_lds_limit_bytes": (_i64, []),

@@ -761,7 +761,7 @@ __device__ __forceinline__ int ritz_rotation(double app, double aqq, double apq,
 }
 
 __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ HB, int stride, int hw, int steps, int flags,
-                                                    double eig_tol, double floor_tol, double floor_level,
+                                                    double eig_tol, double floor_tol, double floor_level, double stall_ratio,
                                                     double* __restrict__ Y, double* __restrict__ status,
                                                     int32_t* __restrict__ gate) {
     extern __shared__ double sm[];
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         const bool first = flags & 1, at_max = flags & 2;
         const bool breakdown = beta[0] == 0.0 && beta[4] == 0.0 && beta[8] == 0.0;
         const double prev = status[12];
-        bool floor_hit = !first && r > 0.25 * prev && r <= floor_tol;
+        bool floor_hit = !first && r > stall_ratio * prev && r <= floor_tol;
         if (floor_level >= 0.0 && r <= 2.0 * floor_level) floor_hit = true;
         const bool stop = eff < steps || breakdown || r <= eig_tol || floor_hit || at_max;
         const bool converged = breakdown || floor_hit || resmax <= eig_tol * scale;
@@ -907,8 +907,9 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
 }
 
 extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags, double eig_tol,
-                          double floor_tol, double floor_level, double* Y, double* status, int32_t* gate, void* stream) {
-    if (!HB || !Y || !status || !gate || steps < 1 || steps > VICAN_RITZ_MAX_STEPS || hw < 9 * steps || row_stride < hw + 9)
+                          double floor_tol, double floor_level, double stall_ratio, double* Y, double* status, int32_t* gate,
+                          void* stream) {
+    if (!HB || !Y || !status || !gate || !(stall_ratio > 0.0 && stall_ratio < 1.0) || steps < 1 || steps > VICAN_RITZ_MAX_STEPS || hw < 9 * steps || row_stride < hw + 9)
         return set_err(VICAN_ERR_ARG, "vican_ritz: bad argument");
     const int n = 3 * steps, N = n + (n & 1), ld = N | 1, half = N / 2;
     const size_t lds = ((size_t)2 * N * ld + 2 * half) * sizeof(double) + (size_t)half * sizeof(int) + 16;
@@ -921,7 +922,7 @@ extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int3
     int threads = ((half * half + 63) / 64) * 64;            // one thread per 2x2 block, at most 1024
     threads = threads > 1024 ? 1024 : threads;
     hipLaunchKernelGGL(ritz_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, HB, row_stride, hw, steps,
-                       flags, eig_tol, floor_tol, floor_level, Y, status, gate);
+                       flags, eig_tol, floor_tol, floor_level, stall_ratio, Y, status, gate);
     LAUNCH_CHECK("vican_ritz");
     return VICAN_OK;
 }

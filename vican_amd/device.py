@@ -341,10 +341,11 @@ class HipBackend:
         self._ck(self.lib.vican_chol_qr3(n, _ptr(R), _ptr(G), _ptr(V), ld, col0, _ptr(beta_out), _ptr(x_out),
                                          float(pivot_floor), _stream()), "vican_chol_qr3")
 
-    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate):
+    def ritz(self, HB, hw, steps, flags, eig_tol, floor_tol, floor_level, Y, status, gate, stall_ratio=0.25):
         """Device Ritz step over the first `steps` rows of HB (include/vican_hip.h: vican_ritz)."""
         self._ck(self.lib.vican_ritz(_ptr(HB), HB.stride(0), hw, steps, flags, float(eig_tol), float(floor_tol),
-                                     float(floor_level), _ptr(Y), _ptr(status), _ptr(gate), _stream()), "vican_ritz")
+                                     float(floor_level), float(stall_ratio), _ptr(Y), _ptr(status), _ptr(gate), _stream()),
+                 "vican_ritz")
 
     @contextlib.contextmanager
     def gated(self, gate):

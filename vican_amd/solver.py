@@ -130,11 +130,13 @@ class RotationSolver:
         if with_z:
             K.right_solve3(self.zraw, self.beta0, self.z)
 
-    def _ritz(self, steps, first, floor_level):
+    def _ritz(self, steps, first, floor_level, gap=4):
         """Enqueue the device Ritz step for the first `steps` blocks and the asynchronous read-back of its
-        verdict; returns the handle to wait on."""
+        verdict; returns the handle to wait on.  gap: Lanczos steps since the previous check of this run - a residual
+        counts as stalled (rounding floor of f32 blocks) if it fell by less than 2x over one step / 4x over several."""
         flags = (1 if first else 0) | (2 if steps >= self.m_max else 0)
-        self.K.ritz(self.HB, self.hw, steps, flags, self.eig_tol, self.floor_tol, floor_level, self.Yd, self.status, self.gate)
+        self.K.ritz(self.HB, self.hw, steps, flags, self.eig_tol, self.floor_tol, floor_level, self.Yd, self.status, self.gate,
+                    stall_ratio=0.5 if gap <= 1 else 0.25)
         self.stats["n_check"] = self.stats.get("n_check", 0) + 1
         return self.K.post_status(self.status)
 
@@ -161,7 +163,11 @@ class RotationSolver:
                 # the same graph was solved before (time series, benchmark loop): go straight to the step
                 # count that sufficed last time instead of paying for checks that are known to fail
                 next_check = min(max(self.pred_steps[it], 1), self.m_max)
-            level = self.floor_level[it] if (restart == 0 and it in self.floor_level) else -1.0
+            # residual level of the rounding floor: remembered per iteration index, else the one met by the previous
+            # iteration (a property of the f32 products, not of the iterate)
+            level = -1.0
+            if restart == 0 and it is not None:
+                level = self.floor_level.get(it, self.floor_level.get(it - 1, -1.0))
             prev_res, floor_hit, prev_steps, first = None, False, 0, True
             while True:
                 j = steps
@@ -176,7 +182,7 @@ class RotationSolver:
                 steps += 1
                 total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
-                    handle = self._ritz(steps, first, level)
+                    handle = self._ritz(steps, first, level, gap=steps - prev_steps)
                     first = False
                     with K.gated(self.gate):                   # speculative: runs iff the device says converged
                         K.tall_combine(n, self.V, ld, 3 * steps, self.Yd, self.X)
@@ -196,7 +202,10 @@ class RotationSolver:
                         break
                     # a failed check costs less than one edge sweep on large graphs (device Ritz step, cancelled
                     # speculative launches), so the first few steps are checked one by one
-                    next_check = min(steps + (1 if steps < 8 and not self.small_graph else self.check_every), self.m_max)
+                    # ... and so is the step after a check that failed inside the band where an f32 rounding floor can
+                    # sit (r <= floor_tol): a stalled residual is then recognised one step later, not check_every later
+                    near_floor = self.floor_tol > 1e-12 and r <= self.floor_tol
+                    next_check = min(steps + (1 if (steps < 8 and not self.small_graph) or near_floor else self.check_every), self.m_max)
             th = st[7:12].copy()
             self.th4 = float(st[15])                    # fourth smallest Ritz value (NaN if the basis is too small)
             if conv:
