@@ -130,18 +130,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     import tempfile
     flags = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC,
              *os.environ.get("VICAN_CFLAGS", "").split()]
+    # (the sweep file is compiled five times: once without its hot kernel, once per sweep mode - see its header)
+    sweep = SOURCES[0]
+    jobs = [(sweep, ["-DVICAN_SWEEP_SPLIT", "-DVICAN_SWEEP_PART=%d" % m], "sweep_part%d.o" % m) for m in range(4)]
+    jobs += [(sweep, ["-DVICAN_SWEEP_SPLIT"], "sweep_main.o")]
+    jobs += [(src, [], os.path.basename(src) + ".o") for src in SOURCES[1:]]
     with tempfile.TemporaryDirectory(prefix="_build_", dir=CSRC) as tmp:        # objects stay inside the tree
-        objs = [os.path.join(tmp, os.path.basename(src) + ".o") for src in SOURCES]
+        objs = [os.path.join(tmp, name) for _, _, name in jobs]
 
         def compile_one(job):
-            src, obj = job
-            cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
+            (src, extra, _), obj = job
+            cmd = [hipcc_path(), *flags, *extra, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             return subprocess.run(cmd, capture_output=True, text=True)
 
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:
-            for res in pool.map(compile_one, zip(SOURCES, objs)):
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as pool:
+            for res in pool.map(compile_one, zip(jobs, objs)):
                 if res.returncode != 0:
                     raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]

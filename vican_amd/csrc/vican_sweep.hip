@@ -15,6 +15,18 @@
 //   * phase 2 (w_t = Lambda_T^-1 y_t) runs on 9*rows threads from LDS-staged duals.
 #include "common.cuh"
 
+// Build layout.  Compiled as ONE translation unit this file contains everything.  The in-tree build
+// (vican_amd/_lib.py) splits it to compile in parallel - the hot kernel has ~190 instantiations:
+//   -DVICAN_SWEEP_SPLIT                       everything except the hot kernel; the sweep modes are reached through
+//                                             vican_sweep_part_<mode>()
+//   -DVICAN_SWEEP_SPLIT -DVICAN_SWEEP_PART=m  only the hot kernel, its launchers and vican_sweep_part_<m>()
+#if defined(VICAN_SWEEP_PART) && !defined(VICAN_SWEEP_SPLIT)
+#error "VICAN_SWEEP_PART needs VICAN_SWEEP_SPLIT"
+#endif
+#define SWEEP_PART_ARGS const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt, \
+                        double* lamT_out, const double* rnorm, double* fx, void* stream
+#ifndef VICAN_SWEEP_PART
+
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
 extern "C" int vican_abi_version(void) { return 7; }
@@ -456,6 +468,9 @@ extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t
     return VICAN_OK;
 }
 
+#endif  // !VICAN_SWEEP_PART
+
+#if !defined(VICAN_SWEEP_SPLIT) || defined(VICAN_SWEEP_PART)
 // ---------------------------------------------------------------------------
 // THE HOT KERNEL
 // ---------------------------------------------------------------------------
@@ -905,6 +920,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
 #endif
 }
 
+#endif  // hot kernel
+
+#ifndef VICAN_SWEEP_PART
 // Rt[t], lamT_inv[t] from Z_t (stored in lamT_inv by the MODE 1 sweep), in place; omega bound.
 __global__ __launch_bounds__(256) void dual_svd_kernel(const int32_t* __restrict__ gate, int n_time, double* __restrict__ Rt,
                                                        double* __restrict__ lamT_inv, const double* __restrict__ rnorm,
@@ -934,7 +952,9 @@ __global__ __launch_bounds__(256) void dual_svd_kernel(const int32_t* __restrict
     for (int i = threadIdx.x; i < nloc; i += 256) { Rt[(size_t)t0 * 9 + i] = sh[1][i]; lamT_inv[(size_t)t0 * 9 + i] = sh[0][i]; }
     wg_raise_bound(om, &fx[4]);
 }
+#endif  // !VICAN_SWEEP_PART
 
+#if !defined(VICAN_SWEEP_SPLIT) || defined(VICAN_SWEEP_PART)
 template <typename S, int BLOCK, int MODE, int CP, bool ROWPAR>
 static int launch_sweep2(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* Rt,
                          double* lamT_out, const double* rnorm, double* fx, hipStream_t st) {
@@ -981,6 +1001,30 @@ static int dispatch_sweep(const vican_graph_t* g, const double* lamT_inv, const 
     return launch_sweep<double, 256, MODE>(SWEEP_ARGS);
 #undef SWEEP_ARGS
 }
+#endif  // hot kernel launchers
+
+#if defined(VICAN_SWEEP_PART)
+#define SWEEP_CAT2(a, b) a##b
+#define SWEEP_CAT(a, b) SWEEP_CAT2(a, b)
+extern "C" __attribute__((visibility("hidden"))) int SWEEP_CAT(vican_sweep_part_, VICAN_SWEEP_PART)(SWEEP_PART_ARGS) {
+    return dispatch_sweep<VICAN_SWEEP_PART>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+}
+#else   // everything below: not in the kernel-only parts
+#if defined(VICAN_SWEEP_SPLIT)
+extern "C" {
+__attribute__((visibility("hidden"))) int vican_sweep_part_0(SWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_sweep_part_1(SWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_sweep_part_2(SWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_sweep_part_3(SWEEP_PART_ARGS);
+}
+template <int MODE>
+static int dispatch_sweep(SWEEP_PART_ARGS) {
+    if (MODE == 0) return vican_sweep_part_0(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+    if (MODE == 1) return vican_sweep_part_1(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+    if (MODE == 2) return vican_sweep_part_2(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+    return vican_sweep_part_3(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+}
+#endif
 
 extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart,
                               double* fx, void* stream) {
@@ -1143,3 +1187,4 @@ extern "C" int vican_block_op_z(const vican_graph_t* g, const double* lamT_inv, 
     if (rc < 0) return rc;
     return vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 3, fx + 7, z, stream);
 }
+#endif  // !VICAN_SWEEP_PART
