@@ -1,0 +1,81 @@
+"""Randomised end-to-end parity on the GPU: drop-in API vs the oracle (pinned against the real reference by
+tests/test_oracle_golden.py) on seeded random scenes of varying shape, noise, weights, filter and dtype - the
+combinations the fixed goldens do not enumerate."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import golden_cases as gc                                   # noqa: E402
+from vican_amd import synth                                 # noqa: E402
+from vican_amd.geometry import SE3, geodesic                # noqa: E402
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    mode = "camera" if seed % 4 else "object"
+    n_cam = 1 if mode == "object" else int(rng.integers(2, 30))
+    n_time = int(rng.integers(20, 400))
+    n_marker = int(rng.integers(2, 12)) if mode == "camera" else int(rng.integers(4, 24))
+    scene = synth.make_scene(n_cam=n_cam, n_time=n_time, n_marker=n_marker, seed=seed)
+    sig = float(10.0 ** rng.uniform(-4, -2))
+    if mode == "camera":
+        flat = synth.make_camera_edges(scene, cpt=int(min(n_cam, rng.integers(2, 5))), mpv=int(rng.integers(1, 4)),
+                                       sigma_r=sig, sigma_t=sig, seed=seed + 1)
+    else:
+        flat = synth.make_object_edges(scene, mpv=int(rng.integers(2, 6)), sigma_r=sig, sigma_t=sig, seed=seed + 1)
+    weights = [("w_unit", "w_unit"), ("w_area_mild", "w_area_mild_t")][seed % 2]
+    filt = "f_err" if seed % 3 == 0 else "f_all"
+    dt = np.float32 if seed % 2 else np.float64
+    return mode, scene, flat, weights, filt, dt
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene_matches_oracle(seed):
+    from oracle import bipgo_oracle as orc
+    from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync
+    mode, scene, flat, (wr, wt), filt, dt = make_case(seed)
+    src = synth.edges_to_dict(flat, SE3)
+    nr, nt, ff = gc.CALLABLES[wr], gc.CALLABLES[wt], gc.CALLABLES[filt]
+    info, oinfo, rec = {}, {}, {}
+    scipy_cg = orc.cg
+
+    def cg_and_converged(A, b, *a, **k):        # also the converged solution of the oracle's own system (as make_golden.py)
+        x, code = scipy_cg(A, b, *a, **k)
+        xt, _ = scipy_cg(A, b, rtol=1e-14, maxiter=200000)
+        rec["dist"] = float(np.linalg.norm((np.asarray(x) - np.asarray(xt)).reshape(-1, 3), axis=1).max())
+        return x, code
+
+    orc.cg = cg_and_converged
+    try:
+        if mode == "camera":
+            cons = synth.constraints_from_scene(scene, SE3)
+            res = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, info=info)
+            try:
+                ref = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=True, info=oinfo)
+            except TypeError:
+                # one or two cameras: the reference's eigs(k=5) needs k < 3C - 1 and raises (scipy: "Cannot use
+                # scipy.linalg.eig for sparse A with k >= N - 1"); the product solves these (deliberately more capable)
+                assert info["n_cam"] <= 2
+                assert all(np.isfinite(p.R()).all() and np.isfinite(p.t()).all() for p in res.values())
+                return
+        else:
+            res = object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, info=info)
+            ref = orc.object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=True, info=oinfo)
+    finally:
+        orc.cg = scipy_cg
+    assert [str(k) for k in res] == [str(k) for k in ref]
+    R = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res])
+    Rr = np.stack([np.asarray(ref[k].R(), dtype=np.float64) for k in ref])
+    t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in res])
+    tr = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
+    rot = float(geodesic(R, Rr).max())
+    assert rot < (1e-7 if dt == np.float64 else 5e-6), (seed, rot)
+    # translations: scipy's CG stops at relres 1e-5, `dist` away from the converged solution of its own system; after
+    # a few dozen iterations without re-orthogonalisation rounding-level differences have grown to that order, so two
+    # correct implementations of the same recurrence agree to about that distance (measured over 130 seeds: up to
+    # 1.4 x dist, with identical iteration counts), not better
+    err = float(np.linalg.norm(t - tr, axis=1).max())
+    tol = max(1e-6 if dt == np.float64 else 5e-4, 3.0 * rec["dist"])
+    assert err < tol, (seed, err, rec["dist"])
+    assert abs(info["cg_iters"] - oinfo["cg_iters"]) <= (1 if wt == "w_unit" else 12)
