@@ -30,6 +30,33 @@ def make_case(seed):
     return mode, scene, flat, weights, filt, dt
 
 
+@pytest.mark.parametrize("seed", [5, 10, 15, 20, 25, 30])
+def test_random_scene_direct_solver_matches_oracle(seed):
+    """lsqr_solver="direct" (scipy LSQR semantics on the GPU) on the same random scenes."""
+    from oracle import bipgo_oracle as orc
+    from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync
+    mode, scene, flat, (wr, wt), filt, dt = make_case(seed)
+    src = synth.edges_to_dict(flat, SE3)
+    nr, nt, ff = gc.CALLABLES[wr], gc.CALLABLES[wt], gc.CALLABLES[filt]
+    info = {}
+    if mode == "camera":
+        cons = synth.constraints_from_scene(scene, SE3)
+        res = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "direct", dt, info=info)
+        try:
+            ref = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "direct", dt, loop=True)
+        except TypeError:
+            assert info["n_cam"] <= 2
+            return
+    else:
+        res = object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "direct", dt, info=info)
+        ref = orc.object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "direct", dt, loop=True)
+    t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in res])
+    tr = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
+    err = float(np.linalg.norm(t - tr, axis=1).max())
+    # LSQR stops on atol = btol = 1e-6 (relative): the iterates of two implementations agree far below that accuracy
+    assert err < (1e-5 if dt == np.float64 else 1e-3) * (1.0 + float(np.abs(tr).max())), (seed, err, info.get("lsqr_iters"))
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scene_matches_oracle(seed):
     from oracle import bipgo_oracle as orc
