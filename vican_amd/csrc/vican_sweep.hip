@@ -312,6 +312,22 @@ extern "C" int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t 
 }
 
 // rnorm[t] = sum_c |M_ct|_F ; fx[5] = max |M_ct|_F ; fx[6] = max_t rnorm[t]
+// Raise a bound (fx[4..6]) to the workgroup's maximum with ONE atomic: same-address device-scope atomics are serialised at the memory
+// side (~10 ns each; measured: 1600 per-wavefront atomics = most of a 20 us kernel at T = 100000).
+__device__ __forceinline__ void wg_raise_bound(double om, double* target) {
+    __shared__ double sh_max[16];
+    __syncthreads();                        // callable twice in a row
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = om;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) m = fmax(m, sh_max[i]);
+        if (m > 0.0) atomic_max_pos(target, m);
+    }
+}
+
 template <typename S>
 __global__ void block_norms_kernel(vican_graph_t g, double* __restrict__ rnorm, double* __restrict__ fx) {
     extern __shared__ double lds[];
@@ -334,9 +350,8 @@ __global__ void block_norms_kernel(vican_graph_t g, double* __restrict__ rnorm, 
     __syncthreads();
     double rmax = 0.0;
     for (int r = threadIdx.x; r < nrows; r += blockDim.x) { rnorm[r0 + r] = lds[r]; rmax = fmax(rmax, lds[r]); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { amax = fmax(amax, __shfl_down(amax, o, 64)); rmax = fmax(rmax, __shfl_down(rmax, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomic_max_pos(&fx[5], amax); atomic_max_pos(&fx[6], rmax); }
+    wg_raise_bound(amax, &fx[5]);
+    wg_raise_bound(rmax, &fx[6]);
 }
 
 extern "C" int vican_block_norms(const vican_graph_t* g, double* rnorm, double* fx, void* stream) {
@@ -353,21 +368,6 @@ extern "C" int vican_block_norms(const vican_graph_t* g, double* rnorm, double* 
         hipLaunchKernelGGL(block_norms_kernel<double>, dim3(g->n_chunk), dim3(256), lds, st, *g, rnorm, fx);
     LAUNCH_CHECK("vican_block_norms");
     return VICAN_OK;
-}
-
-// Raise fx[4] to the workgroup's maximum with ONE atomic: same-address device-scope atomics are serialised at the memory
-// side (~10 ns each; measured: 1600 per-wavefront atomics = most of a 20 us kernel at T = 100000).
-__device__ __forceinline__ void wg_raise_bound(double om, double* target) {
-    __shared__ double sh_max[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) om = fmax(om, __shfl_down(om, o, 64));
-    if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = om;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = 0.0;
-        for (int i = 0; i < (int)(blockDim.x + 63) / 64; ++i) m = fmax(m, sh_max[i]);
-        if (m > 0.0) atomic_max_pos(target, m);
-    }
 }
 
 // Initial duals from the stored row sums d_t (bipgo.py:271-276): lamT_inv[t] = I/d_t, and the
