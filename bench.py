@@ -131,6 +131,15 @@ def main():
             self.events.append((e0, e1))
             self.fold_z(z_out)                             # ... then the slab fold
 
+        def block_op_slabs(self, lamT_inv, x):             # Lanczos steps: the fold happens inside the next kernel
+            if not self.record:
+                return super().block_op_slabs(lamT_inv, x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.block_op_raw(lamT_inv, x)
+            e1.record()
+            self.events.append((e0, e1))
+
     K = TimedBackend(g)
     comm = Comm()
     rot = RotationSolver(K, comm)

@@ -267,11 +267,15 @@ int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t
  * three device-side grid barriers instead of seven dependent launches.  ws: scratch of
  * vican_lanczos_coop_ws_doubles(n_cam) doubles; sync_ws: two 32-bit words, zero before the first call
  * (the kernel leaves them zero).  n_cam <= 1024.  Results equal vican_lanczos_cam_step up to the order
- * of the (fixed-order, deterministic) partial sums.                                              */
+ * of the (fixed-order, deterministic) partial sums.
+ * zpart != NULL: z is taken straight from the fixed-point slabs [n_slab][9][n_cam] of the preceding
+ * vican_block_op (folded per workgroup with the conversion of vican_slab_reduce_fx: pa = fx+3, pb = fx+7),
+ * which saves the separate fold launch of every Lanczos step; the argument z is then ignored.    */
 int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam);
 int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                            const double* z, double* ws, double* Hcol, double* beta, double* x_out,
-                           double pivot_floor, uint32_t* sync_ws, void* stream);
+                           double pivot_floor, uint32_t* sync_ws, const void* zpart, int32_t n_slab,
+                           const double* pa, const double* pb, void* stream);
 
 /* Ritz step on the device (replaces the shift-invert ARPACK call of bipgo.py:288 together with the
  * Lanczos steps).  HB[steps][row_stride]: row j = projected column V^T L Q_j ([hw/3][3] row-major,

@@ -413,7 +413,13 @@ class NumpyBackend:
         nrm2_w_out.numpy()[0] = float((wn[:rows] ** 2).sum())
 
     # composites (same call surface as HipBackend)
-    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
+    def block_op_slabs(self, lamT_inv, x):
+        self._zslab = torch.zeros(3 * self.C, 3, dtype=torch.float64)
+        self.block_op(lamT_inv, x, self._zslab)
+
+    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor, from_slabs=False):
+        if from_slabs:
+            z = self._zslab
         n, ka = 3 * (lamC.numel() // 9), 3 * (j + 1)
         self.lap_apply(lamC, V, ld, 3 * j, z, R)
         self.tall_gram(n, V, ld, ka, R, H); self.tall_update(n, V, ld, ka, H, R, Hcol, 0)

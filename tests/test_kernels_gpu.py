@@ -477,3 +477,34 @@ def test_lanczos_seed_matches_the_launch_sequence(n):
     V, beta, xrow = H.zeros(3 * (m + 1) * n), H.zeros(9), H.zeros(n, 3)
     H.lanczos_seed(H.from_numpy(x1), V, n, beta, xrow)
     assert beta.cpu().numpy()[8] == 0.0 and not xrow.cpu().numpy()[:, 2].any() and np.isfinite(xrow.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4], CONFIGS[6]])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_lanczos_step_folding_the_slabs_itself(cfg, dt):
+    """lanczos_cam_step(from_slabs=True) - the cooperative kernel reads z from the sweep's fixed-point slabs - gives
+    bit-identical results to slab fold + step (same exact integer sums, same conversion)."""
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 700 + C, dt, bt, nwg, er)
+    rng = np.random.default_rng(9)
+    n, j, m = 3 * C, 1, 4
+    Q = np.linalg.qr(rng.standard_normal((n, 3 * (j + 1))))[0]
+    V0 = np.zeros((3 * (m + 1), n)); V0[: 3 * (j + 1)] = Q.T
+    lamT, cd = H.empty(T, 9), H.empty(C)
+    H.init_duals(lamT, cd)
+    lamC = H.empty(C, 9); H.scaled_identity(cd, lamC)
+    x = H.from_numpy(np.ascontiguousarray(Q[:, 3 * j: 3 * j + 3]))
+    outs = []
+    for from_slabs in (False, True):
+        V = H.from_numpy(V0.reshape(-1).copy())
+        R, Hs, G = H.empty(3 * n), H.empty(3 * (m + 1) * 3), H.empty(9)
+        Hcol, beta, xo, z = H.zeros(3 * (m + 1) * 3), H.zeros(9), H.empty(n, 3), H.zeros(n, 3)
+        if from_slabs:
+            H.block_op_slabs(lamT, x)
+            H.lanczos_cam_step(lamC, V, n, j, z, R, Hs, G, Hcol, beta, xo, 0.0, from_slabs=True)
+        else:
+            H.block_op(lamT, x, z)
+            H.lanczos_cam_step(lamC, V, n, j, z, R, Hs, G, Hcol, beta, xo, 0.0)
+        outs.append([t.clone() for t in (Hcol, beta, xo, V)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -546,12 +546,16 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
                                                                int j, const double* __restrict__ z, double* ws,
                                                                double* __restrict__ Hcol, double* __restrict__ beta_out,
                                                                double* __restrict__ x_out, double pivot_floor,
-                                                               unsigned int* sync) {
+                                                               unsigned int* sync, const long long* __restrict__ zpart,
+                                                               int n_slab, const double* __restrict__ pa,
+                                                               const double* __restrict__ pb) {
     extern __shared__ double vs[];                       // [ka][COOP_ROWS]: this workgroup's rows of the basis,
     __shared__ double rs[3][COOP_ROWS];                  // read from global memory ONCE for all four uses
     __shared__ double h[KA_MAX * 3], h2[KA_MAX * 3];
     __shared__ double g6[4][6], G6s[6];
     __shared__ double stage[COOP_STAGE];
+    __shared__ long long zred[8][9 * COOP_CAMS];         // slab fold (zpart != NULL): partial sums of 8 slab groups
+    __shared__ double zl[9 * COOP_CAMS];                 // ... and this workgroup's rows of z
     const int nwg = (int)gridDim.x, wg = (int)blockIdx.x, tid = threadIdx.x;
 #ifdef COOP_STAMP
     unsigned long long ts[12]; int nts = 0;
@@ -570,6 +574,30 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         const int k = t / COOP_ROWS, i = t - k * COOP_ROWS;
         vs[t] = i < nsl ? V[(size_t)k * ld + row0 + i] : 0.0;
     }
+    // z straight from the sweep's fixed-point slabs [n_slab][9][n_cam] (what vican_slab_reduce_fx would produce - one
+    // launch less per Lanczos step): this workgroup's cameras only, exact integer sums, same conversion
+    if (zpart) {
+        const int lane = tid & 31, grp = tid >> 5, ncl = c1 - c0;
+        long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane < ncl)
+            for (int s = grp; s < n_slab; s += 8) {
+                const long long* sp = zpart + (size_t)s * 9 * n_cam + c0 + lane;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) acc[q] += sp[(size_t)q * n_cam];
+            }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) zred[grp][q * COOP_CAMS + lane] = acc[q];
+        __syncthreads();
+        const double sc = 1.0 * (pa ? *pa : 1.0) * (pb ? *pb : 1.0);
+        for (int t = tid; t < 9 * COOP_CAMS; t += blockDim.x) {
+            long long sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += zred[k][t];
+            const int q = t / COOP_CAMS, cl = t - q * COOP_CAMS;
+            zl[cl * 9 + q] = (double)sum * sc;
+        }
+        __syncthreads();
+    }
     // A Q_j = Lambda_C Q_j - z on this slice
     if (tid < c1 - c0) {
         const int c = c0 + tid;
@@ -585,7 +613,7 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
 #pragma unroll
             for (int b = 0; b < 3; ++b)
                 rs[b][3 * tid + i] = L[i * 3] * q[b] + L[i * 3 + 1] * q[3 + b] + L[i * 3 + 2] * q[6 + b] -
-                                     z[(size_t)(3 * c + i) * 3 + b];
+                                     (zpart ? zl[tid * 9 + i * 3 + b] : z[(size_t)(3 * c + i) * 3 + b]);
     }
     __syncthreads();
     // two Gram-Schmidt passes against the whole basis
@@ -669,8 +697,10 @@ extern "C" int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam) {
 }
 extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j, const double* z,
                                       double* ws, double* Hcol, double* beta, double* x_out, double pivot_floor,
-                                      uint32_t* sync_ws, void* stream) {
-    if (n_cam <= 0 || n_cam > 32 * COOP_CAMS || !lamC || !V || !z || !ws || !Hcol || !beta || !x_out || !sync_ws || j < 0 ||
+                                      uint32_t* sync_ws, const void* zpart, int32_t n_slab, const double* pa, const double* pb,
+                                      void* stream) {
+    if (n_cam <= 0 || n_cam > 32 * COOP_CAMS || !lamC || !V || (!z && !zpart) || (zpart && n_slab <= 0) || !ws || !Hcol || !beta ||
+        !x_out || !sync_ws || j < 0 ||
         3 * (j + 1) > 128 || ld < 3 * n_cam)                 // basis slice in LDS: 128 x 96 doubles = 96 KB
         return set_err(VICAN_ERR_ARG, "vican_lanczos_cam_coop: bad argument");
     const int nwg = (n_cam + COOP_CAMS - 1) / COOP_CAMS;                    // <= 32 workgroups: always co-resident
@@ -682,7 +712,7 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
         configured = 128 * COOP_ROWS * 8;
     }
     hipLaunchKernelGGL(lanczos_cam_coop_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, ws, Hcol,
-                       beta, x_out, pivot_floor, sync_ws);
+                       beta, x_out, pivot_floor, sync_ws, (const long long*)zpart, n_slab, pa, pb);
     LAUNCH_CHECK("vican_lanczos_cam_coop");
     return VICAN_OK;
 }

@@ -168,6 +168,9 @@ class HipBackend:
         self.dev = graph.device
         self.C, self.T = graph.n_cam, graph.n_time
         self.storage_f64 = graph.storage_dtype == torch.float64
+        # folding the sweep's slabs inside the (<= 32 workgroup) camera-side kernel pays off while there are few of them:
+        # measured -3..-8 % of the rotation stage at 40 slabs (large_shop), +1.3 % at 256 (stress) - tools/ab_fold.py
+        self.fold_in_step_ok = graph.n_wg <= 64
         self._gref = C.byref(graph.desc)
         nwg = graph.n_wg
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
@@ -259,16 +262,24 @@ class HipBackend:
             self._gram_ws = torch.empty(_lib.GRAM_WS_DOUBLES, dtype=torch.float64, device=self.dev)
         return self._gram_ws
 
-    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor):
+    def block_op_slabs(self, lamT_inv, x):
+        """The sweep of P x only: the result stays in the fixed-point slabs for lanczos_cam_step(from_slabs=True)."""
+        self.block_op_raw(lamT_inv, x)
+
+    def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor, from_slabs=False):
         n_nodes = lamC.numel() // 9             # C for the eliminated solver, C + T for the general one
         if self.coop_cam_step and n_nodes == self.C:
             if self._coop_ws is None:
                 self._coop_ws = torch.zeros(int(self.lib.vican_lanczos_coop_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
                 self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            fxp = self.g.fx.data_ptr()
+            slabs = (_ptr(self.zpart), self.g.n_wg, C.c_void_p(fxp + 24), C.c_void_p(fxp + 56)) if from_slabs else (None, 0, None, None)
             self._ck(self.lib.vican_lanczos_cam_coop(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(self._coop_ws), _ptr(Hcol),
-                                                     _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), _stream()),
-                     "vican_lanczos_cam_coop")
+                                                     _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), *slabs,
+                                                     _stream()), "vican_lanczos_cam_coop")
             return
+        if from_slabs:
+            self.fold_z(z)
         ws = self._gram_workspace(3 * n_nodes)
         self._ck(self.lib.vican_lanczos_cam_step(n_nodes, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(R), _ptr(H), _ptr(G),
                                                  _ptr(Hcol), _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(ws),

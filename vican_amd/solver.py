@@ -110,13 +110,21 @@ class RotationSolver:
         self.zraw = K.empty(n, 3)                   # P_new rc from the fused dual update (see _tail)
         self.z_ready = False
         self.fuse_dual_op = True
+        # single rank, few slabs: the camera-side Lanczos kernel folds the sweep's slabs itself (one launch less per step)
+        self.fold_in_step = bool(getattr(K, "fold_in_step_ok", True))
         self.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
 
     # -- operator ------------------------------------------------------------
     def apply_P(self, x, z):
+        """z = P x for the next lanczos_cam_step.  Single rank: the sweep's slabs are folded inside that step's kernel
+        (returns True: z itself is not written); sharded: fold, then all-reduce the camera-side partials."""
+        self.stats["sweeps"] += 1
+        if self.comm.world == 1 and self.fold_in_step and hasattr(self.K, "block_op_slabs"):
+            self.K.block_op_slabs(self.lamT, x)
+            return True
         self.K.block_op(self.lamT, x, z)
         self.comm.allreduce(z)
-        self.stats["sweeps"] += 1
+        return False
 
     # -- spectral step ---------------------------------------------------------
     def _seed_block(self, x0, with_z=False):
@@ -171,14 +179,15 @@ class RotationSolver:
             prev_res, floor_hit, prev_steps, first = None, False, 0, True
             while True:
                 j = steps
+                in_slabs = False
                 if not (j == 0 and have_z):
                     # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
                     #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
-                    self.apply_P(self.xrow, self.z)
+                    in_slabs = bool(self.apply_P(self.xrow, self.z))
                 # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
                 # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
                 K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
-                                   self.HB[j, self.hw:], self.xrow, self.pivot_floor)
+                                   self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
                 steps += 1
                 total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
