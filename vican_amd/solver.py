@@ -158,6 +158,7 @@ class RotationSolver:
         failed one cancels the speculative work on the device."""
         K, n, ld = self.K, self.n, self.ld
         total_steps, floor_at = 0, 0
+        th4_last = float("nan")                     # fourth smallest Ritz value of the most recent check that had one
         for restart in range(self.max_restarts + 1):
             have_z = restart == 0 and self.z_ready
             self._seed_block(x0, with_z=have_z)
@@ -199,6 +200,8 @@ class RotationSolver:
                             tail()
                     st = K.wait_status(handle)
                     r, stop, conv, floor_hit, eff, breakdown = st[0], st[2] != 0, st[3] != 0, st[4] != 0, int(st[5]), st[6] != 0
+                    if st[15] == st[15]:
+                        th4_last = float(st[15])
                     # noise floor: with f32 blocks the products carry ~6e-8 relative rounding, so the Ritz
                     # residual stalls somewhere below `floor_tol`; a stalled residual there is converged
                     # (the rule itself is evaluated by vican_ritz; here only the bookkeeping for later solves)
@@ -216,7 +219,8 @@ class RotationSolver:
                     near_floor = self.floor_tol > 1e-12 and r <= self.floor_tol
                     next_check = min(steps + (1 if (steps < 8 and not self.small_graph) or near_floor else self.check_every), self.m_max)
             th = st[7:12].copy()
-            self.th4 = float(st[15])                    # fourth smallest Ritz value (NaN if the basis is too small)
+            self.th4 = th4_last                         # (a restart from converged Ritz vectors may exhaust its Krylov space
+                                                        #  after one block: that check has no fourth value of its own)
             if conv:
                 self.tail_done = tail is not None
                 break
