@@ -126,6 +126,13 @@ class LocalGraph:
         blk = blk.contiguous(); a = a.to(blk.dtype).contiguous()
         if have_t:
             w, u, v = (t.to(dev, torch.float64).contiguous() for t in (w, u, v))
+        if self.n_edges == 0:
+            # a rank without rows (more ranks than timesteps): empty tensors have NULL data pointers, which the C entry
+            # points reject - hand them one zero element each (nothing is read: there are no chunks)
+            col = torch.zeros(1, dtype=torch.int32, device=dev)
+            blk, a = torch.zeros(9, dtype=blk.dtype, device=dev), torch.zeros(1, dtype=blk.dtype, device=dev)
+            if have_t:
+                w, u, v = (torch.zeros(k, dtype=torch.float64, device=dev) for k in (1, 3, 3))
         st = _stream()
         perm_ws = torch.empty(nslot, dtype=torch.int32, device=dev)
         _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w), _ptr(u), _ptr(v),
