@@ -769,13 +769,29 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 }
                 ysum[i] = (double)fix_total<S>(s) * y_inv;
             }
+            // MODE 0: one thread per (row, row of its dual block): 24 contiguous bytes of lamT_inv per thread, three
+            // outputs - a third of the loop trips (and exposed L2 latencies) of one thread per output; the first trip's
+            // dual entries are requested before the barrier
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+            if (MODE == 0 && tid < nrows * 3) {
+                const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)tid * 3;
+                l0 = L[0]; l1 = L[1]; l2 = L[2];
+            }
             __syncthreads();
-            for (int i = tid; i < nrows * 9; i += BLOCK) {
-                if (MODE == 0) {
-                    const int r = i / 9, oo = i - 9 * r, a3 = oo / 3, b3 = oo - 3 * a3;
-                    const double* L = lamT_inv + (size_t)(r0 + r) * 9 + a3 * 3;
-                    wv[i] = pre_scale<S>(dot3<double>(L[0], ysum[r * 9 + b3], L[1], ysum[r * 9 + 3 + b3], L[2], ysum[r * 9 + 6 + b3]), z_scale);
-                } else {
+            if (MODE == 0) {
+                for (int i = tid; i < nrows * 3; i += BLOCK) {
+                    if (i != tid) {
+                        const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)i * 3;
+                        l0 = L[0]; l1 = L[1]; l2 = L[2];
+                    }
+                    const int r = i / 3;
+                    const double* yr = ysum + r * 9;
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; ++b3)
+                        wv[i * 3 + b3] = pre_scale<S>(dot3<double>(l0, yr[b3], l1, yr[3 + b3], l2, yr[6 + b3]), z_scale);
+                }
+            } else {
+                for (int i = tid; i < nrows * 9; i += BLOCK) {
                     lamT_out[(size_t)r0 * 9 + i] = ysum[i];
                     if (MODE == 2) wv[i] = pre_scale<S>(lamT_inv[(size_t)r0 * 9 + i], z_scale);
                 }
