@@ -685,6 +685,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             L0 = L[0]; L1 = L[1]; L2 = L[2];
         }
         if (MODE == 2 && wave < nrows && o < 9) L0 = lamT_inv[(size_t)(r0 + wave) * 9 + o];     // x_time entry o of the row
+        if (ROWPAR && MODE == 0 && tid < nrows * 3) {       // many short rows: this thread's first (row, dual-block row) item
+            const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)tid * 3;
+            L0 = L[0]; L1 = L[1]; L2 = L[2];
+        }
         __builtin_amdgcn_sched_barrier(0);                              // keep these loads ahead of the prefetch
         if (kpref < nchunk) load_chunk<S, EPL>(nxt, g, kpref, tid);      // prefetch: lands during this/next chunk
 
@@ -772,15 +776,17 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             // MODE 0: one thread per (row, row of its dual block): 24 contiguous bytes of lamT_inv per thread, three
             // outputs - a third of the loop trips (and exposed L2 latencies) of one thread per output; the first trip's
             // dual entries are requested before the barrier
-            double l0 = 0.0, l1 = 0.0, l2 = 0.0;
-            if (MODE == 0 && tid < nrows * 3) {
-                const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)tid * 3;
-                l0 = L[0]; l1 = L[1]; l2 = L[2];
+            // (first trip: requested at the top of the body, ahead of the chunk prefetch; second trip: before the barrier)
+            double l0 = L0, l1 = L1, l2 = L2, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+            if (MODE == 0 && tid + BLOCK < nrows * 3) {
+                const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)(tid + BLOCK) * 3;
+                m0 = L[0]; m1 = L[1]; m2 = L[2];
             }
             __syncthreads();
             if (MODE == 0) {
                 for (int i = tid; i < nrows * 3; i += BLOCK) {
-                    if (i != tid) {
+                    if (i == tid + BLOCK) { l0 = m0; l1 = m1; l2 = m2; }
+                    else if (i != tid) {
                         const double* L = lamT_inv + (size_t)r0 * 9 + (size_t)i * 3;
                         l0 = L[0]; l1 = L[1]; l2 = L[2];
                     }
