@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: edges/s through the primal-dual bipartite SE(3) solve.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|large_shop]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stress|large_shop|sparse] [--scaling weak|strong]
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one fresh child
+process per GPU, before this process touches the GPU) and relays rank 0's JSON line; under
+``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` it is one of the ranks.
 
 One "step" = one complete solve of the synthetic graph resident in HBM: rotation
 stage (maxiter = 4 primal-dual iterations, each = block-Lanczos spectral step +
 projections + dual updates) followed by the translation CG.  ``value`` = merged
 (camera,timestep) edges x primal-dual iterations per second of WHOLE-step time,
-summed over ranks (weak scaling: every rank owns ``--timesteps`` rows of one graph
-and a replica of the camera side).  Prints ONE JSON line on rank 0 (contract in
+summed over ranks (``--scaling weak``, default for stress/sparse: every rank owns ``--timesteps``
+rows of one graph; ``--scaling strong``, default for large_shop: the ``--timesteps`` rows of ONE graph
+are split over the ranks by vican_amd.bipgo._shard_rows; the camera side is replicated either way).  Prints ONE JSON line on rank 0 (contract in
 the task statement) with two extra objects:
 
   roofline      dominant kernel = the fused block operator ``block_sweep_kernel<.,.,0>``
@@ -21,7 +26,8 @@ the task statement) with two extra objects:
 Workloads (BASELINE.json configs): ``stress`` = configs[4] "1k cameras x 100k timesteps"
 at visibility rho = 0.25 (25 M merged edges, 1 GB of f32 blocks per GPU: HBM-bound;
 default, it is the largest single-GPU configuration) and ``large_shop`` = configs[2]
-(340 cameras x 10k timesteps x 4 cams/timestep: latency-bound, wall-clock reported).
+(340 cameras x 10k timesteps x 4 cams/timestep: latency-bound, wall-clock reported); ``sparse`` = a long
+realistic capture (100 cameras x 2 M timesteps x 8 cams/timestep, 16 M merged edges: HBM-bound with short rows).
 """
 import argparse
 import json
@@ -43,9 +49,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="stress", choices=["stress", "large_shop"])
+    ap.add_argument("--workload", default="stress", choices=["stress", "large_shop", "sparse"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: --timesteps rows per GPU; strong: --timesteps rows in total, split over the GPUs "
+                         "(default: strong for large_shop, weak otherwise)")
     ap.add_argument("--cams", type=int, default=None)
-    ap.add_argument("--timesteps", type=int, default=None, help="timestep rows PER GPU")
+    ap.add_argument("--timesteps", type=int, default=None, help="timestep rows per GPU (weak) / in total (strong)")
     ap.add_argument("--cams-per-t", type=int, default=None)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage type of the 3x3 blocks")
     ap.add_argument("--maxiter", type=int, default=4)
@@ -58,8 +67,10 @@ def parse():
 
 
 def cpu_baseline(C, cpt, T_sample, maxiter, seed=0, loop=False):
-    """Oracle rotation loop (explicit P via SpGEMM, eigs shift-invert, batched LAPACK svd) on a
-    reduced-T sample of the same workload; single host core (ARPACK/SuperLU/LAPACK 3x3)."""
+    """The oracle's FULL solve - rotation loop (explicit P via SpGEMM, eigs shift-invert, LAPACK 3x3 svd) followed by
+    the translation stage (incidence matrix, normal equations, scipy cg) - on a reduced-T sample of the same
+    workload; single host core (ARPACK/SuperLU/LAPACK 3x3).  loop=True is the reference-shaped variant (per-node
+    Python loops, what a user of the reference runs today), loop=False the vectorised one (batched numpy svd)."""
     from oracle import bipgo_oracle as orc
     from vican_amd import synth
     g = synth.make_merged_graph_torch(C, T_sample, cpt, torch.device("cpu"), torch.float64, seed=seed)
@@ -68,23 +79,152 @@ def cpu_baseline(C, cpt, T_sample, maxiter, seed=0, loop=False):
     cam = g["col"].numpy().astype(np.int64)
     blocks = g["blk"].numpy().reshape(-1, 3, 3)
     a = g["a"].numpy()
-    t0 = time.perf_counter()
-    orc.so3sync_arrays(C, T_sample, cam, time_idx, blocks, a, maxiter, dtype=np.float32, loop=loop)
-    dt = time.perf_counter() - t0
     E = len(cam)
+    # translation stage inputs: one source edge per merged edge (k_t = a, measured translation u / w, root marker)
+    w, u = g["w"].numpy(), g["u"].numpy()
+    eye = np.broadcast_to(np.eye(3), (E, 3, 3))
+    t0 = time.perf_counter()
+    Rc, Rt = orc.so3sync_arrays(C, T_sample, cam, time_idx, blocks, a, maxiter, dtype=np.float32, loop=loop)
+    t1 = time.perf_counter()
+    info = {}
+    orc.translation_arrays(C + T_sample, cam, C + time_idx, Rc[cam], Rt[time_idx], u / w[:, None], eye, np.zeros((E, 3)),
+                           np.sqrt(w), "conjugate_gradient", np.float32, info, loop)
+    t2 = time.perf_counter()
+    dt = t2 - t0
     return {"value": E * maxiter / dt, "unit": "edges/s", "cores": 1, "kind": "port",
-            "sample": "oracle.so3sync_arrays (explicit P SpGEMM + scipy eigs(k=5,sigma=-1e-6) + %s numpy svd), " % (
-                "per-node (reference-shaped)" if loop else "batched") +
-                      "C=%d, T=%d, %d cams/timestep, E=%d merged edges, maxiter=%d, f32, %.1f s on 1 of %d host cores; "
-                      "rotation loop only" % (C, T_sample, cpt, E, maxiter, dt, os.cpu_count()),
-            "seconds": dt}
+            "sample": "oracle full solve = so3sync_arrays (explicit P SpGEMM + scipy eigs(k=5,sigma=-1e-6) + %s numpy svd) "
+                      "+ translation_arrays (incidence matrix, J^T J, scipy cg: %s iterations), " % (
+                          "per-node (reference-shaped)" if loop else "batched (vectorised)", info.get("cg_iters")) +
+                      "C=%d, T=%d, %d cams/timestep, E=%d merged edges, maxiter=%d, f32, %.1f s (rotation %.1f s + translation "
+                      "%.1f s) on 1 of %d host cores" % (C, T_sample, cpt, E, maxiter, dt, t1 - t0, t2 - t1, os.cpu_count()),
+            "seconds": dt, "rotation_seconds": t1 - t0, "translation_seconds": t2 - t1,
+            "rotation_edges_per_s": E * maxiter / (t1 - t0)}
+
+
+def cpu_baselines(C, cpt, T_sample, maxiter):
+    """Both variants SURVEY.md 8(d) asks for; the headline object is the vectorised one (so that the GPU/CPU ratio is
+    not inflated by interpreter overhead), the reference-shaped one rides along."""
+    vec = cpu_baseline(C, cpt, T_sample, maxiter, loop=False)
+    try:
+        ref = cpu_baseline(C, cpt, T_sample, maxiter, loop=True)
+    except Exception as exc:
+        ref = {"value": None, "error": repr(exc)}
+    out = dict(vec)
+    out["variants"] = {"vectorised": vec, "reference_shaped": ref}
+    return out
+
+
+def large_shop_wall_clock(args, dev, tdt, comm):
+    """Wall-clock of full solves of a large_shop-sized graph (BASELINE configs[2]): warm (solver objects reused, what a
+    time series of captures pays per solve), cold (graph already packed, fresh backend + solver objects: what one call
+    of the drop-in pays after the host front-end), pack (CSR arrays resident in HBM -> chunked layout + graph
+    constants), and the host front-end (`flatten`: edge dict -> merged CSR, vectorised NumPy + the user's callables)
+    on a dict of the same size; beside them the oracle's full solve on the host (both variants)."""
+    from vican_amd import frontend, synth
+    from vican_amd.device import HipBackend, LocalGraph
+    from vican_amd.solver import RotationSolver, TranslationSolver
+    Cl, Tl2, cl = 340, 10000, 4
+    gr = synth.make_merged_graph_torch(Cl, Tl2, cl, dev, tdt, seed=0)
+
+    def pack():
+        return LocalGraph(Cl, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+
+    def solve(rot, tr, K):
+        rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+        tr.poll_every = 8
+        rc, Rt = rot.run(args.maxiter)
+        tr.setup(rc, Rt)
+        tr.solve(3 * (Cl + Tl2))
+        K.synchronize()
+
+    g2 = pack()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g2 = pack()
+    torch.cuda.synchronize()
+    t_pack = (time.perf_counter() - t0) / 3
+    cold = []
+    for _ in range(3):                                   # fresh backend + solvers each time (first one also pays module warm-up)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K2 = HipBackend(g2)
+        rot2, tr2 = RotationSolver(K2, comm), TranslationSolver(K2, comm)
+        solve(rot2, tr2, K2)
+        cold.append(time.perf_counter() - t0)
+    for _ in range(2):
+        solve(rot2, tr2, K2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        solve(rot2, tr2, K2)
+    torch.cuda.synchronize()
+    res = {"ms_per_solve": (time.perf_counter() - t0) / 5 * 1e3, "cold_ms": min(cold[1:]) * 1e3, "first_call_ms": cold[0] * 1e3,
+           "t_pack_ms": t_pack * 1e3, "cameras": Cl, "timesteps": Tl2, "merged_edges": g2.n_edges,
+           "lanczos_steps": rot2.stats["lanczos_steps"], "cg_iters": tr2.info.get("cg_iters"), "solves_timed": 5}
+    try:                                                 # host front-end on an edge dict of this size (2 markers per view)
+        from vican_amd.geometry import SE3
+        scene = synth.make_scene(n_cam=Cl, n_time=Tl2, n_marker=6, seed=0)
+        flat = synth.make_camera_edges(scene, cpt=cl, mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=1)
+        src = synth.edges_to_dict(flat, SE3)
+        cons = synth.constraints_from_scene(scene, SE3)
+        unit, keep = (lambda e: 1.0), (lambda e: True)
+        t0 = time.perf_counter()
+        prob = frontend.flatten(src, cons, unit, unit, keep, np.float32)
+        res["t_flatten_ms"] = (time.perf_counter() - t0) * 1e3
+        res["flatten_source_edges"] = int(prob.n_src)
+    except Exception as exc:
+        res["t_flatten_ms"] = None
+        res["flatten_error"] = repr(exc)
+    if not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baselines(Cl, cl, Tl2, args.maxiter)
+        except Exception as exc:
+            res["cpu_baseline"] = {"value": None, "error": repr(exc)}
+    return res
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: start N fresh rank processes (this process has not touched the GPU and never
+    does), relay rank 0's output, fail if any rank fails.  Never re-executes the current process."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+    if ndev < n and "VICAN_DIST_BACKEND" not in env:
+        # fewer devices than ranks: RCCL refuses two ranks on one GPU, so the ranks share devices over gloo
+        # (functional run of the sharded path; the JSON line reports `devices`)
+        env["VICAN_DIST_BACKEND"] = "gloo"
+        print("bench.py: %d ranks on %d device(s): ranks share devices, collectives over gloo" % (n, ndev), file=sys.stderr)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit("bench.py: rank exit codes %s" % rcs)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under "
+                 "torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
     # one process per GPU; VICAN_DIST_BACKEND=gloo lets several ranks share one device (functional test of
@@ -104,12 +244,22 @@ def main():
     from vican_amd.device import HipBackend, LocalGraph
     from vican_amd.solver import Comm, RotationSolver, TranslationSolver
 
+    from vican_amd.bipgo import _shard_rows
     if args.workload == "stress":
-        C, Tl, cpt = args.cams or 1000, args.timesteps or 100000, args.cams_per_t or 250
+        C, Tn, cpt = args.cams or 1000, args.timesteps or 100000, args.cams_per_t or 250
+    elif args.workload == "sparse":
+        C, Tn, cpt = args.cams or 100, args.timesteps or 2000000, args.cams_per_t or 8
     else:
-        C, Tl, cpt = args.cams or 340, args.timesteps or 10000, args.cams_per_t or 4
+        C, Tn, cpt = args.cams or 340, args.timesteps or 10000, args.cams_per_t or 4
+    scaling = args.scaling or ("strong" if args.workload == "large_shop" else "weak")
+    if scaling == "weak":
+        T_total, r0, Tl = Tn * world, rank * Tn, Tn
+    else:                                               # one graph of Tn rows, split like solve_problem does
+        T_total = Tn
+        r0, r1 = _shard_rows(Tn, world, rank)
+        Tl = r1 - r0
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    gr = synth.make_merged_graph_torch(C, Tl, cpt, dev, tdt, seed=0, t_offset=rank * Tl)
+    gr = synth.make_merged_graph_torch(C, Tl, cpt, dev, tdt, seed=0, t_offset=r0)
     g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"],
                    block_threads=args.block_threads, n_copy=args.n_copy)
     E_local = g.n_edges
@@ -144,7 +294,7 @@ def main():
     comm = Comm()
     rot = RotationSolver(K, comm)
     tr = TranslationSolver(K, comm)
-    n_unknowns = 3 * (C + Tl * world)
+    n_unknowns = 3 * (C + T_total)
 
     def step(split=False):
         """One full solve.  split=True also syncs between the rotation and the translation stage to time them
@@ -196,7 +346,11 @@ def main():
         kern_ms = kern_ms[kern_ms >= 0.1 * np.median(kern_ms)]
     op_bytes = g.op_bytes()
     achieved = op_bytes / (kern_ms.mean() * 1e-3) / 1e9 if len(kern_ms) else 0.0
-    E_total = E_local * world
+    cnt = torch.tensor([float(E_local), float(comm.n_allreduce)], dtype=torch.float64, device=dev)
+    n_allreduce_total = comm.n_allreduce
+    if world > 1:
+        torch.distributed.all_reduce(cnt)
+    E_total = int(cnt[0].item())
     value = E_total * args.maxiter * args.steps / elapsed
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
     # (profiles/<tag>_sweep_counters.json, written by tools/collect_profiles.py); null if none matches
@@ -213,13 +367,15 @@ def main():
     out = {
         "metric": "edges/sec through bipartite_se3sync primal-dual iter",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s: %d cameras x %d timesteps/GPU x %d cams/timestep, %d merged edges/GPU, "
-                               "maxiter=%d + CG translation solve, blocks stored %s" % (
-                                   args.workload, C, Tl, cpt, E_local, args.maxiter, args.dtype),
+        "config": {"workload": "%s: %d cameras x %d timesteps (%s) x %d cams/timestep, %d merged edges in total "
+                               "(%d on rank 0), maxiter=%d + CG translation solve, blocks stored %s" % (
+                                   args.workload, C, T_total, "%d per GPU" % Tn if scaling == "weak" else "split over the GPUs",
+                                   cpt, E_total, E_local, args.maxiter, args.dtype),
                    "arithmetic": "%s block products, exact 64-bit fixed-point accumulation, f64 camera side and CG" % args.dtype,
-                   "parallelism": "timestep-sharded x%d, camera side replicated" % world},
+                   "parallelism": "timestep-sharded x%d, camera side replicated" % world,
+                   "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
         "roofline": {"bound": "hbm", "kernel": "block_sweep_kernel<MODE=0> (vican_block_op)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
@@ -231,7 +387,9 @@ def main():
                    "lanczos_checks": rot.stats.get("n_check"),
                    "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
                    "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
-                   "rot_edges_per_s": E_total * args.maxiter / t_rot if t_rot else None},
+                   "rot_edges_per_s": E_total * args.maxiter / t_rot if t_rot else None,
+                   "edges_rank0": E_local, "rows_rank0": Tl,
+                   "n_allreduce_per_solve": n_allreduce_total / max(args.steps + args.warmup, 1)},
     }
     if rank == 0 and world == 1 and args.workload == "stress" and not args.no_large_shop:
         # second half of BASELINE.json's metric: wall-clock of a full solve of a large_shop-sized graph
@@ -239,35 +397,13 @@ def main():
         try:
             del K, g, rot, tr
             torch.cuda.empty_cache()
-            Cl, Tl2, cl = 340, 10000, 4
-            gr = synth.make_merged_graph_torch(Cl, Tl2, cl, dev, tdt, seed=0)
-            g2 = LocalGraph(Cl, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
-            K2 = HipBackend(g2)
-            rot2, tr2 = RotationSolver(K2, comm), TranslationSolver(K2, comm)
-
-            def solve2():
-                rot2.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
-                tr2.poll_every = 8
-                rc, Rt = rot2.run(args.maxiter)
-                tr2.setup(rc, Rt)
-                tr2.solve(3 * (Cl + Tl2))
-                K2.synchronize()
-            for _ in range(2):
-                solve2()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                solve2()
-            torch.cuda.synchronize()
-            out["detail"]["large_shop_wall_clock"] = {
-                "ms_per_solve": (time.perf_counter() - t0) / 5 * 1e3, "cameras": Cl, "timesteps": Tl2, "merged_edges": g2.n_edges,
-                "lanczos_steps": rot2.stats["lanczos_steps"], "cg_iters": tr2.info.get("cg_iters"), "solves_timed": 5}
+            out["detail"]["large_shop_wall_clock"] = large_shop_wall_clock(args, dev, tdt, comm)
         except Exception as exc:
             out["detail"]["large_shop_wall_clock"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        Ts = args.cpu_sample_timesteps or (300 if args.workload == "stress" else 10000)
+        Ts = args.cpu_sample_timesteps or {"stress": 300, "sparse": 20000}.get(args.workload, 10000)
         try:
-            out["cpu_baseline"] = cpu_baseline(C, cpt, Ts, args.maxiter, loop=(args.workload == "large_shop"))
+            out["cpu_baseline"] = cpu_baselines(C, cpt, Ts, args.maxiter)
         except Exception as exc:                                  # the baseline must never sink the line
             out["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if rank == 0:

@@ -292,7 +292,8 @@ int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t
  * status[VICAN_RITZ_STATUS_DOUBLES]: [0] r, [1] max|theta|, [2] stop, [3] converged, [4] floor_hit,
  * [5] eff, [6] breakdown (all pivots of the last beta zero), [7..9] three smallest Ritz values,
  * [10..11] the two largest (NaN when 3 eff < 5), [12] r (read back as r_prev by the next call),
- * [13] Jacobi sweeps, [14] unscaled residual, [15] 4th smallest Ritz value (NaN if none).  steps <= VICAN_RITZ_MAX_STEPS.    */
+ * [13] 5th smallest Ritz value (NaN if none; with [7..9] and [15] the counterpart of the five values eigs(k=5, sigma=-1e-6)
+ * returns, whose max|.| <= 1e-6 ends the reference's loop, bipgo.py:283), [14] unscaled residual, [15] 4th smallest Ritz value (NaN if none).  steps <= VICAN_RITZ_MAX_STEPS.    */
 #define VICAN_RITZ_MAX_STEPS 32
 #define VICAN_RITZ_STATUS_DOUBLES 16
 int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, int32_t flags,

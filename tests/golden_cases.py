@@ -92,7 +92,7 @@ MAXITER = 4
 LARGE_SHOP = dict(mode="camera", scene=dict(n_cam=340, n_time=10000, n_marker=12, seed=91),
                   edges=dict(cpt=4, mpv=2, sigma_r=1e-2, sigma_t=1e-2, seed=92),
                   noise_r="w_area_mild", noise_t="w_area_mild_t", filt="f_all",
-                  runs=[("conjugate_gradient", "float32")])
+                  runs=[("conjugate_gradient", "float32"), ("conjugate_gradient", "float64")])
 
 
 def build_flat(case: dict):

@@ -105,7 +105,7 @@ class NumpyBackend:
         st[:7] = [r, scale, float(stop), float(converged), float(floor_hit), eff, float(breakdown)]
         st[7:10] = th[:3]
         st[10:12] = th[-2:] if ka >= 5 else np.nan
-        st[12], st[13], st[14], st[15] = r, 0.0, resmax, (th[3] if ka >= 4 else np.nan)
+        st[12], st[13], st[14], st[15] = r, (th[4] if ka >= 5 else np.nan), resmax, (th[3] if ka >= 4 else np.nan)
         gate[0] = 1 if (stop and converged) else 0
 
     # allocation

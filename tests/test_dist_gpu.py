@@ -1,0 +1,69 @@
+"""BASELINE configs[3] on the hardware that is available: the timestep-sharded solve through the HIP kernels with TWO
+ranks.  A 1-GPU box cannot run RCCL with two ranks on one device, so the ranks share cuda:0 and the collectives go over
+gloo (VICAN_DIST_BACKEND=gloo) - every kernel launch, shard, all-reduce call site and the bench launcher are the ones
+an 8-GPU RCCL run uses; only the transport differs.
+
+The rank processes are fresh children (never an exec of a process that has touched the GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ, VICAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_two_ranks_sharded_hip_solve_matches_single_rank():
+    """tools/dist_probe.py: tiny and uneven problems (including a rank WITHOUT rows) in f64 and f32, sharded over
+    two ranks, against the single-rank solve of the same problem inside the same processes."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_probe.py")]
+    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(res.stdout[-3000:])
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "dist probe: mismatches 0" in res.stdout
+
+
+@pytest.mark.parametrize("workload,scaling", [("large_shop", "strong"), ("stress", "weak")])
+def test_bench_launches_its_own_ranks(workload, scaling):
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports n_gpus = 2; large_shop is
+    strong scaling (one graph of 10 000 rows split over the ranks), stress weak (rows per GPU)."""
+    extra = ["--cams", "200", "--timesteps", "4000", "--cams-per-t", "50"] if workload == "stress" else []
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+           "--no-cpu-baseline", *extra]
+    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["detail"]["cg_converged"] and out["value"] > 0
+    assert out["detail"]["n_allreduce_per_solve"] > 0
+    if scaling == "strong":
+        assert out["detail"]["rows_rank0"] == 5000
+    else:
+        assert out["detail"]["rows_rank0"] == 4000
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr

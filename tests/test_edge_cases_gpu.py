@@ -69,6 +69,22 @@ def test_degree_one_timesteps_are_legal():
     assert abs(out_h[4]["cg_iters"] - out_n[4]["cg_iters"]) <= 1
 
 
+def test_maxiter_zero_raises_like_the_reference():
+    """maxiter = 0: the reference's loop body never runs and it dies on the unbound `r_c` (bipgo.py:346); the drop-in
+    must not hand uninitialised device buffers to the translation stage."""
+    from vican_amd.bipgo import bipartite_se3sync, object_bipartite_se3sync
+    from vican_amd.geometry import SE3
+    scene = synth.make_scene(n_cam=4, n_time=10, n_marker=3, seed=1)
+    src = synth.edges_to_dict(synth.make_camera_edges(scene, cpt=2, mpv=2, seed=2), SE3)
+    cons = synth.constraints_from_scene(scene, SE3)
+    one = lambda e: 1.0
+    with pytest.raises(UnboundLocalError, match="r_c"):
+        bipartite_se3sync(src, cons, one, one, lambda e: True, 0, "conjugate_gradient", np.float64)
+    osrc = synth.edges_to_dict(synth.make_object_edges(scene, mpv=3, seed=3), SE3)
+    with pytest.raises(UnboundLocalError, match="r_c"):
+        object_bipartite_se3sync(osrc, one, one, lambda e: True, 0, "conjugate_gradient", np.float32)
+
+
 def test_api_error_paths():
     from vican_amd.bipgo import bipartite_se3sync
     from vican_amd.geometry import SE3
@@ -95,12 +111,17 @@ def test_disconnected_graph_warns_and_still_returns():
     case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", g)
     both = dict(src)
     both.update({("x" + c, "9" + tm): v for (c, tm), v in src.items()})
+    info = {}
     with pytest.warns(DisconnectedGraphWarning, match="2 connected components"):
-        res = bipartite_se3sync(both, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+        res = bipartite_se3sync(both, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64, info=info)
     assert len(res) == 2 * (len(g["gt_R_cam"]) + len(g["gt_R_obj"]))
     assert all(np.isfinite(p.R()).all() and np.isfinite(p.t()).all() for p in res.values())
     # inside the component of the gauge camera relative rotations equal those of the single-rig solve
-    one = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+    # (two components = six null vectors: all five eigenvalues the reference would see are ~0, so its loop ends after
+    #  the first iteration - bipgo.py:283 - and so does the product's when its fourth and fifth Ritz values say so)
+    n_it = info["early_exit"] or gc.MAXITER
+    assert len(info["lanczos_steps"]) == n_it
+    one = bipartite_se3sync(src, cons, nr, nt, ff, n_it, "conjugate_gradient", np.float64)
     keys = [k for k in one if "_" not in k]
     ra = np.stack([res[k].R() @ res[keys[0]].R().T for k in keys])
     rb = np.stack([one[k].R() @ one[keys[0]].R().T for k in keys])

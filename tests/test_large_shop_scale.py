@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import golden_cases as gc
-from util import expected, load_golden, pose_errors, translation_tol
+from util import cg_sensitivity, expected, iteration_slack, load_golden, pose_errors, translation_tol
 from vican_amd import synth
 from vican_amd.geometry import SE3
 
@@ -26,38 +26,51 @@ def case():
     return g, src, cons, fns
 
 
-def test_oracle_matches_reference_at_large_shop_scale(case):
+G9_TR_BOUND = 2e-3     # absolute regression bound (m): a few times what is measured (3e-4) and what the reference itself moves by
+
+
+def test_translation_bound_is_the_references_own_reproducibility():
+    """The g9 tolerance is not a free parameter: 4 x the largest movement of the reference's own answer under 1e-15
+    perturbations of its right-hand side (5.3e-4 m in both dtypes, 101..106 iterations)."""
+    for dt in ("float32", "float64"):
+        move, iters = cg_sensitivity("g9_large_shop", dt)
+        assert 1e-5 < move.max() < 1e-3 and iters.max() - iters.min() <= 6
+        assert translation_tol("g9_large_shop", dt) <= 2.2e-3
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_oracle_matches_reference_at_large_shop_scale(case, dt):
     from oracle import bipgo_oracle as orc
     g, src, cons, (nr, nt, ff) = case
-    exp = expected(g, "conjugate_gradient", "float32")
+    exp = expected(g, "conjugate_gradient", dt)
     info = {}
-    res = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float32, loop=True, info=info)
+    res = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.dtype(dt).type, loop=True, info=info)
     rot, tr = pose_errors(res, exp)
-    assert rot < 5e-6, rot
-    # 105 CG iterations at relres 1e-5 leave the reference 16 m from the converged solution of its own system
-    # (golden `dist_tight`); the restatement makes the same scipy calls on the same data and still lands close
-    assert tr < translation_tol(exp, False), tr
-    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= 2
+    assert rot < (5e-6 if dt == "float32" else 1e-7), rot
+    # ~100 CG iterations at relres 1e-5 on a singular system: the reference's own answer moves by up to 5e-4 m under
+    # 1e-15 perturbations (tests/golden/cg_sensitivity.npz); the restatement makes the same scipy calls and lands inside
+    assert tr < min(translation_tol("g9_large_shop", dt), G9_TR_BOUND), tr
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack("g9_large_shop", dt, extra=2)
 
 
 @pytest.mark.gpu
-def test_dropin_matches_reference_at_large_shop_scale(case):
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_dropin_matches_reference_at_large_shop_scale(case, dt):
     from vican.bipgo import bipartite_se3sync
     g, src, cons, (nr, nt, ff) = case
-    exp = expected(g, "conjugate_gradient", "float32")
+    exp = expected(g, "conjugate_gradient", dt)
     info = {}
     res = bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
-                            lsqr_solver="conjugate_gradient", dtype=np.float32, info=info)
+                            lsqr_solver="conjugate_gradient", dtype=np.dtype(dt).type, info=info)
     rot, tr = pose_errors(res, exp)
-    print("large_shop scale: rot %.2e rad, trans %.3e m (reference is %.1f m from its own converged solution), cg %d vs %d, "
-          "solve %.1f ms (reference %.1f s)" % (rot, tr, float(exp["dist_tight"]), info["cg_iters"], int(exp["cg_iters"]),
-                                               1e3 * (info["t_rot"] + info["t_trans"]), float(exp["ref_wall_s"])))
-    assert rot < 5e-6 <= 1e-4, rot
-    assert tr < translation_tol(exp, False), tr
-    # scipy's stopping rule is reproduced, but after ~100 iterations without re-orthogonalisation the residual hovers
-    # around rtol |b| non-monotonically (as on g4, tests/test_parity_gpu.py): which dip below the threshold is caught
-    # first moves by tens of iterations under rounding-level differences (measured: 118 against the reference's 105)
-    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= 30
+    print("large_shop scale %s: rot %.2e rad, trans %.3e m (the reference moves by up to %.1e m against itself), cg %d vs %d, "
+          "solve %.1f ms (reference %.1f s)" % (dt, rot, tr, float(cg_sensitivity("g9_large_shop", dt)[0].max()), info["cg_iters"],
+                                               int(exp["cg_iters"]), 1e3 * (info["t_rot"] + info["t_trans"]), float(exp["ref_wall_s"])))
+    assert rot < (5e-6 if dt == "float32" else 1e-7), rot               # north star: 1e-4 rad
+    assert tr < min(translation_tol("g9_large_shop", dt), G9_TR_BOUND), tr
+    # scipy's stopping rule is reproduced; the reference itself stops anywhere between 101 and 106 iterations under
+    # rounding-level perturbations (the residual hovers around rtol |b| non-monotonically)
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= 15
     ev3 = np.sort(info["evals"][:, :3], axis=1)
     evr = np.sort(exp["evals"], axis=1)[:, :3]
-    assert np.abs(ev3 - evr).max() < 1e-4 * np.abs(exp["evals"]).max()
+    assert np.abs(ev3 - evr).max() < (1e-4 if dt == "float32" else 1e-7) * np.abs(exp["evals"]).max()

@@ -24,11 +24,26 @@ def _write_dataset(root, scene, flat):
     save_edges(synth.edges_to_dict(flat, SE3), os.path.join(root, "cam_marker_edges.pt"))
 
 
+# the `vican` imports of main.ipynb cell 1, verbatim (the third-party ones - matplotlib, seaborn, shapely - are not in this image)
+CELL1_IMPORTS = """
+from vican.cam import estimate_pose_mp
+from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync
+from vican.plot import plot2D
+from vican.geometry import optimize_gauge_SE3, distance_SO3, angle
+from vican.dataset import Dataset
+"""
+
+
 def test_notebook_flow(tmp_path):
     import torch                                                          # cell 1 imports
-    from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync
-    from vican.geometry import optimize_gauge_SE3, distance_SO3, angle   # noqa: F401
-    from vican.dataset import Dataset
+    ns = {}
+    exec(CELL1_IMPORTS, ns)
+    bipartite_se3sync, object_bipartite_se3sync = ns["bipartite_se3sync"], ns["object_bipartite_se3sync"]
+    optimize_gauge_SE3, distance_SO3, Dataset, plot2D = ns["optimize_gauge_SE3"], ns["distance_SO3"], ns["Dataset"], ns["plot2D"]
+    with pytest.raises(NotImplementedError, match="cam_marker_edges.pt"):     # cells 3/5: the detector is out of scope, loudly
+        ns["estimate_pose_mp"](cams=[], im_filenames=[], aruco="DICT_4X4_1000", marker_size=0.276,
+                               corner_refine="CORNER_REFINE_APRILTAG", marker_ids=["0"], flags="SOLVEPNP_IPPE_SQUARE",
+                               brightness=-150, contrast=120)
     from vican_amd.evaluate import calibration_errors, format_error_table
     # stands in for shapely Polygon(...).area; the synthetic marker squares are tiny (6-12 px), so an offset keeps the
     # area**6 weights of cell 3 within a factor ~2 of each other as on real renders (heavy-tailed weights are the
@@ -87,3 +102,20 @@ def test_notebook_flow(tmp_path):
     assert res["missing"] == []
     assert res["table"]["SO(3)"]["max"] < 0.1          # degrees  (measurement noise 1e-3 rad = 0.06 deg per edge)
     assert res["table"]["E(3)"]["max"] < 1.0           # centimetres (1 mm per edge, ~100 edges per camera)
+
+    # cell 11: the three plot2D calls (estimates in the ground-truth gauge, ground-truth cameras, object track)
+    class Axes:
+        def __init__(self):
+            self.calls = []
+
+        def scatter(self, x, y, s, marker=None, c=None):
+            self.calls.append((np.asarray(x), np.asarray(y)))
+    ax = Axes()
+    valid_cam_ids = [c for c in dataset.cams if c in pose_est]
+    G = optimize_gauge_SE3([dataset.cams[c].extrinsics.inv() for c in valid_cam_ids],          # cell 9
+                           [pose_est[c].inv() for c in valid_cam_ids])
+    plot2D(ax, pose_est, idx=valid_cam_ids, left_gauge=G.inv(), view="xy", marker="x", s=30, c="blue")
+    plot2D(ax, dataset.cams, view="xy", marker="x", s=30, c="red")
+    assert len(ax.calls) == 2 and ax.calls[0][0].shape == (len(valid_cam_ids),)
+    # estimates moved into the ground-truth gauge land on the ground-truth cameras (centimetres)
+    assert np.abs(ax.calls[0][0] - ax.calls[1][0]).max() < 0.02 and np.abs(ax.calls[0][1] - ax.calls[1][1]).max() < 0.02

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import golden_cases as gc                                                   # noqa: E402
-from util import expected, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
+from util import expected, iteration_slack, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
 
 CG_RUNS = [(n, d) for n, c in gc.CASES.items() for (s, d) in c["runs"] if s == "conjugate_gradient"]
 
@@ -30,14 +30,16 @@ def test_dropin_api_matches_reference(name, dt):
                                        maxiter=gc.MAXITER, lsqr_solver="conjugate_gradient", dtype=dtype, info=info)
     rot, tr = pose_errors(res, exp)
     assert rot < ROT_TOL[dt] <= 1e-4, rot
-    assert tr < translation_tol(exp, dt == "float64"), tr
+    assert tr < translation_tol(name, dt), tr
+    if name == "g4_illcond" and info["cg_iters"] == int(exp["cg_iters"]):
+        assert tr < 1e-3, tr          # stopped at the reference's iteration: then the iterate itself must match
     # iteration count: exact (+-1) on the well-conditioned cases.  On the heavy-tailed-weight case g4 (the
     # reference itself is 17 m from the converged solution there) CG has lost conjugacy after ~15 iterations
     # and the relative residual jumps erratically between 4e-4 and 5e-6: it dips below rtol = 1e-5 at
     # iterations 21 (9.0e-6, marginal), 25, 28 and 31/32, and which dip is caught first flips under 1e-14
     # perturbations of the rotations (measured with the NumPy backend: 20 or 24 iterations) - so only the
     # window of those dips is comparable there.
-    slack = 1 if name != "g4_illcond" else 12
+    slack = iteration_slack(name, dt)
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= slack
     first = next(iter(res.values()))
     assert first.R().dtype == dtype and first.t().dtype == np.float64       # bipgo.py:484-487 types

@@ -1,0 +1,105 @@
+"""Translation stage in isolation (reference bipgo.py:445-478): the CG path is fed the REFERENCE's own rotations (from
+the goldens) instead of the product's, so whatever distance remains to the reference's translations is the
+translation kernels' alone - right-hand side J^T b, the Laplacian product and scipy's CG recurrence - and not the
+3e-7 rad by which two f32 rotation stages differ.  This is the evidence behind the translation tolerances of the
+end-to-end parity tests: with identical rotations the loosely converged iterate (rtol 1e-5) is tracked to ~1e-9 m on
+unit weights (g2, g5: exactly reproducible) and stays inside the reference's OWN reproducibility band elsewhere
+(tests/golden/cg_sensitivity.npz: scipy's answer on the reference's system moves by 6e-5 m on g3 and 5e-4 m on g9 when
+its right-hand side changes by one unit in the last place - CG on a singular system picks up null-space components whose
+transient Ritz values make the iterate hypersensitive)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from numpy_backend import NumpyBackend
+from test_solver_cpu import flatten_case
+from util import expected
+from vican_amd.solver import Comm, TranslationSolver
+
+from util import iteration_slack, translation_tol
+
+# (case, dtype): tolerance = the reference's own reproducibility band (util.translation_tol), 1e-9 m where it is exact
+CASES = [("g2_small", "float64"), ("g3_medium", "float64"), ("g3_medium", "float32"), ("g4_illcond", "float64"),
+         ("g5_strings", "float64")]
+
+
+def stage_tol(name, dt):
+    t = translation_tol(name, dt)
+    return 1e-9 if t <= 1e-6 else t
+
+
+def reference_rotations(prob, exp):
+    """node<-world blocks (what the solver keeps) of the reference's world<-node output rotations."""
+    R = {str(k): exp["R"][i] for i, k in enumerate(exp["keys"])}
+    rc = np.stack([R[str(c)].T for c in prob.cam_names]).reshape(-1, 3)
+    rt = np.stack([R[str(s) + "_0"].T for s in prob.time_names]).reshape(-1, 9)
+    return rc, rt
+
+
+def run_stage(K, prob, exp):
+    rc, rt = reference_rotations(prob, exp)
+    tr = TranslationSolver(K, Comm.single())
+    tr.setup(K.from_numpy(rc), K.from_numpy(rt))
+    x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
+    pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
+    pos.update({str(s) + "_0": x_t.cpu().numpy()[i] for i, s in enumerate(prob.time_names)})
+    t = np.stack([pos[str(k)] for k in exp["keys"]])
+    return float(np.linalg.norm(t - exp["t"], axis=1).max()), tr.info
+
+
+@pytest.mark.parametrize("name,dt", CASES)
+def test_translation_stage_alone_numpy_backend(name, dt):
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type)
+    dist, info = run_stage(K, prob, exp)
+    assert dist < stage_tol(name, dt), dist
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+
+
+def hip_backend(prob, dt):
+    from vican_amd.device import HipBackend, LocalGraph
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tdt = torch.float32 if dt == "float32" else torch.float64
+    to = lambda a, d=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, d)
+    g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt),
+                   to(prob.w), to(prob.u), to(prob.v))
+    return HipBackend(g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dt", CASES)
+def test_translation_stage_alone_on_gpu(name, dt):
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    dist, info = run_stage(hip_backend(prob, dt), prob, exp)
+    print("%s %s: translation stage alone, reference rotations in: %.2e m from the reference's iterate, cg %d vs %d" % (
+        name, dt, dist, info["cg_iters"], int(exp["cg_iters"])))
+    assert dist < stage_tol(name, dt), dist
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_translation_stage_alone_at_large_shop_scale(dt):
+    """g9 (BASELINE configs[2] scale, ~105 CG iterations): with the reference's rotations fed in, the CG kernels stay
+    inside the band by which the reference's own answer moves under 1e-15 perturbations (up to 5.3e-4 m) and stop
+    within its own iteration spread."""
+    from util import load_golden
+    from vican_amd import frontend, synth
+    from vican_amd.geometry import SE3
+    g = load_golden("g9_large_shop")
+    exp = expected(g, "conjugate_gradient", dt)
+    if not exp:
+        pytest.skip("golden has no %s run" % dt)
+    scene, flat = gc.build_flat(gc.LARGE_SHOP)
+    src = synth.edges_to_dict(flat, SE3)
+    cons = synth.constraints_from_scene(scene, SE3)
+    nr, nt, ff = (gc.CALLABLES[gc.LARGE_SHOP[k]] for k in ("noise_r", "noise_t", "filt"))
+    prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
+    dist, info = run_stage(hip_backend(prob, dt), prob, exp)
+    print("g9 %s: translation stage alone: %.2e m from the reference's iterate, cg %d vs %d" % (
+        dt, dist, info["cg_iters"], int(exp["cg_iters"])))
+    assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack("g9_large_shop", dt, extra=4)

@@ -49,15 +49,40 @@ def pose_errors(res, exp):
     return rot, tr
 
 
-def translation_tol(exp, f64=True):
-    """Translation parity tolerance (metres).
+_SENS = None
 
-    The reference stops CG at relres 1e-5, i.e. its answer is `dist_tight` away from the
-    converged solution of its own system (0.15 mm on g2, 0.8 mm on g3, 17 m on the
-    heavy-tailed g4 - stored in the goldens).  Once CG has lost Lanczos orthogonality
-    (non-unit weights, >~20 iterations) rounding-level input differences move the iterate by
-    a fraction of that distance, so two correct implementations can only agree to within it
-    (SURVEY.md section 7).  Unit-weight cases agree to ~1e-8 m and are held to 1e-6 m."""
-    base = 1e-6 if f64 else 5e-4
-    d = float(exp.get("dist_tight", np.nan))
-    return max(base, 0.25 * d) if np.isfinite(d) else base
+
+def cg_sensitivity(name, dt):
+    """The REFERENCE's own reproducibility on a golden case (tests/golden/cg_sensitivity.npz, written by
+    tests/golden/make_cg_sensitivity.py from the real reference): how far its translations move (m, 8 trials) and the
+    CG iteration counts it stops at when its right-hand side is perturbed by 1e-15 relative.  (None, None) if unknown."""
+    global _SENS
+    if _SENS is None:
+        z = np.load(os.path.join(GOLDEN_DIR, "cg_sensitivity.npz"), allow_pickle=False)
+        _SENS = {k: z[k] for k in z.files}
+    tag = "%s_%s_" % (name, np.dtype(dt).name)
+    return _SENS.get(tag + "self_move"), _SENS.get(tag + "iters")
+
+
+def translation_tol(name, dt):
+    """Translation parity tolerance (metres) for a golden case.
+
+    The reference's scipy CG (rtol 1e-5, singular Laplacian system) is hypersensitive: fed right-hand sides that
+    differ by one unit in the last place, scipy's OWN answer on the reference's OWN system moves by 1e-14 m on unit
+    weights (g1, g2, g5), 6e-5 / 2e-4 m on g3, up to 5e-4 m at large_shop scale (g9) and by metres on the
+    heavy-tailed g4 (measured with the real reference, tests/golden/make_cg_sensitivity.py).  No independent
+    implementation can agree with the reference better than the reference agrees with itself, so the bound is
+    4 x the largest movement seen in 8 trials (the trials sample a long-tailed distribution: 1.5e-5 ... 5.3e-4 on
+    g9), floored at 1e-6 m where the reference is reproducible to rounding.  tests/test_translation_stage.py shows
+    the same thing from the other side: with the reference's own rotations fed in, the translation kernels alone
+    stay inside this band."""
+    move, _ = cg_sensitivity(name, dt)
+    base = 1e-6
+    return base if move is None else max(base, 4.0 * float(move.max()))
+
+
+def iteration_slack(name, dt, extra=1):
+    """CG iterations may differ from the golden's by the spread the reference itself shows under 1e-15
+    perturbations (g9: 101..106, g4: 20..24), plus `extra`."""
+    _, iters = cg_sensitivity(name, dt)
+    return extra if iters is None else int(iters.max() - iters.min()) + extra

@@ -62,6 +62,9 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
         raise UnboundLocalError("local variable 't_est' referenced before assignment")
+    if maxiter < 1:
+        # the reference's loop body never runs and `r_c` is unbound at bipgo.py:346
+        raise UnboundLocalError("local variable 'r_c' referenced before assignment")
     if not torch.cuda.is_available():
         raise VicanError("no GPU visible: vican_amd has no CPU fallback")
     comm = Comm(group)
@@ -116,6 +119,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     if info is not None:
         info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
                     eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
+                    early_exit=rot.stats.get("early_exit"),
                     cg_iters=tr.info.get("cg_iters"), cg_relres=tr.info.get("relres"), lsqr_iters=tr.info.get("lsqr_iters"),
                     lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T,
                     n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=g.n_chunk, n_wg=g.n_wg,

@@ -796,7 +796,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
                                                     int32_t* __restrict__ gate) {
     extern __shared__ double sm[];
     __shared__ int s_eff, s_idx[5];
-    __shared__ double s_th4;
+    __shared__ double s_th4, s_th5;
     __shared__ double s_red[16];
     const int tid = threadIdx.x, B = blockDim.x;
     if (tid == 0) {
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
 
     // ranks of the eigenvalues (ties broken by index): one thread per eigenvalue
     if (tid < 5) s_idx[tid] = -1;
-    if (tid == 0) s_th4 = __longlong_as_double(0x7ff8000000000000LL);
+    if (tid == 0) s_th4 = s_th5 = __longlong_as_double(0x7ff8000000000000LL);
     __syncthreads();
     if (tid < n) {
         const double d = A[tid * ld + tid];
@@ -893,6 +893,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         }
         if (rank < 3) s_idx[rank] = tid;                                    // three smallest
         if (rank == 3) s_th4 = d;                                           // fourth smallest (reported only)
+        if (rank == 4) s_th5 = d;                                           // fifth smallest (the reference's max_eval exit)
         if (n >= 2 && rank >= n - 2) s_idx[3 + (rank - (n - 2))] = tid;     // second largest, largest
         if (n == 1) s_idx[4] = tid;
     }
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         for (int k = 0; k < 3; ++k) status[7 + k] = s_idx[k] >= 0 ? A[s_idx[k] * ld + s_idx[k]] : nan;
         status[10] = n >= 5 ? A[s_idx[3] * ld + s_idx[3]] : nan;
         status[11] = n >= 5 ? th_max : nan;
-        status[12] = r; status[13] = sweeps; status[14] = resmax; status[15] = s_th4;
+        status[12] = r; status[13] = s_th5; status[14] = resmax; status[15] = s_th4;
         *gate = (stop && converged) ? 1 : 0;
     }
 }

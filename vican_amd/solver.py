@@ -202,6 +202,8 @@ class RotationSolver:
                     r, stop, conv, floor_hit, eff, breakdown = st[0], st[2] != 0, st[3] != 0, st[4] != 0, int(st[5]), st[6] != 0
                     if st[15] == st[15]:
                         th4_last = float(st[15])
+                    # counterpart of the five values the reference's eigs(k=5, sigma=-1e-6) returns (bipgo.py:288-292)
+                    self.small5 = np.array([st[7], st[8], st[9], st[15], st[13]])
                     # noise floor: with f32 blocks the products carry ~6e-8 relative rounding, so the Ritz
                     # residual stalls somewhere below `floor_tol`; a stalled residual there is converged
                     # (the rule itself is evaluated by vican_ritz; here only the bookkeeping for later solves)
@@ -274,9 +276,20 @@ class RotationSolver:
         self.stats["sweeps"] += 2
 
     def run(self, maxiter):
+        if maxiter < 1:
+            # the reference leaves its loop without ever binding r_c and dies at bipgo.py:346
+            raise UnboundLocalError("local variable 'r_c' referenced before assignment")
         self.init()
         tol_final = self.eig_tol
+        self.small5 = None
         for it in range(maxiter):
+            # bipgo.py:283: the reference ends its loop once all five returned eigenvalues are <= 1e-6 in magnitude
+            # (>= 5 near-null vectors: only graphs with several components).  The five smallest Ritz values bound
+            # the five smallest eigenvalues from above, so the exit taken here is one the reference takes too; the
+            # converse can fail while theta_4, theta_5 are unconverged (disconnected graphs).
+            if self.small5 is not None and np.all(np.isfinite(self.small5)) and np.abs(self.small5).max() <= 1e-6:
+                self.stats["early_exit"] = it
+                break
             # The outer primal-dual iteration contracts errors of earlier spectral steps by orders of
             # magnitude per iteration (checked against the reference goldens: the schedule below leaves the
             # final rotations within 1e-12 rad of the fully converged variant), so only the last two spectral
