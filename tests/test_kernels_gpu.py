@@ -277,8 +277,9 @@ def test_ritz_matches_lapack_and_gate_semantics(steps, dead_at):
         assert int(gd.item()) == int(gn[0]), (flags, sd, sn)
         np.testing.assert_array_equal(sd[2:7], sn[2:7])      # stop, converged, floor_hit, eff, breakdown
         np.testing.assert_allclose(sd[7:12], sn[7:12], rtol=1e-12, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(sd[[13, 15]], sn[[13, 15]], rtol=1e-12, atol=1e-13, equal_nan=True)   # 5th and 4th smallest
         np.testing.assert_allclose(sd[[0, 1, 14]], sn[[0, 1, 14]], rtol=1e-7)
-        assert sd[12] == sd[0] and 1 <= sd[13] <= 20, sd[13]
+        assert sd[12] == sd[0]
         eff = int(sn[5])
         yd, yn = Yd.cpu().numpy(), Yn.numpy()
         assert np.all(yd[3 * eff:3 * steps] == 0.0)

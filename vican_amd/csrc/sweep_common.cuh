@@ -1,0 +1,75 @@
+// sweep_common.cuh - register-level helpers shared by the two edge sweeps (vican_sweep.hip: one workgroup per
+// chunk of 256..1024 lanes; vican_wsweep.hip: one wavefront per chunk): vector loads of a chunk's planes, the
+// fixed-point conversions and the explicitly rounded 3-term dot product.
+#pragma once
+#include "common.cuh"
+
+static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32 ? 4 : 8; }
+// camera planes are padded to a compile-time stride CP (256, 512 or 1024 entries) so that the nine
+// component planes are reached with LDS immediate offsets instead of per-access address math
+static inline int64_t plane_stride(int32_t n_cam) { return n_cam <= 256 ? 256 : (n_cam <= 512 ? 512 : 1024); }
+
+template <typename S> struct Vec;
+template <> struct Vec<float>  { typedef float4  type; static constexpr int N = 4; };
+template <> struct Vec<double> { typedef double2 type; static constexpr int N = 2; };
+
+template <typename S> __device__ __forceinline__ S vget(const typename Vec<S>::type& v, int j);
+template <> __device__ __forceinline__ float vget<float>(const float4& v, int j) {
+    return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+}
+template <> __device__ __forceinline__ double vget<double>(const double2& v, int j) { return j == 0 ? v.x : v.y; }
+
+template <typename S, int EPL>
+struct ChunkRegs {
+    typename Vec<S>::type m[9];
+    uint32_t id[EPL];
+};
+
+template <typename S, int EPL>
+__device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int tid) {
+    typedef typename Vec<S>::type V;
+    const S* blk = (const S*)g.blk;
+    const size_t pbase = (size_t)k * 9 * g.slots + (size_t)tid * EPL;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) c.m[p] = *(const V*)(blk + pbase + (size_t)p * g.slots);
+    const uint32_t* ip = g.idx + (size_t)k * g.slots + (size_t)tid * EPL;
+    if (EPL == 4) { const uint4 t = *(const uint4*)ip; c.id[0] = t.x; c.id[1] = t.y; c.id[2] = t.z; c.id[3] = t.w; }
+    else          { const uint2 t = *(const uint2*)ip; c.id[0] = t.x; c.id[1] = t.y; }
+}
+
+template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);
+template <> __device__ __forceinline__ float pre_scale<float>(double v, double) { return (float)v; }
+template <> __device__ __forceinline__ double pre_scale<double>(double v, double) { return v; }
+// Contribution -> 64-bit fixed point.  f64 blocks: magic-number conversion (common.cuh to_fix).
+// f32 blocks: the raw bit pattern of fma(v, scale, 1.5*2^52) WITHOUT subtracting the bias - a sum of N
+// patterns is off by N * 0x4338'0000'0000'0000, which only touches bits 48..63, and the true total
+// (|.| < 2^46 by the choice of scale in fx_finish) is the sign-extended low 48 bits (fix_total).  One VALU
+// instruction less per contribution; a 24-bit f32 product is still represented without loss down to
+// 2^-46 of the TOTAL bound.
+template <typename S> __device__ __forceinline__ u64 fix_of(S v, double scale);
+template <> __device__ __forceinline__ u64 fix_of<double>(double v, double scale) { return to_fix(v, scale); }
+template <> __device__ __forceinline__ u64 fix_of<float>(float v, double scale) {
+    return (u64)__double_as_longlong(fma((double)v, scale, 6755399441055744.0));
+}
+template <typename S> __device__ __forceinline__ long long fix_total(long long s);
+template <> __device__ __forceinline__ long long fix_total<float>(long long s) { return (long long)((u64)s << 16) >> 16; }
+template <> __device__ __forceinline__ long long fix_total<double>(long long s) { return s; }
+
+// a0 b0 + a1 b1 + a2 b2 with the roundings spelled out (one product, two fused multiply-adds).  The chunk body
+// below is instantiated once per register set of the ping-pong ring, and WHICH instance processes a given chunk
+// depends on the order the tickets are drawn; left to -ffp-contract=fast the two instances were compiled to
+// different mixes of (packed) mul/add/fma for one pair of outputs in one instantiation (<float,768,0,512>), i.e.
+// launches differed in the last f32 bit of z components (1,1),(1,2) about once in 30 - found by repetition.
+template <typename S>
+__device__ __forceinline__ S dot3(S a0, S b0, S a1, S b1, S a2, S b2) {
+#ifdef VICAN_DOT3_PLAIN          /* A/B only: lets the compiler contract (and reproduces the nondeterminism) */
+    return a0 * b0 + a1 * b1 + a2 * b2;
+#endif
+#pragma clang fp contract(off)
+    // (measured against mul/mul/fma/add and mul/mul/mul/add/add formulations and against the compiler's own choice:
+    //  all within the +-3 % run-to-run spread of the launch time)
+    S t = a0 * b0;
+    t = __builtin_elementwise_fma(a1, b1, t);
+    return __builtin_elementwise_fma(a2, b2, t);
+}
+
