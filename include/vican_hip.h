@@ -50,6 +50,9 @@ extern "C" {
 
 #define VICAN_PAD_SLOT 0xFFFFFFFFu
 
+#define VICAN_LAYOUT_BLOCK 0
+#define VICAN_LAYOUT_WAVE  1
+
 /* Graph view: sizes + device pointers of the chunked edge layout. */
 typedef struct vican_graph {
     int32_t n_cam;            /* C  (<= 65535) */
@@ -63,13 +66,19 @@ typedef struct vican_graph {
     int32_t n_copy;           /* lane-striped copies of the per-row accumulators (power of 2, <= 32) */
     int32_t wg_chunk_cap;     /* most chunks one workgroup of a block sweep may take (dynamic tickets, see
                                  vican_block_op); >= ceil(n_chunk / n_wg); 0 = unlimited */
+    int32_t layout;           /* VICAN_LAYOUT_BLOCK: a chunk is processed by a whole workgroup (slots = block_threads *
+                                 edges_per_lane).  VICAN_LAYOUT_WAVE: a chunk is processed by ONE wavefront (slots = 64 *
+                                 edges_per_lane, max_rows <= 64) and a workgroup of wg_waves wavefronts (block_threads =
+                                 64 * wg_waves) shares the camera tables - rotation sweeps only (vican_block_op(_z),
+                                 vican_dual_update(_op)); the translation kernels and vican_bip_apply take block layouts */
+    int32_t wg_waves;         /* wavefronts per workgroup of the wave layout: 4, 8 or 12 (0 in the block layout) */
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 7 */
+int vican_abi_version(void);            /* 8 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -95,6 +104,9 @@ int vican_plan_chunks(int32_t n_time, const int32_t* row_ptr_host, int32_t slots
  * offers per workgroup.                                                        */
 int64_t vican_sweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy);
 int64_t vican_lds_limit_bytes(void);
+/* The same for the wave layout: camera tables shared by the workgroup + per wavefront the striped row accumulators,
+ * the folded row sums and the phase-3 operand of its chunk.                                   */
+int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t n_waves);
 /* Largest max_rows for which every sweep kernel (operator, rhs, CG) fits in LDS;
  * <= 0 means the camera tables alone do not fit.                              */
 int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy);
@@ -130,13 +142,15 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
  * [7] 2^-shift of the last vican_block_op (its scales are raised by 2^shift when the actual
  * max_c |x_c|_F is below x_bound), [8] x_bound, [9] z scale for a phase-3 operand bounded by x_bound itself
  * (vican_dual_update_op), [10] two 32-bit counters of the block sweeps' chunk scheduler (zero between
- * launches), [11] inverse of [9].
+ * launches), [11] inverse of [9], [12..19] sixteen 32-bit counters of the wave-layout sweeps' scheduler (eight pool counters of
+ * the work-stealing tail, one per group of workgroups with equal blockIdx mod 8, and the finished-workgroups count; zero
+ * between launches).
  * vican_block_norms zeroes fx and fills rnorm[t] = sum_c |M_ct|_F, fx[5], fx[6];
  * vican_init_duals / vican_dual_update refresh fx[4]; vican_fx_finish turns the bounds into
  * power-of-two scales given |x_c|_F <= x_bound and n_add = max rows handled by one workgroup;
  * a contribution gets up to 47 bits; totals stay below 2^61 (f64 blocks) or 2^46 (f32 blocks, whose
  * accumulators hold raw magic-number bit patterns that are sign-extended from 48 bits at the end). */
-#define VICAN_FX_DOUBLES 12
+#define VICAN_FX_DOUBLES 20
 int vican_block_norms(const vican_graph_t* g, double* rnorm /*[T]*/, double* fx, void* stream);
 int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream);
 /* fx[4] for caller-supplied duals (instead of vican_init_duals / vican_dual_update). */

@@ -31,10 +31,13 @@ def make_backends(C, T, deg_lo, deg_hi, seed, dt, block_threads=None, n_wg=None,
     rp, col, blk, a, w, u, v = random_graph(C, T, deg_lo, deg_hi, seed, empty_rows)
     tdt = torch.float32 if dt == np.float32 else torch.float64
     dev = torch.device("cuda:0")
+    # block_threads: a workgroup size = block layout; "wave" / "wave4|8|12" = one wavefront per chunk (vican_wsweep.hip)
+    kw = dict(block_threads=block_threads, layout="block" if block_threads else None)
+    if isinstance(block_threads, str):
+        kw = dict(layout="wave", wg_waves=int(block_threads[4:]) if len(block_threads) > 4 else None)
     g = LocalGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev),
                    torch.from_numpy(blk).to(dev, tdt), torch.from_numpy(a).to(dev, tdt),
-                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev),
-                   block_threads=block_threads, n_wg=n_wg)
+                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev), n_wg=n_wg, **kw)
     return HipBackend(g), NumpyBackend(C, rp, col, blk, a, w, u, v, storage=dt), g
 
 
@@ -46,6 +49,13 @@ CONFIGS = [  # C, T, deg_lo, deg_hi, block_threads, n_wg, empty_rows
     (300, 200, 50, 300, 512, 9, False),
     (400, 300, 100, 400, 768, 6, False),
     (700, 64, 300, 700, 1024, 5, False),
+    # wave layout: rows of at most 256 (f32) / 128 (f64) edges
+    (5, 40, 1, 3, "wave", None, False),
+    (37, 300, 1, 12, "wave4", None, True),
+    (64, 500, 20, 64, "wave8", 7, False),
+    (300, 900, 60, 128, "wave12", 9, False),
+    (1000, 200, 100, 128, "wave12", None, False),
+    (100, 4000, 2, 9, "wave12", 5, False),
 ]
 
 
@@ -161,7 +171,7 @@ def test_gauge_project_and_lanczos_helpers():
     assert b[1, 1] == 0.0 and np.all(xh.cpu().numpy()[:, 1] == 0.0)
 
 
-@pytest.mark.parametrize("cfg", CONFIGS[:6])
+@pytest.mark.parametrize("cfg", CONFIGS[:6] + CONFIGS[8:11])
 def test_translation_kernels_and_cg(cfg):
     """rhs / degrees / every CG kernel step by step against the NumPy state machine."""
     from vican_amd.solver import Comm, TranslationSolver
@@ -188,7 +198,7 @@ def test_translation_kernels_and_cg(cfg):
     assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)
 
 
-@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4]])
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4], CONFIGS[9]])
 def test_lsqr_kernels(cfg):
     """LSQR translation solve: HIP kernels vs the NumPy restatement, same host driver."""
     from vican_amd.solver import Comm, LsqrTranslationSolver
@@ -480,7 +490,7 @@ def test_lanczos_seed_matches_the_launch_sequence(n):
     assert beta.cpu().numpy()[8] == 0.0 and not xrow.cpu().numpy()[:, 2].any() and np.isfinite(xrow.cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4], CONFIGS[6]])
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4], CONFIGS[6], CONFIGS[8], CONFIGS[10], CONFIGS[12]])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_lanczos_step_folding_the_slabs_itself(cfg, dt):
     """lanczos_cam_step(from_slabs=True) - the cooperative kernel reads z from the sweep's fixed-point slabs - gives

@@ -14,16 +14,18 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libvican_hip.so")
+LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so")      # VICAN_LIB: diagnostic builds (tools/)
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip")]
-HEADERS = [os.path.join(CSRC, "common.cuh")]
-FX_DOUBLES = 12
+WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
+HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "sweep_common.cuh"), WSWEEP]
+FX_DOUBLES = 20
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
 INCLUDE = os.path.join(ROOT, "include")
 
 STORE_F32, STORE_F64 = 0, 1
+LAYOUT_BLOCK, LAYOUT_WAVE = 0, 1
 PAD_SLOT = 0xFFFFFFFF
 
 
@@ -32,7 +34,7 @@ class Graph(C.Structure):
     _fields_ = [
         ("n_cam", C.c_int32), ("n_time", C.c_int32), ("n_chunk", C.c_int32), ("slots", C.c_int32),
         ("max_rows", C.c_int32), ("storage", C.c_int32), ("block_threads", C.c_int32), ("n_wg", C.c_int32),
-        ("n_copy", C.c_int32), ("wg_chunk_cap", C.c_int32),
+        ("n_copy", C.c_int32), ("wg_chunk_cap", C.c_int32), ("layout", C.c_int32), ("wg_waves", C.c_int32),
         ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
     ]
 
@@ -61,6 +63,7 @@ PROTOTYPES = {
     "vican_plan_chunks": (C.c_int, [_i32, _vp, _i32, _i32, _vp, _i32]),
     "vican_sweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_lds_limit_bytes": (_i64, []),
+    "vican_wsweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "vican_max_rows_for": (_i32, [_i32, _i32, _i32]),
     "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
@@ -119,43 +122,63 @@ def hipcc_path() -> str:
     raise VicanError("hipcc not found - cannot build libvican_hip.so")
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so``."""
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")])
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
-    # one hipcc per translation unit, in parallel (the sweep file alone instantiates ~190 kernels), then a link step
-    import concurrent.futures
-    import tempfile
-    flags = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC,
-             *os.environ.get("VICAN_CFLAGS", "").split()]
-    # (the sweep file is compiled five times: once without its hot kernel, once per sweep mode - see its header)
-    sweep = SOURCES[0]
-    jobs = [(sweep, ["-DVICAN_SWEEP_SPLIT", "-DVICAN_SWEEP_PART=%d" % m], "sweep_part%d.o" % m) for m in range(4)]
-    jobs += [(sweep, ["-DVICAN_SWEEP_SPLIT"], "sweep_main.o")]
-    jobs += [(src, [], os.path.basename(src) + ".o") for src in SOURCES[1:]]
-    with tempfile.TemporaryDirectory(prefix="_build_", dir=CSRC) as tmp:        # objects stay inside the tree
-        objs = [os.path.join(tmp, name) for _, _, name in jobs]
+def build_library(force: bool = False, verbose: bool = False, out: str = None, extra_flags=()) -> str:
+    """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so`` (or ``out``).
 
-        def compile_one(job):
-            (src, extra, _), obj = job
-            cmd = [hipcc_path(), *flags, *extra, "-c", src, "-o", obj]
+    One hipcc per translation unit, in parallel, then a link step.  Objects are cached in-tree
+    (``csrc/_build_cache/<sha1 of flags + source + headers>.o``), so diagnostic variants (``extra_flags``) and
+    rebuilds after a one-file edit only recompile what changed; ``force`` ignores the cache."""
+    out = out or LIB_PATH
+    deps = SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")]
+    if not force and not extra_flags and os.path.exists(out):
+        if os.path.getmtime(out) >= max(os.path.getmtime(p) for p in deps):
+            return out
+    import concurrent.futures
+    import hashlib
+    flags_all = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC,
+                 *os.environ.get("VICAN_CFLAGS", "").split(), *extra_flags]
+    # the two sweep files are compiled once per sweep mode plus once without their hot kernel (see their headers):
+    # ~190 + ~160 kernel instantiations
+    sweep = SOURCES[0]
+    jobs = [(sweep, ["-DVICAN_SWEEP_SPLIT", "-DVICAN_SWEEP_PART=%d" % m]) for m in range(4)]
+    jobs += [(sweep, ["-DVICAN_SWEEP_SPLIT"])]
+    jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT", "-DVICAN_WSWEEP_PART=%d" % m]) for m in (0, 1, 3)]
+    jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT"])]
+    jobs += [(src, []) for src in SOURCES[1:]]
+    cache = os.path.join(CSRC, "_build_cache")
+    os.makedirs(cache, exist_ok=True)
+    hdr = b"".join(open(p, "rb").read() for p in sorted(set(HEADERS) - {WSWEEP}) + [os.path.join(INCLUDE, "vican_hip.h")])
+
+    def compile_one(job):
+        src, extra = job
+        text = open(src, "rb").read()
+        # a -DNAME flag that neither this file nor a header mentions cannot change its object: variants share objects
+        flags = [f for f in flags_all if not (f.startswith("-D") and f[2:].split("=")[0].encode() not in text + hdr)]
+        key = hashlib.sha1(" ".join(flags + extra).encode() + text + hdr).hexdigest()
+        obj = os.path.join(cache, key + ".o")
+        if force or not os.path.exists(obj):
+            cmd = [hipcc_path(), *flags, *extra, "-c", src, "-o", obj + ".tmp"]
             if verbose:
                 print(" ".join(cmd))
-            return subprocess.run(cmd, capture_output=True, text=True)
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(obj + ".tmp", obj)
+        return obj
 
-        with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as pool:
-            for res in pool.map(compile_one, zip(jobs, objs)):
-                if res.returncode != 0:
-                    raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
-        cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
-        if verbose:
-            print(" ".join(cmd))
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise VicanError("hipcc link failed:\n" + res.stdout + res.stderr)
-    return LIB_PATH
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as pool:
+        objs = list(pool.map(compile_one, jobs))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise VicanError("hipcc link failed:\n" + res.stdout + res.stderr)
+    # keep the cache bounded: drop objects not used by the last few builds
+    stale = sorted((os.path.getatime(os.path.join(cache, f)), f) for f in os.listdir(cache) if f.endswith(".o"))
+    for _, f in stale[:-80]:
+        os.remove(os.path.join(cache, f))
+    return out
 
 
 def load():

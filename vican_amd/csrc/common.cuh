@@ -27,6 +27,7 @@ static inline int set_err(int code, const char* fmt, const char* a = "") {
     } while (0)
 
 int vican_check_graph(const vican_graph_t* g, const char* who);   // vican_sweep.hip
+int vican_check_block_graph(const vican_graph_t* g, const char* who);   // ... and layout == VICAN_LAYOUT_BLOCK
 
 // Launch gate (vican_set_gate, per host thread, defined in vican_sweep.hip): kernels that honour it take
 // `const int32_t* gate` as their last parameter and start with GATE_RETURN - the whole grid exits

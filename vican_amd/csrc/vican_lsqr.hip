@@ -291,7 +291,7 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int n, doub
 extern "C" int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
                                  const double* rc, const double* rt, double* u, double* sw, double* part, double* nrm2_out,
                                  void* stream) {
-    if (int r = vican_check_graph(g, "vican_lsqr_init_u")) return r;
+    if (int r = vican_check_block_graph(g, "vican_lsqr_init_u")) return r;
     if (!w || !ue || !ve || !rc || !rt || !u || !sw || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_init_u: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)8 * (9 * g->n_cam + 9 * g->max_rows + 16);
@@ -303,7 +303,7 @@ extern "C" int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const 
 
 extern "C" int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,
                                  double coef, double* u, double* part, double* nrm2_out, void* stream) {
-    if (int r = vican_check_graph(g, "vican_lsqr_u_step")) return r;
+    if (int r = vican_check_block_graph(g, "vican_lsqr_u_step")) return r;
     if (!sw || !v_c || !v_t || !u || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_u_step: null pointer");
     if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_u_step: more than 4 rows per lane in a chunk");
     hipStream_t st = (hipStream_t)stream;
@@ -317,7 +317,7 @@ extern "C" int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const
 extern "C" int vican_lsqr_v_step(const vican_graph_t* g, const double* sw, const double* u, double inv_beta, double beta,
                                  double* v_t, void* vc_part, double* part, double* nrm2_t_out, double smax, double n_add,
                                  double* inv_out, void* stream) {
-    if (int r = vican_check_graph(g, "vican_lsqr_v_step")) return r;
+    if (int r = vican_check_block_graph(g, "vican_lsqr_v_step")) return r;
     if (!sw || !u || !v_t || !vc_part || !part || !nrm2_t_out || !inv_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_v_step: null pointer");
     if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_v_step: more than 4 rows per lane in a chunk");
     hipStream_t st = (hipStream_t)stream;

@@ -30,7 +30,7 @@
 #include "sweep_common.cuh"
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 7; }
+extern "C" int vican_abi_version(void) { return 8; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
@@ -77,18 +77,35 @@ extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_
     return (int32_t)m;
 }
 
+extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t n_waves);
+
 int vican_check_graph(const vican_graph_t* g, const char* who) {
-    if (!g || g->n_cam <= 0 || g->n_cam > 65535 || g->n_time < 0 || g->n_chunk < 0 || !g->idx || !g->blk ||
+    if (!g || g->n_cam <= 0 || g->n_cam > 65535 || g->n_time < 0 || g->n_chunk < 0 || !g->idx ||
         !g->chunk_row0 || g->n_wg <= 0)
         return set_err(VICAN_ERR_ARG, "%s: bad graph descriptor", who);
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
+    const int nc = g->n_copy;
+    if (nc < 1 || nc > 32 || (nc & (nc - 1))) return set_err(VICAN_ERR_ARG, "%s: n_copy must be a power of two <= 32", who);
+    if (g->layout == VICAN_LAYOUT_WAVE) {
+        if ((g->wg_waves != 4 && g->wg_waves != 8 && g->wg_waves != 12) || g->block_threads != 64 * g->wg_waves || g->slots != 64 * epl)
+            return set_err(VICAN_ERR_ARG, "%s: wave layout needs wg_waves in {4, 8, 12}, block_threads = 64 wg_waves, slots = 64 * (16 / sizeof(storage))", who);
+        if (g->n_cam > 1024 || g->max_rows <= 0 || g->max_rows > 64 ||
+            vican_wsweep_lds_bytes(g->n_cam, g->max_rows, g->storage, nc, g->wg_waves) > vican_lds_limit_bytes())
+            return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS (wave layout)", who);
+        return 0;
+    }
+    if (g->layout != VICAN_LAYOUT_BLOCK) return set_err(VICAN_ERR_ARG, "%s: unknown layout", who);
     if ((g->block_threads != 256 && g->block_threads != 512 && g->block_threads != 768 && g->block_threads != 1024) ||
         g->slots != g->block_threads * epl)
         return set_err(VICAN_ERR_ARG, "%s: slots must be block_threads * (16 / sizeof(storage))", who);
-    const int nc = g->n_copy;
-    if (nc < 1 || nc > 32 || (nc & (nc - 1))) return set_err(VICAN_ERR_ARG, "%s: n_copy must be a power of two <= 32", who);
     if (g->max_rows <= 0 || g->max_rows > vican_max_rows_for(g->n_cam, g->storage, nc))
         return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", who);
+    return 0;
+}
+// entry points that only take the block layout (translation kernels, vican_bip_apply)
+int vican_check_block_graph(const vican_graph_t* g, const char* who) {
+    if (int rc = vican_check_graph(g, who)) return rc;
+    if (g->layout != VICAN_LAYOUT_BLOCK) return set_err(VICAN_ERR_ARG, "%s: needs a block-layout graph", who);
     return 0;
 }
 
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
     int32_t* pm = perm + (size_t)k * g.slots;
     for (int s = lane; s < g.slots; s += 64) pm[s] = -1;
     __syncthreads();
-    const int G = g.block_threads / 32;             // lane groups (of 32 lanes) = lanes per camera class
+    const int G = g.slots / epl / 32;               // lane groups (of 32 lanes) = lanes per camera class
     int pure_lanes = 0, left_cnt = 0;               // lane c (< 32): state of class c
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int r = r_first; r < r_last; ++r) {
@@ -191,7 +208,7 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= g.slots) return;
     const int r0 = g.chunk_row0[k], r1 = g.chunk_row0[k + 1];
-    S* blk = (S*)g.blk;
+    S* blk = blk_csr ? (S*)g.blk : nullptr;      // a layout that only carries the translation arrays has no block planes
     uint32_t* idx = (uint32_t*)g.idx;
     const size_t base = (size_t)k * g.slots + s;
     const int e = perm[base];
@@ -202,8 +219,10 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
             if (row_ptr[mid] <= e) lo = mid; else hi = mid;
         }
         idx[base] = (uint32_t)col[e] | ((uint32_t)(lo - r0) << 16);
+        if (blk) {
 #pragma unroll
-        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = blk_csr[(size_t)e * 9 + p];
+            for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = blk_csr[(size_t)e * 9 + p];
+        }
         if (a_out) a_out[base] = a_csr[e];
         if (w_out) w_out[base] = w_csr[e];
         if (u_out)
@@ -212,8 +231,10 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
             for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = v_csr[(size_t)e * 3 + p];
     } else {
         idx[base] = VICAN_PAD_SLOT;
+        if (blk) {
 #pragma unroll
-        for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = (S)0;
+            for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = (S)0;
+        }
         if (a_out) a_out[base] = (S)0;
         if (w_out) w_out[base] = 0.0;
         if (u_out) for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
@@ -226,11 +247,11 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
                                 const double* u_csr, const double* v_csr, void* a_out, double* w_out,
                                 double* u_out, double* v_out, int32_t* perm_ws, void* stream) {
     if (int rc = vican_check_graph(g, "vican_pack_edges")) return rc;
-    if (!row_ptr || !col || !blk_csr || !perm_ws) return set_err(VICAN_ERR_ARG, "vican_pack_edges: null input");
+    if (!row_ptr || !col || !perm_ws || (blk_csr && !g->blk)) return set_err(VICAN_ERR_ARG, "vican_pack_edges: null input");
     if (g->n_chunk == 0) return VICAN_OK;
     dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const int epl = g->slots / g->block_threads;
+    const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
     hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
     const int32_t* perm = perm_ws;
     if (g->storage == VICAN_STORE_F32)
@@ -355,7 +376,7 @@ __global__ void block_norms_kernel(vican_graph_t g, double* __restrict__ rnorm, 
 
 extern "C" int vican_block_norms(const vican_graph_t* g, double* rnorm, double* fx, void* stream) {
     if (int rc = vican_check_graph(g, "vican_block_norms")) return rc;
-    if (!rnorm || !fx) return set_err(VICAN_ERR_ARG, "vican_block_norms: null pointer");
+    if (!rnorm || !fx || !g->blk) return set_err(VICAN_ERR_ARG, "vican_block_norms: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(fx, 0, VICAN_FX_DOUBLES * sizeof(double), st) != hipSuccess)
         return set_err(VICAN_ERR_LAUNCH, "vican_block_norms: memset failed");
@@ -985,6 +1006,16 @@ static int dispatch_sweep(SWEEP_PART_ARGS) {
 }
 #endif
 
+// graphs in the wave layout (one wavefront per chunk): vican_wsweep.hip
+extern "C" __attribute__((visibility("hidden"))) int vican_wsweep(int mode, const vican_graph_t* g, const double* lamT_inv, const double* x,
+                                                                  u64* zpart, double* lamT_out, double* fx, void* stream);
+template <int MODE>
+static int sweep_any(SWEEP_PART_ARGS) {
+    if (!g->blk) return set_err(VICAN_ERR_ARG, "%s: graph without block planes", "vican sweep");
+    if (g->layout == VICAN_LAYOUT_WAVE) return vican_wsweep(MODE, g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    return dispatch_sweep<MODE>(g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx, stream);
+}
+
 extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart,
                               double* fx, void* stream) {
     if (int rc = vican_check_graph(g, "vican_block_op")) return rc;
@@ -1018,17 +1049,28 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
                     h ? "-last" : "0", sum[h][5] / g->n_wg, sum[h][0] / g->n_wg, sum[h][1] / g->n_wg, sum[h][2] / g->n_wg, sum[h][3] / g->n_wg, sum[h][4] / g->n_wg);
     }
 #else
-    if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, nullptr, nullptr, nullptr, fx, stream)) return rc;
+    if (int rc = sweep_any<0>(g, lamT_inv, x, (u64*)zpart, nullptr, nullptr, nullptr, fx, stream)) return rc;
 #endif
     LAUNCH_CHECK("vican_block_op");
     return VICAN_OK;
 }
 
+#ifdef VICAN_WSTAMP
+// diagnostic builds only (tools/wsweep_time.py --stamp): the wave sweep with its wall-clock stamps -> stamp_out
+extern "C" int vican_block_op_stamp(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx,
+                                    double* stamp_out, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_block_op_stamp")) return rc;
+    if (g->layout != VICAN_LAYOUT_WAVE) return set_err(VICAN_ERR_ARG, "vican_block_op_stamp: wave layout only");
+    return vican_wsweep(0, g, lamT_inv, x, (u64*)zpart, stamp_out, fx, stream);
+}
+#endif
+
 // Both halves of R~ [x_cam; x_time] (non-eliminated solver): y_time[t] = sum_c M_ct^T x_cam[c] (exact fixed-point
 // row sums -> f64), z_cam = slab-reduced sum_t M_ct x_time[t].  fx must hold the scales of vican_bip_scales.
 extern "C" int vican_bip_apply(const vican_graph_t* g, const double* x_cam, const double* x_time, void* zpart,
                                double* fx, double* z_cam, double* y_time, void* stream) {
-    if (int rc = vican_check_graph(g, "vican_bip_apply")) return rc;
+    if (int rc = vican_check_block_graph(g, "vican_bip_apply")) return rc;
+    if (!g->blk) return set_err(VICAN_ERR_ARG, "vican_bip_apply: graph without block planes");
     if (!x_cam || !x_time || !zpart || !fx || !z_cam || !y_time) return set_err(VICAN_ERR_ARG, "vican_bip_apply: null pointer");
     if (g->n_chunk == 0) return set_err(VICAN_ERR_ARG, "vican_bip_apply: graph without edges");
     if (int rc = dispatch_sweep<2>(g, x_time, x_cam, (u64*)zpart, nullptr, y_time, nullptr, fx, stream)) return rc;
@@ -1053,7 +1095,7 @@ extern "C" int vican_dual_update(const vican_graph_t* g, const double* rc_, doub
             return set_err(VICAN_ERR_LAUNCH, "vican_dual_update: memset failed");
         return VICAN_OK;
     }
-    if (int rc = dispatch_sweep<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
+    if (int rc = sweep_any<1>(g, nullptr, rc_, nullptr, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
     hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_vican_gate,
                        g->n_time, Rt, lamT_inv, rnorm, fx);
     LAUNCH_CHECK("vican_dual_update");
@@ -1072,7 +1114,7 @@ extern "C" int vican_dual_update_op(const vican_graph_t* g, const double* rc_, d
             return set_err(VICAN_ERR_LAUNCH, "vican_dual_update_op: memset failed");
         return VICAN_OK;
     }
-    if (int rc = dispatch_sweep<3>(g, nullptr, rc_, (u64*)zpart, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
+    if (int rc = sweep_any<3>(g, nullptr, rc_, (u64*)zpart, Rt, lamT_inv, rnorm, fx, stream)) return rc;   // zeroes fx[4]
     LAUNCH_CHECK("vican_dual_update_op");
     if (int rc = vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 11, nullptr, z_raw, stream)) return rc;
     hipLaunchKernelGGL(dual_svd_kernel, dim3((g->n_time + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_vican_gate,

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
 extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
                                const double* rt, double* rhs_t, void* rhs_c_part, double gmax, double n_add,
                                double* inv_out, void* stream) {
-    if (int r = vican_check_graph(g, "vican_trans_rhs")) return r;
+    if (int r = vican_check_block_graph(g, "vican_trans_rhs")) return r;
     if (!u || !v || !rc || !rt || !rhs_t || !rhs_c_part || !inv_out || !(gmax >= 0))
         return set_err(VICAN_ERR_ARG, "vican_trans_rhs: bad argument");
     double inv;
@@ -208,7 +208,7 @@ __global__ void scale_weights_kernel(vican_graph_t g, const double* __restrict__
 }
 extern "C" int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s_cam, const double* s_row,
                                    double* w_out, void* stream) {
-    if (int r = vican_check_graph(g, "vican_scale_weights")) return r;
+    if (int r = vican_check_block_graph(g, "vican_scale_weights")) return r;
     if (!w || !s_cam || !s_row || !w_out) return set_err(VICAN_ERR_ARG, "vican_scale_weights: null pointer");
     if (g->n_chunk == 0) return VICAN_OK;
     hipLaunchKernelGGL(scale_weights_kernel, dim3((g->slots + 255) / 256, g->n_chunk), dim3(256), 0, (hipStream_t)stream, *g, w,
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
 extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
                               const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
                               const vican_cg_state_t* st, void* stream) {
-    if (int r = vican_check_graph(g, "vican_cg_sweep")) return r;
+    if (int r = vican_check_block_graph(g, "vican_cg_sweep")) return r;
     if (!w || !deg_t || !p_c || !r_t || !p_t || !q_t || !qc_part || !pq_part || !st)
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);

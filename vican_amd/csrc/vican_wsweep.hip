@@ -1,0 +1,491 @@
+// vican_wsweep.hip - the edge sweep with ONE WAVEFRONT PER CHUNK ("wave layout", vican_graph_t.layout == 1).
+//
+// Same mathematics, same data layout and the same exact 64-bit fixed-point accumulation as block_sweep_kernel
+// (vican_sweep.hip), but a chunk is 64 lanes x EPL slots = whole timestep rows with at most 256 (f32) / 128 (f64)
+// edges, and a wavefront takes a chunk through all three phases on its own:
+//
+//     phase 1   y_row += M^T x_cam           x gathered from the workgroup's LDS planes, striped row accumulators in
+//                                            the WAVE's private LDS region
+//     phase 2   w_row  = Lambda_T^-1 y_row   lanes of the same wavefront: fold the stripes, 3x3 product per row
+//     phase 3   z_cam += M w_row             blocks still in registers; z accumulators shared by the workgroup
+//
+// LDS operations of one wavefront execute in issue order, so the phases need NO workgroup barrier: the only
+// __syncthreads() of the kernel are in the prologue and before the slab write-out.  Why: the block sweep is neither
+// HBM- nor issue-bound (PMC, round 1: VALU 55 % busy, LDS 43 %, HBM at 85 % of the streaming ceiling) - its 12
+// wavefronts move through the phases in lock-step, so the LDS-atomic phase, the VALU phase and the row fold never
+// overlap and every barrier costs the skew of the slowest wavefront.  Here the wavefronts of a workgroup drift
+// apart: while one issues its phase-3 atomics another multiplies and a third waits for its next chunk, each with
+// its own prefetch in flight.
+//
+// Scheduling.  Chunks are handed out in two levels, both dynamic, neither on the critical path:
+//   * device level: one counter (fx[12]) hands out RANGES of NW or 2 NW consecutive chunks to workgroups - a few
+//     thousand device-scope atomics per launch, each issued by ONE wavefront of the workgroup a full round before the
+//     workgroup runs dry, so nobody waits for it;
+//   * workgroup level: the wavefronts draw single chunks of the published ranges through an LDS ticket counter.
+// Why both: wavefronts of one CU progress unevenly (static round-robin inside the workgroup: 194-199 us, LDS tickets
+// 185 us on the same box), and XCDs get different shares of the HBM bandwidth (static ranges per workgroup: mean finish
+// time by XCD between 181 and 202 us of a 212 us launch).  A first attempt that let wavefronts steal from a pool with
+// blocking device-scope atomics made the launch SLOWER the larger the pool (10 % pool 208 us, 28 % 236 us): the
+// round trip of an atomic under a saturated memory system is many microseconds.
+// Sums are exact integers, so which wavefront adds a chunk cannot change a bit of the result; a cap on the ranges a
+// workgroup may take keeps the number of adds into one z accumulator within the bound fx_finish assumed.
+#include "sweep_common.cuh"
+
+#ifndef VICAN_WSWEEP_PART
+
+extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t n_waves) {
+    const int64_t s = ssize(storage), cp = plane_stride(n_cam);
+    const int64_t per_wave = (((int64_t)max_rows * 9 * (8LL * n_copy + 8 + s)) + 15) & ~15LL;
+    return 9LL * cp * (s + 8) + (int64_t)n_waves * per_wave + 256;
+}
+
+#endif
+
+#if !defined(VICAN_WSWEEP_SPLIT) || defined(VICAN_WSWEEP_PART)
+
+// MODE 0: zpart[wg] = sum M (lamT_inv (sum M^T x))          operator P x
+// MODE 1: lamT_out[t] = Z_t = sum_c M_ct^T x_c               dual update (SVDs in dual_svd_kernel)
+// MODE 3: MODE 1 and zpart[wg] = sum M polar(Z_t)            dual update fused with the next operator application
+template <typename S, int NW, int MODE, int CP, int TRIPS>
+__global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
+                                                             const double* __restrict__ lamT_inv,
+                                                             const double* __restrict__ x, u64* __restrict__ zpart,
+                                                             double* __restrict__ lamT_out, double* __restrict__ fx) {
+    GATE_RETURN(gate);
+#ifdef VICAN_WSTAMP     /* diagnostic build: wall-clock structure of the launch -> lamT_out (unused by MODE 0), 100 MHz ticks */
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int EPL = Vec<S>::N, BLOCK = NW * 64;
+    constexpr bool HAS_Z = (MODE == 0 || MODE == 3);
+    // TRIPS: (row, dual-block row) items per lane in phase 2 = ceil(3 max_rows / 64), 1..3 (max_rows <= 64)
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double s_xm[16];
+    const int C = g.n_cam, nx = 9 * CP, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane_copy = lane & cmask;
+    u64* zs = (u64*)lds_raw;                                   // [9][CP] planes, shared by the workgroup
+    S* xs = (S*)(zs + (HAS_Z ? nx : 0));                       // [9][CP] planes
+    const size_t per_wave = (((size_t)RW * 9 * (8 * ncopy + 8 + sizeof(S))) + 15) & ~(size_t)15;
+    unsigned char* wbase = (unsigned char*)(xs + nx) + (size_t)wave * per_wave;
+    u64* ys = (u64*)wbase;                                     // [RW * 9][ncopy] striped row accumulators (this wave's)
+    double* yv = (double*)(ys + (size_t)RW * 9 * ncopy);       // [RW * 9] folded row sums
+    S* wv = (S*)(yv + (size_t)RW * 9);                         // [RW * 9] phase-3 operand
+    const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
+
+    // ---- chunk scheduler (see the header).  Ranges are published in a ring of 8 LDS entries {first ticket, end ticket,
+    // first chunk}; the wavefront that draws the ticket NW before the end of the newest range fetches the next one.
+    const int nwg = (int)gridDim.x, nchunk = g.n_chunk;
+    unsigned int* sched = (unsigned int*)(fx + 12);            // [0] ranges handed out (units of NW chunks), [8] workgroups finished
+    constexpr int NONE = 0x7fffffff, RING = 8;
+    const int unit0 = nchunk >= 4 * NW * nwg ? 2 : 1;          // implicit first range of workgroup w: units [unit0 w, unit0 (w + 1))
+    const int cap_units = g.wg_chunk_cap > 0 ? g.wg_chunk_cap / NW : 0x3fffffff;
+    __shared__ int s_cnt, s_npub, s_done, s_units, s_v0[RING], s_v1[RING], s_base[RING];
+    if (tid == 0) {
+        const int base = (int)blockIdx.x * unit0 * NW;
+        int len = nchunk - base; len = len < 0 ? 0 : (len > unit0 * NW ? unit0 * NW : len);
+        s_cnt = 0; s_v0[0] = 0; s_v1[0] = len; s_base[0] = base; s_npub = 1; s_units = unit0;
+#ifdef VICAN_W_STATIC       /* experiment: one static contiguous range per workgroup, no device-level scheduling */
+        const int c0 = (int)(((long long)blockIdx.x * nchunk) / nwg), c1 = (int)(((long long)(blockIdx.x + 1) * nchunk) / nwg);
+        s_v1[0] = c1 - c0; s_base[0] = c0; s_done = 1;
+#else
+        s_done = len < unit0 * NW ? 1 : 0;                     // the queue ends inside (or before) this range
+#endif
+    }
+    __syncthreads();
+    int my_r = 0;                                              // newest ring entry this wavefront has looked at (wave-uniform)
+    // ticket -> chunk.  Tickets are unique in the workgroup; entries are published in ticket order.
+    auto resolve = [&](const int v) -> int {
+        for (;;) {
+            const int npub = __hip_atomic_load(&s_npub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define LDSV(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)     /* never cached in a register */
+            while (my_r < npub - 1 && v >= LDSV(s_v1[my_r & (RING - 1)])) ++my_r;
+            const int e = my_r & (RING - 1), v0 = LDSV(s_v0[e]), v1 = LDSV(s_v1[e]);
+            if (v < v1) {
+                const int k = LDSV(s_base[e]) + (v - v0);
+#ifndef VICAN_W_STATIC
+                // the one wavefront whose ticket sits a round before the end of the NEWEST range fetches the next range
+                const int trig = v1 - v0 > NW ? v1 - NW : v0;
+                if (v == trig && my_r == npub - 1 && !__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    const int taken = LDSV(s_units);
+                    int done = 1, nb = 0, nl = 0;
+                    if (taken < cap_units) {
+                        // two units while the queue is long (fewer atomics), one towards its end (finer balance)
+                        const int want = (long long)(k + 2 * nwg * NW) * 8 < (long long)nchunk * 7 ? 2 : 1;
+                        unsigned int p = 0;
+                        if (lane == 0) p = __hip_atomic_fetch_add(&sched[0], (unsigned)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        p = (unsigned int)__builtin_amdgcn_readfirstlane((int)p);
+                        const long long first = ((long long)unit0 * nwg + p) * NW;
+                        if (first < nchunk) {
+                            nb = (int)first; nl = (int)((long long)nchunk - first < want * NW ? nchunk - first : want * NW);
+                            done = nl < want * NW;
+                        }
+                    }
+                    if (lane == 0) {
+                        if (nl > 0) {
+                            const int e2 = (my_r + 1) & (RING - 1);
+                            s_v0[e2] = v1; s_v1[e2] = v1 + nl; s_base[e2] = nb; s_units = taken + (nl + NW - 1) / NW;
+                        }
+                        if (done) __hip_atomic_store(&s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (nl > 0) __hip_atomic_store(&s_npub, npub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS stores of a wave: in order
+                    }
+                }
+#endif
+                return k;
+            }
+            if (my_r < npub - 1) continue;                     // (entries were published meanwhile)
+            if (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &&
+                __hip_atomic_load(&s_npub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == npub) return NONE;
+            __builtin_amdgcn_s_sleep(8);                       // the next range is on its way
+        }
+    };
+    auto draw = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;                                              // (valid in lane 0; resolved later)
+    };
+    int kc = resolve(__builtin_amdgcn_readfirstlane(draw()));
+    int kn1 = resolve(__builtin_amdgcn_readfirstlane(draw()));
+    ChunkRegs<S, EPL> ra, rb;
+    // first row of a chunk and of the chunk behind it: VECTOR loads (every lane the same address) issued one body
+    // ahead.  Scalar loads would share lgkmcnt with the LDS operations and, returning out of order, turn every LDS wait
+    // of the body into lgkmcnt(0) until they land (thousands of cycles under a saturated memory system).
+    const int kmax = nchunk - 1;
+    auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
+    int2 va = load_rows(kc), vb;              // (chunk_row0 has n_chunk + 1 entries; 8-byte loads may be unaligned: fine)
+
+    // ---- prologue (as block_sweep_kernel): measure max_c |x_c|_F, stage x as planes, zero the accumulators
+    constexpr int XC = (CP + BLOCK - 1) / BLOCK;
+    double xv[XC][9];
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        const int c = tid + m * BLOCK;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0;
+    }
+    const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8], fx9 = (MODE == 3) ? fx[9] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    load_chunk<S, EPL>(ra, g, kc < kmax ? kc : kmax, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    double xm2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) q += xv[m][i] * xv[m][i];
+        xm2 = fmax(xm2, q);
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) xm2 = fmax(xm2, __shfl_xor(xm2, o2, 64));
+    if (lane == 0) s_xm[wave] = xm2;
+#pragma unroll
+    for (int m = 0; m < XC; ++m) {
+        const int c = tid + m * BLOCK;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], 1.0);
+        }
+    }
+    if (HAS_Z) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
+    for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
+    __syncthreads();
+    xm2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) xm2 = fmax(xm2, s_xm[i]);
+    int shift = 0;
+    if (xm2 > 0.0) { const double r2 = fx8 * fx8 / xm2; shift = r2 >= 1.0 ? (ilogb(r2) >> 1) : 0; }
+    shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
+    if (MODE == 3) shift = 0;                                  // phase-3 operand = polar factors, |.|_F = x_bound
+    const double up = ldexp(1.0, shift);
+    const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = (MODE == 3) ? fx9 : fx2 * up;
+    if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;   // omega bound: raised by dual_svd_kernel
+
+#ifdef VICAN_WSTAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
+#define WSTAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WSTAMP0() do {} while (0)
+#define WSTAMP(i) do {} while (0)
+#endif
+    // body: this wavefront processes the chunk held in `cur` (its row bounds in `vrow`, loaded a body ago), prefetches
+    // chunk kpref into `nxt` and requests kpref's row bounds (returned; consumed by the next body).  Every
+    // vector-memory operation of the body is UNCONDITIONAL (indices clamped instead): results retire in issue order,
+    // and a load that may or may not have been issued makes the compiler wait for vmcnt(0) - i.e. for the whole
+    // prefetch - wherever an older result is needed.
+    auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int2 vrow, const int kpref, int& ticket) -> int2 {
+        WSTAMP0();
+        ticket = draw();                                       // for the chunk after next; resolved after the body
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x);
+        const int nrows = __builtin_amdgcn_readfirstlane(vrow.y) - r0;
+        const int kp = kpref < kmax ? kpref : kmax;
+        const int2 vnext = load_rows(kp);
+        // dual-block rows for phase 2, one (row, block row) item = 24 contiguous bytes per lane: the chunk's rows are
+        // consecutive, so these loads are fully coalesced.  Issued BEFORE the prefetch (in-order retirement again).
+        double L[TRIPS][3];
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                int j = lane + 64 * t;
+                j = j < nrows * 3 ? j : 0;                  // lanes without an item re-read item 0 (never used)
+                const double* Lp = lamT_inv + (size_t)r0 * 9 + (size_t)j * 3;
+                L[t][0] = Lp[0]; L[t][1] = Lp[1]; L[t][2] = Lp[2];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk<S, EPL>(nxt, g, kp, lane);
+
+#if defined(VICAN_WABLATE) && VICAN_WABLATE == 1      /* loads only: streaming rate of this access pattern */
+        {
+            float keep = 0.f;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
+            if (keep == 123.456f && cur.id[0] == 77u) ys[0] = 1ull;
+            return vnext;
+        }
+#endif
+        // ---- phase 1
+        WSTAMP(0);                      // descriptors, dual loads, prefetch issue
+#ifdef VICAN_WSTAMP                     /* wait for this chunk's data here so that the wait is booked separately */
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        WSTAMP(1);
+#endif
+        uint32_t cam[EPL], row[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
+            row[j] = pad ? 0u : (cur.id[j] >> 16);
+        }
+        {
+            S acc[9], xc[9], xn[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xc[q] = xs[q * CP + cam[0]];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                if (j + 1 < EPL) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) xn[q] = xs[q * CP + cam[j + 1]];
+                }
+                const bool cont = j > 0 && row[j] == row[j - 1];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const S c = dot3<S>(vget<S>(cur.m[0 + a], j), xc[b], vget<S>(cur.m[3 + a], j), xc[3 + b],
+                                            vget<S>(cur.m[6 + a], j), xc[6 + b]);
+                        acc[a * 3 + b] = cont ? acc[a * 3 + b] + c : c;
+                    }
+                const bool last = (j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j];
+                if (last) {
+                    u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
+#if defined(VICAN_WABLATE) && (VICAN_WABLATE == 4 || VICAN_WABLATE == 5)    /* no phase-1 atomics */
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) asm volatile("" :: "v"(acc[q]));
+#else
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) lds_add_fix(yr + q * ncopy, fix_of<S>(acc[q], y_scale));
+#endif
+                }
+                if (j + 1 < EPL) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) xc[q] = xn[q];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        WSTAMP(2);                      // phase 1
+#if defined(VICAN_WABLATE) && VICAN_WABLATE == 2      /* phase 1 only */
+        return vnext;
+#endif
+
+        // ---- phase 2 (this wavefront's rows only; LDS operations of a wavefront execute in order)
+        for (int i = lane; i < nrows * 9; i += 64) {
+            const int oo = i % 9;
+            long long s = 0;
+            for (int c = 0; c < ncopy; ++c) {
+                const int a = i * ncopy + ((c + oo) & cmask);
+                s += (long long)ys[a];
+                ys[a] = 0ull;
+            }
+            const double y = (double)fix_total<S>(s) * y_inv;
+            yv[i] = y;
+            if (MODE != 0) lamT_out[(size_t)r0 * 9 + i] = y;        // Z_t for dual_svd_kernel (contiguous over the chunk)
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int j = lane + 64 * t;
+                if (j < nrows * 3) {
+                    const double* yr = yv + (j / 3) * 9;
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; ++b3)
+                        wv[j * 3 + b3] = pre_scale<S>(dot3<double>(L[t][0], yr[b3], L[t][1], yr[3 + b3], L[t][2], yr[6 + b3]), z_scale);
+                }
+            }
+        }
+        if (MODE == 3) {
+            for (int r = lane; r < nrows; r += 64) {
+                double R[9];
+                polar_newton3(yv + r * 9, R);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) wv[r * 9 + q] = pre_scale<S>(R[q], z_scale);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        WSTAMP(3);                      // phase 2
+
+        if (HAS_Z) {
+            // ---- phase 3
+            S w[9];
+            uint32_t prow = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                if (row[j] != prow) {
+                    prow = row[j];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) w[q] = wv[row[j] * 9 + q];
+                }
+                u64* zc = zs + cam[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const S v = dot3<S>(vget<S>(cur.m[i * 3 + 0], j), w[b], vget<S>(cur.m[i * 3 + 1], j), w[3 + b],
+                                            vget<S>(cur.m[i * 3 + 2], j), w[6 + b]);
+#if defined(VICAN_WABLATE) && (VICAN_WABLATE == 3 || VICAN_WABLATE == 5)    /* no phase-3 atomics */
+                        asm volatile("" :: "v"(v));
+#else
+                        lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
+#endif
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#ifdef VICAN_WSTAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // book the drain of this chunk's LDS atomics to phase 3
+#endif
+        WSTAMP(4);                      // phase 3
+        return vnext;
+    };
+
+#ifdef VICAN_WSTAMP
+    const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef VICAN_WSTAMP
+    int n_done = 0;
+#define WCOUNT() (++n_done)
+#else
+#define WCOUNT() ((void)0)
+#endif
+#pragma unroll 1
+    while (kc != NONE) {
+        int t;
+        vb = body(ra, rb, va, kn1, t);       // (va: rows of kc; returns the rows of kn1)
+        WCOUNT();
+        kc = kn1; kn1 = resolve(__builtin_amdgcn_readfirstlane(t));
+        if (kc == NONE) break;
+        va = body(rb, ra, vb, kn1, t);
+        WCOUNT();
+        kc = kn1; kn1 = resolve(__builtin_amdgcn_readfirstlane(t));
+    }
+    // the last workgroup to get here re-arms the range counter for the next launch (device-scope atomics only - a
+    // device-scope fence would write back this XCD's whole L2)
+    __syncthreads();
+    if (tid == 0 && __hip_atomic_fetch_add(&sched[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1u) {
+        __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sched[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef VICAN_WSTAMP
+    const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (HAS_Z) {
+        u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout [9][C]
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            for (int c = tid; c < C; c += BLOCK) zp[q * C + c] = (u64)fix_total<S>((long long)zs[q * CP + c]);
+    }
+#ifdef VICAN_WSTAMP
+    if (MODE == 0 && lamT_out && lane == 0) {
+        double* o = lamT_out + ((size_t)blockIdx.x * NW + wave) * 10;
+        o[0] = (double)rt_begin; o[1] = (double)rt_loop0; o[2] = (double)rt_loop1; o[3] = (double)__builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 5; ++i) o[4 + i] = (double)st_acc[i];
+        o[9] = (double)n_done;
+    }
+#endif
+}
+
+template <typename S, int NW, int MODE, int CP, int TRIPS>
+static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                          double* fx, hipStream_t st) {
+    const size_t lds = (size_t)vican_wsweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy, NW);
+    auto kern = wave_sweep_kernel<S, NW, MODE, CP, TRIPS>;
+    static size_t configured = 0;       // per instantiation
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican wave sweep");
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW * 64), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, lamT_out, fx);
+    return 0;
+}
+template <typename S, int NW, int MODE, int CP>
+static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                          double* fx, hipStream_t st) {
+    if (MODE != 0 || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (3 * g->max_rows <= 128) return launch_wsweep4<S, NW, MODE, CP, 2>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep4<S, NW, MODE, CP, 3>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+}
+template <typename S, int NW, int MODE>
+static int launch_wsweep2(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                          double* fx, hipStream_t st) {
+    if (g->n_cam <= 256) return launch_wsweep3<S, NW, MODE, 256>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->n_cam <= 512) return launch_wsweep3<S, NW, MODE, 512>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep3<S, NW, MODE, 1024>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+}
+template <typename S, int MODE>
+static int launch_wsweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                          double* fx, hipStream_t st) {
+    if (g->wg_waves == 12) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->wg_waves == 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep2<S, 4, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+}
+template <int MODE>
+static int dispatch_wsweep(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                           double* fx, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (g->storage == VICAN_STORE_F32) return launch_wsweep1<float, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep1<double, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+}
+#endif
+
+#define WSWEEP_PART_ARGS const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out, \
+                         double* fx, void* stream
+#if defined(VICAN_WSWEEP_PART)
+#define WSWEEP_CAT2(a, b) a##b
+#define WSWEEP_CAT(a, b) WSWEEP_CAT2(a, b)
+extern "C" __attribute__((visibility("hidden"))) int WSWEEP_CAT(vican_wsweep_part_, VICAN_WSWEEP_PART)(WSWEEP_PART_ARGS) {
+    return dispatch_wsweep<VICAN_WSWEEP_PART>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+}
+#else
+#if defined(VICAN_WSWEEP_SPLIT)
+extern "C" {
+__attribute__((visibility("hidden"))) int vican_wsweep_part_0(WSWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_wsweep_part_1(WSWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_wsweep_part_3(WSWEEP_PART_ARGS);
+}
+#endif
+// entry used by vican_sweep.hip's dispatcher for graphs in the wave layout
+extern "C" __attribute__((visibility("hidden"))) int vican_wsweep(int mode, WSWEEP_PART_ARGS) {
+#if defined(VICAN_WSWEEP_SPLIT)
+    if (mode == 0) return vican_wsweep_part_0(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 1) return vican_wsweep_part_1(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 3) return vican_wsweep_part_3(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+#else
+    if (mode == 0) return dispatch_wsweep<0>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 1) return dispatch_wsweep<1>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 3) return dispatch_wsweep<3>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+#endif
+    return set_err(VICAN_ERR_ARG, "%s: this sweep mode needs the block layout", "vican wave sweep");
+}
+#endif

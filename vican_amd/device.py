@@ -39,17 +39,120 @@ def _stream():
     return h
 
 
+class _Layout:
+    """One chunked edge layout of a rank's rows (device arrays + the vican_graph_t view of them)."""
+
+    def __init__(self, lib, kind, n_cam, n_time, rp_host, deg_max, deg_avg, n_edges, storage, dev, block_threads=None, n_wg=None,
+                 n_copy=None, wg_waves=None):
+        epl = 4 if storage == _lib.STORE_F32 else 2
+        self.kind, self.n_time = kind, n_time
+        lim = int(lib.vican_lds_limit_bytes())
+        if kind == "wave":
+            # one wavefront per chunk (vican_wsweep.hip): 64 lanes x EPL slots, whole rows, <= 64 rows per chunk
+            slots = 64 * epl
+            rows_target = max(1, min(64, int(math.ceil(1.25 * slots / deg_avg)) + 1))
+            if n_copy is None:        # lanes of a wavefront that share a row = deg / EPL
+                n_copy = 1
+                while n_copy < 32 and n_copy * epl < deg_avg:
+                    n_copy *= 2
+            if wg_waves is None:
+                wg_waves = 12
+                if n_edges < 12 * slots * N_CU:          # small graphs: fewer wavefronts per workgroup, more workgroups
+                    wg_waves = 8 if n_edges >= 8 * slots * N_CU else 4
+            fits = lambda rows, nc, nw: int(lib.vican_wsweep_lds_bytes(n_cam, rows, storage, nc, nw)) <= lim
+            while not fits(rows_target, n_copy, wg_waves) and n_copy > 1:
+                n_copy //= 2
+            while not fits(rows_target, n_copy, wg_waves) and wg_waves > 4:
+                wg_waves -= 4
+            while not fits(rows_target, n_copy, wg_waves) and rows_target > 1:
+                rows_target -= 1
+            if not fits(rows_target, n_copy, wg_waves):
+                raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % n_cam)
+            max_rows, block_threads = rows_target, 64 * wg_waves
+        else:
+            wg_waves = 0
+            if block_threads is None:
+                # 768 threads (12 wavefronts, <= 168 VGPRs) holds two register sets of a chunk without
+                # spilling and measured fastest on the HBM-bound stress graph; small graphs use 256 so
+                # that there are enough chunks to occupy the chip
+                block_threads = 768 if n_edges >= 768 * epl * N_CU else 256
+                if deg_max > 256 * epl:
+                    block_threads = 768
+                if deg_max > 768 * epl:
+                    block_threads = 1024
+            slots = block_threads * epl
+            # lane-striped copies of the row accumulators: as many as LDS allows while a chunk can
+            # still hold its natural number of rows (slots / average degree)
+            rows_target = min(65535, int(math.ceil(1.25 * slots / deg_avg)) + 1)
+            if n_copy is None:
+                n_copy = 8        # measured: 4..32 copies are within 3 % on the stress graph; 8 leaves LDS for rows
+                while n_copy > 1 and lib.vican_max_rows_for(n_cam, storage, n_copy) < rows_target:
+                    n_copy //= 2
+            max_rows = int(lib.vican_max_rows_for(n_cam, storage, n_copy))
+            if max_rows < 1:
+                raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % n_cam)
+            max_rows = min(max_rows, max(rows_target, 1))
+        cap = n_time + 2
+        c0 = np.empty(cap, dtype=np.int32)
+        nchunk = _lib.check(lib.vican_plan_chunks(n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
+                                                   C.c_void_p(c0.ctypes.data), cap), "vican_plan_chunks")
+        self.chunk_row0_host = c0[: nchunk + 1].copy()
+        rows_per_chunk = np.diff(self.chunk_row0_host) if nchunk else np.zeros(0, np.int32)
+        self.max_rows = int(rows_per_chunk.max()) if nchunk else 1
+        self.n_chunk, self.slots, self.block_threads, self.n_copy, self.wg_waves = int(nchunk), slots, block_threads, int(n_copy), wg_waves
+        if kind == "wave":
+            lds = int(lib.vican_wsweep_lds_bytes(n_cam, self.max_rows, storage, n_copy, wg_waves))
+            per_wg = wg_waves
+        else:
+            lds = int(lib.vican_sweep_lds_bytes(n_cam, self.max_rows, storage, n_copy))
+            per_wg = 1
+        occ = max(1, min(lim // lds, 2048 // block_threads))
+        if n_wg is None:
+            n_wg = max(1, min(-(-self.n_chunk // per_wg), N_CU * occ))
+        self.n_wg = int(n_wg)
+        # max timestep rows one workgroup handles (bounds the adds into one z accumulator)
+        bounds = (np.arange(self.n_wg + 1, dtype=np.int64) * self.n_chunk) // self.n_wg
+        self.rows_per_wg_max = int(np.diff(self.chunk_row0_host[bounds]).max()) if nchunk else 1
+        if kind == "wave":
+            # ranges of NW / 2 NW chunks are handed to the workgroups by a device counter (vican_wsweep.hip); a workgroup
+            # takes at most `cap` chunks, which bounds the adds into one of its z accumulators
+            per = -(-self.n_chunk // self.n_wg) if nchunk else 1
+            self.wg_chunk_cap = (-(-13 * per // (10 * wg_waves)) + 3) * wg_waves
+            self.rows_per_wg_sweep = max(min(n_time, self.wg_chunk_cap * self.max_rows), 1)
+        else:
+            # the block sweeps hand chunks out dynamically (tickets); a workgroup takes at most `cap` of them, which
+            # bounds the adds into one of its z accumulators
+            per = -(-self.n_chunk // self.n_wg) if nchunk else 1
+            self.wg_chunk_cap = per + max(2, -(-per // 8))
+            self.rows_per_wg_sweep = max(self.rows_per_wg_max, min(n_time, self.wg_chunk_cap * self.max_rows), 1)
+        self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
+        self.nslot = max(1, self.n_chunk) * slots
+        self.idx = torch.empty(self.nslot, dtype=torch.int32, device=dev)
+
+    def describe(self, n_cam, storage, blk):
+        self.desc = _lib.Graph(n_cam, self.n_time, self.n_chunk, self.slots, self.max_rows, storage, self.block_threads,
+                               self.n_wg, self.n_copy, self.wg_chunk_cap, _lib.LAYOUT_WAVE if self.kind == "wave" else _lib.LAYOUT_BLOCK,
+                               self.wg_waves, None if blk is None else blk.data_ptr(), self.idx.data_ptr(), self.chunk_row0.data_ptr())
+        return self.desc
+
+
 class LocalGraph:
-    """Chunked layout of this rank's timestep rows.
+    """Chunked layout(s) of this rank's timestep rows.
 
     Parameters are device tensors in timestep-major CSR order:
     row_ptr (T+1,) int32, col (E,) int32 (ascending camera index inside a row),
     blk (E,9) / a (E,) in the storage dtype (float32 or float64), and optionally
     the translation-stage arrays w (E,), u (E,3), v (E,3) in float64.
+
+    layout: "wave" = one wavefront per chunk of <= 256 (f32) / 128 (f64) slots (vican_wsweep.hip; rows must fit a
+    chunk), "block" = one workgroup per chunk of 1024..4096 slots (vican_sweep.hip), None = wave where the rows allow
+    it without more padding than the block layout needs (VICAN_LAYOUT overrides).  The translation arrays always live
+    in a block layout (`desc_t`; the same object as `desc` when the rotation layout is a block layout).
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None, n_copy=None):
+                 n_wg=None, n_copy=None, layout=None, wg_waves=None):
+        import os
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VicanError("vican_amd needs a GPU (MI355X); there is no CPU fallback")
@@ -66,61 +169,39 @@ class LocalGraph:
         rp_host = row_ptr.to("cpu", torch.int32).contiguous()
         deg = (rp_host[1:] - rp_host[:-1]) if self.n_time else torch.zeros(1, dtype=torch.int32)
         deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
-        if block_threads is None:
-            # 768 threads (12 wavefronts, <= 168 VGPRs) holds two register sets of a chunk without
-            # spilling and measured fastest on the HBM-bound stress graph; small graphs use 256 so
-            # that there are enough chunks to occupy the chip
-            block_threads = 768 if self.n_edges >= 768 * epl * N_CU else 256
-            if deg_max > 256 * epl:
-                block_threads = 768
-            if deg_max > 768 * epl:
-                block_threads = 1024
-        slots = block_threads * epl
-        # lane-striped copies of the row accumulators: as many as LDS allows while a chunk can
-        # still hold its natural number of rows (slots / average degree)
-        rows_target = min(65535, int(math.ceil(1.25 * slots / deg_avg)) + 1)
-        if n_copy is None:
-            n_copy = 8        # measured: 4..32 copies are within 3 % on the stress graph; 8 leaves LDS for rows
-            while n_copy > 1 and lib.vican_max_rows_for(self.n_cam, storage, n_copy) < rows_target:
-                n_copy //= 2
-        max_rows = int(lib.vican_max_rows_for(self.n_cam, storage, n_copy))
-        if max_rows < 1:
-            raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % self.n_cam)
-        max_rows = min(max_rows, max(rows_target, 1))
-        cap = self.n_time + 2
-        c0 = np.empty(cap, dtype=np.int32)
-        nchunk = _lib.check(lib.vican_plan_chunks(self.n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
-                                                   C.c_void_p(c0.ctypes.data), cap), "vican_plan_chunks")
-        self.chunk_row0_host = c0[: nchunk + 1].copy()
-        rows_per_chunk = np.diff(self.chunk_row0_host) if nchunk else np.zeros(0, np.int32)
-        self.max_rows = int(rows_per_chunk.max()) if nchunk else 1
-        self.n_chunk, self.slots, self.block_threads, self.n_copy = int(nchunk), slots, block_threads, int(n_copy)
-        lds = int(lib.vican_sweep_lds_bytes(self.n_cam, self.max_rows, storage, n_copy))
-        occ = max(1, min(int(lib.vican_lds_limit_bytes()) // lds, 2048 // block_threads))
-        if n_wg is None:
-            n_wg = max(1, min(self.n_chunk, N_CU * occ))
-        self.n_wg = int(n_wg)
-        # max timestep rows one workgroup handles (bounds the adds into one z accumulator)
-        bounds = (np.arange(self.n_wg + 1, dtype=np.int64) * self.n_chunk) // self.n_wg
-        self.rows_per_wg_max = int(np.diff(self.chunk_row0_host[bounds]).max()) if nchunk else 1
-        # the block sweeps hand chunks out dynamically (tickets); a workgroup takes at most `cap` of them, which
-        # bounds the adds into one of its z accumulators
-        per = -(-self.n_chunk // self.n_wg) if nchunk else 1
-        self.wg_chunk_cap = per + max(2, -(-per // 8))
-        self.rows_per_wg_sweep = max(self.rows_per_wg_max, min(self.n_time, self.wg_chunk_cap * self.max_rows), 1)
-        self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
-        nslot = max(1, self.n_chunk) * slots
-        self.blk = torch.empty(9 * nslot, dtype=blk.dtype, device=dev)
-        self.idx = torch.empty(nslot, dtype=torch.int32, device=dev)
-        self.a = torch.empty(nslot, dtype=blk.dtype, device=dev)
+        layout = layout or os.environ.get("VICAN_LAYOUT") or None
+        if layout not in (None, "wave", "block"):
+            raise ValueError("layout must be 'wave', 'block' or None")
+        mk = lambda kind, **kw: _Layout(lib, kind, self.n_cam, self.n_time, rp_host, deg_max, deg_avg, self.n_edges, storage, dev, **kw)
+        rot = None
+        if layout != "block" and block_threads is None and deg_max <= 64 * epl and self.n_cam <= 1024 and self.n_edges > 0:
+            try:
+                rot = mk("wave", n_wg=n_wg, n_copy=n_copy, wg_waves=wg_waves)
+            except _lib.VicanError:
+                rot = None
+            if rot is not None and layout is None and rot.nslot > 1.06 * max(self.n_edges, 1) + 64 * epl * 8:
+                rot = None                                   # rows pack badly into 64-lane chunks: the block layout pads less
+        if rot is None:
+            if layout == "wave":
+                raise _lib.VicanError("the wave layout needs rows of at most %d edges and C <= 1024" % (64 * epl))
+            rot = mk("block", block_threads=block_threads, n_wg=n_wg, n_copy=n_copy)
         have_t = w is not None
-        self.w = torch.empty(nslot, dtype=torch.float64, device=dev) if have_t else None
-        self.u = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
-        self.v = torch.empty(3 * nslot, dtype=torch.float64, device=dev) if have_t else None
-        self.desc = _lib.Graph(self.n_cam, self.n_time, self.n_chunk, slots, self.max_rows, storage, block_threads,
-                               self.n_wg, self.n_copy, self.wg_chunk_cap, self.blk.data_ptr(), self.idx.data_ptr(),
-                               self.chunk_row0.data_ptr())
-        gref = C.byref(self.desc)
+        tl = rot if (rot.kind == "block" or not have_t) else mk("block")
+        self.rot, self.tl = rot, tl
+        self.layout = rot.kind
+        # the rotation layout's numbers under the historical attribute names
+        self.chunk_row0_host, self.max_rows, self.n_chunk, self.slots = rot.chunk_row0_host, rot.max_rows, rot.n_chunk, rot.slots
+        self.block_threads, self.n_copy, self.n_wg, self.wg_waves = rot.block_threads, rot.n_copy, rot.n_wg, rot.wg_waves
+        self.rows_per_wg_max, self.wg_chunk_cap, self.rows_per_wg_sweep = rot.rows_per_wg_max, rot.wg_chunk_cap, rot.rows_per_wg_sweep
+        self.chunk_row0, self.idx = rot.chunk_row0, rot.idx
+        self.blk = torch.empty(9 * rot.nslot, dtype=blk.dtype, device=dev)
+        self.a = torch.empty(rot.nslot, dtype=blk.dtype, device=dev)
+        self.w = torch.empty(tl.nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.u = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.v = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
+        self.desc = rot.describe(self.n_cam, storage, self.blk)
+        self.desc_t = self.desc if tl is rot else tl.describe(self.n_cam, storage, None)
+        gref, gref_t = C.byref(self.desc), C.byref(self.desc_t)
         row_ptr = row_ptr.to(dev, torch.int32).contiguous()
         col = col.to(dev, torch.int32).contiguous()
         blk = blk.contiguous(); a = a.to(blk.dtype).contiguous()
@@ -134,10 +215,15 @@ class LocalGraph:
             if have_t:
                 w, u, v = (torch.zeros(k, dtype=torch.float64, device=dev) for k in (1, 3, 3))
         st = _stream()
-        perm_ws = torch.empty(nslot, dtype=torch.int32, device=dev)
-        _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w), _ptr(u), _ptr(v),
-                                        _ptr(self.a), _ptr(self.w), _ptr(self.u), _ptr(self.v), _ptr(perm_ws), st),
-                   "vican_pack_edges")
+        perm_ws = torch.empty(max(rot.nslot, tl.nslot), dtype=torch.int32, device=dev)
+        same = tl is rot
+        _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w) if same else None,
+                                        _ptr(u) if same else None, _ptr(v) if same else None, _ptr(self.a),
+                                        _ptr(self.w) if same else None, _ptr(self.u) if same else None,
+                                        _ptr(self.v) if same else None, _ptr(perm_ws), st), "vican_pack_edges")
+        if have_t and not same:
+            _lib.check(lib.vican_pack_edges(gref_t, _ptr(row_ptr), _ptr(col), None, None, _ptr(w), _ptr(u), _ptr(v), None,
+                                            _ptr(self.w), _ptr(self.u), _ptr(self.v), _ptr(perm_ws), st), "vican_pack_edges")
         # graph constants
         T1 = max(self.n_time, 1)
         f64 = dict(dtype=torch.float64, device=dev)
@@ -152,7 +238,7 @@ class LocalGraph:
             self.row_sum_w, self.cam_sum_w = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
             # bounds that size the fixed-point scales of the translation stage (host scalars, once)
             self.wmax = float(w.max()) if self.n_edges else 1.0
-            _lib.check(lib.vican_edge_sums(gref, _ptr(self.w), 1, self.wmax, _ptr(self.row_sum_w), _ptr(self.cam_sum_w),
+            _lib.check(lib.vican_edge_sums(gref_t, _ptr(self.w), 1, self.wmax, _ptr(self.row_sum_w), _ptr(self.cam_sum_w),
                                            _ptr(cam_ws), st), "vican_edge_sums")
             self.gmax = float((u.norm(dim=1) + v.norm(dim=1)).max()) if self.n_edges else 1.0
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
@@ -178,14 +264,17 @@ class HipBackend:
         # folding the sweep's slabs inside the (<= 32 workgroup) camera-side kernel pays off while there are few of them:
         # measured -3..-8 % of the rotation stage at 40 slabs (large_shop), +1.3 % at 256 (stress) - tools/ab_fold.py
         self.fold_in_step_ok = graph.n_wg <= 64
+        self.layout = graph.layout
         self._gref = C.byref(graph.desc)
-        nwg = graph.n_wg
+        self._gref_t = C.byref(graph.desc_t)            # layout of the translation arrays (block layout)
+        self.tl = graph.tl
+        nwg = max(graph.n_wg, graph.tl.n_wg)
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
         self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
         self.rr_part = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
-        self.n_add = float(max(graph.rows_per_wg_max, graph.slots) + 1)
+        self.n_add = float(max(graph.tl.rows_per_wg_max, graph.tl.slots) + 1)
         self._status_host = {}
         self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
         self._coop_ws, self._coop_sync, self._gram_ws = None, None, None
@@ -294,8 +383,8 @@ class HipBackend:
                  "vican_lanczos_cam_step")
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
-        part = self.zpart[: self.g.n_wg * 3 * self.C]
-        self._ck(self.lib.vican_cg_iter_local(self._gref, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
+        part = self.zpart[: self.tl.n_wg * 3 * self.C]
+        self._ck(self.lib.vican_cg_iter_local(self._gref_t, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
                                               _ptr(p_t), _ptr(q_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq), float(rtol),
                                               _ptr(self.rr_part), int(n_rr_part), self.n_add, _ptr(st), _stream()),
                  "vican_cg_iter_local")
@@ -418,10 +507,10 @@ class HipBackend:
         deg_c.copy_(self.g.cam_sum_w)
 
     def trans_rhs(self, rc, rt, rhs_t, rhs_c):
-        nwg = self.g.n_wg
+        nwg = self.tl.n_wg
         part = self.zpart[: nwg * 3 * self.C]
         inv = C.c_double(0.0)
-        self._ck(self.lib.vican_trans_rhs(self._gref, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t),
+        self._ck(self.lib.vican_trans_rhs(self._gref_t, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t),
                                           _ptr(part), self.g.gmax, self.n_add, C.byref(inv), _stream()), "vican_trans_rhs")
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(rhs_c), _stream()),
                  "vican_slab_reduce_fx")
@@ -437,7 +526,7 @@ class HipBackend:
         """CG sweeps use w~ = w s_c s_t (<= 1) until clear_cg_scaling()."""
         if self._w_scaled is None:
             self._w_scaled = torch.empty_like(self.g.w)
-        self._ck(self.lib.vican_scale_weights(self._gref, _ptr(self.g.w), _ptr(s_c), _ptr(s_t), _ptr(self._w_scaled), _stream()),
+        self._ck(self.lib.vican_scale_weights(self._gref_t, _ptr(self.g.w), _ptr(s_c), _ptr(s_t), _ptr(self._w_scaled), _stream()),
                  "vican_scale_weights")
         self._cg_w, self._cg_wmax = self._w_scaled, 1.0
 
@@ -454,9 +543,9 @@ class HipBackend:
 
     def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
         """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
-        nwg = self.g.n_wg
+        nwg = self.tl.n_wg
         part = self.zpart[: nwg * 3 * self.C]
-        self._ck(self.lib.vican_cg_sweep(self._gref, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
+        self._ck(self.lib.vican_cg_sweep(self._gref_t, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
                                          _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, 1.0, C.c_void_p(st.data_ptr() + 8 * _lib.CG_F["qinv"]),
                                                None, _ptr(qcpq), _stream()), "vican_slab_reduce_fx")
@@ -478,30 +567,30 @@ class HipBackend:
 # -- LSQR ("direct") wrappers, attached to HipBackend ------------------------------------------
 def _lsqr_alloc(self):
     if not hasattr(self, "_lsqr_u"):
-        nslot = max(1, self.g.n_chunk) * self.g.slots
+        nslot = max(1, self.tl.n_chunk) * self.tl.slots
         self._lsqr_u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
         self._lsqr_sw = torch.zeros(nslot, dtype=torch.float64, device=self.dev)       # sqrt(w), written by lsqr_init_u
-        self._lsqr_part = torch.zeros(max(self.g.n_wg, 1024), dtype=torch.float64, device=self.dev)
+        self._lsqr_part = torch.zeros(max(self.tl.n_wg, 1024), dtype=torch.float64, device=self.dev)
 
 
 def _lsqr_init_u(self, rc, rt, nrm2_out):
     _lsqr_alloc(self)
-    self._ck(self.lib.vican_lsqr_init_u(self._gref, _ptr(self.g.w), _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt),
+    self._ck(self.lib.vican_lsqr_init_u(self._gref_t, _ptr(self.g.w), _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt),
                                         _ptr(self._lsqr_u), _ptr(self._lsqr_sw), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()),
              "vican_lsqr_init_u")
 
 
 def _lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
-    self._ck(self.lib.vican_lsqr_u_step(self._gref, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
+    self._ck(self.lib.vican_lsqr_u_step(self._gref_t, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
                                         _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
 
 
 def _lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
     """v_t updated in place; acc_c[3C] = this rank's camera-side sums (all-reduce, then lsqr_cam_v)."""
-    nwg = self.g.n_wg
+    nwg = self.tl.n_wg
     part = self.zpart[: nwg * 3 * self.C]
     inv = C.c_double(0.0)
-    self._ck(self.lib.vican_lsqr_v_step(self._gref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
+    self._ck(self.lib.vican_lsqr_v_step(self._gref_t, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
                                         _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self.n_add,
                                         C.byref(inv), _stream()), "vican_lsqr_v_step")
     self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
