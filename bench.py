@@ -16,10 +16,11 @@ rows of one graph; ``--scaling strong``, default for large_shop: the ``--timeste
 are split over the ranks by vican_amd.bipgo._shard_rows; the camera side is replicated either way).  Prints ONE JSON line on rank 0 (contract in
 the task statement) with two extra objects:
 
-  roofline      dominant kernel = the fused block operator ``block_sweep_kernel<.,.,0>``
-                (z = R~ Lambda_T^-1 R~^T x).  achieved = algorithmic bytes per launch
-                (E(9s+4) + 4(T+1) + 72T + 2*72C) / mean launch time from
-                HIP events recorded on the launch stream inside the timed steps.
+  roofline      dominant kernel = the fused block operator z = R~ Lambda_T^-1 R~^T x
+                (``wave_sweep_kernel<.,.,0>``, or ``block_sweep_kernel<.,.,0>`` on graphs whose rows do not fit
+                the wave layout).  achieved = algorithmic bytes per launch (SURVEY.md 8(d):
+                E(9s+4) + 4(T+1) + 72T + 2*72C) / mean duration of its launches inside the timed steps, from HIP
+                events bound to each launch's own dispatch on the launch stream (vican_set_launch_events).
   cpu_baseline  the oracle (NumPy/SciPy port of the reference's rotation loop, same
                 third-party calls) timed on rank 0's host cores on a bounded sample.
 
@@ -267,28 +268,24 @@ def main():
     torch.cuda.empty_cache()
 
     class TimedBackend(HipBackend):
-        """HIP events around every launch of the dominant kernel (on the launch stream)."""
-        events = []
+        """HIP events bound to every launch of the dominant kernel (vican_set_launch_events: start / stop of the
+        dispatch itself on the launch stream - no event command sits in the stream next to the kernel, so the
+        5-8 us of queue idle that an event pair recorded around a launch adds are not part of the measurement)."""
+        events, timers = [], []
         record = False
+
+        def block_op_raw(self, lamT_inv, x):
+            if self.record and self.timers:
+                pair = self.timers.pop()
+                self.time_next_sweep(pair)
+                self.events.append(pair)
+            return super().block_op_raw(lamT_inv, x)
 
         def block_op(self, lamT_inv, x, z_out):
             if not self.record:
                 return super().block_op(lamT_inv, x, z_out)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
             self.block_op_raw(lamT_inv, x)                 # the sweep kernel alone ...
-            e1.record()
-            self.events.append((e0, e1))
             self.fold_z(z_out)                             # ... then the slab fold
-
-        def block_op_slabs(self, lamT_inv, x):             # Lanczos steps: the fold happens inside the next kernel
-            if not self.record:
-                return super().block_op_slabs(lamT_inv, x)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.block_op_raw(lamT_inv, x)
-            e1.record()
-            self.events.append((e0, e1))
 
     K = TimedBackend(g)
     comm = Comm()
@@ -319,10 +316,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    K.timers = K.make_launch_timers(64)
     barrier()
-    # HIP events bracket every launch of the dominant kernel in the LAST timed step only: an event pair costs
-    # about 11 us of queue idle around the launch (kernel trace: 5.6 us gaps before and after an instrumented
-    # sweep, none otherwise - tools/gap_probe.py), i.e. ~3 % of a step if every launch were instrumented.
+    # HIP events are bound to every launch of the dominant kernel of the LAST timed step (its sync between the two
+    # stages, for the stage split, costs a pipeline bubble - one instrumented step is enough).
     t_rot = t_tr = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -376,7 +373,7 @@ def main():
                    "arithmetic": "%s block products, exact 64-bit fixed-point accumulation, f64 camera side and CG" % args.dtype,
                    "parallelism": "timestep-sharded x%d, camera side replicated" % world,
                    "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
-        "roofline": {"bound": "hbm", "kernel": "block_sweep_kernel<MODE=0> (vican_block_op)",
+        "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
                      "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
@@ -386,7 +383,7 @@ def main():
                    "eig_resid": rot.stats["resid"], "cg_iters": tr.info.get("cg_iters"),
                    "lanczos_checks": rot.stats.get("n_check"),
                    "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
-                   "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
+                   "layout": g.layout, "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
                    "rot_edges_per_s": E_total * args.maxiter / t_rot if t_rot else None,
                    "edges_rank0": E_local, "rows_rank0": Tl,
                    "n_allreduce_per_solve": n_allreduce_total / max(args.steps + args.warmup, 1)},

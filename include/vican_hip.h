@@ -89,6 +89,14 @@ int vican_abi_version(void);            /* 8 */
  * NULL (the default) disables gating.                                                        */
 int vican_set_gate(const int32_t* gate);
 
+/* Launch timer (state of the calling host thread).  The NEXT launch of an edge sweep (vican_block_op(_z),
+ * vican_dual_update(_op), vican_bip_apply) binds the two HIP events (hipEvent_t passed as void*, created by the caller
+ * with timing enabled) to its own dispatch - start / stop = begin / end of the kernel on the device - and clears them;
+ * hipEventElapsedTime(start, stop) after the stream has passed the launch is the kernel's duration, the number a
+ * rocprofv3 kernel trace reports.  (An event pair recorded AROUND a launch also times the 5-8 us the queue idles
+ * between an event command and the next dispatch.)  NULLs cancel.                                            */
+int vican_set_launch_events(void* start_event, void* stop_event);
+
 /* ---- host-side planning (no GPU needed) ---------------------------------
  * Cut T rows (host row_ptr[T+1]) into chunks of whole rows with at most
  * `slots` edges and `max_rows` rows.  Writes first-row indices to

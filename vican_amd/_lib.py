@@ -54,6 +54,7 @@ PROTOTYPES = {
     "vican_last_error": (C.c_char_p, []),
     "vican_abi_version": (C.c_int, []),
     "vican_set_gate": (C.c_int, [_vp]),
+    "vican_set_launch_events": (C.c_int, [_vp, _vp]),
     "vican_lanczos_coop_ws_doubles": (_i64, [_i32]),
     "vican_lanczos_cam_coop": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "vican_jacobi_scale": (C.c_int, [_i32, _vp, _vp, _vp]),

@@ -2,6 +2,7 @@
 // reductions, 3x3 SVD / polar factor, LDS budget).  Included by every .hip file.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -34,6 +35,20 @@ int vican_check_block_graph(const vican_graph_t* g, const char* who);   // ... a
 // unless *gate == 1 at execution time (speculatively enqueued work that a device-side decision cancels).
 extern thread_local const int32_t* g_vican_gate;
 #define GATE_RETURN(gate) do { if ((gate) != nullptr && *(gate) != 1) return; } while (0)
+// Launch timer (vican_set_launch_events, per host thread, defined in vican_sweep.hip): the NEXT edge-sweep launch binds
+// these two HIP events to its own dispatch (hipExtLaunchKernelGGL: start / stop = begin / end of the kernel on the
+// device, the timestamps a kernel trace shows) and clears them.  An event pair recorded around a launch instead also
+// times the 5-8 us the queue idles between an event command and the next dispatch.
+extern thread_local hipEvent_t g_vican_ev_start, g_vican_ev_stop;
+#define VICAN_LAUNCH_SWEEP(kern, grid, block, lds, st, ...)                                                        \
+    do {                                                                                                           \
+        if (g_vican_ev_start && g_vican_ev_stop) {                                                                 \
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(lds), st, g_vican_ev_start, g_vican_ev_stop, 0, __VA_ARGS__); \
+            g_vican_ev_start = g_vican_ev_stop = nullptr;                                                          \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                           \
+        }                                                                                                          \
+    } while (0)
 static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 96LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 144) + 256; }
 static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 48LL * n_cam + (int64_t)max_rows * (48LL * n_copy + 96) + 256; }
 // ---------------------------------------------------------------------------

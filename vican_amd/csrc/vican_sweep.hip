@@ -34,6 +34,11 @@ extern "C" int vican_abi_version(void) { return 8; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
+thread_local hipEvent_t g_vican_ev_start = nullptr, g_vican_ev_stop = nullptr;
+extern "C" int vican_set_launch_events(void* start_event, void* stop_event) {
+    g_vican_ev_start = (hipEvent_t)start_event; g_vican_ev_stop = (hipEvent_t)stop_event;
+    return VICAN_OK;
+}
 
 // ---------------------------------------------------------------------------
 // host-side planning + LDS budget
@@ -946,7 +951,7 @@ static int launch_sweep2(const vican_graph_t* g, const double* lamT_inv, const d
             return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican sweep");
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
+    VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(BLOCK), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, Rt, lamT_out, rnorm, fx);
     return 0;
 }
 

@@ -79,18 +79,23 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     const int unit0 = nchunk >= 4 * NW * nwg ? 2 : 1;          // implicit first range of workgroup w: units [unit0 w, unit0 (w + 1))
     const int cap_units = g.wg_chunk_cap > 0 ? g.wg_chunk_cap / NW : 0x3fffffff;
     __shared__ int s_cnt, s_npub, s_done, s_units, s_v0[RING], s_v1[RING], s_base[RING];
-    if (tid == 0) {
-        const int base = (int)blockIdx.x * unit0 * NW;
-        int len = nchunk - base; len = len < 0 ? 0 : (len > unit0 * NW ? unit0 * NW : len);
-        s_cnt = 0; s_v0[0] = 0; s_v1[0] = len; s_base[0] = base; s_npub = 1; s_units = unit0;
+    // first range of workgroup w (implicit, no atomic): units [unit0 w, unit0 (w + 1)); its first NW tickets are implicit
+    // too - wavefront i holds ticket i - so that the first chunk is requested before the prologue barrier
 #ifdef VICAN_W_STATIC       /* experiment: one static contiguous range per workgroup, no device-level scheduling */
-        const int c0 = (int)(((long long)blockIdx.x * nchunk) / nwg), c1 = (int)(((long long)(blockIdx.x + 1) * nchunk) / nwg);
-        s_v1[0] = c1 - c0; s_base[0] = c0; s_done = 1;
+    const int base0 = (int)(((long long)blockIdx.x * nchunk) / nwg);
+    const int len0 = (int)(((long long)(blockIdx.x + 1) * nchunk) / nwg) - base0;
 #else
-        s_done = len < unit0 * NW ? 1 : 0;                     // the queue ends inside (or before) this range
+    const int base0 = (int)blockIdx.x * unit0 * NW;
+    const int len0 = nchunk - base0 < 0 ? 0 : (nchunk - base0 > unit0 * NW ? unit0 * NW : nchunk - base0);
+#endif
+    if (tid == 0) {
+        s_cnt = NW; s_v0[0] = 0; s_v1[0] = len0; s_base[0] = base0; s_npub = 1; s_units = unit0;
+#ifdef VICAN_W_STATIC
+        s_done = 1;
+#else
+        s_done = len0 < unit0 * NW ? 1 : 0;                    // the queue ends inside (or before) this range
 #endif
     }
-    __syncthreads();
     int my_r = 0;                                              // newest ring entry this wavefront has looked at (wave-uniform)
     // ticket -> chunk.  Tickets are unique in the workgroup; entries are published in ticket order.
     auto resolve = [&](const int v) -> int {
@@ -142,8 +147,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         if (lane == 0) t = __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t;                                              // (valid in lane 0; resolved later)
     };
-    int kc = resolve(__builtin_amdgcn_readfirstlane(draw()));
-    int kn1 = resolve(__builtin_amdgcn_readfirstlane(draw()));
+    int kc = wave < len0 ? base0 + wave : NONE, kn1 = NONE;
     ChunkRegs<S, EPL> ra, rb;
     // first row of a chunk and of the chunk behind it: VECTOR loads (every lane the same address) issued one body
     // ahead.  Scalar loads would share lgkmcnt with the LDS operations and, returning out of order, turn every LDS wait
@@ -187,6 +191,10 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     if (HAS_Z) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
     for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
     __syncthreads();
+    if (kc != NONE) {
+        (void)resolve(wave);                                   // (the implicit ticket may be the one that fetches the next range)
+        kn1 = resolve(__builtin_amdgcn_readfirstlane(draw()));
+    }
     xm2 = 0.0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) xm2 = fmax(xm2, s_xm[i]);
@@ -426,7 +434,7 @@ static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const 
             return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican wave sweep");
         configured = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW * 64), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, lamT_out, fx);
+    VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW * 64), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, lamT_out, fx);
     return 0;
 }
 template <typename S, int NW, int MODE, int CP>
@@ -446,8 +454,11 @@ static int launch_wsweep2(const vican_graph_t* g, const double* lamT_inv, const 
 template <typename S, int MODE>
 static int launch_wsweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
-    if (g->wg_waves == 12) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    if (g->wg_waves == 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    // MODE 3 carries the Newton polar iteration (~60 live VGPRs on top of the two chunk register sets): at 12 wavefronts
+    // (168 VGPRs) it spills 65 registers and ran 774 us against 181 us for MODE 0 - it runs with 8 wavefronts (230 VGPRs,
+    // no spills) on the same graph; the per-wavefront LDS regions and the chunk cap do not depend on the launch shape
+    if (g->wg_waves == 12 && MODE != 3) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->wg_waves >= 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     return launch_wsweep2<S, 4, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
 }
 template <int MODE>
