@@ -72,13 +72,16 @@ typedef struct vican_graph {
                                  64 * wg_waves) shares the camera tables - rotation sweeps only (vican_block_op(_z),
                                  vican_dual_update(_op)); the translation kernels and vican_bip_apply take block layouts */
     int32_t wg_waves;         /* wavefronts per workgroup of the wave layout: 4, 8 or 12 (0 in the block layout) */
+    int32_t stream_nt;        /* 1: the sweeps read blk / idx with non-temporal loads (edge stream far larger than the
+                                 256 MB Infinity Cache); 0: plain loads (cache-resident graphs are re-read from cache) */
+    int32_t reserved;
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 8 */
+int vican_abi_version(void);            /* 9 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),

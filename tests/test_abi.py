@@ -31,11 +31,11 @@ def test_every_header_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), "library does not export %s" % s
         assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
-    assert lib.vican_abi_version() == 8
+    assert lib.vican_abi_version() == 9
 
 
 def test_struct_sizes():
-    assert C.sizeof(_lib.Graph) == 12 * 4 + 3 * 8
+    assert C.sizeof(_lib.Graph) == 14 * 4 + 3 * 8
     assert _lib.CG_STATE_DOUBLES * 8 == 16 * 8 + 4 * 4
 
 

@@ -30,7 +30,7 @@
 #include "sweep_common.cuh"
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 8; }
+extern "C" int vican_abi_version(void) { return 9; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
@@ -92,7 +92,7 @@ int vican_check_graph(const vican_graph_t* g, const char* who) {
     const int nc = g->n_copy;
     if (nc < 1 || nc > 32 || (nc & (nc - 1))) return set_err(VICAN_ERR_ARG, "%s: n_copy must be a power of two <= 32", who);
     if (g->layout == VICAN_LAYOUT_WAVE) {
-        if ((g->wg_waves != 4 && g->wg_waves != 8 && g->wg_waves != 12) || g->block_threads != 64 * g->wg_waves || g->slots != 64 * epl)
+        if ((g->wg_waves != 4 && g->wg_waves != 8 && g->wg_waves != 12 && g->wg_waves != 16) || g->block_threads != 64 * g->wg_waves || g->slots != 64 * epl)
             return set_err(VICAN_ERR_ARG, "%s: wave layout needs wg_waves in {4, 8, 12}, block_threads = 64 wg_waves, slots = 64 * (16 / sizeof(storage))", who);
         if (g->n_cam > 1024 || g->max_rows <= 0 || g->max_rows > 64 ||
             vican_wsweep_lds_bytes(g->n_cam, g->max_rows, g->storage, nc, g->wg_waves) > vican_lds_limit_bytes())

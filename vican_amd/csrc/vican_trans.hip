@@ -10,7 +10,7 @@
 // order-independent sums are what makes two runs of this solver agree with each other.
 // The fixed-point scale of every CG sweep follows a running bound on max|p| kept in the
 // device-resident state; no host round trip.
-#include "common.cuh"
+#include "sweep_common.cuh"
 
 #define CG_PARTS 512
 
@@ -53,16 +53,19 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 
+    // (52 B per edge, read once: non-temporal loads when the stream is larger than the caches - g.stream_nt)
     auto load_edges = [&](RhsRegs<EPL>& e, int k) {
         const size_t s = (size_t)k * g.slots + (size_t)tid * EPL;
-        if (EPL == 4) { const uint4 t = *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
-        else          { const uint2 t = *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+        const bool nt = g.stream_nt != 0;
+        if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
+        else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const size_t o = ((size_t)k * 3 + p) * g.slots + (size_t)tid * EPL;
 #pragma unroll
             for (int j = 0; j < EPL; j += 2) {
-                const double2 a = *(const double2*)(u + o + j), b = *(const double2*)(v + o + j);
+                const double2 a = nt ? stream_load((const double2*)(u + o + j)) : *(const double2*)(u + o + j);
+                const double2 b = nt ? stream_load((const double2*)(v + o + j)) : *(const double2*)(v + o + j);
                 e.u[p][j] = a.x; e.u[p][j + 1] = a.y; e.v[p][j] = b.x; e.v[p][j + 1] = b.y;
             }
         }
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
 
     auto body = [&](RhsRegs<EPL>& cur, RhsRegs<EPL>& nxt, const int k, const int buf) {
         const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        if (k + 1 < k1) { load_edges(nxt, k + 1); load_rows(k + 1); }          // in flight during this chunk
+        load_edges(nxt, k + 1 < k1 ? k + 1 : k);                               // in flight during this chunk (unconditional: exact vmcnt waits)
+        if (k + 1 < k1) load_rows(k + 1);
         const double* rtb = rts + buf * mr9;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
@@ -368,15 +372,20 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 
+    // (edge words: non-temporal loads when the stream cannot stay cached between two CG iterations - g.stream_nt)
     auto load_edges = [&](CgRegs<EPL>& e, int k) {
         const size_t s = (size_t)k * g.slots + (size_t)tid * EPL;
         if (EPL == 4) {
-            const uint4 t = *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
-            const double2 a = *(const double2*)(w + s), b = *(const double2*)(w + s + 2);
+            uint4 t; double2 a, b;
+            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)(w + s)); b = stream_load((const double2*)(w + s + 2)); }
+            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)(w + s); b = *(const double2*)(w + s + 2); }
+            e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
-            const uint2 t = *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y;
-            const double2 a = *(const double2*)(w + s); e.w[0] = a.x; e.w[1] = a.y;
+            uint2 t; double2 a;
+            if (g.stream_nt) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
+            else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
+            e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
         }
     };
     // rows of chunk k: p (updated p = r + beta p on all but the first iteration) and deg
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     };
     // body(k): edges `cur`; `rx` holds the rows of chunk k+1 (committed at the end), `ry` receives those of k+2
     auto body = [&](CgRegs<EPL>& cur, CgRegs<EPL>& nxt, RowRegs& rx, RowRegs& ry, const int k, const int buf) {
-        if (k + 1 < k1) load_edges(nxt, k + 1);                                // in flight during this chunk
+        load_edges(nxt, k + 1 < k1 ? k + 1 : k);                               // in flight during this chunk (unconditional: exact vmcnt waits)
         if (k + 2 < k1) load_rows(ry, k + 2);
         const double* pt = pts + buf * mr3;
         u64* qtb = qt + (size_t)buf * mr3 * ncopy;

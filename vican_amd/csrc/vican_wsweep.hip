@@ -61,7 +61,8 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double s_xm[16];
     const int C = g.n_cam, nx = 9 * CP, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lane_copy = lane & cmask;
+    const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar registers, not one VGPR per use
     u64* zs = (u64*)lds_raw;                                   // [9][CP] planes, shared by the workgroup
     S* xs = (S*)(zs + (HAS_Z ? nx : 0));                       // [9][CP] planes
     const size_t per_wave = (((size_t)RW * 9 * (8 * ncopy + 8 + sizeof(S))) + 15) & ~(size_t)15;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
     __syncthreads();
     if (kc != NONE) {
-        (void)resolve(wave);                                   // (the implicit ticket may be the one that fetches the next range)
+        if (wave == 0 && len0 <= NW) (void)resolve(0);         // (a short first range: ticket 0 is the one that fetches the next)
         kn1 = resolve(__builtin_amdgcn_readfirstlane(draw()));
     }
     xm2 = 0.0;
@@ -203,7 +204,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
     if (MODE == 3) shift = 0;                                  // phase-3 operand = polar factors, |.|_F = x_bound
     const double up = ldexp(1.0, shift);
-    const double y_scale = fx0 * up, y_inv = fx1 / up, z_scale = (MODE == 3) ? fx9 : fx2 * up;
+    // (wave-uniform doubles that live through the whole loop: into scalar registers)
+    auto uni = [](double v) -> double {
+        const long long b = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double y_scale = uni(fx0 * up), y_inv = uni(fx1 / up), z_scale = uni((MODE == 3) ? fx9 : fx2 * up);
     if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;   // omega bound: raised by dual_svd_kernel
 
@@ -257,20 +264,20 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         WSTAMP(1);
 #endif
+        // LEAN (16 wavefronts = 128 VGPRs): no double-buffered x gather, camera / row indices re-derived in phase 3
+        constexpr bool LEAN = NW >= 16;
+        auto cam_of = [&](uint32_t id) -> uint32_t { return id == VICAN_PAD_SLOT ? pad_cam : (id & 0xFFFFu); };
+        auto row_of = [&](uint32_t id) -> uint32_t { return id == VICAN_PAD_SLOT ? 0u : (id >> 16); };
         uint32_t cam[EPL], row[EPL];
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
-            cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
-            row[j] = pad ? 0u : (cur.id[j] >> 16);
-        }
+        for (int j = 0; j < EPL; ++j) { cam[j] = cam_of(cur.id[j]); row[j] = row_of(cur.id[j]); }
         {
             S acc[9], xc[9], xn[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) xc[q] = xs[q * CP + cam[0]];
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                if (j + 1 < EPL) {
+                if (!LEAN && j + 1 < EPL) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) xn[q] = xs[q * CP + cam[j + 1]];
                 }
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                 }
                 if (j + 1 < EPL) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) xc[q] = xn[q];
+                    for (int q = 0; q < 9; ++q) xc[q] = LEAN ? xs[q * CP + cam[j + 1]] : xn[q];
                 }
             }
         }
@@ -349,12 +356,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             uint32_t prow = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                if (row[j] != prow) {
-                    prow = row[j];
+                const uint32_t rowj = LEAN ? row_of(cur.id[j]) : row[j], camj = LEAN ? cam_of(cur.id[j]) : cam[j];
+                if (rowj != prow) {
+                    prow = rowj;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) w[q] = wv[row[j] * 9 + q];
+                    for (int q = 0; q < 9; ++q) w[q] = wv[rowj * 9 + q];
                 }
-                u64* zc = zs + cam[j];
+                u64* zc = zs + camj;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -457,7 +465,8 @@ static int launch_wsweep1(const vican_graph_t* g, const double* lamT_inv, const 
     // MODE 3 carries the Newton polar iteration (~60 live VGPRs on top of the two chunk register sets): at 12 wavefronts
     // (168 VGPRs) it spills 65 registers and ran 774 us against 181 us for MODE 0 - it runs with 8 wavefronts (230 VGPRs,
     // no spills) on the same graph; the per-wavefront LDS regions and the chunk cap do not depend on the launch shape
-    if (g->wg_waves == 12 && MODE != 3) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->wg_waves == 16 && MODE == 0) return launch_wsweep2<S, 16, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->wg_waves >= 12 && MODE != 3) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (g->wg_waves >= 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     return launch_wsweep2<S, 4, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
 }

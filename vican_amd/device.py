@@ -19,6 +19,7 @@ import torch
 from . import _lib
 
 N_CU = 256
+STREAM_NT_BYTES = 192 << 20       # edge streams above this are read with non-temporal loads (LocalGraph, sweep_common.cuh)
 X_BOUND = math.sqrt(3.0)      # |x_c|_F of every sweep input: orthonormal columns / stacked rotations
 
 
@@ -130,9 +131,15 @@ class _Layout:
         self.idx = torch.empty(self.nslot, dtype=torch.int32, device=dev)
 
     def describe(self, n_cam, storage, blk):
+        # an edge stream that cannot stay in the 256 MB Infinity Cache between two sweeps is read with non-temporal loads
+        stream_bytes = self.nslot * (9 * (4 if storage == _lib.STORE_F32 else 8) + 4)
+        if blk is None:                                      # translation layout: index + weight words of the CG sweep
+            stream_bytes = self.nslot * 12
+        self.stream_nt = int(stream_bytes > STREAM_NT_BYTES)
         self.desc = _lib.Graph(n_cam, self.n_time, self.n_chunk, self.slots, self.max_rows, storage, self.block_threads,
                                self.n_wg, self.n_copy, self.wg_chunk_cap, _lib.LAYOUT_WAVE if self.kind == "wave" else _lib.LAYOUT_BLOCK,
-                               self.wg_waves, None if blk is None else blk.data_ptr(), self.idx.data_ptr(), self.chunk_row0.data_ptr())
+                               self.wg_waves, self.stream_nt, 0, None if blk is None else blk.data_ptr(), self.idx.data_ptr(),
+                               self.chunk_row0.data_ptr())
         return self.desc
 
 
