@@ -353,7 +353,7 @@ int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s
 /* Device-resident CG state (one struct in device memory, initialised by vican_cg_init).
  * Mirrors scipy.sparse.linalg.cg (x0 = 0, no preconditioner, stop when |r| < rtol*|b| tested at
  * the top of every iteration).  The sweeps accumulate q = A p in 64-bit fixed point; its scale
- * follows the running bound pmax >= max|p| (|p_new| <= max|r| + beta |p|).                 */
+ * follows a bound pmax >= max|p| that is re-derived every iteration from measured maxima (|p_new| <= max|r| + beta max|p|).   */
 typedef struct vican_cg_state {
     double rho;        /* r.r of the current residual */
     double rho_prev;
@@ -367,10 +367,11 @@ typedef struct vican_cg_state {
     double rr_time;    /* timestep part of r.r (all-reduced across ranks) */
     double rmax_cam;   /* max |r_c| */
     double rmax_time;  /* max |r_t| over THIS rank's rows */
-    double pmax;       /* bound on max |p| (this rank) */
+    double pmax;       /* bound on max |p| (this rank): max(exact max |p_c|, rmax_time + beta pmax_time) */
     double qscale;     /* fixed-point scale of the current sweep, and its inverse */
     double qinv;
     double wmax;       /* max edge weight (graph constant) */
+    double pmax_time;  /* measured max |p_t| of the current iterate over THIS rank's rows (set by the step kernels) */
     int32_t iter;      /* completed iterations */
     int32_t done;      /* 1 once converged: all later kernels are no-ops */
     int32_t first;     /* 1 before the first iteration (p = r) */
@@ -410,7 +411,7 @@ int vican_cg_cam_step(int32_t n_cam, const double* deg_c, const double* qc_sum,
                       const double* pq_time, const double* p_c, double* x_c, double* r_c,
                       vican_cg_state_t* st, void* stream);
 /* Timestep side: x_t += alpha p_t; r_t -= alpha q_t; rr_part[blk] partial r_t.r_t and
- * rr_part[512 + blk] partial max|r_t| (rr_part: >= 1024 doubles); returns the number of
+ * rr_part[512 + blk] partial max|r_t|, rr_part[1024 + blk] partial max|p_t| (rr_part: >= 1536 doubles); returns the number of
  * partials written (>0).                                                       */
 int vican_cg_time_step(int32_t n_time, const double* p_t, const double* q_t, double* x_t,
                        double* r_t, double* rr_part, int32_t part_cap, const vican_cg_state_t* st,

@@ -36,7 +36,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 def test_struct_sizes():
     assert C.sizeof(_lib.Graph) == 14 * 4 + 3 * 8
-    assert _lib.CG_STATE_DOUBLES * 8 == 16 * 8 + 4 * 4
+    assert _lib.CG_STATE_DOUBLES * 8 == 17 * 8 + 4 * 4
 
 
 def plan(lib, rp, slots, max_rows):

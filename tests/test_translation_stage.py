@@ -31,7 +31,7 @@ def stage_tol(name, dt):
 
 def reference_rotations(prob, exp):
     """node<-world blocks (what the solver keeps) of the reference's world<-node output rotations."""
-    R = {str(k): exp["R"][i] for i, k in enumerate(exp["keys"])}
+    R = {str(k): np.asarray(exp["R"][i], dtype=np.float64) for i, k in enumerate(exp["keys"])}     # (f32 goldens store float32)
     rc = np.stack([R[str(c)].T for c in prob.cam_names]).reshape(-1, 3)
     rt = np.stack([R[str(s) + "_0"].T for s in prob.time_names]).reshape(-1, 9)
     return rc, rt
@@ -102,4 +102,8 @@ def test_translation_stage_alone_at_large_shop_scale(dt):
     print("g9 %s: translation stage alone: %.2e m from the reference's iterate, cg %d vs %d" % (
         dt, dist, info["cg_iters"], int(exp["cg_iters"])))
     assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
-    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack("g9_large_shop", dt, extra=4)
+    # iterations: the reference stops between 101 and 106 (goldens, cg_sensitivity fixture); the product's exact 64-bit
+    # fixed-point accumulation resolves 49 bits below max |w p|, scipy's f64 53 bits below every TERM, and q = A p is a
+    # Laplacian product (differences of nearly equal terms): reproduced on the host with a quantised matvec - exact 103,
+    # 49 bits 108-111, the 47 bits below a compounding bound of round 1 118
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack("g9_large_shop", dt, extra=8)

@@ -16,7 +16,7 @@ from vican_amd.solver import Comm, GeneralRotationSolver, RotationSolver   # noq
 C, T, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (1000, 100000, 250)
 dev = torch.device("cuda:0")
 d = synth.make_merged_graph_torch(C, T, K, dev, torch.float32, seed=0)
-g = LocalGraph(C, d["row_ptr"], d["col"], d["blk"], d["a"])
+g = LocalGraph(C, d["row_ptr"], d["col"], d["blk"], d["a"], layout="block")
 H = HipBackend(g)
 N = C + T
 x = torch.linalg.qr(torch.randn(3 * N, 3, dtype=torch.float64, device=dev))[0].contiguous()

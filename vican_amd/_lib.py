@@ -40,11 +40,11 @@ class Graph(C.Structure):
     ]
 
 
-# doubles first (16), then 4 int32: 144 bytes == 18 doubles
-CG_STATE_DOUBLES = 18
+# doubles first (17), then 4 int32: 152 bytes == 19 doubles
+CG_STATE_DOUBLES = 19
 CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9,
-            rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15)
-CG_I = dict(iter=32, done=33, first=34)     # int32 index into the same buffer viewed as int32
+            rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15, pmax_time=16)
+CG_I = dict(iter=34, done=35, first=36)     # int32 index into the same buffer viewed as int32
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _G = C.POINTER(Graph)

@@ -86,12 +86,10 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     t2 = time.perf_counter()
     nloc = r1 - r0
 
-    def gather_rows(loc, width):          # zero-filled full array + sum: simple, T x width doubles
-        if comm.world == 1:
-            return loc[:nloc]
-        full = torch.zeros(T, width, dtype=torch.float64, device=dev)
-        full[r0:r1] = loc[:nloc]
-        return comm.allreduce(full)
+    bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]
+
+    def gather_rows(loc, width):          # one all-gather of the ranks' row blocks
+        return comm.gather_rows(loc.reshape(-1, width), nloc, bounds)
 
     Rt_all = gather_rows(Rt_loc, 9)
     if tight:                                                            # not in the reference (module docstring)
@@ -195,7 +193,8 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
     dev = torch.device("cuda", torch.cuda.current_device())
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
-    g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt))
+    # (the one-pass operator of the non-eliminated variant - sweep MODE 2 - exists for the block layout)
+    g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt), layout="block")
     K = HipBackend(g)
     t1 = time.perf_counter()
     rot = GeneralRotationSolver(K, Comm.single(), eig_tol=eig_tol)

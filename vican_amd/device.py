@@ -136,6 +136,9 @@ class _Layout:
         if blk is None:                                      # translation layout: index + weight words of the CG sweep
             stream_bytes = self.nslot * 12
         self.stream_nt = int(stream_bytes > STREAM_NT_BYTES)
+        import os
+        if blk is None and os.environ.get("VICAN_TL_NT") is not None:       # A/B switch for the translation kernels
+            self.stream_nt = int(os.environ["VICAN_TL_NT"])
         self.desc = _lib.Graph(n_cam, self.n_time, self.n_chunk, self.slots, self.max_rows, storage, self.block_threads,
                                self.n_wg, self.n_copy, self.wg_chunk_cap, _lib.LAYOUT_WAVE if self.kind == "wave" else _lib.LAYOUT_BLOCK,
                                self.wg_waves, self.stream_nt, 0, None if blk is None else blk.data_ptr(), self.idx.data_ptr(),
@@ -278,7 +281,7 @@ class HipBackend:
         nwg = max(graph.n_wg, graph.tl.n_wg)
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
         self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
-        self.rr_part = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+        self.rr_part = torch.zeros(1536, dtype=torch.float64, device=self.dev)      # 3 x CG_PARTS: r.r, max |r_t|, max |p_t|
         self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
         self.n_add = float(max(graph.tl.rows_per_wg_max, graph.tl.slots) + 1)

@@ -58,6 +58,25 @@ class Comm:
             self.n_allreduce += 1
         return t
 
+    def gather_rows(self, loc, n_local, bounds):
+        """Concatenate per-rank row blocks (rank r owns rows bounds[r] .. bounds[r + 1]) into the full [T, width] array
+        on every rank: ONE all-gather of equally sized (padded) blocks - each rank sends only its own rows."""
+        if self.world == 1:
+            return loc[:n_local]
+        width = loc.shape[1]
+        nmax = max(bounds[r + 1] - bounds[r] for r in range(self.world))
+        send = torch.zeros(nmax, width, dtype=loc.dtype, device=loc.device)
+        send[:n_local] = loc[:n_local]
+        recv = torch.empty(self.world * nmax, width, dtype=loc.dtype, device=loc.device)
+        try:
+            torch.distributed.all_gather_into_tensor(recv, send, group=self.group)
+        except RuntimeError:              # (a backend without all-gather for this device type: gloo on GPU tensors)
+            recv.zero_()
+            recv[self.rank * nmax: (self.rank + 1) * nmax] = send
+            torch.distributed.all_reduce(recv, group=self.group)
+        self.n_allgather = getattr(self, "n_allgather", 0) + 1
+        return torch.cat([recv[r * nmax: r * nmax + bounds[r + 1] - bounds[r]] for r in range(self.world)], 0)
+
 
 class RotationSolver:
     def __init__(self, K, comm=None, m_max=32, eig_tol=1e-10, floor_tol=1e-7, min_steps=4, check_every=2, warm_min_steps=2,
