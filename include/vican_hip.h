@@ -69,8 +69,9 @@ typedef struct vican_graph {
     int32_t layout;           /* VICAN_LAYOUT_BLOCK: a chunk is processed by a whole workgroup (slots = block_threads *
                                  edges_per_lane).  VICAN_LAYOUT_WAVE: a chunk is processed by ONE wavefront (slots = 64 *
                                  edges_per_lane, max_rows <= 64) and a workgroup of wg_waves wavefronts (block_threads =
-                                 64 * wg_waves) shares the camera tables - rotation sweeps only (vican_block_op(_z),
-                                 vican_dual_update(_op)); the translation kernels and vican_bip_apply take block layouts */
+                                 64 * wg_waves) shares the camera tables - the rotation sweeps (vican_block_op(_z),
+                                 vican_dual_update(_op)), vican_cg_sweep / vican_cg_iter_local and vican_scale_weights; the other
+                                 translation kernels (right-hand side, LSQR) and vican_bip_apply take block layouts */
     int32_t wg_waves;         /* wavefronts per workgroup of the wave layout: 4, 8 or 12 (0 in the block layout) */
     int32_t stream_nt;        /* 1: the sweeps read blk / idx with non-temporal loads (edge stream far larger than the
                                  256 MB Infinity Cache); 0: plain loads (cache-resident graphs are re-read from cache) */
@@ -118,6 +119,8 @@ int64_t vican_lds_limit_bytes(void);
 /* The same for the wave layout: camera tables shared by the workgroup + per wavefront the striped row accumulators,
  * the folded row sums and the phase-3 operand of its chunk.                                   */
 int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t n_waves);
+/* ... and of the CG Laplacian product on a wave-layout graph (vican_cg_sweep / vican_cg_iter_local).      */
+int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves);
 /* Largest max_rows for which every sweep kernel (operator, rhs, CG) fits in LDS;
  * <= 0 means the camera tables alone do not fit.                              */
 int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_copy);

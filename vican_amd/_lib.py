@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so")      # VICAN_LIB: diagnostic builds (tools/)
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
-           os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip")]
+           os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "sweep_common.cuh"), WSWEEP]
 FX_DOUBLES = 20
@@ -66,6 +66,7 @@ PROTOTYPES = {
     "vican_sweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_lds_limit_bytes": (_i64, []),
     "vican_wsweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "vican_cg_wsweep_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_max_rows_for": (_i32, [_i32, _i32, _i32]),
     "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),

@@ -212,7 +212,7 @@ __global__ void scale_weights_kernel(vican_graph_t g, const double* __restrict__
 }
 extern "C" int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s_cam, const double* s_row,
                                    double* w_out, void* stream) {
-    if (int r = vican_check_block_graph(g, "vican_scale_weights")) return r;
+    if (int r = vican_check_graph(g, "vican_scale_weights")) return r;
     if (!w || !s_cam || !s_row || !w_out) return set_err(VICAN_ERR_ARG, "vican_scale_weights: null pointer");
     if (g->n_chunk == 0) return VICAN_OK;
     hipLaunchKernelGGL(scale_weights_kernel, dim3((g->slots + 255) / 256, g->n_chunk), dim3(256), 0, (hipStream_t)stream, *g, w,
@@ -514,12 +514,17 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
 }
+extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
+                                                                     const double* p_c, const double* r_t, double* p_t, double* q_t,
+                                                                     void* qc_part, double* pq_part, const vican_cg_state_t* st,
+                                                                     void* stream);       // vican_wtrans.hip
 extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
                               const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
                               const vican_cg_state_t* st, void* stream) {
-    if (int r = vican_check_block_graph(g, "vican_cg_sweep")) return r;
+    if (int r = vican_check_graph(g, "vican_cg_sweep")) return r;
     if (!w || !deg_t || !p_c || !r_t || !p_t || !q_t || !qc_part || !pq_part || !st)
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
+    if (g->layout == VICAN_LAYOUT_WAVE) return vican_cg_wsweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream);
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;
     const int nr = (3 * g->max_rows + g->block_threads - 1) / g->block_threads;   // row values per thread (<= 3 EPL)

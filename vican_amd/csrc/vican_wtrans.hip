@@ -1,0 +1,191 @@
+// vican_wtrans.hip - the CG Laplacian product q = A p (reference bipgo.py:476-478, one application per scipy cg
+// iteration) on graphs in the WAVE layout: one wavefront per chunk, no workgroup barrier in the loop.
+//
+// Same arithmetic as cg_sweep_kernel (vican_trans.hip): contributions w p in f64, exact 64-bit fixed-point accumulation
+// (camera sums in the workgroup's LDS table, row sums in the wavefront's own LDS region), q_t = deg_t p_t - sum_c w p_c,
+// the timestep part of p.q, and the update p_t <- r_t + beta p_t folded into the row loads.  What changes is the
+// schedule: the block kernel's 12 wavefronts share a 3072-slot chunk and meet at a barrier per chunk; here a wavefront
+// owns a 256-slot chunk (whole rows), stages its rows' p and deg p in its private LDS region and folds its own row sums -
+// LDS operations of one wavefront execute in order, so nothing has to be synchronised.  Row bounds are requested two
+// chunks ahead and row values (p_t, r_t, deg_t) one chunk ahead, edge words (index + weight, 12 B per edge) one chunk
+// ahead; every vector-memory operation is unconditional (clamped indices) so that the compiler's vmcnt waits are exact.
+// A workgroup owns a contiguous range of chunks and its wavefront i takes chunks c0 + i, c0 + i + NW, ...
+#include "sweep_common.cuh"
+
+extern "C" int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
+    const int64_t per_wave = (((int64_t)max_rows * 3 * (8LL * n_copy + 16)) + 15) & ~15LL;
+    return 48LL * n_cam + (int64_t)n_waves * per_wave + 256;
+}
+
+template <int EPL>
+struct CgWRegs { double w[EPL]; uint32_t id[EPL]; };
+
+template <int NW, int EPL, int TRIPS>
+__global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, const double* __restrict__ w,
+                                                            const double* __restrict__ deg_t, const double* __restrict__ p_c,
+                                                            const double* __restrict__ r_t, double* __restrict__ p_t,
+                                                            double* __restrict__ q_t, u64* __restrict__ qc_part,
+                                                            double* __restrict__ pq_part, const vican_cg_state_t* __restrict__ st) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red[16];
+    if (st->done) return;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
+    const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u64* qc = (u64*)lds_raw;                                   // [3][C] planes, shared by the workgroup
+    double* pcs = (double*)(qc + 3 * C);                       // [3][C] planes
+    const size_t per_wave = (((size_t)RW * 3 * (8 * ncopy + 16)) + 15) & ~(size_t)15;
+    unsigned char* wbase = (unsigned char*)(pcs + 3 * C) + (size_t)wave * per_wave;
+    u64* qt = (u64*)wbase;                                     // [RW * 3][ncopy] striped row accumulators (this wave's)
+    double* pts = (double*)(qt + (size_t)RW * 3 * ncopy);      // [RW * 3] p of the chunk's rows
+    double* dps = pts + RW * 3;                                // [RW * 3] deg * p
+    const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
+    const bool upd = !st->first;
+    const double beta = st->beta, scale = st->qscale, inv = st->qinv;
+    for (int i = tid; i < 3 * C; i += NW * 64) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; }
+    for (int i = lane; i < 3 * RW * ncopy; i += 64) qt[i] = 0ull;
+    const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    const int kmax = g.n_chunk - 1;
+
+    auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
+    auto load_edges = [&](CgWRegs<EPL>& e, int k) {
+        k = k < kmax ? k : kmax;
+        const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
+        if (EPL == 4) {
+            uint4 t; double2 a, b;
+            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)(w + s)); b = stream_load((const double2*)(w + s + 2)); }
+            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)(w + s); b = *(const double2*)(w + s + 2); }
+            e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
+            e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
+        } else {
+            uint2 t; double2 a;
+            if (g.stream_nt) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
+            else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
+            e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
+        }
+    };
+    // row values of a chunk: lane + 64 t < 3 nrows holds (p_t, r_t, deg_t) of one (row, component) item
+    struct RowVals { double p[TRIPS], r[TRIPS], d[TRIPS]; };
+    auto load_rowvals = [&](RowVals& rv, const int2 vrow) {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            int i = lane + 64 * t;
+            i = i < n3 ? i : 0;                                 // lanes without an item re-read item 0 (never used)
+            const size_t gi = (size_t)r0 * 3 + i;
+            rv.p[t] = p_t[gi]; rv.r[t] = r_t[gi]; rv.d[t] = deg_t[r0 + i / 3];
+        }
+    };
+    __syncthreads();
+
+    int k = c0 + wave;
+    CgWRegs<EPL> ea, eb;
+    RowVals ra, rb;
+    int2 v0 = load_rows(k), v1 = load_rows(k + NW), v2;
+    load_edges(ea, k);
+    load_rowvals(ra, v0);
+    double pq = 0.0;
+
+    // body: chunk k (edges `cur`, row values `rv`, row bounds `vrow`); requests the edge words and row values of chunk
+    // k + NW (row bounds `vnext`, loaded a body ago) and the row bounds of chunk k + 2 NW (returned)
+    auto body = [&](CgWRegs<EPL>& cur, CgWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int kk) -> int2 {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
+        const int2 vnn = load_rows(kk + 2 * NW);
+        load_rowvals(rvn, vnext);
+        __builtin_amdgcn_sched_barrier(0);
+        load_edges(nxt, kk + NW);
+        // commit this chunk's rows: p (updated), deg p into the wavefront's staging; the updated p back to memory
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = lane + 64 * t;
+            if (i < n3) {
+                const double p = upd ? rv.r[t] + beta * rv.p[t] : rv.p[t];
+                pts[i] = p; dps[i] = rv.d[t] * p;
+                if (upd) p_t[(size_t)r0 * 3 + i] = p;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // edges: camera contributions one by one, same-row contributions of a lane pre-summed
+        double acc[3] = {0, 0, 0};
+        uint32_t prow = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
+            const double wj = pad ? 0.0 : cur.w[j];
+            if (row != prow) {
+                if (prow != 0xFFFFFFFFu)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+                prow = row; acc[0] = acc[1] = acc[2] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                acc[i] += wj * pcs[i * C + cam];
+                lds_add_fix(&qc[i * C + cam], to_fix(wj * pts[row * 3 + i], scale));
+            }
+        }
+        if (prow != 0xFFFFFFFFu)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+        __builtin_amdgcn_wave_barrier();
+        // fold this chunk's row sums (exact integer sums of the stripes), q_t, p.q
+        for (int i = lane; i < n3; i += 64) {
+            long long sum = 0;
+            for (int c = 0; c < ncopy; ++c) {
+                const int a = i * ncopy + ((c + i) & cmask);
+                sum += (long long)qt[a];
+                qt[a] = 0ull;
+            }
+            const double qv = dps[i] - (double)sum * inv;
+            q_t[(size_t)r0 * 3 + i] = qv;
+            pq += pts[i] * qv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return vnn;
+    };
+#pragma unroll 1
+    while (k < c1) {
+        v2 = body(ea, eb, ra, rb, v0, v1, k);
+        k += NW;
+        if (k >= c1) break;
+        v0 = body(eb, ea, rb, ra, v1, v2, k);
+        k += NW;
+        // rotate the row-bound registers: (v0, v1, v2) now hold (k + NW, k, -) -> bring them back to (k, k + NW)
+        const int2 tmp = v0; v0 = v2; v1 = tmp;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * C; i += NW * 64) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
+    const double t = block_sum(pq, red);
+    if (tid == 0) pq_part[blockIdx.x] = t;
+}
+
+// launcher: called by vican_cg_sweep for graphs in the wave layout
+extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
+                                                                     const double* p_c, const double* r_t, double* p_t, double* q_t,
+                                                                     void* qc_part, double* pq_part, const vican_cg_state_t* st,
+                                                                     void* stream) {
+    const int nw = g->wg_waves >= 12 ? 12 : (g->wg_waves >= 8 ? 8 : 4);
+    const size_t lds = (size_t)vican_cg_wsweep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
+    if ((int64_t)lds > 160 * 1024) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_cg_sweep (wave layout)");
+    const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64;
+    hipStream_t s = (hipStream_t)stream;
+#define CGW_LAUNCH(NW_, E_, T_)                                                                                           \
+    do {                                                                                                                  \
+        auto kern = cg_wsweep_kernel<NW_, E_, T_>;                                                                        \
+        static size_t conf = 0;                                                                                           \
+        if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+    } while (0)
+#define CGW_PICK(NW_)                                                                                                     \
+    do {                                                                                                                  \
+        if (epl == 4) { if (trips <= 1) CGW_LAUNCH(NW_, 4, 1); else if (trips == 2) CGW_LAUNCH(NW_, 4, 2); else CGW_LAUNCH(NW_, 4, 3); } \
+        else          { if (trips <= 1) CGW_LAUNCH(NW_, 2, 1); else if (trips == 2) CGW_LAUNCH(NW_, 2, 2); else CGW_LAUNCH(NW_, 2, 3); } \
+    } while (0)
+    if (nw == 12) CGW_PICK(12); else if (nw == 8) CGW_PICK(8); else CGW_PICK(4);
+#undef CGW_PICK
+#undef CGW_LAUNCH
+    LAUNCH_CHECK("vican_cg_sweep");
+    return VICAN_OK;
+}

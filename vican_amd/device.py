@@ -209,6 +209,9 @@ class LocalGraph:
         self.w = torch.empty(tl.nslot, dtype=torch.float64, device=dev) if have_t else None
         self.u = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
         self.v = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
+        # the CG sweep runs on the rotation layout when that is a wave layout (vican_wtrans.hip): a second copy of the weights
+        # in its slot order (8 B per edge); u, v (right-hand side, LSQR) stay in the block layout
+        self.w_cg = self.w if tl is rot else (torch.empty(rot.nslot, dtype=torch.float64, device=dev) if have_t else None)
         self.desc = rot.describe(self.n_cam, storage, self.blk)
         self.desc_t = self.desc if tl is rot else tl.describe(self.n_cam, storage, None)
         gref, gref_t = C.byref(self.desc), C.byref(self.desc_t)
@@ -227,9 +230,9 @@ class LocalGraph:
         st = _stream()
         perm_ws = torch.empty(max(rot.nslot, tl.nslot), dtype=torch.int32, device=dev)
         same = tl is rot
-        _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w) if same else None,
+        _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w) if have_t else None,
                                         _ptr(u) if same else None, _ptr(v) if same else None, _ptr(self.a),
-                                        _ptr(self.w) if same else None, _ptr(self.u) if same else None,
+                                        _ptr(self.w_cg) if have_t else None, _ptr(self.u) if same else None,
                                         _ptr(self.v) if same else None, _ptr(perm_ws), st), "vican_pack_edges")
         if have_t and not same:
             _lib.check(lib.vican_pack_edges(gref_t, _ptr(row_ptr), _ptr(col), None, None, _ptr(w), _ptr(u), _ptr(v), None,
@@ -280,7 +283,7 @@ class HipBackend:
         self.tl = graph.tl
         nwg = max(graph.n_wg, graph.tl.n_wg)
         self.zpart = torch.empty(nwg * 9 * self.C, dtype=torch.float64, device=self.dev)   # f64 or i64 slabs
-        self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)
+        self.pq_part = torch.empty(max(nwg, 1), dtype=torch.float64, device=self.dev)    # (nwg: the larger of the two layouts)
         self.rr_part = torch.zeros(1536, dtype=torch.float64, device=self.dev)      # 3 x CG_PARTS: r.r, max |r_t|, max |p_t|
         self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
@@ -288,7 +291,11 @@ class HipBackend:
         self._status_host = {}
         self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
         self._coop_ws, self._coop_sync, self._gram_ws = None, None, None
-        self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w, getattr(graph, "wmax", None)
+        self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w_cg, getattr(graph, "wmax", None)
+        # layout the CG sweep runs on: the rotation layout if it is a wave layout, else the translation block layout
+        cgl = graph.rot if graph.layout == "wave" else graph.tl
+        self._gref_cg, self.cgl = (self._gref if graph.layout == "wave" else self._gref_t), cgl
+        self.n_add_cg = float(max(cgl.rows_per_wg_max, cgl.slots) + 1)
 
     # -- allocation helpers -------------------------------------------------
     def empty(self, *shape, dtype=torch.float64):
@@ -409,10 +416,10 @@ class HipBackend:
                  "vican_lanczos_cam_step")
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
-        part = self.zpart[: self.tl.n_wg * 3 * self.C]
-        self._ck(self.lib.vican_cg_iter_local(self._gref_t, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
+        part = self.zpart[: self.cgl.n_wg * 3 * self.C]
+        self._ck(self.lib.vican_cg_iter_local(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
                                               _ptr(p_t), _ptr(q_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq), float(rtol),
-                                              _ptr(self.rr_part), int(n_rr_part), self.n_add, _ptr(st), _stream()),
+                                              _ptr(self.rr_part), int(n_rr_part), self.n_add_cg, _ptr(st), _stream()),
                  "vican_cg_iter_local")
 
     def cg_iter_finish(self, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t, st):
@@ -551,13 +558,13 @@ class HipBackend:
     def set_cg_scaling(self, s_c, s_t):
         """CG sweeps use w~ = w s_c s_t (<= 1) until clear_cg_scaling()."""
         if self._w_scaled is None:
-            self._w_scaled = torch.empty_like(self.g.w)
-        self._ck(self.lib.vican_scale_weights(self._gref_t, _ptr(self.g.w), _ptr(s_c), _ptr(s_t), _ptr(self._w_scaled), _stream()),
+            self._w_scaled = torch.empty_like(self.g.w_cg)
+        self._ck(self.lib.vican_scale_weights(self._gref_cg, _ptr(self.g.w_cg), _ptr(s_c), _ptr(s_t), _ptr(self._w_scaled), _stream()),
                  "vican_scale_weights")
         self._cg_w, self._cg_wmax = self._w_scaled, 1.0
 
     def clear_cg_scaling(self):
-        self._cg_w, self._cg_wmax = self.g.w, self.g.wmax
+        self._cg_w, self._cg_wmax = self.g.w_cg, self.g.wmax
 
     def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
         self._ck(self.lib.vican_cg_init(self.C, self.T, _ptr(b_c), _ptr(b_t), _ptr(x_c), _ptr(x_t), _ptr(r_c), _ptr(r_t),
@@ -565,13 +572,13 @@ class HipBackend:
 
     def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),
-                                         self.n_add, _ptr(st), _stream()), "vican_cg_begin")
+                                         self.n_add_cg, _ptr(st), _stream()), "vican_cg_begin")
 
     def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
         """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
-        nwg = self.tl.n_wg
+        nwg = self.cgl.n_wg
         part = self.zpart[: nwg * 3 * self.C]
-        self._ck(self.lib.vican_cg_sweep(self._gref_t, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
+        self._ck(self.lib.vican_cg_sweep(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
                                          _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
         self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, 1.0, C.c_void_p(st.data_ptr() + 8 * _lib.CG_F["qinv"]),
                                                None, _ptr(qcpq), _stream()), "vican_slab_reduce_fx")
