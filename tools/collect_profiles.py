@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/profile_%s" % tag
 os.makedirs("profiles", exist_ok=True)
-OURS = ("block_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs",
+OURS = ("block_sweep", "wave_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs",
         "dual_svd", "edge_sums", "block_norms", "pack_edges", "plan_slots", "init_duals", "fx_finish", "duals_bound",
         "scaled_identity", "rows_to_cols", "lanczos_", "ritz_", "right_solve3", "lsqr_", "jacobi", "row_scale")
 
@@ -32,7 +32,7 @@ def counters(sub):
     acc = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            if re.search(r"block_sweep_kernel<\w+, \d+, 0[,>]", r["Kernel_Name"]):
+            if re.search(r"(block|wave)_sweep_kernel<\w+, \d+, 0[,>]", r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
@@ -61,7 +61,7 @@ for name, title in (("timeline_stress.txt", "stress workload (bench.py default),
         tl.append("# %s  (tools/timeline.py)\n%s" % (title, open(fn).read()))
 if tl:
     open("profiles/%s_timeline.txt" % tag, "w").write("\n".join(tl))
-summary = dict(tag=tag, kernel="block_sweep_kernel<.,.,0> (vican_block_op)", counters_mean_per_dispatch=pm, traffic=traffic,
+summary = dict(tag=tag, kernel=(bench["roofline"]["kernel"] if bench else "sweep kernel MODE 0 (vican_block_op)"), counters_mean_per_dispatch=pm, traffic=traffic,
                workload=bench["config"]["workload"] if bench else None,
                bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None)
 json.dump(summary, open("profiles/%s_sweep_counters.json" % tag, "w"), indent=1)
