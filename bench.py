@@ -174,6 +174,13 @@ def large_shop_wall_clock(args, dev, tdt, comm):
         prob = frontend.flatten(src, cons, unit, unit, keep, np.float32)
         res["t_flatten_ms"] = (time.perf_counter() - t0) * 1e3
         res["flatten_source_edges"] = int(prob.n_src)
+        # the same detections handed over as arrays (bipartite_se3sync_arrays: no edge dict, no per-edge callables)
+        cams = flat["cam_key"].astype(str)
+        tm = np.char.partition(flat["marker_key"].astype(str), "_")
+        ones = np.ones(len(cams))
+        t0 = time.perf_counter()
+        frontend.flatten_arrays(cams, tm[:, 0], tm[:, 2], flat["R"], flat["t"], ones, ones, cons, np.float32)
+        res["t_flatten_arrays_ms"] = (time.perf_counter() - t0) * 1e3
     except Exception as exc:
         res["t_flatten_ms"] = None
         res["flatten_error"] = repr(exc)

