@@ -231,6 +231,14 @@ int vican_dual_update_op(const vican_graph_t* g, const double* Rc, double* Rt, d
 /* Z[n][3] = X[n][3] * beta^-1, beta upper triangular [3][3] (zero pivot -> zero column); X may equal Z. */
 int vican_right_solve3(int32_t n, const double* X, const double* beta, double* Z, void* stream);
 
+/* Camera tiling (graphs with more cameras than the LDS-resident sweeps hold; host: device.TiledBackend).  Per-row partial
+ * results of the camera tiles, B[k * b_stride + .] for k < n_b, are summed in tile order:
+ *   A != NULL (width 9):  out[r] = A[r] * sum_k B_k[r]   (3x3 blocks: w_t = Lambda_T,t^-1 * sum_c M_ct^T x_c, bipgo.py:300)
+ *   A == NULL:            out = sum_k B_k                 (n_rows x width doubles)
+ * Honours the launch gate.                                                                                   */
+int vican_sum_apply3(int64_t n_rows, int32_t width, const double* A, const double* B, int32_t n_b, int64_t b_stride,
+                     double* out, void* stream);
+
 /* Batched 3x3 polar / dual blocks (bipgo.py:306-312; geometry.py:189-190):
  * in [n][9] -> R_out [n][9] (nearest rotation, det fixed; may be NULL),
  * lam_out [n][9] (may be NULL): mode & 3 = 1: U S U^T, 2: U S^-1 U^T;

@@ -1,0 +1,96 @@
+"""More cameras than the LDS-resident sweeps hold (C > 1024; the reference has no limit, bipgo.py:225-232): the
+camera-tiled path (device.TiledGraph / TiledBackend) against the NumPy restatement at C = 1500, and - with the tile
+size forced down - against the goldens of the real reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_cases as gc                                                   # noqa: E402
+from numpy_backend import NumpyBackend                                      # noqa: E402
+from test_kernels_gpu import random_graph                                   # noqa: E402
+from util import expected, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
+from vican_amd.solver import Comm, solve_on_backend                         # noqa: E402
+
+
+def _tiled(C, rp, col, blk, a, w, u, v, dt, tile):
+    from vican_amd.device import TiledBackend, TiledGraph
+    dev = torch.device("cuda:0")
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    g = TiledGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(blk).to(dev, tdt),
+                   torch.from_numpy(a).to(dev, tdt), torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev),
+                   tile=tile)
+    return g, TiledBackend(g)
+
+
+@pytest.mark.parametrize("C,T,tile", [(1500, 400, 1024), (90, 300, 32)])
+def test_tiled_operator_and_dual_update_match_numpy(C, T, tile):
+    rp, col, blk, a, w, u, v = random_graph(C, T, 3, 9, 5, False)
+    g, K = _tiled(C, rp, col, blk, a, w, u, v, np.float64, tile)
+    N = NumpyBackend(C, rp, col, blk, a, w, u, v, storage=np.float64)
+    assert len(g.tiles) == -(-C // tile)
+    rng = np.random.default_rng(1)
+    x = np.linalg.qr(rng.standard_normal((3 * C, 3)))[0]
+    lh, ch, ln, cn = K.empty(T, 9), K.empty(C), N.empty(T, 9), N.empty(C)
+    K.init_duals(lh, ch); N.init_duals(ln, cn)
+    assert np.abs(lh.cpu().numpy() - ln.numpy()).max() < 1e-12 and np.abs(ch.cpu().numpy() - cn.numpy()).max() < 1e-10
+    zh, zn = K.empty(3 * C, 3), N.empty(3 * C, 3)
+    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)
+    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-10 * np.abs(zn.numpy()).max()
+    rc = np.linalg.qr(rng.standard_normal((C, 3, 3)))[0].reshape(3 * C, 3)
+    Rh, Rn = K.empty(T, 9), N.empty(T, 9)
+    K.dual_update(K.from_numpy(rc), Rh, lh); N.dual_update(N.from_numpy(rc), Rn, ln)
+    assert np.abs(Rh.cpu().numpy() - Rn.numpy()).max() < 1e-9
+    assert np.abs(lh.cpu().numpy() - ln.numpy()).max() <= 1e-9 * np.abs(ln.numpy()).max()
+    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)        # with the new (full 3x3) duals
+    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-9 * np.abs(zn.numpy()).max()
+
+
+def test_full_solve_with_1500_cameras_matches_numpy():
+    """A consistent synthetic scene (1500 cameras, 2500 timesteps, 4 cameras per timestep, 1e-3 noise) through the whole
+    solve - block Lanczos on 4500-row vectors, tiled operator and dual updates, tiled right-hand side, CG on the
+    weights-only layout - against the NumPy restatement of the same solver."""
+    from vican_amd import synth
+    from vican_amd.device import TiledBackend, TiledGraph
+    C, T = 1500, 2500
+    dev = torch.device("cuda:0")
+    gr = synth.make_merged_graph_torch(C, T, 4, dev, torch.float64, seed=3, sigma_r=1e-3, sigma_t=1e-3)
+    g = TiledGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"], tile=1024)
+    K = TiledBackend(g)
+    assert len(g.tiles) == 2
+    h = {k: gr[k].cpu().numpy() for k in ("row_ptr", "col", "blk", "a", "w", "u", "v")}
+    N = NumpyBackend(C, h["row_ptr"], h["col"], h["blk"], h["a"], h["w"], h["u"], h["v"], storage=np.float64)
+    out_h = solve_on_backend(K, Comm(), 4, 3 * (C + T))
+    out_n = solve_on_backend(N, Comm(), 4, 3 * (C + T))
+    assert np.abs(out_h[0].cpu().numpy() - out_n[0].numpy()).max() < 1e-7          # camera rotations
+    assert np.abs(out_h[1].cpu().numpy()[:T] - out_n[1].numpy()[:T]).max() < 1e-7  # timestep rotations
+    assert abs(out_h[4]["cg_iters"] - out_n[4]["cg_iters"]) <= 3
+    scale = np.abs(out_n[2].numpy()).max()
+    assert np.abs(out_h[2].cpu().numpy() - out_n[2].numpy()).max() < 1e-3 * scale     # loosely converged CG (rtol 1e-5)
+    # ... and close to the ground truth of the scene (gauge: camera 0 at the identity)
+    Rc = out_h[0].cpu().numpy().reshape(C, 3, 3).transpose(0, 2, 1)
+    gt = gr["R_cam"].cpu().numpy()
+    rel = np.einsum("ij,cjk->cik", gt[0].T, gt)
+    assert np.abs(Rc - rel).max() < 5e-2
+
+
+@pytest.mark.parametrize("name,dt", [("g3_medium", "float64"), ("g2_small", "float32")])
+def test_dropin_on_forced_tiles_matches_reference(name, dt, monkeypatch):
+    """VICAN_TILE_CAMS forces the tiled path on a golden case (40 cameras in tiles of 16): same answer as the reference."""
+    from vican.bipgo import bipartite_se3sync
+    monkeypatch.setenv("VICAN_TILE_CAMS", "16" if name == "g3_medium" else "3")
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "conjugate_gradient", dt)
+    info = {}
+    res = bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
+                            lsqr_solver="conjugate_gradient", dtype=np.dtype(dt).type, info=info)
+    assert info["layout"] == "tiled"
+    rot, tr = pose_errors(res, exp)
+    assert rot < (1e-7 if dt == "float64" else 5e-6), rot
+    # (f32 blocks: the tiles' partial sums round differently from the fused sweep: 3e-8 rad in the rotations, 1e-6 m here)
+    assert tr < max(translation_tol(name, dt), 5e-6 if dt == "float32" else 0.0), tr
+    from vican_amd._lib import VicanError
+    with pytest.raises(VicanError, match="direct"):
+        bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "direct", np.dtype(dt).type)

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "vican_dual_update_op": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lanczos_seed": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vican_right_solve3": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
+    "vican_sum_apply3": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),

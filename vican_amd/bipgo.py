@@ -58,7 +58,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                   group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
-    from .device import HipBackend, LocalGraph      # needs the GPU + extension
+    from .device import TILE_CAMS, make_backend      # needs the GPU + extension
 
     if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
@@ -76,9 +76,10 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     e0, e1 = int(prob.row_ptr[r0]), int(prob.row_ptr[r1])
     t0 = time.perf_counter()
     to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
-    g = LocalGraph(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
-                   to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]))
-    K = HipBackend(g)
+    g, K = make_backend(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
+                        to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]))
+    if lsqr_solver == "direct" and g.layout == "tiled":
+        raise VicanError("lsqr_solver='direct' is not available beyond %d cameras (camera-tiled graph); use 'conjugate_gradient'" % TILE_CAMS)
     t1 = time.perf_counter()
     rot = RotationSolver(K, comm, eig_tol=eig_tol)
     rc, Rt_loc = rot.run(maxiter)
@@ -121,7 +122,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                     early_exit=rot.stats.get("early_exit"),
                     cg_iters=tr.info.get("cg_iters"), cg_relres=tr.info.get("relres"), lsqr_iters=tr.info.get("lsqr_iters"),
                     lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T,
-                    n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=g.n_chunk, n_wg=g.n_wg,
+                    n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=getattr(g, "n_chunk", None), n_wg=getattr(g, "n_wg", None), layout=g.layout,
                     t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world)
     return Rc, Rt, x_c.cpu().numpy(), xt_all.cpu().numpy()
 

@@ -86,6 +86,43 @@ extern "C" int vican_right_solve3(int32_t n, const double* X, const double* beta
     return VICAN_OK;
 }
 
+// out[r] = A[r] * (sum_k B[k * b_stride + r])   (3x3 blocks, A != NULL, width 9)   or   out = sum_k B[k * b_stride + .]
+// (A == NULL, any width): per-row partial results of the camera tiles (graphs with more cameras than the LDS-resident
+// sweep holds, device.TiledBackend) summed in tile order and, for the operator, multiplied by the row's dual block.
+__global__ void sum_apply3_kernel(const int32_t* __restrict__ gate, long long n_rows, int width, const double* __restrict__ A,
+                                  const double* __restrict__ B, int n_b, long long b_stride, double* __restrict__ out) {
+    GATE_RETURN(gate);
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (A) {
+        if (r >= n_rows) return;
+        double y[9], a[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { y[q] = 0.0; a[q] = A[r * 9 + q]; }
+        for (int k = 0; k < n_b; ++k)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) y[q] += B[(size_t)k * b_stride + r * 9 + q];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) out[r * 9 + i * 3 + b] = a[i * 3] * y[b] + a[i * 3 + 1] * y[3 + b] + a[i * 3 + 2] * y[6 + b];
+    } else {
+        if (r >= n_rows * width) return;
+        double t = 0.0;
+        for (int k = 0; k < n_b; ++k) t += B[(size_t)k * b_stride + r];
+        out[r] = t;
+    }
+}
+extern "C" int vican_sum_apply3(int64_t n_rows, int32_t width, const double* A, const double* B, int32_t n_b, int64_t b_stride,
+                                double* out, void* stream) {
+    if (n_rows < 0 || width <= 0 || !B || !out || n_b <= 0 || (A && width != 9)) return set_err(VICAN_ERR_ARG, "vican_sum_apply3: bad argument");
+    if (n_rows == 0) return VICAN_OK;
+    const long long n = A ? n_rows : n_rows * width;
+    hipLaunchKernelGGL(sum_apply3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_vican_gate,
+                       (long long)n_rows, width, A, B, n_b, (long long)b_stride, out);
+    LAUNCH_CHECK("vican_sum_apply3");
+    return VICAN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // camera-side dense helpers for block Lanczos.  V: column-major basis, column k
 // at V + k*ld (ld >= n).  R (work block) is column-major [3][n]; x/z are row-major [n][3].

@@ -61,7 +61,9 @@ extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slot
     return nc;
 }
 
-extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024; }
+// (dynamic LDS a kernel may ask for: the 160 KB of a CU minus room for the kernels' few static __shared__ words - a graph that
+//  fitted the 160 KB exactly, C = 1024 in f64 with two accumulator copies, failed at hipFuncSetAttribute)
+extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024 - 1024; }
 
 
 // operator sweep: x table (storage type) + z accumulators (u64) per camera; per row:
@@ -103,6 +105,13 @@ int vican_check_graph(const vican_graph_t* g, const char* who) {
     if ((g->block_threads != 256 && g->block_threads != 512 && g->block_threads != 768 && g->block_threads != 1024) ||
         g->slots != g->block_threads * epl)
         return set_err(VICAN_ERR_ARG, "%s: slots must be block_threads * (16 / sizeof(storage))", who);
+    if (!g->blk) {
+        // a layout that only carries CG weights (camera tiling: the rotation blocks live in per-tile graphs): the CG sweep's
+        // LDS budget alone decides (48 B per camera: C <= ~3300)
+        if (g->max_rows <= 0 || cg_lds_bytes(g->n_cam, g->max_rows, nc) > vican_lds_limit_bytes())
+            return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging of the CG sweep do not fit in LDS", who);
+        return 0;
+    }
     if (g->max_rows <= 0 || g->max_rows > vican_max_rows_for(g->n_cam, g->storage, nc))
         return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", who);
     return 0;

@@ -644,3 +644,210 @@ HipBackend.lsqr_u_step = _lsqr_u_step
 HipBackend.lsqr_v_step = _lsqr_v_step
 HipBackend.lsqr_cam_v = _lsqr_cam_v
 HipBackend.lsqr_update = _lsqr_update
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Camera tiling: graphs with more cameras than the LDS-resident sweeps hold (C > 1024)
+# ---------------------------------------------------------------------------------------------------------------
+TILE_CAMS = 1024
+
+
+class TiledGraph:
+    """The edge set cut by camera range into tiles of at most `tile` cameras, each a block-layout ``LocalGraph`` over ALL
+    timestep rows (camera indices local to the tile), plus one weights-only layout over the full camera set for the CG
+    sweep (its LDS budget is 48 B per camera: C <= ~3300).
+
+    The reference has no camera limit (bipgo.py:225-232); the fused sweeps keep the camera tables in LDS, which caps
+    them at 1024 cameras.  Beyond that the operator z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) is evaluated tile by
+    tile (TiledBackend): every edge block is read twice per application instead of once."""
+
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, tile=None):
+        import os
+        lib = _lib.load()
+        tile = int(tile or os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
+        dev = blk.device
+        self.device, self.n_cam, self.n_time, self.n_edges = dev, int(n_cam), int(row_ptr.numel() - 1), int(col.numel())
+        self.storage_dtype = blk.dtype
+        self.layout = "tiled"
+        have_t = w is not None
+        T = self.n_time
+        row_ptr = row_ptr.to(dev, torch.int64)
+        col = col.to(dev, torch.int64)
+        rows = torch.repeat_interleave(torch.arange(T, device=dev), row_ptr[1:] - row_ptr[:-1])
+        self.bounds = list(range(0, self.n_cam, tile)) + [self.n_cam]
+        self.tiles = []
+        for k in range(len(self.bounds) - 1):
+            c0, c1 = self.bounds[k], self.bounds[k + 1]
+            sel = ((col >= c0) & (col < c1)).nonzero().squeeze(1)
+            rp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+            rp[1:] = torch.cumsum(torch.bincount(rows[sel], minlength=T), 0)
+            pick = lambda x: None if x is None else x[sel].contiguous()
+            self.tiles.append(LocalGraph(c1 - c0, rp.to(torch.int32), (col[sel] - c0).to(torch.int32), blk[sel].contiguous(), a[sel].contiguous(),
+                                         pick(w), pick(u), pick(v), layout="block"))
+        # global graph constants
+        self.row_sum_a = torch.stack([t.row_sum_a for t in self.tiles]).sum(0)
+        self.rnorm = torch.stack([t.rnorm for t in self.tiles]).sum(0)
+        self.cam_sum_a = torch.cat([t.cam_sum_a for t in self.tiles])
+        if have_t:
+            self.row_sum_w = torch.stack([t.row_sum_w for t in self.tiles]).sum(0)
+            self.cam_sum_w = torch.cat([t.cam_sum_w for t in self.tiles])
+            self.wmax = max(t.wmax for t in self.tiles)
+            # weights-only layout over all cameras for the CG sweep
+            storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
+            rp_host = row_ptr.to("cpu", torch.int32).contiguous()
+            deg = rp_host[1:] - rp_host[:-1]
+            deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
+            lim, n_copy = int(lib.vican_lds_limit_bytes()), 8
+            cg_rows = lambda nc: (lim - 256 - 48 * self.n_cam) // (48 * nc + 96)
+            while n_copy > 1 and cg_rows(n_copy) < 8:
+                n_copy //= 2
+            if cg_rows(n_copy) < 1:
+                raise _lib.VicanError("camera vectors of the CG sweep (C=%d) do not fit in LDS (limit about 3300 cameras)" % self.n_cam)
+            cgl = _Layout.__new__(_Layout)
+            epl = 4 if storage == _lib.STORE_F32 else 2
+            bt = 768 if self.n_edges >= 768 * epl * N_CU else 256
+            if deg_max > 256 * epl:
+                bt = 768
+            if deg_max > 768 * epl:
+                bt = 1024
+            slots = bt * epl
+            max_rows = int(min(cg_rows(n_copy), max(1, int(math.ceil(1.25 * slots / deg_avg)) + 1), 65535))
+            cap = T + 2
+            c0a = np.empty(cap, dtype=np.int32)
+            nchunk = _lib.check(lib.vican_plan_chunks(T, C.c_void_p(rp_host.data_ptr()), slots, max_rows, C.c_void_p(c0a.ctypes.data), cap),
+                                "vican_plan_chunks")
+            cgl.kind, cgl.n_time, cgl.chunk_row0_host = "block", T, c0a[: nchunk + 1].copy()
+            cgl.max_rows = int(np.diff(cgl.chunk_row0_host).max()) if nchunk else 1
+            cgl.n_chunk, cgl.slots, cgl.block_threads, cgl.n_copy, cgl.wg_waves = int(nchunk), slots, bt, n_copy, 0
+            cgl.n_wg = max(1, min(cgl.n_chunk, N_CU))
+            b = (np.arange(cgl.n_wg + 1, dtype=np.int64) * cgl.n_chunk) // cgl.n_wg
+            cgl.rows_per_wg_max = int(np.diff(cgl.chunk_row0_host[b]).max()) if nchunk else 1
+            cgl.wg_chunk_cap, cgl.rows_per_wg_sweep = 0, cgl.rows_per_wg_max
+            cgl.chunk_row0 = torch.from_numpy(cgl.chunk_row0_host).to(dev)
+            cgl.nslot = max(1, cgl.n_chunk) * slots
+            cgl.idx = torch.empty(cgl.nslot, dtype=torch.int32, device=dev)
+            self.cgl = cgl
+            self.desc_cg = cgl.describe(self.n_cam, storage, None)
+            self.w_cg = torch.empty(cgl.nslot, dtype=torch.float64, device=dev)
+            perm_ws = torch.empty(cgl.nslot, dtype=torch.int32, device=dev)
+            # (the converted inputs are held in variables until the pack has run: a temporary freed inside the argument
+            #  list is handed to the NEXT conversion by the caching allocator and overwritten before the kernel reads it)
+            rp32, col32, w64 = row_ptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous(), w.to(dev, torch.float64).contiguous()
+            _lib.check(lib.vican_pack_edges(C.byref(self.desc_cg), _ptr(rp32), _ptr(col32), None, None, _ptr(w64), None, None, None,
+                                            _ptr(self.w_cg), None, None, _ptr(perm_ws), _stream()), "vican_pack_edges")
+            torch.cuda.current_stream().synchronize()
+            del rp32, col32, w64
+
+    def op_bytes(self, ncols=3):
+        return sum(t.op_bytes(ncols) for t in self.tiles) * 2
+
+    def padded_slots(self):
+        return sum(t.padded_slots() for t in self.tiles)
+
+
+class TiledBackend(HipBackend):
+    """``HipBackend`` interface on a ``TiledGraph``: the edge sweeps run tile by tile through the one-pass bipartite
+    operator (sweep MODE 2: y_t = sum_c M_ct^T x_c and z_c = sum_t M_ct x_t in one pass over a tile's blocks), the
+    per-row partials of the tiles are summed in tile order by ``vican_sum_apply3``; everything camera-sided (Lanczos
+    step, Ritz, gauge, polar) is the launch-sequence path of the untiled backend, which has no camera limit; the CG
+    runs on the weights-only layout over all cameras.  No fused dual update, no LSQR (``lsqr_solver="direct"`` raises)."""
+    fused_dual_ok = False
+
+    def __init__(self, graph: TiledGraph):
+        self.lib, self.g, self.dev = _lib.load(), graph, graph.device
+        self.C, self.T = graph.n_cam, graph.n_time
+        self.storage_f64 = graph.storage_dtype == torch.float64
+        self.tiles = [HipBackend(t) for t in graph.tiles]
+        self.fold_in_step_ok, self.coop_cam_step, self.layout = False, False, "tiled"
+        self._status_host, self._coop_ws, self._coop_sync, self._gram_ws = {}, None, None, None
+        self.rr_part = torch.zeros(1536, dtype=torch.float64, device=self.dev)
+        self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+        T1, nt = max(self.T, 1), len(self.tiles)
+        self.ypart = torch.zeros(nt, T1, 9, dtype=torch.float64, device=self.dev)      # per-tile row partials
+        self.wrow = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)           # phase-3 operand of the second pass
+        self.zero_rows = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)
+        self.scratch_c = [torch.zeros(3 * (b1 - b0), 3, dtype=torch.float64, device=self.dev) for b0, b1 in zip(graph.bounds[:-1], graph.bounds[1:])]
+        if hasattr(graph, "cgl"):
+            self._gref_cg, self.cgl = C.byref(graph.desc_cg), graph.cgl
+            self.n_add_cg = float(max(graph.cgl.rows_per_wg_max, graph.cgl.slots) + 1)
+            self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w_cg, graph.wmax
+            self.zpart = torch.empty(graph.cgl.n_wg * 3 * self.C, dtype=torch.float64, device=self.dev)
+            self.pq_part = torch.empty(graph.cgl.n_wg, dtype=torch.float64, device=self.dev)
+            self.rhs_part = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)
+
+    def _tile_rows(self, k):
+        b = self.g.bounds
+        return 3 * b[k], 3 * b[k + 1]
+
+    def _sum_apply(self, A, B, n_b, out, width=9):
+        self._ck(self.lib.vican_sum_apply3(self.T, width, _ptr(A), _ptr(B), n_b, B.stride(0), _ptr(out), _stream()), "vican_sum_apply3")
+
+    def _refresh_scales(self, lamT_inv):
+        """omega = max_t |Lambda_t^-1|_F * rnorm[t] with the row norms of ALL tiles, into every tile's scale buffer."""
+        for K in self.tiles:
+            self._ck(self.lib.vican_duals_bound(self.T, _ptr(lamT_inv), _ptr(self.g.rnorm), _ptr(K.g.fx), _stream()), "vican_duals_bound")
+            K._fx_finish()
+
+    def _rows_T(self, x):
+        """ypart[k] = sum_{c in tile k} M_ct^T x_c for every tile (first pass of the one-pass operator; its camera-side
+        half runs on a zero operand and is discarded)."""
+        for k, K in enumerate(self.tiles):
+            r0, r1 = self._tile_rows(k)
+            self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.zero_rows), _ptr(K.zpart), _ptr(K.g.fx),
+                                              _ptr(self.scratch_c[k]), _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
+
+    # -- rotation stage ---------------------------------------------------------------------------------------
+    def init_duals(self, lamT_inv, cam_deg):
+        cam_deg.copy_(self.g.cam_sum_a)
+        K0 = self.tiles[0]
+        self._ck(self.lib.vican_init_duals(self.T, _ptr(self.g.row_sum_a), _ptr(self.g.rnorm), _ptr(lamT_inv), _ptr(K0.g.fx), _stream()),
+                 "vican_init_duals")
+        self._refresh_scales(lamT_inv)
+
+    def set_duals(self, lamT_inv):
+        self._refresh_scales(lamT_inv)
+
+    def block_op(self, lamT_inv, x, z_out):
+        """z_out = P x: rows pass over all tiles, w_t = Lambda_t^-1 (sum of the tiles' row partials), camera pass per tile."""
+        self._rows_T(x)
+        self._sum_apply(lamT_inv, self.ypart, len(self.tiles), self.wrow)
+        for k, K in enumerate(self.tiles):
+            r0, r1 = self._tile_rows(k)
+            self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.wrow), _ptr(K.zpart), _ptr(K.g.fx), _ptr(z_out[r0:r1]),
+                                              _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
+
+    def dual_update(self, rc, Rt, lamT_inv):
+        """Z_t = sum_c M_ct^T R_c over all tiles, then R_t, Lambda_t^-1 = U S^-1 U^T per row (bipgo.py:318-332)."""
+        self._rows_T(rc)
+        self._sum_apply(None, self.ypart, len(self.tiles), self.wrow)
+        self.polar_dual(self.wrow, Rt, lamT_inv, 2)
+        self._refresh_scales(lamT_inv)
+
+    # -- translation stage ------------------------------------------------------------------------------------
+    def trans_degrees(self, deg_t, deg_c):
+        deg_t[: self.g.row_sum_w.numel()].copy_(self.g.row_sum_w)
+        deg_c.copy_(self.g.cam_sum_w)
+
+    def trans_rhs(self, rc, rt, rhs_t, rhs_c):
+        b = self.g.bounds
+        for k, K in enumerate(self.tiles):
+            K.trans_rhs(rc[3 * b[k]: 3 * b[k + 1]], rt, self.rhs_part[k], rhs_c[b[k]: b[k + 1]])
+        self._ck(self.lib.vican_sum_apply3(self.T, 3, None, _ptr(self.rhs_part), len(self.tiles), self.rhs_part.stride(0), _ptr(rhs_t), _stream()),
+                 "vican_sum_apply3")
+
+    def _unsupported(self, *a, **k):
+        raise _lib.VicanError("not available on camera-tiled graphs (more than %d cameras)" % TILE_CAMS)
+
+    dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = _unsupported
+    lsqr_init_u = lsqr_u_step = lsqr_v_step = _unsupported
+
+
+def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None):
+    """(graph, backend) for one rank's rows: the fused layouts up to TILE_CAMS cameras, camera tiles beyond."""
+    import os
+    tile = int(os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
+    if n_cam > tile:
+        g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile)
+        return g, TiledBackend(g)
+    g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v)
+    return g, HipBackend(g)

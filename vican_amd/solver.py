@@ -128,7 +128,7 @@ class RotationSolver:
         self.Rt = K.empty(max(K.T, 1), 9)
         self.zraw = K.empty(n, 3)                   # P_new rc from the fused dual update (see _tail)
         self.z_ready = False
-        self.fuse_dual_op = True
+        self.fuse_dual_op = bool(getattr(K, "fused_dual_ok", True))       # (camera-tiled graphs: two separate passes)
         # single rank, few slabs: the camera-side Lanczos kernel folds the sweep's slabs itself (one launch less per step)
         self.fold_in_step = bool(getattr(K, "fold_in_step_ok", True))
         self.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
