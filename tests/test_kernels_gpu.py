@@ -249,6 +249,42 @@ def test_lanczos_cam_step_variants_agree(C, j):
     assert np.abs(q.T @ q - np.eye(3)).max() < 1e-12 and np.abs(Q.T @ q).max() < 1e-12
 
 
+def test_cooperative_step_repeats_bit_identically():
+    """The cooperative kernel's grid barrier and its cross-workgroup partials use relaxed agent-scope atomics (a release
+    fence would write back the XCD's whole L2): 3000 back-to-back repetitions on the same inputs
+    must reproduce the first result bit for bit (a workgroup reading stale partials would not), with other kernels
+    dirtying the caches in between, and a barrier counter left non-zero by an aborted launch is re-armed by the next
+    eigen-solve (lanczos_seed zeroes it)."""
+    C, j = 1000, 6
+    H, N, _ = make_backends(C, 40, 1, 6, 9, np.float64)
+    rng = np.random.default_rng(12)
+    n, m = 3 * C, 24
+    Q, _ = np.linalg.qr(rng.standard_normal((n, 3 * (j + 1))))
+    Vn = np.zeros((3 * (m + 1), n)); Vn[: 3 * (j + 1)] = Q.T
+    lam = rng.standard_normal((C, 3, 3)); lam = (lam @ np.swapaxes(lam, 1, 2) + np.eye(3)).reshape(C, 9)
+    lamd, zd, V0 = H.from_numpy(lam), H.from_numpy(rng.standard_normal((n, 3))), H.from_numpy(Vn.reshape(-1).copy())
+    V = V0.clone()
+    R, Hs, G, Hcol, beta, x = H.zeros(3 * n), H.zeros(3 * (m + 1) * 3), H.zeros(9), H.zeros(3 * (m + 1) * 3), H.zeros(9), H.zeros(n, 3)
+    H.coop_cam_step = True
+    H.lanczos_cam_step(lamd, V, n, j, zd, R, Hs, G, Hcol, beta, x, 0.0)
+    ref = [t.clone() for t in (V, Hcol, beta, x)]
+    junk = torch.empty(1 << 22, dtype=torch.float64, device="cuda")
+    bad = 0
+    for rep in range(3000):
+        V.copy_(V0)
+        if rep % 7 == 0:
+            junk.normal_()                                   # other traffic through the caches
+        H.lanczos_cam_step(lamd, V, n, j, zd, R, Hs, G, Hcol, beta, x, 0.0)
+        if rep % 50 == 49 or rep < 20:
+            bad += sum(int(not torch.equal(a, b)) for a, b in zip((V, Hcol, beta, x), ref))
+    assert bad == 0
+    # an aborted launch leaves the counter non-zero: the next eigen-solve's seed re-arms it
+    H._coop_sync.fill_(5)
+    x0 = H.from_numpy(rng.standard_normal((n, 3)))
+    H.lanczos_seed(x0, V, n, beta, x)
+    assert int(H._coop_sync.abs().sum()) == 0
+
+
 def _ritz_inputs(steps, m, seed, dead_at=None, gap=True):
     """HB rows as vican_lanczos_cam_step writes them, for a random symmetric projected matrix."""
     rng = np.random.default_rng(seed)

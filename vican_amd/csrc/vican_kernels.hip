@@ -530,6 +530,16 @@ __device__ __forceinline__ void st_agent(double* p, double v) {
 __device__ __forceinline__ double ld_agent(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// Grid barrier of the cooperative step.  Memory ordering, deliberately NOT release/acquire: every datum that crosses
+// workgroups here is written with st_agent (an agent-scope atomic store: write-through to the device coherence point)
+// and read with ld_agent (an agent-scope atomic load: never served from this CU's L1), the __syncthreads() in front of
+// the arrival makes every wavefront wait for its outstanding stores (s_waitcnt vmcnt(0)) before thread 0 adds to the
+// counter, and the counter itself is an agent-scope atomic - so the data is at the coherence point before any other
+// workgroup can see the count.  A release on the arrival / acquire on the exit would be the portable form under the HIP
+// memory model, but at agent scope they lower to an L2 write-back / invalidate of everything this XCD holds - the sweep's
+// 18 MB of slabs included, ~10 us per barrier.  The reliance on this ISA behaviour is pinned by
+// tests/test_kernels_gpu.py::test_cooperative_step_repeats_bit_identically (3000 repetitions, bit-identical), and the
+// counter is zeroed by the host at the start of every eigen-solve (device.HipBackend.lanczos_seed).
 __device__ __forceinline__ void coop_grid_sync(unsigned int* counter, unsigned int target) {
     __syncthreads();
     if (threadIdx.x == 0) {
