@@ -411,6 +411,44 @@ def test_jacobi_scaling_kernels(cfg):
     assert H._cg_w is g.w
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_fused_dual_update_redo_path(dt):
+    """The 12-wavefront fused dual-update sweep carries no SVD: a row whose Newton polar iteration does not apply raises
+    the redo word and the gated 8-wavefront kernel (with the SVD path) reruns the sweep (vican_wsweep.hip, FB).  Rows of
+    one edge with an ill-conditioned camera operand (cond 5e3) force that path: the result is bit-identical to the same
+    graph planned for 8 wavefronts (single launch, SVD in the kernel), the redo word is cleared afterwards, and a second
+    call with well-conditioned operands (no redo) is again identical between the two plans."""
+    C, T = 100, 3000
+    H12, N, g12 = make_backends(C, T, 1, 24, 77, dt, "wave12", 6)
+    H8, _, g8 = make_backends(C, T, 1, 24, 77, dt, "wave8", 6)
+    assert g12.wg_waves == 12 and g8.wg_waves == 8
+    rng = np.random.default_rng(8)
+    u, v = synth.random_rotations(rng, C), synth.random_rotations(rng, C)
+    # per camera U_c diag(1, 1, 2e-4) V_c^T: |.|_F < sqrt 3, normalised det 3.7e-4 < 1e-3 - rows of one edge are
+    # ill-conditioned (but 1e3 above the f32 products' rounding), sums over several cameras are not
+    bad = ((u * np.array([1.0, 1.0, 2e-4])) @ np.swapaxes(v, 1, 2)).reshape(3 * C, 3)
+    good = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    for rc, redo in ((bad, True), (good, False)):
+        outs = []
+        for K, g in ((H12, g12), (H8, g8)):
+            lam0, cd = K.empty(T, 9), K.empty(C)
+            K.init_duals(lam0, cd)
+            Rt, L, z = K.zeros(T, 9), K.zeros(T, 9), K.empty(3 * C, 3)
+            K.dual_update_op(K.from_numpy(rc), Rt, L, z)
+            torch.cuda.synchronize()
+            assert int(g.fx.view(torch.int32)[2 * 12 + 4]) == 0         # redo word re-armed by dual_svd_kernel
+            outs.append((Rt, L, z))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        Rn, Ln, zn = N.zeros(T, 9), N.zeros(T, 9), N.empty(3 * C, 3)
+        N.dual_update_op(N.from_numpy(rc), Rn, Ln, zn)
+        scale = np.abs(zn.numpy()).max()
+        tol = (1e-7 if dt == np.float64 else 1e-4) if redo else (1e-9 if dt == np.float64 else 3e-6)
+        assert np.abs(outs[0][2].cpu().numpy() - zn.numpy()).max() <= tol * scale
+    # the rows that forced the redo exist: rows of one edge
+    assert (np.diff(N.row_ptr) == 1).sum() > 50
+
+
 @pytest.mark.parametrize("cfg", CONFIGS)
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_fused_dual_update_op(cfg, dt):

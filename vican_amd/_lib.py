@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so") 
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
-HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "sweep_common.cuh"), WSWEEP]
+HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
 FX_DOUBLES = 20
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N

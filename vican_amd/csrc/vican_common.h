@@ -1,4 +1,4 @@
-// common.cuh - shared helpers of the vican HIP kernels (error plumbing, wavefront
+// vican_common.h - shared helpers of the vican HIP kernels (error plumbing, wavefront
 // reductions, 3x3 SVD / polar factor, LDS budget).  Included by every .hip file.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,7 +1,7 @@
 // vican_kernels.hip - camera-side and translation-stage kernels: batched 3x3 polar /
 // gauge fix, dense helpers of the block Lanczos iteration, right-hand side and the
 // conjugate-gradient kernels.  The hot edge sweep lives in vican_sweep.hip.
-#include "common.cuh"
+#include "vican_common.h"
 
 // ---------------------------------------------------------------------------
 // batched polar / gauge

@@ -9,7 +9,7 @@
 // the host (two small device->host reads per iteration); everything O(E) runs here:
 //   u-step   u <- s (v_t - v_c) - coef * u          (12 + 2*24 algorithmic bytes / edge)
 //   v-step   v <- J~^T (u / beta) - beta v           (12 + 24 bytes / edge, fixed-point sums)
-#include "common.cuh"
+#include "vican_common.h"
 #include <type_traits>
 
 #define LSQR_PARTS 1024

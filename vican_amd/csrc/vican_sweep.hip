@@ -13,7 +13,7 @@
 //   * the row accumulators (y_t) are striped over `n_copy` lane-indexed copies so the 64
 //     lanes of a wavefront that sit in the same timestep row never share an address;
 //   * phase 2 (w_t = Lambda_T^-1 y_t) runs on 9*rows threads from LDS-staged duals.
-#include "common.cuh"
+#include "vican_common.h"
 
 // Build layout.  Compiled as ONE translation unit this file contains everything.  The in-tree build
 // (vican_amd/_lib.py) splits it to compile in parallel - the hot kernel has ~190 instantiations:
@@ -27,7 +27,7 @@
                         double* lamT_out, const double* rnorm, double* fx, void* stream
 #ifndef VICAN_SWEEP_PART
 
-#include "sweep_common.cuh"
+#include "vican_sweep_common.h"
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
 extern "C" int vican_abi_version(void) { return 9; }
@@ -508,7 +508,7 @@ extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t
 // ---------------------------------------------------------------------------
 // THE HOT KERNEL
 // ---------------------------------------------------------------------------
-#include "sweep_common.cuh"
+#include "vican_sweep_common.h"
 
 // MODE 0: zpart[wg] (fixed point) = sum M * (lamT_inv * (sum M^T x))      (operator P x)
 // MODE 1: per row SVD of (sum M^T x) -> Rt, lamT_inv, omega bound         (dual update)
@@ -945,6 +945,7 @@ __global__ __launch_bounds__(256) void dual_svd_kernel(const int32_t* __restrict
     __syncthreads();
     for (int i = threadIdx.x; i < nloc; i += 256) { Rt[(size_t)t0 * 9 + i] = sh[1][i]; lamT_inv[(size_t)t0 * 9 + i] = sh[0][i]; }
     wg_raise_bound(om, &fx[4]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned int*)(fx + 12))[VICAN_SCHED_REDO] = 0u;   // re-arm the fused sweep's redo word
 }
 #endif  // !VICAN_SWEEP_PART
 

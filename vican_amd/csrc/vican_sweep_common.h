@@ -1,8 +1,12 @@
-// sweep_common.cuh - register-level helpers shared by the two edge sweeps (vican_sweep.hip: one workgroup per
+// vican_sweep_common.h - register-level helpers shared by the two edge sweeps (vican_sweep.hip: one workgroup per
 // chunk of 256..1024 lanes; vican_wsweep.hip: one wavefront per chunk): vector loads of a chunk's planes, the
 // fixed-point conversions and the explicitly rounded 3-term dot product.
 #pragma once
-#include "common.cuh"
+#include "vican_common.h"
+
+// words of the scheduler block (unsigned int*)(fx + 12) shared by the sweeps: [0] chunk ranges handed out, [8] workgroups
+// finished, [VICAN_SCHED_REDO] raised by the fused dual-update sweep when a row needs the in-kernel SVD (vican_wsweep.hip)
+#define VICAN_SCHED_REDO 4
 
 static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32 ? 4 : 8; }
 // camera planes are padded to a compile-time stride CP (256, 512 or 1024 entries) so that the nine
@@ -75,7 +79,7 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
 template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);
 template <> __device__ __forceinline__ float pre_scale<float>(double v, double) { return (float)v; }
 template <> __device__ __forceinline__ double pre_scale<double>(double v, double) { return v; }
-// Contribution -> 64-bit fixed point.  f64 blocks: magic-number conversion (common.cuh to_fix).
+// Contribution -> 64-bit fixed point.  f64 blocks: magic-number conversion (vican_common.h to_fix).
 // f32 blocks: the raw bit pattern of fma(v, scale, 1.5*2^52) WITHOUT subtracting the bias - a sum of N
 // patterns is off by N * 0x4338'0000'0000'0000, which only touches bits 48..63, and the true total
 // (|.| < 2^46 by the choice of scale in fx_finish) is the sign-extended low 48 bits (fix_total).  One VALU

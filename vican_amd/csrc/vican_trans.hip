@@ -10,7 +10,7 @@
 // order-independent sums are what makes two runs of this solver agree with each other.
 // The fixed-point scale of every CG sweep follows a running bound on max|p| kept in the
 // device-resident state; no host round trip.
-#include "sweep_common.cuh"
+#include "vican_sweep_common.h"
 
 #define CG_PARTS 512
 

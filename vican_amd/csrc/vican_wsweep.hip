@@ -29,7 +29,7 @@
 // round trip of an atomic under a saturated memory system is many microseconds.
 // Sums are exact integers, so which wavefront adds a chunk cannot change a bit of the result; a cap on the ranges a
 // workgroup may take keeps the number of adds into one z accumulator within the bound fx_finish assumed.
-#include "sweep_common.cuh"
+#include "vican_sweep_common.h"
 
 #ifndef VICAN_WSWEEP_PART
 
@@ -46,7 +46,13 @@ extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32
 // MODE 0: zpart[wg] = sum M (lamT_inv (sum M^T x))          operator P x
 // MODE 1: lamT_out[t] = Z_t = sum_c M_ct^T x_c               dual update (SVDs in dual_svd_kernel)
 // MODE 3: MODE 1 and zpart[wg] = sum M polar(Z_t)            dual update fused with the next operator application
-template <typename S, int NW, int MODE, int CP, int TRIPS>
+// FB (MODE 3): rows whose Newton polar iteration does not apply (ill-conditioned Z_t) take the SVD inside the kernel.
+// That path is a function call, and a call site makes the register allocator spill in the streaming loop at 12
+// wavefronts (168 VGPRs: 89 spilled, 774 us against 181 us for MODE 0; without the call 164 VGPRs, no spills).  The
+// 12-wavefront instantiation is therefore built with FB = false: such a row raises the word sched[4] instead, and the
+// launcher enqueues the 8-wavefront FB = true instantiation right behind it, gated on that word - it reruns the whole
+// sweep (same outputs) only when a row needed it; dual_svd_kernel clears the word.
+template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true>
 __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
                                                              const double* __restrict__ lamT_inv,
                                                              const double* __restrict__ x, u64* __restrict__ zpart,
@@ -342,7 +348,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         if (MODE == 3) {
             for (int r = lane; r < nrows; r += 64) {
                 double R[9];
-                polar_newton3(yv + r * 9, R);
+                if (FB) {
+                    polar_newton3(yv + r * 9, R);
+                } else if (!polar_newton_core(yv + r * 9, R)) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) R[q] = 0.0;
+                    sched[VICAN_SCHED_REDO] = 1u;               // the gated FB instantiation redoes this sweep
+                }
 #pragma unroll
                 for (int q = 0; q < 9; ++q) wv[r * 9 + q] = pre_scale<S>(R[q], z_scale);
             }
@@ -431,40 +443,49 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #endif
 }
 
-template <typename S, int NW, int MODE, int CP, int TRIPS>
+static thread_local const int32_t* w_gate_override = nullptr;     // the redo launch of MODE 3 runs under its own gate
+template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true>
 static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
     const size_t lds = (size_t)vican_wsweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy, NW);
-    auto kern = wave_sweep_kernel<S, NW, MODE, CP, TRIPS>;
+    auto kern = wave_sweep_kernel<S, NW, MODE, CP, TRIPS, FB>;
     static size_t configured = 0;       // per instantiation
     if (lds > configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return set_err(VICAN_ERR_LAUNCH, "%s: cannot raise dynamic LDS limit", "vican wave sweep");
         configured = lds;
     }
-    VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW * 64), lds, st, g_vican_gate, *g, lamT_inv, x, zpart, lamT_out, fx);
+    VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW * 64), lds, st, w_gate_override ? w_gate_override : g_vican_gate, *g, lamT_inv, x,
+                       zpart, lamT_out, fx);
     return 0;
 }
-template <typename S, int NW, int MODE, int CP>
+template <typename S, int NW, int MODE, int CP, bool FB>
 static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
-    if (MODE != 0 || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    if (3 * g->max_rows <= 128) return launch_wsweep4<S, NW, MODE, CP, 2>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    return launch_wsweep4<S, NW, MODE, CP, 3>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (MODE != 0 || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (3 * g->max_rows <= 128) return launch_wsweep4<S, NW, MODE, CP, 2, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep4<S, NW, MODE, CP, 3, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
 }
-template <typename S, int NW, int MODE>
+template <typename S, int NW, int MODE, bool FB = true>
 static int launch_wsweep2(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
-    if (g->n_cam <= 256) return launch_wsweep3<S, NW, MODE, 256>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    if (g->n_cam <= 512) return launch_wsweep3<S, NW, MODE, 512>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    return launch_wsweep3<S, NW, MODE, 1024>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->n_cam <= 256) return launch_wsweep3<S, NW, MODE, 256, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->n_cam <= 512) return launch_wsweep3<S, NW, MODE, 512, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep3<S, NW, MODE, 1024, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
 }
 template <typename S, int MODE>
 static int launch_wsweep1(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
-    // MODE 3 carries the Newton polar iteration (~60 live VGPRs on top of the two chunk register sets): at 12 wavefronts
-    // (168 VGPRs) it spills 65 registers and ran 774 us against 181 us for MODE 0 - it runs with 8 wavefronts (230 VGPRs,
-    // no spills) on the same graph; the per-wavefront LDS regions and the chunk cap do not depend on the launch shape
+    // the per-wavefront LDS regions and the chunk cap do not depend on the launch shape: a graph planned for 12 wavefronts
+    // can be swept by the 8-wavefront instantiation
+    if (MODE == 3 && g->wg_waves >= 12) {
+        // 12 wavefronts without the in-kernel SVD path, then the 8-wavefront kernel with it under the redo word (see FB)
+        if (int rc = launch_wsweep2<S, 12, MODE, false>(g, lamT_inv, x, zpart, lamT_out, fx, st)) return rc;
+        w_gate_override = (const int32_t*)((const unsigned int*)(fx + 12) + VICAN_SCHED_REDO);
+        const int rc = launch_wsweep2<S, 8, MODE, true>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+        w_gate_override = nullptr;
+        return rc;
+    }
     if (g->wg_waves == 16 && MODE == 0) return launch_wsweep2<S, 16, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (g->wg_waves >= 12 && MODE != 3) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (g->wg_waves >= 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);

@@ -10,11 +10,31 @@
 // chunks ahead and row values (p_t, r_t, deg_t) one chunk ahead, edge words (index + weight, 12 B per edge) one chunk
 // ahead; every vector-memory operation is unconditional (clamped indices) so that the compiler's vmcnt waits are exact.
 // A workgroup owns a contiguous range of chunks and its wavefront i takes chunks c0 + i, c0 + i + NW, ...
-#include "sweep_common.cuh"
+#include "vican_sweep_common.h"
 
 extern "C" int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
     const int64_t per_wave = (((int64_t)max_rows * 3 * (8LL * n_copy + 16)) + 15) & ~15LL;
     return 48LL * n_cam + (int64_t)n_waves * per_wave + 256;
+}
+
+#ifdef VICAN_CGWSTAMP   /* diagnostic build (tools/cgsweep_time.py --stamp): wall-clock structure of the launch, per wavefront */
+__device__ double* cgw_stamp_buf = nullptr;
+extern "C" int vican_cgw_stamp_buffer(double* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(cgw_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? VICAN_OK : VICAN_ERR_ARG;
+}
+#define CSTAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CSTAMP0() do {} while (0)
+#define CSTAMP(i) do {} while (0)
+#endif
+
+// v of the lane a DPP control selects (quad permutes 0xB1 = lane ^ 1, 0x4E = lane ^ 2; 0x141 = mirror inside a half row)
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
 template <int EPL>
@@ -29,6 +49,11 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red[16];
     if (st->done) return;
+#ifdef VICAN_CGWSTAMP
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = 0;
+    int n_done = 0;
+#endif
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
     const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,11 +115,32 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     // body: chunk k (edges `cur`, row values `rv`, row bounds `vrow`); requests the edge words and row values of chunk
     // k + NW (row bounds `vnext`, loaded a body ago) and the row bounds of chunk k + 2 NW (returned)
     auto body = [&](CgWRegs<EPL>& cur, CgWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int kk) -> int2 {
+        CSTAMP0();
         const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
         const int2 vnn = load_rows(kk + 2 * NW);
         load_rowvals(rvn, vnext);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef VICAN_CGW_DEPTH2
+        load_edges(nxt, kk + 2 * NW);
+#else
         load_edges(nxt, kk + NW);
+#endif
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) asm volatile("" :: "v"(rv.p[t]), "v"(rv.r[t]), "v"(rv.d[t]));
+        return vnn;
+#endif
+        CSTAMP(0);                      // row bounds (a wait), issue of the prefetches
+#ifdef VICAN_CGWSTAMP                   /* wait for this chunk's data here so that the wait is booked separately */
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) asm volatile("" :: "v"(rv.p[t]), "v"(rv.r[t]), "v"(rv.d[t]));
+        CSTAMP(1);
+        ++n_done;
+#endif
         // commit this chunk's rows: p (updated), deg p into the wavefront's staging; the updated p back to memory
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -106,45 +152,105 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // edges: camera contributions one by one, same-row contributions of a lane pre-summed
-        double acc[3] = {0, 0, 0};
-        uint32_t prow = 0xFFFFFFFFu;
+        CSTAMP(2);                      // commit
+        // edges.  LDS operations of a wavefront return in order, so a read issued after an atomic waits for it: all the
+        // reads of the lane's EPL edges first (camera values; the row's p where the row changes), then the arithmetic,
+        // then nothing but atomics - camera contributions one by one, same-row contributions of a lane pre-summed.
+        uint32_t cam[EPL], row[EPL];
+        double wj[EPL], pc[EPL][3], pr[EPL][3];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
-            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
-            const double wj = pad ? 0.0 : cur.w[j];
-            if (row != prow) {
-                if (prow != 0xFFFFFFFFu)
+            cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu); row[j] = pad ? 0u : (cur.id[j] >> 16);
+#if defined(VICAN_CGW_SWZ) && VICAN_CGW_SWZ == 1      /* timing experiment: bank swizzle of the camera index (results wrong at the table's end) */
+            { uint32_t c2 = cam[j] ^ ((cam[j] >> 4) & 15u); cam[j] = c2 < (uint32_t)C ? c2 : cam[j]; }
+#elif defined(VICAN_CGW_SWZ) && VICAN_CGW_SWZ == 2    /* timing experiment: pseudo-random camera */
+            { uint32_t c2 = (cam[j] * 2654435761u >> 7) % (uint32_t)C; cam[j] = c2; }
+#endif
+            wj[j] = pad ? 0.0 : cur.w[j];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
-                prow = row; acc[0] = acc[1] = acc[2] = 0.0;
+            for (int i = 0; i < 3; ++i) pc[j][i] = pcs[i * C + cam[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            if (j == 0 || row[j] != row[j - 1]) {               // a lane's slots are consecutive edges: mostly one row
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pr[j][i] = pts[row[j] * 3 + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pr[j][i] = pr[j - 1][i];
             }
+        }
+        u64 fc[EPL][3], fr[EPL][3];
+        {
+            double acc[3] = {0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                if (j > 0 && row[j] != row[j - 1]) acc[0] = acc[1] = acc[2] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    acc[i] += wj[j] * pc[j][i];
+                    fc[j][i] = to_fix(wj[j] * pr[j][i], scale);
+                    fr[j][i] = to_fix(acc[i], scale);            // used where the lane's run of this row ends
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                acc[i] += wj * pcs[i * C + cam];
-                lds_add_fix(&qc[i * C + cam], to_fix(wj * pts[row * 3 + i], scale));
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
+                asm volatile("" :: "v"(fc[j][i]));
+#else
+                lds_add_fix(&qc[i * C + cam[j]], fc[j][i]);
+#endif
             }
-        }
-        if (prow != 0xFFFFFFFFu)
+            if (j == EPL - 1 || row[j] != row[j + 1]) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
-        __builtin_amdgcn_wave_barrier();
-        // fold this chunk's row sums (exact integer sums of the stripes), q_t, p.q
-        for (int i = lane; i < n3; i += 64) {
-            long long sum = 0;
-            for (int c = 0; c < ncopy; ++c) {
-                const int a = i * ncopy + ((c + i) & cmask);
-                sum += (long long)qt[a];
-                qt[a] = 0ull;
+                for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(row[j] * 3 + i) * ncopy + lane_copy], fr[j][i]);
             }
-            const double qv = dps[i] - (double)sum * inv;
-            q_t[(size_t)r0 * 3 + i] = qv;
-            pq += pts[i] * qv;
         }
         __builtin_amdgcn_wave_barrier();
+        CSTAMP(3);                      // edges
+        // fold this chunk's row sums (exact integer sums of the stripes), q_t, p.q: one lane per (item, stripe) word,
+        // the n_copy words of an item summed across neighbouring lanes
+        for (int base = 0; base < n3 * ncopy; base += 64) {
+            const int a = base + lane;
+            const bool live = a < n3 * ncopy;
+            u64 sum = 0ull;
+            if (live) { sum = qt[a]; qt[a] = 0ull; }
+            if (ncopy >= 2) sum += dpp_u64<0xB1>(sum);          // lane ^ 1
+            if (ncopy >= 4) sum += dpp_u64<0x4E>(sum);          // lane ^ 2
+            if (ncopy >= 8) sum += dpp_u64<0x141>(sum);         // mirror inside 8 lanes: the other quad's total
+            if (live && (a & cmask) == 0) {
+                const int i = a / ncopy;
+                const double qv = dps[i] - (double)(long long)sum * inv;
+                q_t[(size_t)r0 * 3 + i] = qv;
+                pq += pts[i] * qv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        CSTAMP(4);                      // fold
         return vnn;
     };
+#ifdef VICAN_CGWSTAMP
+    const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef VICAN_CGW_DEPTH2
+    // edge words two chunks ahead (three register buffers), row values one ahead (two buffers): period 6
+    CgWRegs<EPL> ec;
+    load_edges(eb, k + NW);
+#pragma unroll 1
+    while (k < c1) {
+        v2 = body(ea, ec, ra, rb, v0, v1, k); k += NW; if (k >= c1) break;
+        v0 = body(eb, ea, rb, ra, v1, v2, k); k += NW; if (k >= c1) break;
+        v1 = body(ec, eb, ra, rb, v2, v0, k); k += NW; if (k >= c1) break;
+        v2 = body(ea, ec, rb, ra, v0, v1, k); k += NW; if (k >= c1) break;
+        v0 = body(eb, ea, ra, rb, v1, v2, k); k += NW; if (k >= c1) break;
+        v1 = body(ec, eb, rb, ra, v2, v0, k); k += NW;
+    }
+#else
 #pragma unroll 1
     while (k < c1) {
         v2 = body(ea, eb, ra, rb, v0, v1, k);
@@ -155,10 +261,22 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         // rotate the row-bound registers: (v0, v1, v2) now hold (k + NW, k, -) -> bring them back to (k, k + NW)
         const int2 tmp = v0; v0 = v2; v1 = tmp;
     }
+#endif
+#ifdef VICAN_CGWSTAMP
+    const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
     for (int i = tid; i < 3 * C; i += NW * 64) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
+#ifdef VICAN_CGWSTAMP
+    if (lane == 0 && cgw_stamp_buf) {
+        double* o = cgw_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 10;
+        o[0] = (double)rt_begin; o[1] = (double)rt_loop0; o[2] = (double)rt_loop1; o[3] = (double)__builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 5; ++i) o[4 + i] = (double)st_acc[i];
+        o[9] = (double)n_done;
+    }
+#endif
 }
 
 // launcher: called by vican_cg_sweep for graphs in the wave layout

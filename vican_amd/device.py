@@ -18,8 +18,19 @@ import torch
 
 from . import _lib
 
-N_CU = 256
-STREAM_NT_BYTES = 192 << 20       # edge streams above this are read with non-temporal loads (LocalGraph, sweep_common.cuh)
+_N_CU = None
+
+
+def n_cu():
+    """Compute units of the device the plans are sized for (256 on an MI355X; 256 also when planning without a GPU)."""
+    global _N_CU
+    if _N_CU is None:
+        _N_CU = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) \
+            if torch.cuda.is_available() else 256
+    return _N_CU
+
+
+STREAM_NT_BYTES = 192 << 20       # edge streams above this are read with non-temporal loads (LocalGraph, vican_sweep_common.h)
 X_BOUND = math.sqrt(3.0)      # |x_c|_F of every sweep input: orthonormal columns / stacked rotations
 
 
@@ -58,8 +69,8 @@ class _Layout:
                     n_copy *= 2
             if wg_waves is None:
                 wg_waves = 12
-                if n_edges < 12 * slots * N_CU:          # small graphs: fewer wavefronts per workgroup, more workgroups
-                    wg_waves = 8 if n_edges >= 8 * slots * N_CU else 4
+                if n_edges < 12 * slots * n_cu():          # small graphs: fewer wavefronts per workgroup, more workgroups
+                    wg_waves = 8 if n_edges >= 8 * slots * n_cu() else 4
             fits = lambda rows, nc, nw: int(lib.vican_wsweep_lds_bytes(n_cam, rows, storage, nc, nw)) <= lim
             while not fits(rows_target, n_copy, wg_waves) and n_copy > 1:
                 n_copy //= 2
@@ -76,7 +87,7 @@ class _Layout:
                 # 768 threads (12 wavefronts, <= 168 VGPRs) holds two register sets of a chunk without
                 # spilling and measured fastest on the HBM-bound stress graph; small graphs use 256 so
                 # that there are enough chunks to occupy the chip
-                block_threads = 768 if n_edges >= 768 * epl * N_CU else 256
+                block_threads = 768 if n_edges >= 768 * epl * n_cu() else 256
                 if deg_max > 256 * epl:
                     block_threads = 768
                 if deg_max > 768 * epl:
@@ -109,7 +120,7 @@ class _Layout:
             per_wg = 1
         occ = max(1, min(lim // lds, 2048 // block_threads))
         if n_wg is None:
-            n_wg = max(1, min(-(-self.n_chunk // per_wg), N_CU * occ))
+            n_wg = max(1, min(-(-self.n_chunk // per_wg), n_cu() * occ))
         self.n_wg = int(n_wg)
         # max timestep rows one workgroup handles (bounds the adds into one z accumulator)
         bounds = (np.arange(self.n_wg + 1, dtype=np.int64) * self.n_chunk) // self.n_wg
@@ -295,6 +306,22 @@ class HipBackend:
         # layout the CG sweep runs on: the rotation layout if it is a wave layout, else the translation block layout
         cgl = graph.rot if graph.layout == "wave" else graph.tl
         self._gref_cg, self.cgl = (self._gref if graph.layout == "wave" else self._gref_t), cgl
+        if graph.layout == "wave":
+            # The CG sweep needs a third of the rotation sweep's LDS (3 + 3 camera planes against 9 + 9) and 61 VGPRs: several
+            # of its workgroups fit on a compute unit where the rotation sweep has one.  It runs on a copy of the graph
+            # descriptor with n_wg multiplied (the slab buffer holds 9 C words per rotation workgroup, the CG sweep writes 3 C).
+            import copy
+            import os
+            mult = int(os.environ.get("VICAN_CG_WGMULT") or 1)
+            lds1 = int(self.lib.vican_cg_wsweep_lds_bytes(self.C, cgl.max_rows, cgl.n_copy, cgl.wg_waves)) + 512
+            mult = max(1, min(mult, 3, int(self.lib.vican_lds_limit_bytes()) // lds1, max(1, cgl.n_chunk // (cgl.n_wg * cgl.wg_waves * 4))))
+            if mult > 1:
+                self._desc_cg = type(graph.desc).from_buffer_copy(graph.desc)
+                self._desc_cg.n_wg = cgl.n_wg * mult
+                self._gref_cg = C.byref(self._desc_cg)
+                self.cgl = copy.copy(cgl)
+                self.cgl.n_wg = cgl.n_wg * mult
+                self.pq_part = torch.empty(self.cgl.n_wg, dtype=torch.float64, device=self.dev)
         self.n_add_cg = float(max(cgl.rows_per_wg_max, cgl.slots) + 1)
 
     # -- allocation helpers -------------------------------------------------
@@ -709,7 +736,7 @@ class TiledGraph:
                 raise _lib.VicanError("camera vectors of the CG sweep (C=%d) do not fit in LDS (limit about 3300 cameras)" % self.n_cam)
             cgl = _Layout.__new__(_Layout)
             epl = 4 if storage == _lib.STORE_F32 else 2
-            bt = 768 if self.n_edges >= 768 * epl * N_CU else 256
+            bt = 768 if self.n_edges >= 768 * epl * n_cu() else 256
             if deg_max > 256 * epl:
                 bt = 768
             if deg_max > 768 * epl:
@@ -723,7 +750,7 @@ class TiledGraph:
             cgl.kind, cgl.n_time, cgl.chunk_row0_host = "block", T, c0a[: nchunk + 1].copy()
             cgl.max_rows = int(np.diff(cgl.chunk_row0_host).max()) if nchunk else 1
             cgl.n_chunk, cgl.slots, cgl.block_threads, cgl.n_copy, cgl.wg_waves = int(nchunk), slots, bt, n_copy, 0
-            cgl.n_wg = max(1, min(cgl.n_chunk, N_CU))
+            cgl.n_wg = max(1, min(cgl.n_chunk, n_cu()))
             b = (np.arange(cgl.n_wg + 1, dtype=np.int64) * cgl.n_chunk) // cgl.n_wg
             cgl.rows_per_wg_max = int(np.diff(cgl.chunk_row0_host[b]).max()) if nchunk else 1
             cgl.wg_chunk_cap, cgl.rows_per_wg_sweep = 0, cgl.rows_per_wg_max
