@@ -82,7 +82,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 9 */
+int vican_abi_version(void);            /* 10 */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),
@@ -440,6 +440,23 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
                          const double* p_c, double* x_c, double* r_c, const double* p_t,
                          const double* q_t, double* x_t, double* r_t, double* rr_part,
                          int32_t part_cap, vican_cg_state_t* st, void* stream);
+
+/* The whole CG solve as ONE cooperative launch (vican_cgres.hip) for wave-layout graphs whose n_wg workgroups are
+ * co-resident (n_wg <= compute units, <= 256) and whose per-workgroup rows fit in LDS: replaces the vican_cg_init /
+ * vican_cg_iter_local / vican_cg_iter_finish sequence of scipy.sparse.linalg.cg at bipgo.py:476-478 on capture-sized
+ * graphs, where that sequence is bound by launch latency.  Same recurrences, stopping test (|r| < rtol |b| at the top of
+ * an iteration, at most max_iter iterations) and fixed-point accumulation; the floating-point partial sums of r.r and
+ * p.q are grouped per workgroup and the scale bound uses measured maxima on both node sets, so the iterates agree with
+ * the multi-kernel path to rounding.  b_c [C][3], b_t [T][3]: right-hand side; x_c, x_t: solution; slab: n_wg * 3C 64-bit
+ * words; ws: vican_cg_resident_ws_doubles() doubles, zeroed ONCE by the caller (holds the barrier counter, re-armed by
+ * every launch); wmax: max edge weight; rows_per_wg: most rows in one workgroup's chunk range [n_chunk b / n_wg,
+ * n_chunk (b + 1) / n_wg); st receives the final state (iter, done, rho, bnorm2, ...).  n_add as for vican_cg_begin.   */
+int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t rows_per_wg);
+int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg);
+int vican_cg_resident(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
+                      const double* b_c, const double* b_t, double* x_c, double* x_t, void* slab, double* ws,
+                      double rtol, int32_t max_iter, double n_add, double wmax, int32_t rows_per_wg,
+                      vican_cg_state_t* st, void* stream);
 
 /* ---- LSQR translation solve (lsqr_solver="direct", bipgo.py:479-480) -------------------
  * scipy.sparse.linalg.lsqr on the incidence matrix is reproduced on the MERGED system

@@ -31,7 +31,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), "library does not export %s" % s
         assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
-    assert lib.vican_abi_version() == 9
+    assert lib.vican_abi_version() == 10
 
 
 def test_struct_sizes():

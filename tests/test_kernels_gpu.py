@@ -198,6 +198,55 @@ def test_translation_kernels_and_cg(cfg):
     assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[9], CONFIGS[10], CONFIGS[12], (340, 10000, 2, 6, "wave", None, False)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_cg_resident_matches_multikernel(cfg, dt):
+    """vican_cg_resident (the whole CG as one cooperative launch, vican_cgres.hip) against the multi-kernel path on the same
+    device: same iteration count, iterates equal to rounding (the floating-point partial sums are grouped differently),
+    bit-identical on repeats; the Jacobi-scaled tight solver through both; an iteration budget is honoured exactly."""
+    from vican_amd.solver import Comm, TightTranslationSolver, TranslationSolver
+    C, T, lo, hi, bt, nwg, er = cfg
+    H, N, g = make_backends(C, T, lo, hi, 200 + C, dt, bt, nwg, er)
+    assert H.cg_resident_ok
+    rng = np.random.default_rng(2)
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    rt = synth.random_rotations(rng, T).reshape(T, 9)
+    for cls, rtol in ((TranslationSolver, 1e-8), (TranslationSolver, 1e-5), (TightTranslationSolver, 1e-10)):
+        outs = []
+        for resident in (True, False, True):
+            H._cgres_ok = resident
+            ts = cls(H, Comm(), rtol=rtol)
+            ts.small_graph = True
+            ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+            x_c, x_t = ts.solve(3 * (C + T))
+            assert bool(ts.info.get("resident", False)) == resident and ts.info["converged"]
+            outs.append((x_c.clone(), x_t.clone(), ts.info["cg_iters"], ts.info["relres"]))
+        H._cgres_ok = True
+        scale = max(float(outs[1][1].abs().max()), 1.0)
+        assert abs(outs[0][2] - outs[1][2]) <= 1, (outs[0][2], outs[1][2])
+        if outs[0][2] == outs[1][2]:
+            # (both iterates satisfy |r| < rtol |b|; rounding differences of the recurrences are amplified towards that level)
+            tol = 1e3 * rtol * scale
+            assert float((outs[0][0] - outs[1][0]).abs().max()) < tol and float((outs[0][1] - outs[1][1]).abs().max()) < tol
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]) and outs[0][2] == outs[2][2]
+    # iteration budget: exactly maxiter updates, not converged (scipy: info = maxiter)
+    ts = TranslationSolver(H, Comm(), rtol=1e-14)
+    ts.small_graph = True
+    ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+    ts.solve(3 * (C + T), maxiter=3)
+    assert ts.info["cg_iters"] == 3 and not ts.info["converged"] and ts.info["resident"]
+    x3 = ts.x_t.cpu().numpy().copy()
+    tn = TranslationSolver(N, Comm(), rtol=1e-14)
+    tn.setup(N.from_numpy(rc), N.from_numpy(rt))
+    # the NumPy state machine run for the same three updates
+    N.cg_init(tn.b_c, tn.b_t, tn.x_c, tn.x_t, tn.r_c, tn.r_t, tn.p_c, tn.p_t, tn.st)
+    n_part = 0
+    for _ in range(3):
+        N.cg_iter_local(tn.deg_t, tn.r_c, tn.p_c, tn.r_t, tn.p_t, tn.q_t, tn.qcpq, 1e-14, tn.st, n_part)
+        n_part = N.cg_iter_finish(tn.deg_c, tn.qcpq, tn.p_c, tn.x_c, tn.r_c, tn.p_t, tn.q_t, tn.x_t, tn.r_t, tn.st)
+    assert np.abs(x3 - tn.x_t.numpy()).max() < 1e-9 * max(np.abs(x3).max(), 1e-30)
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[2], CONFIGS[4], CONFIGS[9]])
 def test_lsqr_kernels(cfg):
     """LSQR translation solve: HIP kernels vs the NumPy restatement, same host driver."""

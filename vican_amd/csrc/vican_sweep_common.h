@@ -112,3 +112,14 @@ __device__ __forceinline__ S dot3(S a0, S b0, S a1, S b1, S a2, S b2) {
     return __builtin_elementwise_fma(a2, b2, t);
 }
 
+// scale = 2^e with  c*2^e <= 2^47  (one contribution; lanes pre-sum <= 4 of them: < 2^51)  and
+// c*n_add*2^e <= 2^61 (one accumulator)
+__device__ __host__ inline double fix_scale(double c, double n_add, double* inv, int bits = 47) {
+    c = c > 1e-300 ? c : 1e-300;
+    int e = bits - (int)ceil(log2(c));
+    const int e2 = 61 - (int)ceil(log2(c * (n_add > 1 ? n_add : 1)));
+    e = e < e2 ? e : e2;
+    e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+    *inv = ldexp(1.0, -e);
+    return ldexp(1.0, e);
+}

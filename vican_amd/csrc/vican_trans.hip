@@ -14,17 +14,6 @@
 
 #define CG_PARTS 512
 
-// scale = 2^e with  c*2^e <= 2^47  (one contribution; lanes pre-sum <= 4 of them: < 2^51)  and
-// c*n_add*2^e <= 2^61 (one accumulator)
-__device__ __host__ inline double fix_scale(double c, double n_add, double* inv, int bits = 47) {
-    c = c > 1e-300 ? c : 1e-300;
-    int e = bits - (int)ceil(log2(c));
-    const int e2 = 61 - (int)ceil(log2(c * (n_add > 1 ? n_add : 1)));
-    e = e < e2 ? e : e2;
-    e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
-    *inv = ldexp(1.0, -e);
-    return ldexp(1.0, e);
-}
 
 // ---------------------------------------------------------------------------
 // right-hand side:  g_ct = Rc_c^T u_ct + Rt_t^T v_ct ;  rhs_t = sum_c g_ct ; rhs_c = -sum_t g_ct

@@ -12,6 +12,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -600,6 +601,26 @@ class HipBackend:
     def cg_init(self, b_c, b_t, x_c, x_t, r_c, r_t, p_c, p_t, st):
         self._ck(self.lib.vican_cg_init(self.C, self.T, _ptr(b_c), _ptr(b_t), _ptr(x_c), _ptr(x_t), _ptr(r_c), _ptr(r_t),
                                         _ptr(p_c), _ptr(p_t), _ptr(st), _ptr(self.ws), self._cg_wmax, _stream()), "vican_cg_init")
+
+    @property
+    def cg_resident_ok(self):
+        """The whole CG as one cooperative launch (vican_cgres.hip): wave-layout graphs whose workgroups are co-resident."""
+        if getattr(self, "_cgres_ok", None) is None:
+            l = self.cgl
+            self._cgres_ok = bool(
+                os.environ.get("VICAN_CG_RESIDENT", "1") != "0" and self.layout == "wave" and self._gref_cg is self._gref and
+                l.n_chunk > 0 and l.n_wg <= min(n_cu(), 256) and
+                int(self.lib.vican_cg_resident_lds_bytes(self.C, l.max_rows, l.n_copy, l.rows_per_wg_max)) <= int(self.lib.vican_lds_limit_bytes()))
+        return self._cgres_ok
+
+    def cg_resident(self, deg_t, deg_c, b_c, b_t, x_c, x_t, rtol, maxiter, st):
+        if getattr(self, "_cgres_ws", None) is None:
+            n = int(self.lib.vican_cg_resident_ws_doubles(self.C, self.cgl.n_wg))
+            self._cgres_ws = torch.zeros(n, dtype=torch.float64, device=self.dev)       # zeroed once: holds the barrier counter
+        self._ck(self.lib.vican_cg_resident(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(b_c), _ptr(b_t), _ptr(x_c),
+                                            _ptr(x_t), _ptr(self.zpart), _ptr(self._cgres_ws), float(rtol),
+                                            int(min(maxiter, 2 ** 31 - 1)), self.n_add_cg, float(self._cg_wmax),
+                                            int(self.cgl.rows_per_wg_max), _ptr(st), _stream()), "vican_cg_resident")
 
     def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),

@@ -412,10 +412,19 @@ class TranslationSolver:
     def solve(self, n_unknowns_total, maxiter=None):
         K, comm, st = self.K, self.comm, self.st
         multi = comm.world > 1
+        maxiter = 10 * n_unknowns_total if maxiter is None else maxiter       # scipy default
+        if not multi and self.small_graph and getattr(K, "cg_resident_ok", False):
+            # capture-sized graphs: the whole solve as one cooperative launch (an iteration of the multi-kernel path is
+            # four dependent launches of a few microseconds each - launch latency only)
+            K.cg_resident(self.deg_t, self.deg_c, self.b_c, self.b_t, self.x_c, self.x_t, self.rtol, maxiter, st)
+            s = self._state()
+            self._n_solves += 1
+            self.info = dict(cg_iters=s["iter"], converged=bool(s["done"]), resident=True,
+                             relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+            return self.x_c, self.x_t
         K.cg_init(self.b_c, self.b_t, self.x_c, self.x_t, self.r_c, self.r_t, self.p_c, self.p_t, st)
         if multi:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
-        maxiter = 10 * n_unknowns_total if maxiter is None else maxiter       # scipy default
         n_part, it_launched, s = 0, 0, None
 
         def one_iteration(n_part):
