@@ -70,13 +70,6 @@ __device__ __forceinline__ double cgr_sum(double s, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int CTRL>
-__device__ __forceinline__ u64 cgr_dpp_u64(u64 v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
-    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
 // LDS: camera side 8 (5 * 3C + C) bytes; per wavefront the striped row accumulators and the staging of a chunk's rows;
 // the four timestep vectors of the workgroup's own rows
 extern "C" int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t rows_per_wg) {
@@ -254,9 +247,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
                 const bool live = a < nr3 * ncopy;
                 u64 sum = 0ull;
                 if (live) { sum = qt[a]; qt[a] = 0ull; }
-                if (ncopy >= 2) sum += cgr_dpp_u64<0xB1>(sum);
-                if (ncopy >= 4) sum += cgr_dpp_u64<0x4E>(sum);
-                if (ncopy >= 8) sum += cgr_dpp_u64<0x141>(sum);
+                sum = stripe_sum(sum, ncopy);
                 if (live && (a & cmask) == 0) {
                     const int i = a / ncopy;
                     const double qv = dps[i] - (double)(long long)sum * inv;
@@ -286,7 +277,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         for (int e = j0 + (tid >> 3); e < j1; e += CGR_THREADS / 8) {
             u64 sum = 0ull;
             for (int q = tid & 7; q < nwg; q += 8) sum += cgr_ld(slab + (size_t)q * n3 + e);
-            sum += cgr_dpp_u64<0xB1>(sum); sum += cgr_dpp_u64<0x4E>(sum); sum += cgr_dpp_u64<0x141>(sum);
+            sum = stripe_sum(sum, 8);
             if ((tid & 7) == 0) cgr_st(qc_sum + e, sum);
         }
         RSTAMP(4);

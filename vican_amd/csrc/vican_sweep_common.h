@@ -123,3 +123,21 @@ __device__ __host__ inline double fix_scale(double c, double n_add, double* inv,
     *inv = ldexp(1.0, -e);
     return ldexp(1.0, e);
 }
+
+// Sum of a 64-bit value over the aligned group of `ncopy` (power of two <= 32) neighbouring lanes, in every lane of the
+// group: DPP quad permutes (lane ^ 1, lane ^ 2), mirrors inside 8 and 16 lanes, one cross-row shuffle for 32.  Used to
+// fold the lane-striped fixed-point row accumulators with one LDS read per lane instead of ncopy dependent ones.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ u64 stripe_sum(u64 v, const int ncopy) {
+    if (ncopy >= 2) v += dpp_u64<0xB1>(v);           // quad_perm [1,0,3,2]
+    if (ncopy >= 4) v += dpp_u64<0x4E>(v);           // quad_perm [2,3,0,1]
+    if (ncopy >= 8) v += dpp_u64<0x141>(v);          // row_half_mirror: the other quad's total
+    if (ncopy >= 16) v += dpp_u64<0x140>(v);         // row_mirror: the other half row's total
+    if (ncopy >= 32) v += (u64)__shfl_xor((long long)v, 16, 64);
+    return v;
+}

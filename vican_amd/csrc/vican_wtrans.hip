@@ -29,14 +29,6 @@ extern "C" int vican_cgw_stamp_buffer(double* buf) {
 #define CSTAMP(i) do {} while (0)
 #endif
 
-// v of the lane a DPP control selects (quad permutes 0xB1 = lane ^ 1, 0x4E = lane ^ 2; 0x141 = mirror inside a half row)
-template <int CTRL>
-__device__ __forceinline__ u64 dpp_u64(u64 v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
-    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
 template <int EPL>
 struct CgWRegs { double w[EPL]; uint32_t id[EPL]; };
 
@@ -220,9 +212,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             const bool live = a < n3 * ncopy;
             u64 sum = 0ull;
             if (live) { sum = qt[a]; qt[a] = 0ull; }
-            if (ncopy >= 2) sum += dpp_u64<0xB1>(sum);          // lane ^ 1
-            if (ncopy >= 4) sum += dpp_u64<0x4E>(sum);          // lane ^ 2
-            if (ncopy >= 8) sum += dpp_u64<0x141>(sum);         // mirror inside 8 lanes: the other quad's total
+            sum = stripe_sum(sum, ncopy);
             if (live && (a & cmask) == 0) {
                 const int i = a / ncopy;
                 const double qv = dps[i] - (double)(long long)sum * inv;
