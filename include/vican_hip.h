@@ -281,10 +281,12 @@ int vican_chol_qr3(int32_t n, const double* R, const double* G, double* V, int32
 /* Start block of an eigen-solve as one launch (n <= VICAN_SEED_MAX_N rows): G = X0^T X0, upper Cholesky
  * G = beta^T beta (pivot rule of vican_chol_qr3 with pivot_floor 0), Q0 = X0 beta^-1 -> basis columns 0..2 of V and
  * x_out (row-major [n][3], must differ from X0), beta_out [3][3]; if Zraw != NULL also Z = Zraw beta^-1
- * (vican_right_solve3).  Equivalent to vican_rows_to_cols + vican_tall_gram + vican_chol_qr3 up to summation order. */
+ * (vican_right_solve3).  Equivalent to vican_rows_to_cols + vican_tall_gram + vican_chol_qr3 up to summation order.
+ * coop_sync (may be NULL): the two barrier words of vican_lanczos_cam_coop, zeroed here - an eigen-solve starts with
+ * armed barriers even if an earlier launch was torn down.                                                          */
 #define VICAN_SEED_MAX_N 16384
 int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, double* beta_out, double* x_out,
-                       const double* Zraw, double* Z, void* stream);
+                       const double* Zraw, double* Z, void* coop_sync, void* stream);
 /* X[n][3] (row-major) = V[:, :ka] Y[ka][3] */
 int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const double* Y,
                        double* X, void* stream);

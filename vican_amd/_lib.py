@@ -91,7 +91,7 @@ PROTOTYPES = {
     "vican_lanczos_cam_step": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, C.c_int64, _vp]),
     "vican_block_op_z": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_dual_update_op": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vican_lanczos_seed": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lanczos_seed": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_right_solve3": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "vican_sum_apply3": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),

@@ -308,10 +308,11 @@ extern "C" int vican_chol_qr3(int32_t n, const double* R, const double* G, doubl
 __global__ __launch_bounds__(VICAN_SEED_THREADS) void lanczos_seed_kernel(int n, const double* __restrict__ X0, double* __restrict__ V,
                                                                             int ld, double* __restrict__ beta_out,
                                                                             double* __restrict__ x_out, const double* __restrict__ Zraw,
-                                                                            double* __restrict__ Z) {
+                                                                            double* __restrict__ Z, unsigned int* __restrict__ rearm) {
     __shared__ double red[16][6];
     __shared__ double sb[9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rearm && tid < 2) rearm[tid] = 0u;      // barrier counters of the cooperative step (first use: the next launch)
     double g[6] = {0, 0, 0, 0, 0, 0};
     for (int i = tid; i < n; i += VICAN_SEED_THREADS) {
         const double a = X0[(size_t)i * 3], b = X0[(size_t)i * 3 + 1], c = X0[(size_t)i * 3 + 2];
@@ -353,11 +354,11 @@ __global__ __launch_bounds__(VICAN_SEED_THREADS) void lanczos_seed_kernel(int n,
     }
 }
 extern "C" int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, double* beta_out, double* x_out,
-                                  const double* Zraw, double* Z, void* stream) {
+                                  const double* Zraw, double* Z, void* coop_sync, void* stream) {
     if (n <= 0 || n > VICAN_SEED_MAX_N || !X0 || !V || !beta_out || !x_out || ld < n || (Zraw && !Z) || X0 == x_out)
         return set_err(VICAN_ERR_ARG, "vican_lanczos_seed: bad argument");
     hipLaunchKernelGGL(lanczos_seed_kernel, dim3(1), dim3(VICAN_SEED_THREADS), 0, (hipStream_t)stream, n, X0, V, ld, beta_out,
-                       x_out, Zraw, Z);
+                       x_out, Zraw, Z, (unsigned int*)coop_sync);
     LAUNCH_CHECK("vican_lanczos_seed");
     return VICAN_OK;
 }
@@ -539,7 +540,7 @@ __device__ __forceinline__ double ld_agent(const double* p) {
 // memory model, but at agent scope they lower to an L2 write-back / invalidate of everything this XCD holds - the sweep's
 // 18 MB of slabs included, ~10 us per barrier.  The reliance on this ISA behaviour is pinned by
 // tests/test_kernels_gpu.py::test_cooperative_step_repeats_bit_identically (3000 repetitions, bit-identical), and the
-// counter is zeroed by the host at the start of every eigen-solve (device.HipBackend.lanczos_seed).
+// counter is zeroed at the start of every eigen-solve (by the seed kernel, vican_lanczos_seed(coop_sync)).
 __device__ __forceinline__ void coop_grid_sync(unsigned int* counter, unsigned int target) {
     __syncthreads();
     if (threadIdx.x == 0) {

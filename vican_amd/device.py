@@ -476,14 +476,14 @@ class HipBackend:
     def lanczos_seed(self, x0, V, ld, beta0, xrow, zraw=None, z=None):
         """Start block in one launch (include/vican_hip.h: vican_lanczos_seed); False if the vectors are too long."""
         n = x0.numel() // 3
-        if self._coop_sync is not None:
-            # re-arm the cooperative step's grid-barrier counter at the start of every eigen-solve: a completed launch
-            # leaves it at zero, but a launch that faulted or was torn down would make the next one pass its barriers early
-            self._coop_sync.zero_()
         if n > _lib.SEED_MAX_N:
+            if self._coop_sync is not None:
+                self._coop_sync.zero_()
             return False
-        self._ck(self.lib.vican_lanczos_seed(n, _ptr(x0), _ptr(V), ld, _ptr(beta0), _ptr(xrow), _ptr(zraw), _ptr(z), _stream()),
-                 "vican_lanczos_seed")
+        # (the seed kernel also re-arms the cooperative step's grid-barrier counters: a completed launch leaves them at
+        #  zero, but a launch that faulted or was torn down would make the next one pass its barriers early)
+        self._ck(self.lib.vican_lanczos_seed(n, _ptr(x0), _ptr(V), ld, _ptr(beta0), _ptr(xrow), _ptr(zraw), _ptr(z),
+                                             _ptr(self._coop_sync), _stream()), "vican_lanczos_seed")
         return True
 
     def right_solve3(self, X, beta, Z):
