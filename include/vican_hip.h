@@ -287,6 +287,18 @@ int vican_chol_qr3(int32_t n, const double* R, const double* G, double* V, int32
 #define VICAN_SEED_MAX_N 16384
 int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, double* beta_out, double* x_out,
                        const double* Zraw, double* Z, void* coop_sync, void* stream);
+/* Block Lanczos steps j0 .. j1 - 1 (operator sweep vican_block_op + camera-side step vican_lanczos_cam_coop per step, i.e.
+ * the ARPACK iteration behind eigs at bipgo.py:288) as ONE cooperative launch (vican_lres.hip) for wave-layout graphs whose
+ * grid is co-resident, C <= 512: blocks of the first two chunks per wavefront stay in registers, the basis rows of the
+ * camera workgroups in LDS, five grid barriers per step.  Bit-identical to the two-launch sequence.  V: column-major basis
+ * [3 (m + 1)][ld] with blocks 0 .. j0 filled; xrow [3C][3]: block j0 (in) -> block j1 (out); HB [m][hb_stride]: row j gets
+ * the projected column (9 (j + 1) doubles) and beta_j at offset hw (the layout vican_ritz reads); zpart: n_wg * 9C words;
+ * ws: vican_lanczos_resident_ws_doubles() doubles, zeroed ONCE by the caller; fx as for vican_block_op.                 */
+int64_t vican_lanczos_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t j1);
+int64_t vican_lanczos_resident_ws_doubles(int32_t n_cam);
+int vican_lanczos_resident(const vican_graph_t* g, const double* lamT_inv, const double* lamC, double* V, int32_t ld,
+                           int32_t j0, int32_t j1, double* xrow, double* HB, int32_t hb_stride, int32_t hw, void* zpart,
+                           double* ws, const double* fx, double pivot_floor, void* stream);
 /* X[n][3] (row-major) = V[:, :ka] Y[ka][3] */
 int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const double* Y,
                        double* X, void* stream);

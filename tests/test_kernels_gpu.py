@@ -334,6 +334,53 @@ def test_cooperative_step_repeats_bit_identically():
     assert int(H._coop_sync.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("cfg", [(100, 4000, 2, 9, None), (340, 10000, 2, 6, None), (37, 300, 1, 12, None), (300, 3000, 20, 60, None),
+                                 (5, 40, 1, 3, None), (300, 900, 60, 128, 9)])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_lanczos_resident_matches_the_launch_pairs(cfg, dt):
+    """vican_lanczos_resident (a run of Lanczos steps as one cooperative launch, vican_lres.hip) against the sequence of
+    vican_block_op + vican_lanczos_cam_coop launches: basis, projected columns, beta blocks and the next sweep input
+    bit-identical - in one run, split into two runs (j0 > 0), and on repeats."""
+    C, T, lo, hi, nwg = cfg
+    H, N, g = make_backends(C, T, lo, hi, 900 + C, dt, "wave", nwg)
+    m = min(10, C - 1)
+    if nwg is not None and nwg < -(-C // 32):
+        assert H.lanczos_resident_steps(m) == 0                 # (fewer workgroups than camera slices: not eligible)
+        return
+    assert H.lanczos_resident_steps(m) == m
+    n, ld, hw = 3 * C, 3 * C, 3 * (m + 1) * 3
+    rng = np.random.default_rng(5)
+    lam, cd, lamC = H.empty(T, 9), H.empty(C), H.empty(C, 9)
+    H.init_duals(lam, cd)
+    H.scaled_identity(cd, lamC)
+    x0 = H.from_numpy(rng.standard_normal((n, 3)))
+
+    def fresh():
+        V, HB, xrow, beta0 = H.zeros(3 * (m + 1) * n), H.zeros(m, hw + 9), H.empty(n, 3), H.empty(9)
+        assert H.lanczos_seed(x0, V, ld, beta0, xrow)
+        return V, HB, xrow
+
+    # the launch pairs
+    V1, HB1, x1 = fresh()
+    R, Hs, G, z = H.zeros(3 * n), H.zeros(3 * (m + 1) * 3), H.zeros(9), H.empty(n, 3)
+    for j in range(m):
+        H.block_op_slabs(lam, x1)
+        H.lanczos_cam_step(lamC, V1, ld, j, z, R, Hs, G, HB1[j, :hw], HB1[j, hw:], x1, 0.0, from_slabs=True)
+    # one resident run, two resident runs, a repeat
+    outs = []
+    for cuts in ((0, m), (0, 3, m), (0, m)):
+        V2, HB2, x2 = fresh()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                H.lanczos_resident(lam, lamC, V2, ld, a, b, x2, HB2, hw, 0.0)
+        outs.append((V2, HB2, x2))
+    torch.cuda.synchronize()
+    for V2, HB2, x2 in outs:
+        assert torch.equal(V1, V2) and torch.equal(HB1, HB2) and torch.equal(x1, x2)
+    q = V1.cpu().numpy().reshape(3 * (m + 1), n)
+    assert np.abs(q @ q.T - np.eye(3 * (m + 1))).max() < 1e-10                 # (the basis is orthonormal)
+
+
 def _ritz_inputs(steps, m, seed, dead_at=None, gap=True):
     """HB rows as vican_lanczos_cam_step writes them, for a random symmetric projected matrix."""
     rng = np.random.default_rng(seed)

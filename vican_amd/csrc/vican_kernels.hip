@@ -2,6 +2,7 @@
 // gauge fix, dense helpers of the block Lanczos iteration, right-hand side and the
 // conjugate-gradient kernels.  The hot edge sweep lives in vican_sweep.hip.
 #include "vican_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // batched polar / gauge
@@ -549,20 +550,32 @@ __device__ __forceinline__ void coop_grid_sync(unsigned int* counter, unsigned i
     }
     __syncthreads();
 }
-// partial H = V[:, :ka]^T R over this workgroup's rows (wave per basis vector), to part[ka*3];
-// vs: this workgroup's rows of the basis, staged in LDS as [ka][COOP_ROWS]
+// partial H = V[:, :ka]^T R over this workgroup's rows, to part[ka*3]; vs: this workgroup's rows of the basis, staged in
+// LDS as [ka][COOP_ROWS].  8 lanes per element: strided rows, then a DPP sum over the 8 lanes.  (The first version gave a
+// wavefront to each basis vector and reduced three sums over 64 lanes with shuffles - 36 ds_bpermute per vector, ~1.2 us,
+// i.e. 11 us per Gram-Schmidt pass at 36 vectors: the camera-side step grew from 12 to 30 us along an eigen-solve.)
+__device__ __forceinline__ double coop_dpp8_sum(double v) {
+    auto mv = [](double x, auto ctrl) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, decltype(ctrl)::value, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    };
+    v += mv(v, std::integral_constant<int, 0xB1>());       // lane ^ 1
+    v += mv(v, std::integral_constant<int, 0x4E>());       // lane ^ 2
+    v += mv(v, std::integral_constant<int, 0x141>());      // mirror inside 8 lanes
+    return v;
+}
 __device__ __forceinline__ void coop_gram(const double* __restrict__ vs, int ka, int nsl,
                                           const double (*rs)[COOP_ROWS], double* __restrict__ part, int nwg, int wg) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = wave; k < ka; k += nw) {
+    const int seg = threadIdx.x & 7;
+    for (int e = threadIdx.x >> 3; e < ka * 3; e += (int)(blockDim.x >> 3)) {
+        const int k = e / 3, c = e - 3 * k;
         const double* v = vs + k * COOP_ROWS;
-        double s0 = 0, s1 = 0, s2 = 0;
-        for (int i = lane; i < nsl; i += 64) { const double vi = v[i]; s0 += vi * rs[0][i]; s1 += vi * rs[1][i]; s2 += vi * rs[2][i]; }
-        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0) {                                   // layout [3 ka][nwg]: one element's partials are contiguous
-            st_agent(part + (size_t)(k * 3) * nwg + wg, s0); st_agent(part + (size_t)(k * 3 + 1) * nwg + wg, s1);
-            st_agent(part + (size_t)(k * 3 + 2) * nwg + wg, s2);
-        }
+        double s = 0.0;
+        for (int i = seg; i < nsl; i += 8) s += v[i] * rs[c][i];
+        s = coop_dpp8_sum(s);
+        if (seg == 0) st_agent(part + (size_t)e * nwg + wg, s);       // layout [3 ka][nwg]: one element's partials are contiguous
     }
 }
 // out[t] = sum_w part[t][w] (fixed order).  The device-scope loads cost ~150 ns each when one thread issues them

@@ -200,16 +200,28 @@ class RotationSolver:
             while True:
                 j = steps
                 in_slabs = False
-                if not (j == 0 and have_z):
-                    # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
-                    #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
-                    in_slabs = bool(self.apply_P(self.xrow, self.z))
-                # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
-                # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
-                K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
-                                   self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
-                steps += 1
-                total_steps += 1
+                # capture-sized graphs, single rank: all steps up to the next check as ONE cooperative launch (sweep and
+                # camera-side step per Lanczos step, vican_lres.hip) - bit-identical to the launch pairs below
+                j_res = 0
+                if (self.comm.world == 1 and self.small_graph and self.N == getattr(K, "C", -1) and hasattr(K, "lanczos_resident_steps")
+                        and not (j == 0 and have_z)):
+                    j_res = K.lanczos_resident_steps(min(max(next_check, j + 1), self.m_max))
+                if j_res > j:
+                    K.lanczos_resident(self.lamT, self.lamC, self.V, ld, j, j_res, self.xrow, self.HB, self.hw, self.pivot_floor)
+                    self.stats["sweeps"] += j_res - j
+                    total_steps += j_res - j
+                    steps = j_res
+                else:
+                    if not (j == 0 and have_z):
+                        # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
+                        #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
+                        in_slabs = bool(self.apply_P(self.xrow, self.z))
+                    # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
+                    # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
+                    K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
+                                       self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
+                    steps += 1
+                    total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
                     handle = self._ritz(steps, first, level, gap=steps - prev_steps)
                     first = False
