@@ -293,12 +293,13 @@ int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, doubl
  * camera workgroups in LDS, five grid barriers per step.  Bit-identical to the two-launch sequence.  V: column-major basis
  * [3 (m + 1)][ld] with blocks 0 .. j0 filled; xrow [3C][3]: block j0 (in) -> block j1 (out); HB [m][hb_stride]: row j gets
  * the projected column (9 (j + 1) doubles) and beta_j at offset hw (the layout vican_ritz reads); zpart: n_wg * 9C words;
- * ws: vican_lanczos_resident_ws_doubles() doubles, zeroed ONCE by the caller; fx as for vican_block_op.                 */
+ * ws: vican_lanczos_resident_ws_doubles() doubles; sync_ws: the two barrier words of vican_lanczos_cam_coop (zeroed by
+ * vican_lanczos_seed at the start of every eigen-solve); fx as for vican_block_op.                                       */
 int64_t vican_lanczos_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t j1);
 int64_t vican_lanczos_resident_ws_doubles(int32_t n_cam);
 int vican_lanczos_resident(const vican_graph_t* g, const double* lamT_inv, const double* lamC, double* V, int32_t ld,
                            int32_t j0, int32_t j1, double* xrow, double* HB, int32_t hb_stride, int32_t hw, void* zpart,
-                           double* ws, const double* fx, double pivot_floor, void* stream);
+                           double* ws, uint32_t* sync_ws, const double* fx, double pivot_floor, void* stream);
 /* X[n][3] (row-major) = V[:, :ka] Y[ka][3] */
 int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const double* Y,
                        double* X, void* stream);
@@ -462,8 +463,7 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
  * an iteration, at most max_iter iterations) and fixed-point accumulation; the floating-point partial sums of r.r and
  * p.q are grouped per workgroup and the scale bound uses measured maxima on both node sets, so the iterates agree with
  * the multi-kernel path to rounding.  b_c [C][3], b_t [T][3]: right-hand side; x_c, x_t: solution; slab: n_wg * 3C 64-bit
- * words; ws: vican_cg_resident_ws_doubles() doubles, zeroed ONCE by the caller (holds the barrier counter, re-armed by
- * every launch); wmax: max edge weight; rows_per_wg: most rows in one workgroup's chunk range [n_chunk b / n_wg,
+ * words; ws: vican_cg_resident_ws_doubles() doubles (its barrier counter is zeroed in-stream by every call); wmax: max edge weight; rows_per_wg: most rows in one workgroup's chunk range [n_chunk b / n_wg,
  * n_chunk (b + 1) / n_wg); st receives the final state (iter, done, rho, bnorm2, ...).  n_add as for vican_cg_begin.   */
 int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t rows_per_wg);
 int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg);

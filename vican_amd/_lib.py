@@ -111,7 +111,7 @@ PROTOTYPES = {
     "vican_cg_resident": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _i32, _vp, _vp]),
     "vican_lanczos_resident_lds_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "vican_lanczos_resident_ws_doubles": (_i64, [_i32]),
-    "vican_lanczos_resident": (C.c_int, [_G, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f64, _vp]),
+    "vican_lanczos_resident": (C.c_int, [_G, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),

@@ -28,12 +28,18 @@ __device__ __forceinline__ double cgr_ld(const double* p) { return __hip_atomic_
 __device__ __forceinline__ void cgr_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 cgr_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// grid barrier (see coop_grid_sync in vican_kernels.hip for the ordering argument): the counter only grows during a launch
+// grid barrier: a counter that only grows during a launch, with an agent-scope RELEASE before the arrival and ACQUIRE after
+// the exit.  On a capture-sized graph the L2 holds little dirty data, so the write-back / invalidate these fences lower to
+// costs 0.4 us per barrier (the cooperative Lanczos step on the stress graph, with 18 MB of slabs in L2, pays 10 us and
+// therefore relies on agent-scope atomics alone - vican_kernels.hip); what crosses workgroups is still written and read
+// with agent-scope atomics, the fences make the ordering a property of the memory model instead of the ISA.
 __device__ __forceinline__ void cgr_grid_sync(unsigned int* counter, unsigned int target) {
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -355,9 +361,9 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
 }
 
 // The whole CG solve in one launch (wave-layout graphs whose grid is co-resident: n_wg <= compute units).
-// x_c [C][3], x_t [T][3]: solution; slab: n_wg * 3C 64-bit words; ws: vican_cg_resident_ws_doubles doubles, ZEROED once by the
-// caller (barrier counter); rows_per_wg: max rows of one workgroup's chunk range [n_chunk b / n_wg, n_chunk (b + 1) / n_wg);
-// st: receives the final state (iter, done, rho, bnorm2, ...).
+// x_c [C][3], x_t [T][3]: solution; slab: n_wg * 3C 64-bit words; ws: vican_cg_resident_ws_doubles doubles (the barrier counter
+// in it is zeroed in-stream by every call); rows_per_wg: max rows of one workgroup's chunk range [n_chunk b / n_wg,
+// n_chunk (b + 1) / n_wg); st: receives the final state (iter, done, rho, bnorm2, ...).
 extern "C" int vican_cg_resident(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c, const double* b_c,
                                  const double* b_t, double* x_c, double* x_t, void* slab, double* ws, double rtol, int32_t max_iter,
                                  double n_add, double wmax, int32_t rows_per_wg, vican_cg_state_t* st, void* stream) {
@@ -376,6 +382,10 @@ extern "C" int vican_cg_resident(const vican_graph_t* g, const double* w, const 
     const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64;
     if (trips > 3) return set_err(VICAN_ERR_CAPACITY, "vican_cg_resident: more than 64 rows per chunk");
     hipStream_t s = (hipStream_t)stream;
+    // the barrier counter (behind the [3C] sums and the [n_wg][4] partials): armed here, so that a launch that was torn down
+    // cannot make the next one pass its barriers early
+    if (hipMemsetAsync(ws + 3 * (size_t)g->n_cam + 4 * (size_t)g->n_wg, 0, 8, s) != hipSuccess)
+        return set_err(VICAN_ERR_LAUNCH, "vican_cg_resident: memset failed");
 #define CGR_LAUNCH(E_, T_)                                                                                                \
     do {                                                                                                                  \
         auto kern = cg_resident_kernel<E_, T_>;                                                                           \

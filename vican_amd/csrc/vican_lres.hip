@@ -34,12 +34,15 @@ __device__ __forceinline__ double lr_ld(const double* p) {
 __device__ __forceinline__ void lr_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 lr_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// grid barrier (ordering argument: coop_grid_sync in vican_kernels.hip); the counter only grows during a launch
+// grid barrier: a counter that only grows during a launch, agent-scope RELEASE before the arrival and ACQUIRE after the exit
+// (0.8 us per barrier on a capture-sized graph; see cgr_grid_sync in vican_cgres.hip)
 __device__ __forceinline__ void lr_grid_sync(unsigned int* counter, unsigned int target) {
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -111,8 +114,8 @@ struct LrChunk {
 template <typename S, int CP, int TRIPS>
 __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
     const int32_t* __restrict__ gate, vican_graph_t g, const double* __restrict__ lamT_inv, const double* __restrict__ lamC, double* V,
-    int ld, int j0, int j1, double* xrow, double* HB, int hb_stride, int hw, u64* zpart, double* ws, const double* __restrict__ fx,
-    double pivot_floor) {
+    int ld, int j0, int j1, double* xrow, double* HB, int hb_stride, int hw, u64* zpart, double* ws, unsigned int* sync,
+    const double* __restrict__ fx, double pivot_floor) {
     GATE_RETURN(gate);
     constexpr int EPL = Vec<S>::N;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -151,12 +154,11 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
     double* part1 = ws;
     double* part2 = ws + (size_t)ncw * hs_cap;
     double* partG = ws + (size_t)2 * ncw * hs_cap;
-    unsigned int* sync = (unsigned int*)(ws + (size_t)ncw * (2 * hs_cap + 8));
     unsigned int nbar = 0;
     auto gsync = [&]() { ++nbar; lr_grid_sync(sync, nbar * (unsigned)nwg); };
 #ifdef VICAN_LRSTAMP    /* diagnostic build: wall clock (100 MHz ticks) per phase and step of workgroup 0 -> ws tail [step][12] */
     unsigned long long st_t = __builtin_amdgcn_s_memrealtime();
-    double* st_out = (double*)(sync + 2);
+    double* st_out = ws + (size_t)ncw * (2 * hs_cap + 8);
 #define LSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
                        if (wg == 0 && tid == 0 && j - j0 < 64) st_out[(j - j0) * 12 + (i)] = (double)(t_ - st_t); st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -475,13 +477,14 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
 // vican_lanczos_cam_coop: V [3 (m + 1)][ld] column-major basis with blocks 0 .. j0 filled, xrow [3C][3] = block j0 row-major
 // (in) / block j1 (out), HB [m][hb_stride]: row j receives the projected column (3 * 3 (j + 1) doubles) and, from offset hw,
 // beta_j (9 doubles) - the layout vican_ritz reads.  zpart: n_wg * 9C 64-bit words; ws: vican_lanczos_resident_ws_doubles()
-// doubles, zeroed ONCE by the caller (barrier counter).  Honours the launch gate (vican_set_gate).
+// doubles; sync_ws: two zeroed 32-bit words (the barrier counters - the same pair vican_lanczos_cam_coop uses, re-armed by
+// vican_lanczos_seed at the start of every eigen-solve).  Honours the launch gate (vican_set_gate).
 extern "C" int vican_lanczos_resident(const vican_graph_t* g, const double* lamT_inv, const double* lamC, double* V, int32_t ld,
                                       int32_t j0, int32_t j1, double* xrow, double* HB, int32_t hb_stride, int32_t hw, void* zpart,
-                                      double* ws, const double* fx, double pivot_floor, void* stream) {
+                                      double* ws, uint32_t* sync_ws, const double* fx, double pivot_floor, void* stream) {
     if (int rc = vican_check_graph(g, "vican_lanczos_resident")) return rc;
     if (g->layout != VICAN_LAYOUT_WAVE || !g->blk) return set_err(VICAN_ERR_ARG, "vican_lanczos_resident: wave layout with block planes only");
-    if (!lamT_inv || !lamC || !V || !xrow || !HB || !zpart || !ws || !fx || j0 < 0 || j1 <= j0 || 3 * j1 > LR_KA_MAX ||
+    if (!lamT_inv || !lamC || !V || !xrow || !HB || !zpart || !ws || !sync_ws || !fx || j0 < 0 || j1 <= j0 || 3 * j1 > LR_KA_MAX ||
         ld < 3 * g->n_cam || hw < 9 * j1 || hb_stride < hw + 9)
         return set_err(VICAN_ERR_ARG, "vican_lanczos_resident: bad argument");
     if (g->n_chunk == 0) return set_err(VICAN_ERR_ARG, "vican_lanczos_resident: graph without edges");
@@ -506,7 +509,7 @@ extern "C" int vican_lanczos_resident(const vican_graph_t* g, const double* lamT
             conf = lds;                                                                                                   \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(LR_THREADS), lds, s, g_vican_gate, *g, lamT_inv, lamC, V, (int)ld, (int)j0, \
-                           (int)j1, xrow, HB, (int)hb_stride, (int)hw, (u64*)zpart, ws, fx, pivot_floor);                 \
+                           (int)j1, xrow, HB, (int)hb_stride, (int)hw, (u64*)zpart, ws, sync_ws, fx, pivot_floor);                 \
     } while (0)
 #define LR_PICK2(S_, CP_) do { if (trips <= 1) LR_LAUNCH(S_, CP_, 1); else if (trips == 2) LR_LAUNCH(S_, CP_, 2); else LR_LAUNCH(S_, CP_, 3); } while (0)
 #define LR_PICK(S_) do { if (g->n_cam <= 256) LR_PICK2(S_, 256); else LR_PICK2(S_, 512); } while (0)

@@ -443,15 +443,16 @@ class HipBackend:
                                                  0 if ws is None else ws.numel(), _stream()),
                  "vican_lanczos_cam_step")
 
-    def lanczos_resident_steps(self, j1_want):
+    def lanczos_resident_steps(self, j1_want, force=False):
         """Largest j1 <= j1_want for which Lanczos steps .. j1 - 1 can run as one cooperative launch (vican_lres.hip); 0 if
-        this graph does not qualify (wave layout, C <= 512, co-resident grid that holds the camera workgroups)."""
+        this graph does not qualify (wave layout, C <= 512, co-resident grid that holds the camera workgroups).
+        The solver uses it only when VICAN_LANCZOS_RESIDENT=1: measured 27-32 us per step against ~30 us for the pair of
+        launches - not worth a second code path by default."""
         if getattr(self, "_lres_ok", None) is None:
             g = self.g
-            self._lres_ok = bool(
-                os.environ.get("VICAN_LANCZOS_RESIDENT", "1") != "0" and self.layout == "wave" and self.C <= 512 and g.n_chunk > 0 and
-                g.n_wg <= n_cu() and -(-self.C // 32) <= g.n_wg and g.max_rows <= 64)
-        if not self._lres_ok:
+            self._lres_ok = bool(self.layout == "wave" and self.C <= 512 and g.n_chunk > 0 and g.n_wg <= n_cu() and
+                                 -(-self.C // 32) <= g.n_wg and g.max_rows <= 64)
+        if not self._lres_ok or not (force or os.environ.get("VICAN_LANCZOS_RESIDENT", "0") == "1"):
             return 0
         g, st = self.g, (_lib.STORE_F64 if self.storage_f64 else _lib.STORE_F32)
         j1 = min(int(j1_want), 64)
@@ -463,9 +464,12 @@ class HipBackend:
         """Lanczos steps j0 .. j1 - 1 (sweep + camera-side step each) in one launch; HB row j = [projected column | beta_j]."""
         if getattr(self, "_lres_ws", None) is None:
             self._lres_ws = torch.zeros(int(self.lib.vican_lanczos_resident_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
+        if self._coop_sync is None:                 # (the barrier words shared with the cooperative camera-side step)
+            self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
         self._ck(self.lib.vican_lanczos_resident(self._gref, _ptr(lamT_inv), _ptr(lamC), _ptr(V), ld, int(j0), int(j1), _ptr(xrow),
                                                  _ptr(HB), int(HB.stride(0)), int(hw), _ptr(self.zpart), _ptr(self._lres_ws),
-                                                 _ptr(self.g.fx), float(pivot_floor), _stream()), "vican_lanczos_resident")
+                                                 _ptr(self._coop_sync), _ptr(self.g.fx), float(pivot_floor), _stream()),
+                 "vican_lanczos_resident")
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
         part = self.zpart[: self.cgl.n_wg * 3 * self.C]
