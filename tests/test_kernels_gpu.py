@@ -431,6 +431,50 @@ def test_ritz_matches_lapack_and_gate_semantics(steps, dead_at):
         np.testing.assert_allclose(yd[:3 * eff, :k].T @ yd[:3 * eff, :k], np.eye(k), atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", ["tight_cluster", "exact_triple", "wide", "negative", "graded"])
+@pytest.mark.parametrize("steps", [5, 8, 12, 20])
+def test_ritz_fast_path_on_hard_spectra(kind, steps):
+    """The tridiagonalisation + bisection + inverse-iteration path of vican_ritz (15 <= n <= 64) on spectra that stress it:
+    a cluster of three eigenvalues 1e-13 apart, an exactly triple eigenvalue, a wide range, negative values, a graded
+    matrix - eigenvalues and the invariant subspace of the three smallest against LAPACK, orthonormal Ritz vectors.  (Where
+    its own validation rejects the result the kernel falls back to the Jacobi iteration: same assertions.)"""
+    H, N, g = make_backends(5, 40, 1, 3, 7, np.float64)
+    m, ka = 32, 3 * steps
+    rng = np.random.default_rng(700 + steps)
+    Q = np.linalg.qr(rng.standard_normal((ka, ka)))[0]
+    ev = np.sort(rng.uniform(1.0, 50.0, ka))
+    if kind == "tight_cluster":
+        ev[:3] = 1e-6 * (1.0 + 1e-13 * np.arange(3))
+    elif kind == "exact_triple":
+        ev[:3] = 0.25
+    elif kind == "wide":
+        ev[:3] = [1e-9, 3e-7, 2e-3]; ev[-1] = 1e4
+    elif kind == "negative":
+        ev[:3] = [-3e-8, -1e-9, 4e-7]
+    elif kind == "graded":
+        ev = np.sort(10.0 ** rng.uniform(-8, 2, ka)); ev[3] = max(ev[3], 50 * ev[2])
+    Tm = (Q * ev) @ Q.T
+    Tm = 0.5 * (Tm + Tm.T)
+    hw = 3 * (m + 1) * 3
+    HB = np.zeros((m, hw + 9))
+    for j in range(steps):
+        kj = 3 * (j + 1)
+        HB[j, : kj * 3] = Tm[:kj, 3 * j:3 * j + 3].reshape(-1)
+        HB[j, hw:] = np.triu(rng.standard_normal((3, 3)) * 1e-3 + np.eye(3) * 1e-2).reshape(-1)
+    Yd, std, gd = H.zeros(3 * (m + 1), 3), H.zeros(16), H.zeros(1, dtype=torch.int32)
+    H.ritz(H.from_numpy(HB), hw, steps, 1, 1e-10, 1e-7, -1.0, Yd, std, gd)
+    sd, yd = std.cpu().numpy(), Yd.cpu().numpy()[:ka]
+    w, U = np.linalg.eigh(Tm)
+    nrm = np.linalg.norm(Tm)
+    assert np.abs(sd[7:10] - w[:3]).max() <= 4e-15 * nrm                       # three smallest
+    assert abs(sd[15] - w[3]) <= 4e-15 * nrm and abs(sd[13] - w[4]) <= 4e-15 * nrm and abs(sd[11] - w[-1]) <= 4e-15 * nrm
+    np.testing.assert_allclose(yd.T @ yd, np.eye(3), atol=1e-12)
+    assert np.abs(Tm @ yd - yd * sd[7:10]).max() <= 2e-13 * nrm               # Ritz pairs of T itself
+    if kind != "graded":
+        gap = w[3] - w[2]
+        assert np.abs(yd @ yd.T - U[:, :3] @ U[:, :3].T).max() <= 1e-11 * max(1.0, nrm / gap * 1e-3)
+
+
 def test_gated_launches_are_cancelled_on_the_device():
     """Everything enqueued under a closed gate leaves its outputs untouched; an open gate runs it."""
     H, N, g = make_backends(37, 300, 1, 12, 3, np.float32)

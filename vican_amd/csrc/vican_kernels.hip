@@ -2,6 +2,7 @@
 // gauge fix, dense helpers of the block Lanczos iteration, right-hand side and the
 // conjugate-gradient kernels.  The hot edge sweep lives in vican_sweep.hip.
 #include "vican_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------
@@ -566,6 +567,19 @@ __device__ __forceinline__ double coop_dpp8_sum(double v) {
     v += mv(v, std::integral_constant<int, 0x141>());      // mirror inside 8 lanes
     return v;
 }
+// sum over the 64 lanes, in every lane: DPP inside groups of 16, two cross-row shuffles
+__device__ __forceinline__ double wave_allsum_dpp(double v) {
+    v = coop_dpp8_sum(v);
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x140, 0xF, 0xF, true);          // row_mirror
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x140, 0xF, 0xF, true);
+        v += __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 __device__ __forceinline__ void coop_gram(const double* __restrict__ vs, int ka, int nsl,
                                           const double (*rs)[COOP_ROWS], double* __restrict__ part, int nwg, int wg) {
     const int seg = threadIdx.x & 7;
@@ -851,10 +865,41 @@ __device__ __forceinline__ int ritz_rotation(double app, double aqq, double apq,
     return 1;
 }
 
+// ---- fast path of the Ritz step: Householder tridiagonalisation (Q accumulated) + Sturm-count bisection for the five
+// smallest and two largest eigenvalues + inverse iteration for the three smallest pairs, validated against T itself
+// (residual and orthonormality); the Jacobi iteration below stays as the fallback.  Jacobi is latency-bound per round
+// (N - 1 rounds x 6-9 sweeps x ~0.8 us: 250 us at n = 36); this path is ~n dependent steps of two short matrix-vector
+// products plus a few microseconds of scalar recurrences.
+#define RITZ_FAST_NMAX 64          /* element i of the inverse iteration lives in lane i */
+#define RITZ_FAST_NMIN 15         /* tools/ritz_bench.py: n = 12 44 vs 42 us (Jacobi), 15: 55 vs 63, 24: 85 vs 116, 36: 134 vs 251, 48: 185 vs 391 */
+__device__ __forceinline__ double ritz_rcp(double x) {                 // 1/x to ~1 ulp: v_rcp_f64 + one Newton step
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double ritz_readlane(double v, int lane) {   // lane: wave-uniform
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// number of eigenvalues of the symmetric tridiagonal (d, e) below sigma (LAPACK dlaebz recurrence); dl / e2l: element i of
+// d and of e^2 in lane i's registers (n <= 64) - read with v_readlane, so the serial chain has no memory latency in it
+__device__ __forceinline__ int ritz_sturm(double dl, double e2l, int n, double sigma, double pivmin) {
+    double q = ritz_readlane(dl, 0) - sigma;
+    int cnt = 0;
+    if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
+    for (int i = 1; i < n; ++i) {
+        q = ritz_readlane(dl, i) - sigma - ritz_readlane(e2l, i - 1) * ritz_rcp(q);
+        if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
+    }
+    return cnt;
+}
+
 __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ HB, int stride, int hw, int steps, int flags,
                                                     double eig_tol, double floor_tol, double floor_level, double stall_ratio,
                                                     double* __restrict__ Y, double* __restrict__ status,
-                                                    int32_t* __restrict__ gate) {
+                                                    int32_t* __restrict__ gate, int fast_lds) {
     extern __shared__ double sm[];
     __shared__ int s_eff, s_idx[5];
     __shared__ double s_th4, s_th5;
@@ -898,6 +943,246 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
     const double inv = ldexp(1.0, -ex);
     __syncthreads();
 
+
+    // ---- fast path (see above ritz_kernel): tridiagonalise, bisect, inverse-iterate, validate
+    __shared__ int s_fast;
+    __shared__ double s_tau, s_gl, s_gu, s_piv;
+    if (tid == 0) s_fast = 0;
+#ifdef RITZ_STAMP       /* diagnostic build: 100 MHz ticks per phase -> Y behind the Ritz vectors (tools/ritz_bench.py --stamp) */
+    unsigned long long rst_t = __builtin_amdgcn_s_memrealtime();
+    int rst_n = 0;
+#define RSTAMP() do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (tid == 0 && rst_n < 8) Y[9 * steps + rst_n] = (double)(t_ - rst_t); ++rst_n; rst_t = t_; } while (0)
+#else
+#define RSTAMP() do {} while (0)
+#endif
+    if (n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX && fast_lds) {
+        double* fd = (double*)((((size_t)(cs + 2 * half)) + (size_t)half * sizeof(int) + 15) & ~(size_t)15);
+        double* fe = fd + N; double* fe2 = fe + N; double* fv = fe2 + N; double* fp = fv + N; double* fg = fp + N;
+        double* fth = fg + N;                   // [8] eigenvalues: five smallest, second largest, largest
+        double* zt = fth + 8;                   // [3][N] eigenvectors of the tridiagonal matrix
+        double* ys = zt + 3 * N;                // [3][N] ... and of T
+        const int ln = tid & 63, wv = tid >> 6, nwv = B >> 6;
+        // Householder tridiagonalisation T = Q^T A Q (A overwritten, Q accumulated in V = I): three barriers per step
+        for (int k = 0; k + 2 < n; ++k) {
+            if (wv == 0) {                                  // norm of the column below the subdiagonal; v into fv
+                double sg = 0.0;
+                for (int i = k + 2 + ln; i < n; i += 64) { const double x = A[i * ld + k]; fv[i] = x; sg += x * x; }
+                sg = wave_allsum_dpp(sg);
+                if (ln == 0) {
+                    const double x0 = A[(k + 1) * ld + k];
+                    double tau = 0.0, alpha = x0, v0 = 0.0;
+                    if (sg > 0.0) {                         // (no reflection when the tail of the column is exactly zero)
+                        const double mu = sqrt(x0 * x0 + sg);
+                        alpha = x0 <= 0.0 ? mu : -mu;
+                        v0 = x0 - alpha;
+                        tau = 2.0 / (v0 * v0 + sg);
+                    }
+                    s_tau = tau; fv[k + 1] = v0;
+                    fd[k] = A[k * ld + k]; fe[k] = alpha;
+                }
+            }
+            __syncthreads();
+            const double tau = s_tau;
+            if (tau != 0.0) {                               // (uniform)
+                for (int i = tid >> 3; i < n; i += B >> 3) {    // p = tau A v (rows below k), g = tau Q v: 8 lanes per row
+                    double pa = 0.0, ga = 0.0;
+                    const double* Ar = A + i * ld;
+                    const double* Vr = V + i * ld;
+                    for (int j = k + 1 + (tid & 7); j < n; j += 8) { const double vj = fv[j]; pa += Ar[j] * vj; ga += Vr[j] * vj; }
+                    pa = coop_dpp8_sum(pa); ga = coop_dpp8_sum(ga);
+                    if ((tid & 7) == 0) { fp[i] = tau * pa; fg[i] = tau * ga; }
+                }
+                __syncthreads();
+                double kk = 0.0;                            // K = tau/2 p.v, by every wavefront for itself (same order: same bits)
+                for (int i = k + 1 + ln; i < n; i += 64) kk += fp[i] * fv[i];
+                kk = wave_allsum_dpp(kk);
+                const double K = 0.5 * tau * kk;
+                // A -= v w^T + w v^T on the trailing block, Q -= g v^T on its columns: 32 columns x (B / 32) rows per pass
+                for (int i = wv * 2 + (ln >> 5); i < n; i += 2 * nwv) {
+                    const double vi = i > k ? fv[i] : 0.0, wi = i > k ? fp[i] - K * vi : 0.0, gi = fg[i];
+                    for (int j = k + 1 + (ln & 31); j < n; j += 32) {
+                        const double vj = fv[j], wj = fp[j] - K * vj;
+                        if (i > k) A[i * ld + j] -= vi * wj + wi * vj;
+                        V[i * ld + j] -= gi * vj;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        RSTAMP();       // 0: tridiagonalisation
+        if (tid == 0) {
+            fd[n - 2] = A[(n - 2) * ld + n - 2]; fe[n - 2] = A[(n - 1) * ld + n - 2];
+            fd[n - 1] = A[(n - 1) * ld + n - 1]; fe[n - 1] = 0.0;
+        }
+        __syncthreads();
+        if (wv == 0) {                                      // e^2, Gershgorin interval, pivot floor of the Sturm recurrence
+            double gl = 1e300, gu = -1e300, em = 0.0;
+            for (int i = ln; i < n; i += 64) {
+                const double ei = fe[i], r = (i > 0 ? fabs(fe[i - 1]) : 0.0) + (i + 1 < n ? fabs(ei) : 0.0);
+                fe2[i] = ei * ei;
+                gl = fmin(gl, fd[i] - r); gu = fmax(gu, fd[i] + r); em = fmax(em, ei * ei);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                gl = fmin(gl, __shfl_xor(gl, o, 64)); gu = fmax(gu, __shfl_xor(gu, o, 64)); em = fmax(em, __shfl_xor(em, o, 64));
+            }
+            if (ln == 0) {
+                const double piv = 2.2250738585072014e-308 * fmax(1.0, em);
+                const double w = fmax(fabs(gl), fabs(gu)) * 2.220446049250313e-16 * n * 2.0 + 2.0 * piv;
+                s_gl = gl - w; s_gu = gu + w; s_piv = piv;
+            }
+        }
+        __syncthreads();
+        RSTAMP();       // 1: Gershgorin
+        {   // bisection, 64 trial shifts per round: a wavefront per wanted eigenvalue
+            const double piv = s_piv;
+            const double dl = ln < n ? fd[ln] : 0.0, e2l = ln < n ? fe2[ln] : 0.0;
+            const double btol = 1.1102230246251565e-16 * normf;                       // absolute accuracy asked of an eigenvalue
+            for (int t = wv; t < 7; t += nwv) {
+                const int kk = t < 5 ? t : n - 7 + t;       // 0..4, n-2, n-1
+                double lo = s_gl, hi = s_gu;
+                for (int round = 0; round < 14; ++round) {
+                    const double sig = lo + (hi - lo) * ((double)(ln + 1) * (1.0 / 65.0));
+                    const int c = ritz_sturm(dl, e2l, n, sig, piv);
+                    const unsigned long long mk = __ballot(c >= kk + 1);
+                    const int f = mk ? __ffsll((long long)mk) - 1 : 64;
+                    const double nhi = f < 64 ? __shfl(sig, f, 64) : hi;
+                    const double nlo = f > 0 ? __shfl(sig, f - 1, 64) : lo;
+                    lo = nlo; hi = nhi;
+                    if (hi - lo <= fmax(4.440892098500626e-16 * fmax(fabs(lo), fabs(hi)), btol) + 2.0 * piv) break;
+                }
+                if (ln == 0) fth[t] = 0.5 * (lo + hi);
+            }
+        }
+        __syncthreads();
+        RSTAMP();       // 2: bisection
+        // inverse iteration for the three smallest pairs (dlagtf / dlagts: LU with partial pivoting of T - theta I), one
+        // wavefront per pair, element i of every array in lane i's REGISTERS: the serial recurrences read their operands
+        // with v_readlane and write back under a lane predicate - no memory latency in the chain
+        {
+            const double tiny = fmax(2.220446049250313e-16 * normf, 1e-300);
+            double la = 0.0, lb = 0.0, lc = 0.0, l2 = 0.0, ly = 0.0;
+            int lin = 0;
+            auto rl = [](double v, int lane) -> double { return ritz_readlane(v, lane); };
+            if (wv < 3) {
+                const double th = fth[wv];
+                if (ln < n) { la = fd[ln] - th; lb = fe[ln]; lc = fe[ln]; ly = 1.0 + 0.125 * (double)((ln * 7 + wv * 3) % 11); }
+                for (int i = 0; i + 1 < n; ++i) {
+                    const double ai = rl(la, i), ci = rl(lc, i), bi = rl(lb, i), a1 = rl(la, i + 1), b1 = rl(lb, i + 1);
+                    const bool sw = fabs(ci) > fabs(ai);
+                    const double piv_ = sw ? ci : (ai != 0.0 ? ai : tiny);
+                    const double mult = (sw ? ai : ci) * ritz_rcp(piv_);
+                    const double na1 = sw ? bi - mult * a1 : a1 - mult * bi;
+                    if (ln == i) { la = piv_; lc = mult; lin = sw ? 1 : 0; if (sw) { lb = a1; l2 = b1; } }
+                    if (ln == i + 1) { la = na1; if (sw) lb = -mult * b1; }
+                }
+                { const double an = rl(la, n - 1); if (fabs(an) < tiny && ln == n - 1) la = tiny; }
+            }
+            for (int it = 0; it < 2; ++it) {                // (theta is accurate to rounding: the second iterate is converged;
+                if (wv < 3) {                               //  the validation below catches the rest)
+                    for (int i = 0; i + 1 < n; ++i) {       // forward substitution with the recorded interchanges
+                        const double yi = rl(ly, i), y1 = rl(ly, i + 1), ci = rl(lc, i);
+                        const int sw = __builtin_amdgcn_readlane(lin, i);
+                        const double nyi = sw ? y1 : yi, ny1 = sw ? yi - ci * y1 : y1 - ci * yi;
+                        if (ln == i) ly = nyi;
+                        if (ln == i + 1) ly = ny1;
+                    }
+                    double x1 = 0.0, x2 = 0.0;              // back substitution: x_{i+1}, x_{i+2} carried as uniform values
+                    for (int i = n - 1; i >= 0; --i) {
+                        double pv = rl(la, i);
+                        if (fabs(pv) < tiny) pv = pv < 0.0 ? -tiny : tiny;
+                        const double xi = (rl(ly, i) - rl(lb, i) * x1 - rl(l2, i) * x2) * ritz_rcp(pv);
+                        if (ln == i) ly = xi;
+                        x2 = x1; x1 = xi;
+                    }
+                    // scale against overflow before the products below
+                    double mx = ln < n ? fabs(ly) : 0.0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+                    ly *= mx > 0.0 ? 1.0 / mx : 0.0;
+                }
+                // modified Gram-Schmidt among the three (a cluster of nearly equal eigenvalues shares its vectors otherwise)
+                for (int q = 0; q < 3; ++q) {
+                    if (wv == q) {
+                        for (int p2 = 0; p2 < q; ++p2) {
+                            const double zp = ln < n ? zt[p2 * N + ln] : 0.0;
+                            double dt = ln < n ? ly * zp : 0.0;
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o, 64);
+                            ly -= dt * zp;
+                        }
+                        double nn = ln < n ? ly * ly : 0.0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+                        ly *= nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+                        if (ln < n) zt[q * N + ln] = ly;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        RSTAMP();       // 3: inverse iteration
+        // back-transformation y = Q z, then validation against T itself
+        for (int idx = tid >> 3; idx < 3 * n; idx += B >> 3) {
+            const int k = idx / n, i = idx - k * n;
+            const double* Vr = V + i * ld;
+            const double* z = zt + k * N;
+            double acc = 0.0;
+            for (int j = tid & 7; j < n; j += 8) acc += Vr[j] * z[j];
+            acc = coop_dpp8_sum(acc);
+            if ((tid & 7) == 0) ys[k * N + i] = acc;
+        }
+        for (int i = wv; i < n; i += nwv)                   // T again (the tridiagonalisation overwrote it)
+            for (int c = ln; c < n; c += 64) {
+                const int lo = i < c ? i : c, hi = i < c ? c : i;
+                A[i * ld + c] = HB[(size_t)(hi / 3) * stride + lo * 3 + (hi % 3)];
+            }
+        __syncthreads();
+        double bad = 0.0;
+        for (int idx = tid >> 3; idx < 3 * n; idx += B >> 3) {
+            const int k = idx / n, i = idx - k * n;
+            const double* Ar = A + i * ld;
+            const double* y = ys + k * N;
+            double acc = 0.0;
+            for (int j = tid & 7; j < n; j += 8) acc += Ar[j] * y[j];
+            acc = coop_dpp8_sum(acc);
+            bad = fmax(bad, fabs(acc - fth[k] * y[i]));
+        }
+        if (tid < 9) {
+            const int p2 = tid / 3, q = tid - 3 * p2;
+            double dt = 0.0;
+            for (int i = 0; i < n; ++i) dt += ys[p2 * N + i] * ys[q * N + i];
+            bad = fmax(bad, fabs(dt - (p2 == q ? 1.0 : 0.0)) * normf);
+        }
+        if (!(bad == bad)) bad = 1e300;                     // NaN
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad = fmax(bad, __shfl_xor(bad, o, 64));
+        if (ln == 0) s_red[wv] = bad;
+        __syncthreads();
+        if (tid == 0) {
+            double m = 0.0;
+            for (int w = 0; w < nwv; ++w) m = fmax(m, s_red[w]);
+            bool ok = m <= 1e-13 * normf;
+            for (int t = 0; t < 6 && ok; ++t) if (!(fth[t] <= fth[t + 1])) ok = false;       // ordered: 5 smallest, 2 largest
+            s_fast = ok ? 1 : 0;
+        }
+        __syncthreads();
+        RSTAMP();       // 4: back-transformation + validation
+        if (s_fast) {
+            // hand the result to the common tail in the Jacobi layout: eigenvalue k on the diagonal, its vector in column k
+            for (int idx = tid; idx < 3 * n; idx += B) { const int k = idx / n, i = idx - k * n; V[i * ld + k] = ys[k * N + i]; }
+            if (tid == 0) {
+                for (int k = 0; k < 3; ++k) { A[k * ld + k] = fth[k]; s_idx[k] = k; }
+                A[3 * ld + 3] = fth[5]; A[4 * ld + 4] = fth[6]; s_idx[3] = 3; s_idx[4] = 4;
+                s_th4 = fth[3]; s_th5 = fth[4];
+            }
+        } else {
+            for (int idx = tid; idx < N * N; idx += B) { const int i = idx / N, c = idx - i * N; V[i * ld + c] = (i == c) ? 1.0 : 0.0; }
+        }
+        __syncthreads();
+    }
+    const bool fast = s_fast != 0;
+    if (!fast) {
     // Termination: a sweep without rotations, or - cheaper - a sweep whose largest pivot was already
     // below 1e-8 |T|_F: Jacobi converges quadratically, so that sweep left the off-diagonal part at
     // the 1e-16 |T|_F (|T|_F / gap) level and neither a polishing nor a verifying sweep is needed.
@@ -959,6 +1244,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         if (n == 1) s_idx[4] = tid;
     }
     __syncthreads();
+    }
     // Ritz vectors of the three smallest values -> Y[3 steps][3] (zero rows beyond the effective basis)
     for (int idx = tid; idx < 3 * steps * 3; idx += B) {
         const int i = idx / 3, k = idx - 3 * i;
@@ -1004,7 +1290,11 @@ extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int3
     if (!HB || !Y || !status || !gate || !(stall_ratio > 0.0 && stall_ratio < 1.0) || steps < 1 || steps > VICAN_RITZ_MAX_STEPS || hw < 9 * steps || row_stride < hw + 9)
         return set_err(VICAN_ERR_ARG, "vican_ritz: bad argument");
     const int n = 3 * steps, N = n + (n & 1), ld = N | 1, half = N / 2;
-    const size_t lds = ((size_t)2 * N * ld + 2 * half) * sizeof(double) + (size_t)half * sizeof(int) + 16;
+    size_t lds = ((size_t)2 * N * ld + 2 * half) * sizeof(double) + (size_t)half * sizeof(int) + 16;
+    static int fast_env = -1;
+    if (fast_env < 0) { const char* e = getenv("VICAN_RITZ_FAST"); fast_env = (e && e[0] == '0') ? 0 : 1; }
+    const int fast_lds = fast_env && n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX;     // workspace of the tridiagonalisation path
+    if (fast_lds) lds += ((size_t)26 * N + 16) * sizeof(double) + 16;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         if (hipFuncSetAttribute((const void*)ritz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1013,8 +1303,9 @@ extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int3
     }
     int threads = ((half * half + 63) / 64) * 64;            // one thread per 2x2 block, at most 1024
     threads = threads > 1024 ? 1024 : threads;
+    if (fast_lds && threads < 448) threads = 448;                      // seven wavefronts: one per wanted eigenvalue
     hipLaunchKernelGGL(ritz_kernel, dim3(1), dim3(threads), lds, (hipStream_t)stream, HB, row_stride, hw, steps,
-                       flags, eig_tol, floor_tol, floor_level, stall_ratio, Y, status, gate);
+                       flags, eig_tol, floor_tol, floor_level, stall_ratio, Y, status, gate, fast_lds);
     LAUNCH_CHECK("vican_ritz");
     return VICAN_OK;
 }
