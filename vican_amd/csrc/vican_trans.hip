@@ -246,9 +246,13 @@ __global__ void cg_init_finish_kernel(int n_cam, const double* __restrict__ b_c,
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
+    // (the partials through LDS: 512 dependent global loads by one thread took 36 us; same summation order)
+    __shared__ double sp[2 * CG_PARTS];
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) { sp[i] = part[i]; sp[CG_PARTS + i] = part[CG_PARTS + i]; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0, mt = 0.0, mc = 0.0;
-        for (int i = 0; i < n_part; ++i) { t += part[i]; mt = fmax(mt, part[CG_PARTS + i]); }
+        for (int i = 0; i < n_part; ++i) { t += sp[i]; mt = fmax(mt, sp[CG_PARTS + i]); }
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mc = fmax(mc, red[i]);
         st->rho = 0; st->rho_prev = 0; st->pq = 0; st->alpha = 0; st->beta = 0; st->bnorm2 = 0; st->atol2 = 0;
         st->rr_cam = rc; st->pq_time = 0; st->rr_time = t;
@@ -543,16 +547,21 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
 __global__ void cg_reduce_pq_kernel(const double* __restrict__ pq_part, int n_part, double* __restrict__ out,
                                     const vican_cg_state_t* __restrict__ st) {
     if (st->done) return;
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < n_part; ++i) t += pq_part[i];
-        *out = t;
+    __shared__ double sp[1024];                 // partials through LDS (loaded in parallel), summed in the same fixed order
+    double t = 0.0;
+    for (int k0 = 0; k0 < n_part; k0 += 1024) {
+        const int m = n_part - k0 < 1024 ? n_part - k0 : 1024;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) sp[i] = pq_part[k0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0) for (int i = 0; i < m; ++i) t += sp[i];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *out = t;
 }
 extern "C" int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out, const vican_cg_state_t* st,
                                   void* stream) {
     if (!pq_part || n_part <= 0 || !st || !out) return set_err(VICAN_ERR_ARG, "vican_cg_reduce_pq: bad argument");
-    hipLaunchKernelGGL(cg_reduce_pq_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pq_part, n_part, out, st);
+    hipLaunchKernelGGL(cg_reduce_pq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pq_part, n_part, out, st);
     LAUNCH_CHECK("vican_cg_reduce_pq");
     return VICAN_OK;
 }
@@ -710,11 +719,18 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
 
 __global__ void cg_end_kernel(const double* __restrict__ rr_part, int n_part, vican_cg_state_t* st) {
     if (st->done) return;
-    if (threadIdx.x == 0) cg_close_iteration(rr_part, n_part, st);
+    // (the partials through LDS: up to 3 x 512 dependent global loads by one thread took ~36 us per iteration of a sharded
+    //  solve; same summation order)
+    __shared__ double sp[3 * CG_PARTS];
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+        sp[i] = rr_part[i]; sp[CG_PARTS + i] = rr_part[CG_PARTS + i]; sp[2 * CG_PARTS + i] = rr_part[2 * CG_PARTS + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cg_close_iteration(sp, n_part, st);
 }
 extern "C" int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream) {
     if (!rr_part || n_part <= 0 || !st) return set_err(VICAN_ERR_ARG, "vican_cg_end: bad argument");
-    hipLaunchKernelGGL(cg_end_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rr_part, n_part, st);
+    hipLaunchKernelGGL(cg_end_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rr_part, n_part, st);
     LAUNCH_CHECK("vican_cg_end");
     return VICAN_OK;
 }
