@@ -645,25 +645,43 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
     double* part1 = ws;                                  // [nwg][hs]
     double* part2 = ws + (size_t)nwg * hs;               // [nwg][hs]
     double* partG = ws + (size_t)2 * nwg * hs;           // [nwg][8]
+    // z straight from the sweep's fixed-point slabs [n_slab][9][n_cam] (what vican_slab_reduce_fx would produce - one
+    // launch less per Lanczos step): this workgroup's cameras only, exact integer sums, same conversion.  The slab loads
+    // are issued first and five slabs at a time (45 independent loads per thread: the fold was five dependent round
+    // trips, 3 of the step's 15 us), the basis rows are staged while they are in flight.
+    // (every global load that does not depend on another one is issued up front: the step is a chain of round trips)
+    double Lc[9], qc9[9];
+    const double sc = 1.0 * (pa ? *pa : 1.0) * (pb ? *pb : 1.0);
+    {
+        const int c = tid < c1 - c0 ? c0 + tid : c0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Lc[k] = lamC[(size_t)c * 9 + k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) qc9[i * 3 + b] = V[(size_t)(3 * j + b) * ld + 3 * c + i];
+    }
+    long long zacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (zpart) {
+        const int lane = tid & 31, grp = tid >> 5, ncl = c1 - c0;
+        if (lane < ncl) {
+#pragma unroll 5
+            for (int s = grp; s < n_slab; s += 8) {
+                const long long* sp = zpart + (size_t)s * 9 * n_cam + c0 + lane;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) zacc[q] += sp[(size_t)q * n_cam];
+            }
+        }
+    }
     for (int t = tid; t < ka * COOP_ROWS; t += blockDim.x) {
         const int k = t / COOP_ROWS, i = t - k * COOP_ROWS;
         vs[t] = i < nsl ? V[(size_t)k * ld + row0 + i] : 0.0;
     }
-    // z straight from the sweep's fixed-point slabs [n_slab][9][n_cam] (what vican_slab_reduce_fx would produce - one
-    // launch less per Lanczos step): this workgroup's cameras only, exact integer sums, same conversion
     if (zpart) {
-        const int lane = tid & 31, grp = tid >> 5, ncl = c1 - c0;
-        long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (lane < ncl)
-            for (int s = grp; s < n_slab; s += 8) {
-                const long long* sp = zpart + (size_t)s * 9 * n_cam + c0 + lane;
+        const int lane = tid & 31, grp = tid >> 5;
 #pragma unroll
-                for (int q = 0; q < 9; ++q) acc[q] += sp[(size_t)q * n_cam];
-            }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) zred[grp][q * COOP_CAMS + lane] = acc[q];
+        for (int q = 0; q < 9; ++q) zred[grp][q * COOP_CAMS + lane] = zacc[q];
         __syncthreads();
-        const double sc = 1.0 * (pa ? *pa : 1.0) * (pb ? *pb : 1.0);
         for (int t = tid; t < 9 * COOP_CAMS; t += blockDim.x) {
             long long sum = 0;
 #pragma unroll
@@ -676,18 +694,11 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
     // A Q_j = Lambda_C Q_j - z on this slice
     if (tid < c1 - c0) {
         const int c = c0 + tid;
-        double L[9], q[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L[k] = lamC[(size_t)c * 9 + k];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) q[i * 3 + b] = V[(size_t)(3 * j + b) * ld + 3 * c + i];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int b = 0; b < 3; ++b)
-                rs[b][3 * tid + i] = L[i * 3] * q[b] + L[i * 3 + 1] * q[3 + b] + L[i * 3 + 2] * q[6 + b] -
+                rs[b][3 * tid + i] = Lc[i * 3] * qc9[b] + Lc[i * 3 + 1] * qc9[3 + b] + Lc[i * 3 + 2] * qc9[6 + b] -
                                      (zpart ? zl[tid * 9 + i * 3 + b] : z[(size_t)(3 * c + i) * 3 + b]);
     }
     __syncthreads();
