@@ -30,11 +30,12 @@ def _env():
     return env
 
 
-def test_two_ranks_sharded_hip_solve_matches_single_rank():
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_ranks_sharded_hip_solve_matches_single_rank(nranks):
     """tools/dist_probe.py: tiny and uneven problems (including a rank WITHOUT rows) in f64 and f32, sharded over
-    two ranks, against the single-rank solve of the same problem inside the same processes."""
+    two / three ranks, against the single-rank solve of the same problem inside the same processes."""
     port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", "dist_probe.py")]
     res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     print(res.stdout[-3000:])
@@ -42,22 +43,22 @@ def test_two_ranks_sharded_hip_solve_matches_single_rank():
     assert "dist probe: mismatches 0" in res.stdout
 
 
-@pytest.mark.parametrize("workload,scaling", [("large_shop", "strong"), ("stress", "weak")])
-def test_bench_launches_its_own_ranks(workload, scaling):
-    """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports n_gpus = 2; large_shop is
+@pytest.mark.parametrize("workload,scaling,gpus", [("large_shop", "strong", 2), ("stress", "weak", 2), ("large_shop", "strong", 4)])
+def test_bench_launches_its_own_ranks(workload, scaling, gpus):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself and reports n_gpus = N; large_shop is
     strong scaling (one graph of 10 000 rows split over the ranks), stress weak (rows per GPU)."""
     extra = ["--cams", "200", "--timesteps", "4000", "--cams-per-t", "50"] if workload == "stress" else []
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--workload", workload,
            "--no-cpu-baseline", *extra]
     res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["n_gpus"] == gpus and out["scaling"] == scaling
     assert out["detail"]["cg_converged"] and out["value"] > 0
     assert out["detail"]["n_allreduce_per_solve"] > 0
     if scaling == "strong":
-        assert out["detail"]["rows_rank0"] == 5000
+        assert out["detail"]["rows_rank0"] == 10000 // gpus
     else:
         assert out["detail"]["rows_rank0"] == 4000
 
