@@ -637,7 +637,9 @@ class HipBackend:
             l = self.cgl
             self._cgres_ok = bool(
                 os.environ.get("VICAN_CG_RESIDENT", "1") != "0" and self.layout == "wave" and self._gref_cg is self._gref and
-                l.n_chunk > 0 and l.n_wg <= min(n_cu(), 256) and
+                l.n_chunk > 0 and l.n_wg <= min(n_cu(), 128) and        # (a grid barrier costs 1 us at 40 workgroups, 2 at 128,
+                                                                         #  3.8 at 256: measured CG stage 0.35 / 0.49 ms at 40
+                                                                         #  workgroups, 0.44 / 0.50 at 98, 0.72 / 0.60 at 235)
                 int(self.lib.vican_cg_resident_lds_bytes(self.C, l.max_rows, l.n_copy, l.rows_per_wg_max)) <= int(self.lib.vican_lds_limit_bytes()))
         return self._cgres_ok
 
