@@ -112,11 +112,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         const int2 vnn = load_rows(kk + 2 * NW);
         load_rowvals(rvn, vnext);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef VICAN_CGW_DEPTH2
-        load_edges(nxt, kk + 2 * NW);
-#else
         load_edges(nxt, kk + NW);
-#endif
 #if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
 #pragma unroll
         for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
@@ -154,11 +150,6 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
             cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu); row[j] = pad ? 0u : (cur.id[j] >> 16);
-#if defined(VICAN_CGW_SWZ) && VICAN_CGW_SWZ == 1      /* timing experiment: bank swizzle of the camera index (results wrong at the table's end) */
-            { uint32_t c2 = cam[j] ^ ((cam[j] >> 4) & 15u); cam[j] = c2 < (uint32_t)C ? c2 : cam[j]; }
-#elif defined(VICAN_CGW_SWZ) && VICAN_CGW_SWZ == 2    /* timing experiment: pseudo-random camera */
-            { uint32_t c2 = (cam[j] * 2654435761u >> 7) % (uint32_t)C; cam[j] = c2; }
-#endif
             wj[j] = pad ? 0.0 : cur.w[j];
 #pragma unroll
             for (int i = 0; i < 3; ++i) pc[j][i] = pcs[i * C + cam[j]];
@@ -227,20 +218,6 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #ifdef VICAN_CGWSTAMP
     const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef VICAN_CGW_DEPTH2
-    // edge words two chunks ahead (three register buffers), row values one ahead (two buffers): period 6
-    CgWRegs<EPL> ec;
-    load_edges(eb, k + NW);
-#pragma unroll 1
-    while (k < c1) {
-        v2 = body(ea, ec, ra, rb, v0, v1, k); k += NW; if (k >= c1) break;
-        v0 = body(eb, ea, rb, ra, v1, v2, k); k += NW; if (k >= c1) break;
-        v1 = body(ec, eb, ra, rb, v2, v0, k); k += NW; if (k >= c1) break;
-        v2 = body(ea, ec, rb, ra, v0, v1, k); k += NW; if (k >= c1) break;
-        v0 = body(eb, ea, ra, rb, v1, v2, k); k += NW; if (k >= c1) break;
-        v1 = body(ec, eb, rb, ra, v2, v0, k); k += NW;
-    }
-#else
 #pragma unroll 1
     while (k < c1) {
         v2 = body(ea, eb, ra, rb, v0, v1, k);
@@ -251,7 +228,6 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         // rotate the row-bound registers: (v0, v1, v2) now hold (k + NW, k, -) -> bring them back to (k, k + NW)
         const int2 tmp = v0; v0 = v2; v1 = tmp;
     }
-#endif
 #ifdef VICAN_CGWSTAMP
     const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif

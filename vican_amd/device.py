@@ -307,22 +307,6 @@ class HipBackend:
         # layout the CG sweep runs on: the rotation layout if it is a wave layout, else the translation block layout
         cgl = graph.rot if graph.layout == "wave" else graph.tl
         self._gref_cg, self.cgl = (self._gref if graph.layout == "wave" else self._gref_t), cgl
-        if graph.layout == "wave":
-            # The CG sweep needs a third of the rotation sweep's LDS (3 + 3 camera planes against 9 + 9) and 61 VGPRs: several
-            # of its workgroups fit on a compute unit where the rotation sweep has one.  It runs on a copy of the graph
-            # descriptor with n_wg multiplied (the slab buffer holds 9 C words per rotation workgroup, the CG sweep writes 3 C).
-            import copy
-            import os
-            mult = int(os.environ.get("VICAN_CG_WGMULT") or 1)
-            lds1 = int(self.lib.vican_cg_wsweep_lds_bytes(self.C, cgl.max_rows, cgl.n_copy, cgl.wg_waves)) + 512
-            mult = max(1, min(mult, 3, int(self.lib.vican_lds_limit_bytes()) // lds1, max(1, cgl.n_chunk // (cgl.n_wg * cgl.wg_waves * 4))))
-            if mult > 1:
-                self._desc_cg = type(graph.desc).from_buffer_copy(graph.desc)
-                self._desc_cg.n_wg = cgl.n_wg * mult
-                self._gref_cg = C.byref(self._desc_cg)
-                self.cgl = copy.copy(cgl)
-                self.cgl.n_wg = cgl.n_wg * mult
-                self.pq_part = torch.empty(self.cgl.n_wg, dtype=torch.float64, device=self.dev)
         self.n_add_cg = float(max(cgl.rows_per_wg_max, cgl.slots) + 1)
 
     # -- allocation helpers -------------------------------------------------
