@@ -433,9 +433,9 @@ def test_ritz_matches_lapack_and_gate_semantics(steps, dead_at):
 
 
 @pytest.mark.parametrize("kind", ["tight_cluster", "exact_triple", "wide", "negative", "graded"])
-@pytest.mark.parametrize("steps", [5, 8, 12, 20])
+@pytest.mark.parametrize("steps", [5, 8, 12, 20, 23, 32])
 def test_ritz_fast_path_on_hard_spectra(kind, steps):
-    """The tridiagonalisation + bisection + inverse-iteration path of vican_ritz (15 <= n <= 64) on spectra that stress it:
+    """The tridiagonalisation + bisection + inverse-iteration path of vican_ritz (15 <= n <= 96) on spectra that stress it:
     a cluster of three eigenvalues 1e-13 apart, an exactly triple eigenvalue, a wide range, negative values, a graded
     matrix - eigenvalues and the invariant subspace of the three smallest against LAPACK, orthonormal Ritz vectors.  (Where
     its own validation rejects the result the kernel falls back to the Jacobi iteration: same assertions.)"""

@@ -881,7 +881,7 @@ __device__ __forceinline__ int ritz_rotation(double app, double aqq, double apq,
 // (residual and orthonormality); the Jacobi iteration below stays as the fallback.  Jacobi is latency-bound per round
 // (N - 1 rounds x 6-9 sweeps x ~0.8 us: 250 us at n = 36); this path is ~n dependent steps of two short matrix-vector
 // products plus a few microseconds of scalar recurrences.
-#define RITZ_FAST_NMAX 64          /* element i of the inverse iteration lives in lane i */
+#define RITZ_FAST_NMAX 96          /* (3 x VICAN_RITZ_MAX_STEPS; element i of the serial recurrences lives in lane i % 64) */
 #define RITZ_FAST_NMIN 15         /* tools/ritz_bench.py: n = 12 44 vs 42 us (Jacobi), 15: 55 vs 63, 24: 85 vs 116, 36: 134 vs 251, 48: 185 vs 391 */
 __device__ __forceinline__ double ritz_rcp(double x) {                 // 1/x to ~1 ulp: v_rcp_f64 + one Newton step
     double r = __builtin_amdgcn_rcp(x);
@@ -894,14 +894,19 @@ __device__ __forceinline__ double ritz_readlane(double v, int lane) {   // lane:
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// number of eigenvalues of the symmetric tridiagonal (d, e) below sigma (LAPACK dlaebz recurrence); dl / e2l: element i of
-// d and of e^2 in lane i's registers (n <= 64) - read with v_readlane, so the serial chain has no memory latency in it
-__device__ __forceinline__ int ritz_sturm(double dl, double e2l, int n, double sigma, double pivmin) {
-    double q = ritz_readlane(dl, 0) - sigma;
+// element i of a lane-distributed array of up to 128 entries: slot i / 64 of lane i % 64 (i: wave-uniform)
+__device__ __forceinline__ double ritz_get(double v0, double v1, int i) { return i < 64 ? ritz_readlane(v0, i) : ritz_readlane(v1, i - 64); }
+// number of eigenvalues of the symmetric tridiagonal (d, e) below sigma (LAPACK dlaebz recurrence); element i of d and of
+// e^2 lives in lane i % 64's registers (NS slots: n <= 64 NS) and is read with v_readlane: no memory latency in the chain
+template <int NS>
+__device__ __forceinline__ int ritz_sturm(const double* d, const double* e2, int n, double sigma, double pivmin) {
+    double q = ritz_readlane(d[0], 0) - sigma;
     int cnt = 0;
     if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
     for (int i = 1; i < n; ++i) {
-        q = ritz_readlane(dl, i) - sigma - ritz_readlane(e2l, i - 1) * ritz_rcp(q);
+        const double di = NS == 1 ? ritz_readlane(d[0], i) : ritz_get(d[0], d[NS - 1], i);
+        const double ei = NS == 1 ? ritz_readlane(e2[0], i - 1) : ritz_get(e2[0], e2[NS - 1], i - 1);
+        q = di - sigma - ei * ritz_rcp(q);
         if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
     }
     return cnt;
@@ -1045,16 +1050,20 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         }
         __syncthreads();
         RSTAMP();       // 1: Gershgorin
+        auto small_solve = [&](auto ns_) {                  // NS register slots per lane: 1 for n <= 64, 2 up to 128
+            constexpr int NS = decltype(ns_)::value;
         {   // bisection, 64 trial shifts per round: a wavefront per wanted eigenvalue
             const double piv = s_piv;
-            const double dl = ln < n ? fd[ln] : 0.0, e2l = ln < n ? fe2[ln] : 0.0;
+            double dl[NS], e2l[NS];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) { const int e = ln + 64 * sl; dl[sl] = e < n ? fd[e] : 0.0; e2l[sl] = e < n ? fe2[e] : 0.0; }
             const double btol = 1.1102230246251565e-16 * normf;                       // absolute accuracy asked of an eigenvalue
             for (int t = wv; t < 7; t += nwv) {
                 const int kk = t < 5 ? t : n - 7 + t;       // 0..4, n-2, n-1
                 double lo = s_gl, hi = s_gu;
                 for (int round = 0; round < 14; ++round) {
                     const double sig = lo + (hi - lo) * ((double)(ln + 1) * (1.0 / 65.0));
-                    const int c = ritz_sturm(dl, e2l, n, sig, piv);
+                    const int c = ritz_sturm<NS>(dl, e2l, n, sig, piv);
                     const unsigned long long mk = __ballot(c >= kk + 1);
                     const int f = mk ? __ffsll((long long)mk) - 1 : 64;
                     const double nhi = f < 64 ? __shfl(sig, f, 64) : hi;
@@ -1068,70 +1077,93 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         __syncthreads();
         RSTAMP();       // 2: bisection
         // inverse iteration for the three smallest pairs (dlagtf / dlagts: LU with partial pivoting of T - theta I), one
-        // wavefront per pair, element i of every array in lane i's REGISTERS: the serial recurrences read their operands
-        // with v_readlane and write back under a lane predicate - no memory latency in the chain
+        // wavefront per pair, element i of every array in the REGISTERS of lane i % 64 (slot i / 64): the serial recurrences
+        // read their operands with v_readlane and write back under a lane predicate - no memory latency in the chain
         {
             const double tiny = fmax(2.220446049250313e-16 * normf, 1e-300);
-            double la = 0.0, lb = 0.0, lc = 0.0, l2 = 0.0, ly = 0.0;
-            int lin = 0;
-            auto rl = [](double v, int lane) -> double { return ritz_readlane(v, lane); };
+            double la[NS], lb[NS], lc[NS], l2[NS], ly[NS];
+            int lin[NS];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) { la[sl] = lb[sl] = lc[sl] = l2[sl] = ly[sl] = 0.0; lin[sl] = 0; }
+#define RG(a, i) (NS == 1 ? ritz_readlane((a)[0], (i)) : ritz_get((a)[0], (a)[NS - 1], (i)))
+#define RSET(a, i, v) do { if (ln == ((i) & 63)) { if (NS == 1 || (i) < 64) (a)[0] = (v); else (a)[NS - 1] = (v); } } while (0)
             if (wv < 3) {
                 const double th = fth[wv];
-                if (ln < n) { la = fd[ln] - th; lb = fe[ln]; lc = fe[ln]; ly = 1.0 + 0.125 * (double)((ln * 7 + wv * 3) % 11); }
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int e = ln + 64 * sl;
+                    if (e < n) { la[sl] = fd[e] - th; lb[sl] = fe[e]; lc[sl] = fe[e]; ly[sl] = 1.0 + 0.125 * (double)((e * 7 + wv * 3) % 11); }
+                }
                 for (int i = 0; i + 1 < n; ++i) {
-                    const double ai = rl(la, i), ci = rl(lc, i), bi = rl(lb, i), a1 = rl(la, i + 1), b1 = rl(lb, i + 1);
+                    const double ai = RG(la, i), ci = RG(lc, i), bi = RG(lb, i), a1 = RG(la, i + 1), b1 = RG(lb, i + 1);
                     const bool sw = fabs(ci) > fabs(ai);
                     const double piv_ = sw ? ci : (ai != 0.0 ? ai : tiny);
                     const double mult = (sw ? ai : ci) * ritz_rcp(piv_);
                     const double na1 = sw ? bi - mult * a1 : a1 - mult * bi;
-                    if (ln == i) { la = piv_; lc = mult; lin = sw ? 1 : 0; if (sw) { lb = a1; l2 = b1; } }
-                    if (ln == i + 1) { la = na1; if (sw) lb = -mult * b1; }
+                    RSET(la, i, piv_); RSET(lc, i, mult);
+                    if (ln == (i & 63)) { if (NS == 1 || i < 64) lin[0] = sw ? 1 : 0; else lin[NS - 1] = sw ? 1 : 0; }
+                    if (sw) { RSET(lb, i, a1); RSET(l2, i, b1); }
+                    RSET(la, i + 1, na1);
+                    if (sw) RSET(lb, i + 1, -mult * b1);
                 }
-                { const double an = rl(la, n - 1); if (fabs(an) < tiny && ln == n - 1) la = tiny; }
+                { const double an = RG(la, n - 1); if (fabs(an) < tiny) RSET(la, n - 1, tiny); }
             }
             for (int it = 0; it < 2; ++it) {                // (theta is accurate to rounding: the second iterate is converged;
                 if (wv < 3) {                               //  the validation below catches the rest)
                     for (int i = 0; i + 1 < n; ++i) {       // forward substitution with the recorded interchanges
-                        const double yi = rl(ly, i), y1 = rl(ly, i + 1), ci = rl(lc, i);
-                        const int sw = __builtin_amdgcn_readlane(lin, i);
+                        const double yi = RG(ly, i), y1 = RG(ly, i + 1), ci = RG(lc, i);
+                        const int sw = (NS == 1 || i < 64) ? __builtin_amdgcn_readlane(lin[0], i & 63) : __builtin_amdgcn_readlane(lin[NS - 1], i - 64);
                         const double nyi = sw ? y1 : yi, ny1 = sw ? yi - ci * y1 : y1 - ci * yi;
-                        if (ln == i) ly = nyi;
-                        if (ln == i + 1) ly = ny1;
+                        RSET(ly, i, nyi);
+                        RSET(ly, i + 1, ny1);
                     }
                     double x1 = 0.0, x2 = 0.0;              // back substitution: x_{i+1}, x_{i+2} carried as uniform values
                     for (int i = n - 1; i >= 0; --i) {
-                        double pv = rl(la, i);
+                        double pv = RG(la, i);
                         if (fabs(pv) < tiny) pv = pv < 0.0 ? -tiny : tiny;
-                        const double xi = (rl(ly, i) - rl(lb, i) * x1 - rl(l2, i) * x2) * ritz_rcp(pv);
-                        if (ln == i) ly = xi;
+                        const double xi = (RG(ly, i) - RG(lb, i) * x1 - RG(l2, i) * x2) * ritz_rcp(pv);
+                        RSET(ly, i, xi);
                         x2 = x1; x1 = xi;
                     }
                     // scale against overflow before the products below
-                    double mx = ln < n ? fabs(ly) : 0.0;
+                    double mx = 0.0;
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) mx = fmax(mx, ln + 64 * sl < n ? fabs(ly[sl]) : 0.0);
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-                    ly *= mx > 0.0 ? 1.0 / mx : 0.0;
+                    const double isc = mx > 0.0 ? 1.0 / mx : 0.0;
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) ly[sl] *= isc;
                 }
                 // modified Gram-Schmidt among the three (a cluster of nearly equal eigenvalues shares its vectors otherwise)
                 for (int q = 0; q < 3; ++q) {
                     if (wv == q) {
                         for (int p2 = 0; p2 < q; ++p2) {
-                            const double zp = ln < n ? zt[p2 * N + ln] : 0.0;
-                            double dt = ln < n ? ly * zp : 0.0;
+                            double zp[NS], dt = 0.0;
+#pragma unroll
+                            for (int sl = 0; sl < NS; ++sl) { const int e = ln + 64 * sl; zp[sl] = e < n ? zt[p2 * N + e] : 0.0; dt += e < n ? ly[sl] * zp[sl] : 0.0; }
 #pragma unroll
                             for (int o = 32; o > 0; o >>= 1) dt += __shfl_xor(dt, o, 64);
-                            ly -= dt * zp;
+#pragma unroll
+                            for (int sl = 0; sl < NS; ++sl) ly[sl] -= dt * zp[sl];
                         }
-                        double nn = ln < n ? ly * ly : 0.0;
+                        double nn = 0.0;
+#pragma unroll
+                        for (int sl = 0; sl < NS; ++sl) nn += ln + 64 * sl < n ? ly[sl] * ly[sl] : 0.0;
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
-                        ly *= nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
-                        if (ln < n) zt[q * N + ln] = ly;
+                        const double inn = nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+#pragma unroll
+                        for (int sl = 0; sl < NS; ++sl) { ly[sl] *= inn; if (ln + 64 * sl < n) zt[q * N + ln + 64 * sl] = ly[sl]; }
                     }
                     __syncthreads();
                 }
             }
+#undef RG
+#undef RSET
         }
+        };
+        if (n <= 64) small_solve(std::integral_constant<int, 1>()); else small_solve(std::integral_constant<int, 2>());
         RSTAMP();       // 3: inverse iteration
         // back-transformation y = Q z, then validation against T itself
         for (int idx = tid >> 3; idx < 3 * n; idx += B >> 3) {
@@ -1305,7 +1337,7 @@ extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int3
     static int fast_env = -1;
     if (fast_env < 0) { const char* e = getenv("VICAN_RITZ_FAST"); fast_env = (e && e[0] == '0') ? 0 : 1; }
     const int fast_lds = fast_env && n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX;     // workspace of the tridiagonalisation path
-    if (fast_lds) lds += ((size_t)26 * N + 16) * sizeof(double) + 16;
+    if (fast_lds) lds += ((size_t)12 * N + 8) * sizeof(double) + 32;   // d, e, e^2, v, p, g, 8 eigenvalues, z[3], y[3]
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         if (hipFuncSetAttribute((const void*)ritz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
