@@ -198,7 +198,8 @@ def test_translation_kernels_and_cg(cfg):
     assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)
 
 
-@pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[9], CONFIGS[10], CONFIGS[12], (340, 10000, 2, 6, "wave", None, False)])
+@pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[9], CONFIGS[10], CONFIGS[12], (340, 10000, 2, 6, "wave", None, False),
+                                 (200, 30000, 2, 6, "wave", None, False)])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_cg_resident_matches_multikernel(cfg, dt):
     """vican_cg_resident (the whole CG as one cooperative launch, vican_cgres.hip) against the multi-kernel path on the same
