@@ -225,11 +225,20 @@ class RotationSolver:
                 if steps >= next_check or steps >= self.m_max:
                     handle = self._ritz(steps, first, level, gap=steps - prev_steps)
                     first = False
-                    with K.gated(self.gate):                   # speculative: runs iff the device says converged
+                    # Sharded runs speculate only where a check is expected to pass (a step count remembered from an
+                    # earlier solve of this graph): the tail's all-reduces are issued by the host and cannot be gated, so
+                    # every failed check would pay for two collectives on cancelled data.
+                    speculate = self.comm.world == 1 or (restart == 0 and it in self.pred_steps and steps >= self.pred_steps[it])
+                    if speculate:
+                        with K.gated(self.gate):               # speculative: runs iff the device says converged
+                            K.tall_combine(n, self.V, ld, 3 * steps, self.Yd, self.X)
+                            if tail is not None:
+                                tail()
+                    st = K.wait_status(handle)
+                    if not speculate and st[2] != 0 and st[3] != 0:       # stop and converged: the tail, now that it is known
                         K.tall_combine(n, self.V, ld, 3 * steps, self.Yd, self.X)
                         if tail is not None:
                             tail()
-                    st = K.wait_status(handle)
                     r, stop, conv, floor_hit, eff, breakdown = st[0], st[2] != 0, st[3] != 0, st[4] != 0, int(st[5]), st[6] != 0
                     if st[15] == st[15]:
                         th4_last = float(st[15])
