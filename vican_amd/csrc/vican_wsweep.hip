@@ -88,20 +88,11 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     __shared__ int s_cnt, s_npub, s_done, s_units, s_v0[RING], s_v1[RING], s_base[RING];
     // first range of workgroup w (implicit, no atomic): units [unit0 w, unit0 (w + 1)); its first NW tickets are implicit
     // too - wavefront i holds ticket i - so that the first chunk is requested before the prologue barrier
-#ifdef VICAN_W_STATIC       /* experiment: one static contiguous range per workgroup, no device-level scheduling */
-    const int base0 = (int)(((long long)blockIdx.x * nchunk) / nwg);
-    const int len0 = (int)(((long long)(blockIdx.x + 1) * nchunk) / nwg) - base0;
-#else
     const int base0 = (int)blockIdx.x * unit0 * NW;
     const int len0 = nchunk - base0 < 0 ? 0 : (nchunk - base0 > unit0 * NW ? unit0 * NW : nchunk - base0);
-#endif
     if (tid == 0) {
         s_cnt = NW; s_v0[0] = 0; s_v1[0] = len0; s_base[0] = base0; s_npub = 1; s_units = unit0;
-#ifdef VICAN_W_STATIC
-        s_done = 1;
-#else
         s_done = len0 < unit0 * NW ? 1 : 0;                    // the queue ends inside (or before) this range
-#endif
     }
     int my_r = 0;                                              // newest ring entry this wavefront has looked at (wave-uniform)
     // ticket -> chunk.  Tickets are unique in the workgroup; entries are published in ticket order.
@@ -113,7 +104,6 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             const int e = my_r & (RING - 1), v0 = LDSV(s_v0[e]), v1 = LDSV(s_v1[e]);
             if (v < v1) {
                 const int k = LDSV(s_base[e]) + (v - v0);
-#ifndef VICAN_W_STATIC
                 // the one wavefront whose ticket sits a round before the end of the NEWEST range fetches the next range
                 const int trig = v1 - v0 > NW ? v1 - NW : v0;
                 if (v == trig && my_r == npub - 1 && !__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
@@ -140,7 +130,6 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                         if (nl > 0) __hip_atomic_store(&s_npub, npub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS stores of a wave: in order
                     }
                 }
-#endif
                 return k;
             }
             if (my_r < npub - 1) continue;                     // (entries were published meanwhile)
