@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
                                                       const double* __restrict__ qc_sum, const double* __restrict__ pq_time,
                                                       const double* __restrict__ p_c, double* x_c, double* r_c,
                                                       const double* __restrict__ p_t, const double* __restrict__ q_t,
-                                                      double* x_t, double* r_t, double* __restrict__ rr_part,
+                                                      double* __restrict__ x_t, double* __restrict__ r_t, double* __restrict__ rr_part,
                                                       vican_cg_state_t* st) {
     __shared__ double red[8];
     __shared__ double sh_alpha;
@@ -681,6 +681,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     __syncthreads();
     const double alpha = sh_alpha;
     double rr = 0.0, m = 0.0, mp = 0.0;
+#pragma unroll 4
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double pv = p_t[i];
         x_t[i] += alpha * pv;
