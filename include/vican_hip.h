@@ -82,7 +82,8 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-int vican_abi_version(void);            /* 10 */
+#define VICAN_ABI_VERSION 10            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
  * kernels enqueued by vican_tall_combine, vican_gauge_project, vican_block_op(_z),

@@ -31,7 +31,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), "library does not export %s" % s
         assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
-    assert lib.vican_abi_version() == 10
+    assert lib.vican_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_sizes():
@@ -90,3 +90,13 @@ def test_compute_calls_fail_loudly_without_gpu():
     from vican_amd.frontend import Problem
     with pytest.raises(_lib.VicanError):
         solve_problem(Problem(), 4, "conjugate_gradient")
+
+
+def test_graft_entry_build_hook_runs():
+    """The driver's ``build()`` hook: a full from-source compile for gfx950, the ABI check against the header's
+    VICAN_ABI_VERSION, and the package imports (round 2 shipped a stale ``== 9`` here)."""
+    import __graft_entry__ as entry
+    entry.build()
+    txt = open(os.path.join(ROOT, "include", "vican_hip.h")).read()
+    assert int(re.search(r"#define\s+VICAN_ABI_VERSION\s+(\d+)", txt).group(1)) == _lib.ABI_VERSION
+    assert _lib.load().vican_abi_version() == _lib.ABI_VERSION

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import shutil
 import subprocess
 
@@ -24,6 +25,8 @@ FX_DOUBLES = 20
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
 INCLUDE = os.path.join(ROOT, "include")
+# VICAN_ABI_VERSION of include/vican_hip.h - the one place the number lives; load() rejects a library built from other sources
+ABI_VERSION = int(re.search(r"#define\s+VICAN_ABI_VERSION\s+(\d+)", open(os.path.join(INCLUDE, "vican_hip.h")).read()).group(1))
 
 STORE_F32, STORE_F64 = 0, 1
 LAYOUT_BLOCK, LAYOUT_WAVE = 0, 1
@@ -146,6 +149,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
             return out
     import concurrent.futures
     import hashlib
+    import threading
     flags_all = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-value", "-I", INCLUDE, "-I", CSRC,
                  *os.environ.get("VICAN_CFLAGS", "").split(), *extra_flags]
     # the two sweep files are compiled once per sweep mode plus once without their hot kernel (see their headers):
@@ -159,32 +163,42 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     cache = os.path.join(CSRC, "_build_cache")
     os.makedirs(cache, exist_ok=True)
     hdr = b"".join(open(p, "rb").read() for p in sorted(set(HEADERS) - {WSWEEP}) + [os.path.join(INCLUDE, "vican_hip.h")])
+    # the compiler is part of the key: a toolchain upgrade must not reuse objects
+    tool = subprocess.run([hipcc_path(), "--version"], capture_output=True).stdout
 
     def compile_one(job):
         src, extra = job
         text = open(src, "rb").read()
         # a -DNAME flag that neither this file nor a header mentions cannot change its object: variants share objects
         flags = [f for f in flags_all if not (f.startswith("-D") and f[2:].split("=")[0].encode() not in text + hdr)]
-        key = hashlib.sha1(" ".join(flags + extra).encode() + text + hdr).hexdigest()
+        key = hashlib.sha1(" ".join(flags + extra).encode() + text + hdr + tool).hexdigest()
         obj = os.path.join(cache, key + ".o")
         if force or not os.path.exists(obj):
-            cmd = [hipcc_path(), *flags, *extra, "-c", src, "-o", obj + ".tmp"]
+            # ranks started together may build the same key at once: every process writes its own temporary file
+            tmp = "%s.%d.%d.tmp" % (obj, os.getpid(), threading.get_ident())
+            cmd = [hipcc_path(), *flags, *extra, "-c", src, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
                 raise VicanError("hipcc failed:\n" + res.stdout + res.stderr)
-            os.replace(obj + ".tmp", obj)
+            os.replace(tmp, obj)
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as pool:
         objs = list(pool.map(compile_one, jobs))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out]
+    link_tmp = "%s.%d.tmp" % (out, os.getpid())
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", link_tmp]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(link_tmp):
+            os.remove(link_tmp)
         raise VicanError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(link_tmp, out)
     # keep the cache bounded: drop objects not used by the last few builds
     stale = sorted((os.path.getatime(os.path.join(cache, f)), f) for f in os.listdir(cache) if f.endswith(".o"))
     for _, f in stale[:-80]:
@@ -202,6 +216,10 @@ def load():
             "libvican_hip.so is missing (%s). Build it with `python __graft_entry__.py build` "
             "or vican_amd._lib.build_library(); there is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.vican_abi_version.restype = C.c_int
+    if lib.vican_abi_version() != ABI_VERSION:
+        raise VicanError("%s is stale: it reports ABI %d, this package needs %d - rebuild with "
+                         "`python __graft_entry__.py build`" % (LIB_PATH, lib.vican_abi_version(), ABI_VERSION))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

@@ -30,7 +30,7 @@
 #include "vican_sweep_common.h"
 thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
-extern "C" int vican_abi_version(void) { return 10; }
+extern "C" int vican_abi_version(void) { return VICAN_ABI_VERSION; }
 
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
