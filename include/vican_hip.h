@@ -82,7 +82,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 10            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 11            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -93,6 +93,21 @@ int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the 
  * device cancels it if the eigen-solve has not converged.  All other entry points ignore the gate.
  * NULL (the default) disables gating.                                                        */
 int vican_set_gate(const int32_t* gate);
+
+/* Grid barriers of the cooperative kernels (vican_lanczos_cam_coop, vican_cg_resident, vican_lanczos_resident) - state of
+ * the calling host thread.  Those kernels spin on a device counter, which terminates only if every workgroup of the grid
+ * is resident.  (1) Their launchers refuse grids that could not be co-resident on an idle device (occupancy query x
+ * compute units -> VICAN_ERR_CAPACITY; the caller uses the launch-sequence entry points instead).  (2) Every spin is
+ * bounded: after timeout_us (<= 0: the default, 2 s) of waiting a workgroup writes 1 to *abort_word and leaves, every other
+ * workgroup sees the word in its own spin and leaves too - a device shared with something that keeps part of the grid out
+ * (another process's resident kernel, a CU mask) yields an aborted launch, not a hung queue.  abort_word: 32-bit word the
+ * DEVICE can write and the host can read (pinned host memory: the host then polls it for free), zeroed by the caller;
+ * NULL: unbounded spins (no way to report).  After an abort the outputs of that launch are undefined and its barrier words
+ * must be zeroed before they are used again.                                                                       */
+int vican_set_barrier_abort(uint32_t* abort_word, int64_t timeout_us);
+/* Diagnostic: n_wg workgroups of `threads` threads with lds_bytes of LDS each that do nothing but stay resident for
+ * `microseconds` - stands in for "something else occupies the compute units" in the tests of the bounded barriers.  */
+int vican_test_occupy(int32_t n_wg, int32_t threads, int32_t lds_bytes, int64_t microseconds, void* stream);
 
 /* Launch timer (state of the calling host thread).  The NEXT launch of an edge sweep (vican_block_op(_z),
  * vican_dual_update(_op), vican_bip_apply) binds the two HIP events (hipEvent_t passed as void*, created by the caller
@@ -322,12 +337,15 @@ int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t
  * of the (fixed-order, deterministic) partial sums.
  * zpart != NULL: z is taken straight from the fixed-point slabs [n_slab][9][n_cam] of the preceding
  * vican_block_op (folded per workgroup with the conversion of vican_slab_reduce_fx: pa = fx+3, pb = fx+7),
- * which saves the separate fold launch of every Lanczos step; the argument z is then ignored.    */
+ * which saves the separate fold launch of every Lanczos step; the argument z is then ignored.
+ * fenced != 0: the grid barriers carry agent-scope release / acquire fences (for graphs whose sweeps leave little dirty
+ * data in L2 - up to ~64 slabs - where a fence costs 0.4-0.8 us; with the stress graph's 18 MB of slabs it costs ~10 us and
+ * the kernel relies on its agent-scope atomics alone).  Bounded spins / co-residency check: vican_set_barrier_abort.  */
 int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam);
 int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                            const double* z, double* ws, double* Hcol, double* beta, double* x_out,
                            double pivot_floor, uint32_t* sync_ws, const void* zpart, int32_t n_slab,
-                           const double* pa, const double* pb, void* stream);
+                           const double* pa, const double* pb, int32_t fenced, void* stream);
 
 /* Ritz step on the device (replaces the shift-invert ARPACK call of bipgo.py:288 together with the
  * Lanczos steps).  HB[steps][row_stride]: row j = projected column V^T L Q_j ([hw/3][3] row-major,
@@ -379,8 +397,10 @@ int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s
 
 /* Device-resident CG state (one struct in device memory, initialised by vican_cg_init).
  * Mirrors scipy.sparse.linalg.cg (x0 = 0, no preconditioner, stop when |r| < rtol*|b| tested at
- * the top of every iteration).  The sweeps accumulate q = A p in 64-bit fixed point; its scale
- * follows a bound pmax >= max|p| that is re-derived every iteration from measured maxima (|p_new| <= max|r| + beta max|p|).   */
+ * the top of every iteration).  The sweeps accumulate q = A p in DOUBLE-WORD fixed point (two 64-bit integers per sum:
+ * hi = rint(v qscale), lo = rint((v qscale - hi) 2^lo_bits), i.e. 49 + 48 bits below the bound - every term w p keeps the
+ * 53 bits scipy's f64 product gives it); qscale follows a bound pmax >= max|p| that is re-derived every iteration from
+ * measured maxima (|p_new| <= max|r| + beta max|p|).   */
 typedef struct vican_cg_state {
     double rho;        /* r.r of the current residual */
     double rho_prev;
@@ -400,9 +420,10 @@ typedef struct vican_cg_state {
     double wmax;       /* max edge weight (graph constant) */
     double pmax_time;  /* measured max |p_t| of the current iterate over THIS rank's rows (set by the step kernels) */
     int32_t iter;      /* completed iterations */
-    int32_t done;      /* 1 once converged: all later kernels are no-ops */
+    int32_t done;      /* 1 once converged, -2 when r.r became NaN, -1 when vican_cg_resident's barrier spin was aborted
+                          (vican_set_barrier_abort): all later kernels are no-ops */
     int32_t first;     /* 1 before the first iteration (p = r) */
-    int32_t pad;
+    int32_t lo_bits;   /* bits of the lo word of this sweep's double-word accumulators (48 unless n_add > 2^14) */
 } vican_cg_state_t;
 
 /* x=0, r=b, p=r for both node sets; |b_t|^2 into st->rr_time (caller all-reduces it across
@@ -421,12 +442,17 @@ int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, double rtol,
                    const double* rr_part, int32_t n_part, double n_add, vican_cg_state_t* st,
                    void* stream);
 /* Timestep-major Laplacian sweep: p_t <- r_t + beta p_t (skipped on the first
- * iteration), q_t = deg_t p_t - sum_c w_ct p_c (written), fixed-point slabs
- * qc_part[wg][3][C] = sum_t w_ct p_t (fold with vican_slab_reduce_fx, pa = &st->qinv),
+ * iteration), q_t = deg_t p_t - sum_c w_ct p_c (written), double-word fixed-point slabs
+ * qc_part[wg][2][3][C] = (hi, lo) planes of sum_t w_ct p_t (folded by vican_cg_iter_local),
  * pq_part[wg] = partial p_t.q_t.                                               */
 int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
                    const double* p_c, const double* r_t, double* p_t, double* q_t,
                    void* qc_part, double* pq_part, const vican_cg_state_t* st, void* stream);
+/* Fold of one sweep: qcpq[0:3C] = sum over the n_slab workgroup slabs of qc_part (double-word fixed point -> [C][3] doubles,
+ * each rounded once; exact, order-independent, overflow-proof integer sums) and qcpq[3C] = sum pq_part in a fixed order:
+ * the message a sharded run all-reduces per CG iteration.                          */
+int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
+                  const vican_cg_state_t* st, void* stream);
 /* *out = sum pq_part (the timestep part of p.q); `out` is normally the slot right
  * behind the reduced q_c vector so that ONE all-reduce carries both.           */
 int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out,
@@ -446,7 +472,7 @@ int vican_cg_time_step(int32_t n_time, const double* p_t, const double* q_t, dou
 /* st->rr_time = sum rr_part ; st->rmax_time = max ; st->iter += 1 ; rho_prev = rho. */
 int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_state_t* st, void* stream);
 /* Composites: one CG iteration as two host calls.  vican_cg_iter_local = cg_begin + cg_sweep +
- * slab fold + reduce_pq, leaving [q_c partial | p.q partial] in qcpq[3C+1] (all-reduce it when
+ * vican_cg_fold, leaving [q_c partial | p.q partial] in qcpq[3C+1] (all-reduce it when
  * sharded); vican_cg_iter_finish = cg_cam_step + cg_time_step (returns the number of rr partials). */
 int vican_cg_iter_local(const vican_graph_t* g, const double* w, const double* deg_t, const double* r_c,
                         double* p_c, const double* r_t, double* p_t, double* q_t, void* qc_part,
@@ -463,7 +489,7 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
  * graphs, where that sequence is bound by launch latency.  Same recurrences, stopping test (|r| < rtol |b| at the top of
  * an iteration, at most max_iter iterations) and fixed-point accumulation; the floating-point partial sums of r.r and
  * p.q are grouped per workgroup and the scale bound uses measured maxima on both node sets, so the iterates agree with
- * the multi-kernel path to rounding.  b_c [C][3], b_t [T][3]: right-hand side; x_c, x_t: solution; slab: n_wg * 3C 64-bit
+ * the multi-kernel path to rounding.  b_c [C][3], b_t [T][3]: right-hand side; x_c, x_t: solution; slab: n_wg * 6C 64-bit
  * words; ws: vican_cg_resident_ws_doubles() doubles (its barrier counter is zeroed in-stream by every call); wmax: max edge weight; rows_per_wg: most rows in one workgroup's chunk range [n_chunk b / n_wg,
  * n_chunk (b + 1) / n_wg); st receives the final state (iter, done, rho, bnorm2, ...).  n_add as for vican_cg_begin.   */
 int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t rows_per_wg);

@@ -30,7 +30,7 @@ def svd_polar(mats, mode):
 
 
 class NumpyBackend:
-    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64):
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64, deg_t=None, deg_c=None):
         self.C = int(n_cam)
         self.storage_f64 = np.dtype(storage) == np.float64
         self.T = len(row_ptr) - 1
@@ -42,6 +42,7 @@ class NumpyBackend:
         self.w = None if w is None else np.asarray(w, dtype=np.float64)
         self.u = None if u is None else np.asarray(u, dtype=np.float64).reshape(-1, 3)
         self.v = None if v is None else np.asarray(v, dtype=np.float64).reshape(-1, 3)
+        self.deg_t_in, self.deg_c_in = deg_t, deg_c      # the caller's diagonal of the translation system (frontend: J^T J as scipy forms it)
         self.rr_part_n = 1
         self._rr = 0.0
         self._gate = None
@@ -280,6 +281,10 @@ class NumpyBackend:
     def trans_degrees(self, deg_t, deg_c):
         d = np.zeros(max(self.T, 1)); np.add.at(d, self.row, self.w)
         dc = np.zeros(self.C); np.add.at(dc, self.col, self.w)
+        if self.deg_t_in is not None:
+            d[: self.T] = self.deg_t_in
+        if self.deg_c_in is not None:
+            dc = np.asarray(self.deg_c_in, dtype=np.float64)
         deg_t.numpy()[:] = d; deg_c.numpy()[:] = dc
 
     def jacobi_scale(self, deg, s_out):

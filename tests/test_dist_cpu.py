@@ -36,7 +36,8 @@ def _worker(rank, world, port, name, dt, out_q, tight=False):
         r0, r1 = _shard_rows(T, world, rank)
         e0, e1 = int(prob.row_ptr[r0]), int(prob.row_ptr[r1])
         K = NumpyBackend(prob.n_cam, prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], prob.col[e0:e1], prob.blk[e0:e1],
-                         prob.a[e0:e1], prob.w[e0:e1], prob.u[e0:e1], prob.v[e0:e1], storage=np.dtype(dt).type)
+                         prob.a[e0:e1], prob.w[e0:e1], prob.u[e0:e1], prob.v[e0:e1], storage=np.dtype(dt).type,
+                         deg_t=prob.deg_t[r0:r1], deg_c=prob.deg_c if rank == 0 else np.zeros_like(prob.deg_c))
         comm = Comm()
         rc, Rt, x_c, x_t, stats = solve_on_backend(K, comm, gc.MAXITER, 3 * (prob.n_cam + T), tight=tight)
         full = torch.zeros(T, 12, dtype=torch.float64)
@@ -73,7 +74,7 @@ def test_two_ranks_match_reference_and_single_rank(name, dt):
     assert abs(res["cg_iters"] - int(exp["cg_iters"])) <= 1
     # single-rank run of the same code: identical up to reduction order
     K1 = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v,
-                      storage=np.dtype(dt).type)
+                      storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c)
     rc1, Rt1, xc1, xt1, st1 = solve_on_backend(K1, Comm(), gc.MAXITER, 3 * (prob.n_cam + prob.n_time))
     # (the two runs may detect convergence of a spectral step one Lanczos step apart - the residual test is a
     #  threshold on rounding-level-different sums - so they agree to the eigen-tolerance, not to rounding)

@@ -43,6 +43,21 @@ def test_ranks_sharded_hip_solve_matches_single_rank(nranks):
     assert "dist probe: mismatches 0" in res.stdout
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_large_shop_golden_matches_the_reference(nranks):
+    """BASELINE configs[3] CHECKED, not just run (tools/dist_g9.py): the large_shop-scale golden through the drop-in API with
+    its 10 000 timesteps sharded over 2 / 4 ranks - poses against the REAL reference's with the single-rank tolerances
+    (rotations 1e-7 / 5e-6 rad, translations inside the reference's own reproducibility band, CG iterations inside its
+    101..106 window +- 1), and against the single-rank solve of the same processes."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_g9.py")]
+    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    print(res.stdout[-3000:])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "dist g9: mismatches 0" in res.stdout
+
+
 @pytest.mark.parametrize("workload,scaling,gpus", [("large_shop", "strong", 2), ("stress", "weak", 2), ("large_shop", "strong", 4)])
 def test_bench_launches_its_own_ranks(workload, scaling, gpus):
     """`python bench.py --gpus N` without a launcher starts N ranks itself and reports n_gpus = N; large_shop is

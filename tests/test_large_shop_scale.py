@@ -70,7 +70,9 @@ def test_dropin_matches_reference_at_large_shop_scale(case, dt):
     assert tr < min(translation_tol("g9_large_shop", dt), G9_TR_BOUND), tr
     # scipy's stopping rule is reproduced; the reference itself stops anywhere between 101 and 106 iterations under
     # rounding-level perturbations (the residual hovers around rtol |b| non-monotonically)
-    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= 15
+    from test_translation_stage import reference_window
+    lo, hi = reference_window("g9_large_shop", dt, int(exp["cg_iters"]))
+    assert lo - 1 <= info["cg_iters"] <= hi + 1, (info["cg_iters"], lo, hi)
     ev3 = np.sort(info["evals"][:, :3], axis=1)
     evr = np.sort(exp["evals"], axis=1)[:, :3]
     assert np.abs(ev3 - evr).max() < (1e-4 if dt == "float32" else 1e-7) * np.abs(exp["evals"]).max()

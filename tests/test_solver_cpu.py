@@ -45,7 +45,7 @@ def test_solver_logic_matches_reference(name, dt):
     g, case, prob = flatten_case(name, dt)
     exp = expected(g, "conjugate_gradient", dt)
     K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v,
-                     storage=np.dtype(dt).type)
+                     storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c)
     rc, Rt, x_c, x_t, stats = solve_on_backend(K, Comm(), gc.MAXITER, 3 * (prob.n_cam + prob.n_time))
     R, t = to_pose_arrays(prob, rc, Rt, x_c, x_t, exp["keys"], case["mode"] == "object")
     rot = float(geodesic(R, exp["R"]).max())
@@ -70,7 +70,7 @@ def test_tight_mode_reaches_the_converged_solution(name, tol):
     the reference's default answer is `dist_tight` away (0.15 mm ... 17 m)."""
     g, case, prob = flatten_case(name, "float64")
     exp = expected(g, "conjugate_gradient", "float64")
-    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.float64)
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.float64, deg_t=prob.deg_t, deg_c=prob.deg_c)
     rc, Rt, x_c, x_t, stats = solve_on_backend(K, Comm(), gc.MAXITER, 3 * (prob.n_cam + prob.n_time), tight=True)
     R, t = to_pose_arrays(prob, rc, Rt, x_c, x_t, exp["keys"], False)
     assert stats["converged"] and stats["relres"] < 1e-9 and stats["cg_iters"] < 200
@@ -99,7 +99,7 @@ def lsqr_case(name, dt, backend_factory):
 @pytest.mark.parametrize("name,dt", LSQR_RUNS)
 def test_lsqr_direct_matches_reference(name, dt):
     R, t, exp, stats = lsqr_case(name, dt, lambda prob, dt: NumpyBackend(
-        prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type))
+        prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c))
     f64 = dt == "float64"
     assert float(geodesic(R, exp["R"]).max()) < (1e-8 if f64 else 5e-6)
     assert stats["istop"] in (1, 2)

@@ -52,7 +52,7 @@ def run_stage(K, prob, exp):
 def test_translation_stage_alone_numpy_backend(name, dt):
     g, case, prob = flatten_case(name, dt)
     exp = expected(g, "conjugate_gradient", dt)
-    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type)
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c)
     dist, info = run_stage(K, prob, exp)
     assert dist < stage_tol(name, dt), dist
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
@@ -64,7 +64,7 @@ def hip_backend(prob, dt):
     tdt = torch.float32 if dt == "float32" else torch.float64
     to = lambda a, d=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, d)
     g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt),
-                   to(prob.w), to(prob.u), to(prob.v))
+                   to(prob.w), to(prob.u), to(prob.v), deg_t=to(prob.deg_t), deg_c=to(prob.deg_c))
     return HipBackend(g)
 
 
@@ -102,8 +102,17 @@ def test_translation_stage_alone_at_large_shop_scale(dt):
     print("g9 %s: translation stage alone: %.2e m from the reference's iterate, cg %d vs %d" % (
         dt, dist, info["cg_iters"], int(exp["cg_iters"])))
     assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
-    # iterations: the reference stops between 101 and 106 (goldens, cg_sensitivity fixture); the product's exact 64-bit
-    # fixed-point accumulation resolves 49 bits below max |w p|, scipy's f64 53 bits below every TERM, and q = A p is a
-    # Laplacian product (differences of nearly equal terms): reproduced on the host with a quantised matvec - exact 103,
-    # 49 bits 108-111, the 47 bits below a compounding bound of round 1 118
-    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack("g9_large_shop", dt, extra=8)
+    # iterations: the REAL reference stops at 101 (f64) / 105 (f32) in the golden run, at 103 in the sensitivity run of the
+    # same input (another process: ARPACK's start vector differs, rotations move by 1e-13) and anywhere in 101..106 under
+    # 1e-15 perturbations of its right-hand side.  The product's double-word accumulation (to_fix2: every term keeps its 53
+    # bits) lands inside that window; rounds 1-2 (one word, 47 / 49 bits below a global bound) stopped at 118 / 111.
+    lo, hi = reference_window("g9_large_shop", dt, int(exp["cg_iters"]))
+    assert lo - 1 <= info["cg_iters"] <= hi + 1, (info["cg_iters"], lo, hi)
+
+
+def reference_window(name, dt, golden_iters):
+    """[min, max] of the iteration counts the real reference itself has shown on this case (golden run + the nine runs of
+    tests/golden/cg_sensitivity.npz)."""
+    from util import cg_sensitivity
+    _, iters = cg_sensitivity(name, dt)
+    return min(int(iters.min()), golden_iters), max(int(iters.max()), golden_iters)

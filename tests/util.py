@@ -86,3 +86,53 @@ def iteration_slack(name, dt, extra=1):
     perturbations (g9: 101..106, g4: 20..24), plus `extra`."""
     _, iters = cg_sensitivity(name, dt)
     return extra if iters is None else int(iters.max() - iters.min()) + extra
+
+
+class SelfMovement:
+    """Context manager around the ORACLE's one ``scipy cg`` call (oracle/bipgo_oracle.py, reference bipgo.py:477): lets
+    the call through unchanged and repeats it ``n_trials`` times on right-hand sides perturbed by one unit in the last
+    place (``b * (1 + 1e-15 N(0,1))``, the recipe of tests/golden/make_cg_sensitivity.py, which does the same to the REAL
+    reference for the goldens).  ``self_move`` = how far the oracle's own answer moves (max over nodes, metres, one
+    value per trial), ``iters`` = CG iterations of the unperturbed call and of the trials.  That movement is the floor
+    under any translation tolerance - an independent implementation cannot agree with the reference better than the
+    reference agrees with itself - and, unlike the distance to the converged solution, it is not metres wide."""
+
+    def __init__(self, orc, n_trials=8, seed=12345):
+        self.orc, self.n_trials, self.seed = orc, n_trials, seed
+        self.self_move, self.iters = None, None
+
+    def __enter__(self):
+        self._cg = self.orc.cg
+
+        def cg(A, b, *a, **k):
+            cb = k.pop("callback", None)
+
+            def run(bb, user_cb=None):
+                n = [0]
+
+                def count(xk):
+                    n[0] += 1
+                    if user_cb is not None:
+                        user_cb(xk)
+                x, code = self._cg(A, bb, *a, callback=count, **k)
+                return x, code, n[0]
+            x, code, n0 = run(b, cb)
+            rng = np.random.default_rng(self.seed)
+            moves, iters = [], [n0]
+            for _ in range(self.n_trials):
+                xt, _, nt = run(b * (1.0 + 1e-15 * rng.standard_normal(b.shape)))
+                moves.append(float(np.linalg.norm((np.asarray(xt) - np.asarray(x)).reshape(-1, 3), axis=1).max()))
+                iters.append(nt)
+            self.self_move, self.iters = np.array(moves), np.array(iters)
+            return x, code
+        self.orc.cg = cg
+        return self
+
+    def __exit__(self, *exc):
+        self.orc.cg = self._cg
+        return False
+
+    def bound(self, factor=4.0, floor=1e-6):
+        """Translation tolerance (m): ``factor`` x the largest self-movement seen, floored where the oracle is
+        reproducible to rounding."""
+        return max(floor, factor * float(self.self_move.max()))

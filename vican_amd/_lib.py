@@ -28,6 +28,7 @@ INCLUDE = os.path.join(ROOT, "include")
 # VICAN_ABI_VERSION of include/vican_hip.h - the one place the number lives; load() rejects a library built from other sources
 ABI_VERSION = int(re.search(r"#define\s+VICAN_ABI_VERSION\s+(\d+)", open(os.path.join(INCLUDE, "vican_hip.h")).read()).group(1))
 
+ERR_ARG, ERR_LAUNCH, ERR_CAPACITY = -1, -2, -3          # VICAN_ERR_*
 STORE_F32, STORE_F64 = 0, 1
 LAYOUT_BLOCK, LAYOUT_WAVE = 0, 1
 PAD_SLOT = 0xFFFFFFFF
@@ -48,7 +49,7 @@ class Graph(C.Structure):
 CG_STATE_DOUBLES = 19
 CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9,
             rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15, pmax_time=16)
-CG_I = dict(iter=34, done=35, first=36)     # int32 index into the same buffer viewed as int32
+CG_I = dict(iter=34, done=35, first=36, lo_bits=37)     # int32 index into the same buffer viewed as int32
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _G = C.POINTER(Graph)
@@ -59,9 +60,11 @@ PROTOTYPES = {
     "vican_last_error": (C.c_char_p, []),
     "vican_abi_version": (C.c_int, []),
     "vican_set_gate": (C.c_int, [_vp]),
+    "vican_set_barrier_abort": (C.c_int, [_vp, _i64]),
+    "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_set_launch_events": (C.c_int, [_vp, _vp]),
     "vican_lanczos_coop_ws_doubles": (_i64, [_i32]),
-    "vican_lanczos_cam_coop": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "vican_lanczos_cam_coop": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "vican_jacobi_scale": (C.c_int, [_i32, _vp, _vp, _vp]),
     "vican_row_scale": (C.c_int, [_i32, _i32, _vp, _vp, _vp]),
     "vican_scale_weights": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
@@ -105,6 +108,7 @@ PROTOTYPES = {
     "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_sweep": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_fold": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vican_cg_reduce_pq": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "vican_cg_cam_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_time_step": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -31,7 +31,8 @@ import torch
 from . import frontend
 from ._lib import VicanError
 from .geometry import SE3
-from .solver import Comm, GeneralRotationSolver, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver
+from .solver import (Comm, GeneralRotationSolver, LsqrTranslationSolver, RotationSolver, TightTranslationSolver, TranslationSolver,
+                     with_cooperative_fallback)
 
 __all__ = ["bipartite_se3sync", "bipartite_se3sync_arrays", "object_bipartite_se3sync", "bipartite_so3sync", "solve_problem",
            "DisconnectedGraphWarning"]
@@ -76,42 +77,55 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     e0, e1 = int(prob.row_ptr[r0]), int(prob.row_ptr[r1])
     t0 = time.perf_counter()
     to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    # diagonal of the reference's J^T J as scipy forms it (frontend.flatten_arrays); the camera part is all-reduced by the
+    # solver, so rank 0 carries it and the other ranks contribute zeros
+    deg_t = to(prob.deg_t[r0:r1]) if getattr(prob, "deg_t", None) is not None else None
+    deg_c = None
+    if getattr(prob, "deg_c", None) is not None:
+        deg_c = to(prob.deg_c if comm.rank == 0 else np.zeros_like(prob.deg_c))
     g, K = make_backend(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
-                        to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]))
+                        to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]),
+                        deg_t=deg_t, deg_c=deg_c)
     if lsqr_solver == "direct" and g.layout == "tiled":
         raise VicanError("lsqr_solver='direct' is not available beyond %d cameras (camera-tiled graph); use 'conjugate_gradient'" % TILE_CAMS)
     t1 = time.perf_counter()
-    rot = RotationSolver(K, comm, eig_tol=eig_tol)
-    rc, Rt_loc = rot.run(maxiter)
-    if info is not None:                   # phase timings wanted: costs a pipeline bubble between the two stages
-        K.synchronize()
-    t2 = time.perf_counter()
     nloc = r1 - r0
-
     bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]
 
     def gather_rows(loc, width):          # one all-gather of the ranks' row blocks
         return comm.gather_rows(loc.reshape(-1, width), nloc, bounds)
 
-    Rt_all = gather_rows(Rt_loc, 9)
-    if tight:                                                            # not in the reference (module docstring)
-        tr = TightTranslationSolver(K, comm)
-        tr.setup(rc, Rt_loc)
-        x_c, x_t = tr.solve(3 * (prob.n_cam + T))
-        if not tr.info["converged"]:
-            raise AssertionError("tight CG did not converge")
-    elif lsqr_solver == "direct":                                        # bipgo.py:479-480
-        Rc_h = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()
-        Rt_h = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()
-        tr = LsqrTranslationSolver(K, comm)
-        x_c, x_t = tr.solve(rc, Rt_loc, 3 * (prob.n_cam + T), frontend.bnorm2(prob, Rc_h, Rt_h))
-    else:                                                                # bipgo.py:476-478
-        tr = TranslationSolver(K, comm)
-        tr.setup(rc, Rt_loc)
-        x_c, x_t = tr.solve(3 * (prob.n_cam + T))
-        if not tr.info["converged"]:
-            raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
-    K.synchronize()
+    tm = {}
+
+    def stages():
+        rot = RotationSolver(K, comm, eig_tol=eig_tol)
+        rc, Rt_loc = rot.run(maxiter)
+        if info is not None:                   # phase timings wanted: costs a pipeline bubble between the two stages
+            K.synchronize()
+        tm["t2"] = time.perf_counter()
+        Rt_all = gather_rows(Rt_loc, 9)
+        if tight:                                                            # not in the reference (module docstring)
+            tr = TightTranslationSolver(K, comm)
+            tr.setup(rc, Rt_loc)
+            x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+            if not tr.info["converged"] and not K.barrier_aborted():
+                raise AssertionError("tight CG did not converge")
+        elif lsqr_solver == "direct":                                        # bipgo.py:479-480
+            Rc_h = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()
+            Rt_h = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()
+            tr = LsqrTranslationSolver(K, comm)
+            x_c, x_t = tr.solve(rc, Rt_loc, 3 * (prob.n_cam + T), frontend.bnorm2(prob, Rc_h, Rt_h))
+        else:                                                                # bipgo.py:476-478
+            tr = TranslationSolver(K, comm)
+            tr.setup(rc, Rt_loc)
+            x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+            if not tr.info["converged"] and not K.barrier_aborted():
+                raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
+        return rot, tr, rc, Rt_all, x_c, x_t
+
+    # (a cooperative kernel whose grid barrier timed out - device shared - makes the stages run again on the launch sequences)
+    rot, tr, rc, Rt_all, x_c, x_t = with_cooperative_fallback(K, comm, stages)
+    t2 = tm["t2"]
     t3 = time.perf_counter()
     xt_all = gather_rows(x_t, 3)
     Rc = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()          # bipgo.py:346

@@ -14,8 +14,8 @@
 //     sum_t w p_t (slab per workgroup -> each workgroup folds a slice of the cameras -> everybody reads the 3C sums) and
 //     the partial dot products / maxima.  Everything that crosses is written and read with agent-scope atomics
 //     (write-through / L1-bypassing), the barrier is the relaxed counter of lanczos_cam_coop_kernel.
-// Arithmetic is that of the multi-kernel path: contributions w p in f64, exact 64-bit fixed-point accumulation with the
-// scale of cg_begin_kernel (49 bits below wmax * max(max|p_c|, max|r_t| + beta max|p_t|)), scipy's recurrences and its
+// Arithmetic is that of the multi-kernel path: contributions w p in f64, exact double-word fixed-point accumulation (to_fix2:
+// hi word 49 bits below wmax * max(max|p_c|, max|r_t| + beta max|p_t|) as cg_begin_kernel, lo word 48 more), scipy's recurrences and its
 // stopping test |r| < rtol |b| at the top of every iteration.  Only the grouping of the floating-point partial sums of
 // r.r and p.q differs (per workgroup here, per 1024 elements there), i.e. the iterates agree to rounding, not to the bit.
 #include "vican_sweep_common.h"
@@ -28,21 +28,11 @@ __device__ __forceinline__ double cgr_ld(const double* p) { return __hip_atomic_
 __device__ __forceinline__ void cgr_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 cgr_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// grid barrier: a counter that only grows during a launch, with an agent-scope RELEASE before the arrival and ACQUIRE after
-// the exit.  On a capture-sized graph the L2 holds little dirty data, so the write-back / invalidate these fences lower to
-// costs 0.4 us per barrier (the cooperative Lanczos step on the stress graph, with 18 MB of slabs in L2, pays 10 us and
-// therefore relies on agent-scope atomics alone - vican_kernels.hip); what crosses workgroups is still written and read
-// with agent-scope atomics, the fences make the ordering a property of the memory model instead of the ISA.
-__device__ __forceinline__ void cgr_grid_sync(unsigned int* counter, unsigned int target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
+// grid barrier: vican_grid_sync (vican_common.h) in its fenced form - a counter that only grows during a launch, with an
+// agent-scope RELEASE before the arrival and ACQUIRE after the exit, and a BOUNDED spin.  On a capture-sized graph the L2
+// holds little dirty data, so the write-back / invalidate these fences lower to costs 0.4 us per barrier (the cooperative
+// Lanczos step on the stress graph, with 18 MB of slabs in L2, would pay 10 us); what crosses workgroups is still written
+// and read with agent-scope atomics, the fences make the ordering a property of the memory model instead of the ISA.
 
 // deterministic block reductions of up to three sums and three maxima in one pass: 4 wavefronts
 struct Cgr6 { double s0, s1, s2, a, b, c; };
@@ -79,10 +69,10 @@ __device__ __forceinline__ double cgr_sum(double s, double* red) {
 // LDS: camera side 8 (5 * 3C + C) bytes; per wavefront the striped row accumulators and the staging of a chunk's rows;
 // the four timestep vectors of the workgroup's own rows
 extern "C" int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t rows_per_wg) {
-    const int64_t per_wave = (((int64_t)max_rows * 3 * (8LL * n_copy + 8)) + 15) & ~15LL;
-    return 8LL * (5 * 3 * (int64_t)n_cam + n_cam) + CGR_NW * per_wave + 4LL * 24 * rows_per_wg + 256;
+    const int64_t per_wave = (((int64_t)max_rows * 3 * (16LL * n_copy + 8)) + 15) & ~15LL;
+    return 8LL * (6 * 3 * (int64_t)n_cam + n_cam) + CGR_NW * per_wave + 4LL * 24 * rows_per_wg + 256;
 }
-extern "C" int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg) { return 3LL * n_cam + 4LL * n_wg + 8 + 16; }
+extern "C" int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg) { return 9LL * n_cam + 4LL * n_wg + 8 + 16; }
 
 template <int EPL>
 struct CgrEdges { uint32_t id[EPL]; double w[EPL]; };
@@ -91,15 +81,16 @@ template <int EPL, int TRIPS>
 __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
     vican_graph_t g, const double* __restrict__ w, const double* __restrict__ deg_t, const double* __restrict__ deg_c,
     const double* __restrict__ b_c, const double* __restrict__ b_t, double* __restrict__ x_c, double* __restrict__ x_t, u64* slab,
-    double* ws, double rtol, int max_iter, double n_add, double wmax, int rows_cap, vican_cg_state_t* st) {
+    double* ws, double rtol, int max_iter, double n_add, double wmax, int rows_cap, vican_cg_state_t* st, uint32_t* abort_word,
+    unsigned long long spin_limit) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red[24];
     const int C = g.n_cam, n3 = 3 * C, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
     const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = gridDim.x, wg = blockIdx.x;
-    u64* qc = (u64*)lds_raw;                    // [3][C] planes: camera partial sums of this workgroup (fixed point)
-    double* pcs = (double*)(qc + n3);           // [3][C] planes: p_c
+    u64* qc = (u64*)lds_raw;                    // [2][3][C] planes: camera partial sums of this workgroup (hi words, lo words)
+    double* pcs = (double*)(qc + 2 * n3);       // [3][C] planes: p_c
     double* rcs = pcs + n3;                     // r_c
     double* xcs = rcs + n3;                     // x_c
     double* qcs = xcs + n3;                     // q_c of the current iteration
@@ -108,16 +99,24 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
     double* rts = xts + 3 * (size_t)rows_cap;
     double* pts = rts + 3 * (size_t)rows_cap;
     double* qts = pts + 3 * (size_t)rows_cap;
-    const size_t per_wave = (((size_t)RW * 3 * (8 * ncopy + 8)) + 15) & ~(size_t)15;
+    const size_t per_wave = (((size_t)RW * 3 * (16 * ncopy + 8)) + 15) & ~(size_t)15;
     unsigned char* wbase = (unsigned char*)(qts + 3 * (size_t)rows_cap) + (size_t)wave * per_wave;
-    u64* qt = (u64*)wbase;                      // [RW * 3][ncopy] striped row accumulators (this wavefront's)
-    double* dps = (double*)(qt + (size_t)RW * 3 * ncopy);     // [RW * 3] deg_t p of the chunk's rows
-    // workspace: [3C] folded camera sums (as u64), [nwg][4] partials (r.r, max|r_t|, p.q, max|p_t|), barrier counter
+    u64* qt = (u64*)wbase;                      // [2][RW * 3][ncopy] striped row accumulators (this wavefront's): hi, lo
+    const int lo_t = 3 * RW * ncopy;
+    double* dps = (double*)(qt + (size_t)2 * lo_t);           // [RW * 3] deg_t p of the chunk's rows
+    // workspace: [3][3C] folded camera sums (hi in two halves, lo: fix3_add), [nwg][4] partials (r.r, max|r_t|, p.q, max|p_t|), barrier counter
     u64* qc_sum = (u64*)ws;
-    double* part = ws + n3;
+    double* part = ws + 3 * n3;
     unsigned int* sync = (unsigned int*)(part + 4 * (size_t)nwg);
     unsigned int nbar = 0;
-    auto gsync = [&]() { ++nbar; cgr_grid_sync(sync, nbar * (unsigned)nwg); };
+    const vican_sync_t sy = {sync, abort_word, spin_limit};
+    // a barrier that was not passed (bounded spin, vican_set_barrier_abort) ends the launch: done = -1 tells the host
+    auto gsync = [&]() -> bool {
+        ++nbar;
+        if (vican_grid_sync(sy, nbar * (unsigned)nwg, true)) return true;
+        if (wg == 0 && tid == 0) { st->done = -1; st->iter = 0; }
+        return false;
+    };
 #ifdef VICAN_CGRSTAMP   /* diagnostic build: wall-clock per phase (100 MHz ticks) of workgroup 0 -> ws tail */
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memrealtime();
 #define RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -162,21 +161,24 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         rcs[j] = b; pcs[j] = b; xcs[j] = 0.0; sc += b * b; mc = fmax(mc, fabs(b));
         if (comp == 0) dgc[cam] = deg_c[cam];
     }
-    for (int i = lane; i < 3 * RW * ncopy; i += 64) qt[i] = 0ull;
+    for (int i = lane; i < 2 * lo_t; i += 64) qt[i] = 0ull;
     Cgr6 t = cgr_reduce6(s, sc, 0.0, m, mc, 0.0, red);
     if (tid == 0) { cgr_st(part + 4 * wg, t.s0); cgr_st(part + 4 * wg + 1, t.a); }
     double rr_cam = t.s1, rmax_cam = t.b, pcmax = t.b;
-    gsync();
+    if (!gsync()) return;
     t = cgr_reduce6(tid < nwg ? cgr_ld(part + 4 * tid) : 0.0, 0.0, 0.0, tid < nwg ? cgr_ld(part + 4 * tid + 1) : 0.0, 0.0, 0.0, red);
     double rr_time = t.s0, rmax_time = t.a, pmax_time = 0.0;
     double rho = 0.0, rho_prev = 0.0, bnorm2 = 0.0, atol2 = 0.0, beta = 0.0, alpha = 0.0, pq = 0.0, pmax = 0.0;
     double scale = 1.0, inv = 1.0;
+    const int lob = fix2_lo_bits(n_add);
+    const double lo_scale = ldexp(1.0, lob);
     int iter = 0, done = 0;
 
     for (int k = 0;; ++k) {
         rho = rr_cam + rr_time;
         if (k == 0) { bnorm2 = rho; atol2 = rtol * rtol * rho; }
         if (sqrt(rho) < sqrt(atol2) || rho == 0.0) { done = 1; break; }            // scipy: norm(r) < atol, before the step
+        if (!(rho == rho)) { done = -2; break; }                                     // NaN input: scipy would spin to maxiter; report instead
         if (k >= max_iter) break;
         const bool first = k == 0;
         beta = first ? 0.0 : rho / rho_prev;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         // p = r + beta p on both node sets
         for (int j = tid; j < n3; j += CGR_THREADS) {
             if (!first) pcs[j] = rcs[j] + beta * pcs[j];
-            qc[j] = 0ull;
+            qc[j] = 0ull; qc[n3 + j] = 0ull;
         }
         if (!first)
             for (int i = tid; i < ni; i += CGR_THREADS) pts[i] = rts[i] + beta * pts[i];
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
                     for (int i = 0; i < 3; ++i) pr[j][i] = pr[j - 1][i];
                 }
             }
-            u64 fc[EPL][3], fr[EPL][3];
+            Fix2 fc[EPL][3];
+            double ar[EPL][3];
             {
                 double acc[3] = {0, 0, 0};
 #pragma unroll
@@ -233,30 +236,34 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         acc[i] += wj[j] * pc[j][i];
-                        fc[j][i] = to_fix(wj[j] * pr[j][i], scale);
-                        fr[j][i] = to_fix(acc[i], scale);
+                        fc[j][i] = to_fix2(wj[j] * pr[j][i], scale, lo_scale);
+                        ar[j][i] = acc[i];
                     }
                 }
             }
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) lds_add_fix(&qc[i * C + cam[j]], fc[j][i]);
+                for (int i = 0; i < 3; ++i) { lds_add_fix(&qc[i * C + cam[j]], fc[j][i].hi); lds_add_fix(&qc[n3 + i * C + cam[j]], fc[j][i].lo); }
                 if (j == EPL - 1 || row[j] != row[j + 1]) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(row[j] * 3 + i) * ncopy + lane_copy], fr[j][i]);
+                    for (int i = 0; i < 3; ++i) {
+                        const Fix2 f = to_fix2(ar[j][i], scale, lo_scale);
+                        u64* a = &qt[(row[j] * 3 + i) * ncopy + lane_copy];
+                        lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             for (int base = 0; base < nr3 * ncopy; base += 64) {
                 const int a = base + lane;
                 const bool live = a < nr3 * ncopy;
-                u64 sum = 0ull;
-                if (live) { sum = qt[a]; qt[a] = 0ull; }
-                sum = stripe_sum(sum, ncopy);
+                u64 sum = 0ull, slo = 0ull;
+                if (live) { sum = qt[a]; slo = qt[lo_t + a]; qt[a] = 0ull; qt[lo_t + a] = 0ull; }
+                sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
                 if (live && (a & cmask) == 0) {
                     const int i = a / ncopy;
-                    const double qv = dps[i] - (double)(long long)sum * inv;
+                    const double qv = dps[i] - fix2_value((long long)sum, (long long)slo, lob, inv);
                     qts[l0 + i] = qv;
                     pqs += pl[i] * qv;
                 }
@@ -272,29 +279,30 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         }
         __syncthreads();
         RSTAMP(1);
-        for (int j = tid; j < n3; j += CGR_THREADS) cgr_st(slab + (size_t)wg * n3 + j, qc[j]);
+        for (int j = tid; j < 2 * n3; j += CGR_THREADS) cgr_st(slab + (size_t)wg * 2 * n3 + j, qc[j]);
         const double pq_loc = cgr_sum(pqs, red);
         if (tid == 0) cgr_st(part + 4 * wg + 2, pq_loc);
         RSTAMP(2);
-        gsync();
+        if (!gsync()) return;
         RSTAMP(3);
 
-        // ---- fold this workgroup's slice of the camera sums over all slabs (8 lanes per element, exact integer sums)
+        // ---- fold this workgroup's slice of the camera sums over all slabs (8 lanes per element; exact, overflow-proof integer sums)
         for (int e = j0 + (tid >> 3); e < j1; e += CGR_THREADS / 8) {
-            u64 sum = 0ull;
-            for (int q = tid & 7; q < nwg; q += 8) sum += cgr_ld(slab + (size_t)q * n3 + e);
-            sum = stripe_sum(sum, 8);
-            if ((tid & 7) == 0) cgr_st(qc_sum + e, sum);
+            Fix3 a = {0, 0, 0};
+            for (int q = tid & 7; q < nwg; q += 8)
+                fix3_add(a, (long long)cgr_ld(slab + (size_t)q * 2 * n3 + e), (long long)cgr_ld(slab + (size_t)q * 2 * n3 + n3 + e), lob);
+            const u64 st_ = stripe_sum((u64)a.top, 8), sb_ = stripe_sum((u64)a.bot, 8), sl_ = stripe_sum((u64)a.lo, 8);
+            if ((tid & 7) == 0) { cgr_st(qc_sum + e, st_); cgr_st(qc_sum + n3 + e, sb_); cgr_st(qc_sum + 2 * n3 + e, sl_); }
         }
         RSTAMP(4);
-        gsync();
+        if (!gsync()) return;
         RSTAMP(5);
 
         // ---- alpha, x += alpha p, r -= alpha q (camera side replicated, timestep side on the own rows)
         double sq = tid < nwg ? cgr_ld(part + 4 * tid + 2) : 0.0;               // p.q: timestep partials + camera terms
         for (int j = tid; j < n3; j += CGR_THREADS) {
             const int comp = j / C, cam = j - comp * C;
-            const double q = dgc[cam] * pcs[j] - (double)(long long)cgr_ld(qc_sum + j) * inv;
+            const double q = dgc[cam] * pcs[j] - fix3_value((long long)cgr_ld(qc_sum + j), (long long)cgr_ld(qc_sum + n3 + j), (long long)cgr_ld(qc_sum + 2 * n3 + j), lob, inv);
             qcs[j] = q; sq += pcs[j] * q;
         }
         pq = cgr_sum(sq, red);
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             pcmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         }
         RSTAMP(7);
-        gsync();
+        if (!gsync()) return;
         RSTAMP(8);
         t = cgr_reduce6(tid < nwg ? cgr_ld(part + 4 * tid) : 0.0, 0.0, 0.0, tid < nwg ? cgr_ld(part + 4 * tid + 1) : 0.0,
                         tid < nwg ? cgr_ld(part + 4 * tid + 3) : 0.0, 0.0, red);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             st->rho = rho; st->rho_prev = rho_prev; st->pq = pq; st->alpha = alpha; st->beta = beta; st->bnorm2 = bnorm2;
             st->atol2 = atol2; st->rr_cam = rr_cam; st->pq_time = 0.0; st->rr_time = rr_time; st->rmax_cam = rmax_cam;
             st->rmax_time = rmax_time; st->pmax = pmax; st->qscale = scale; st->qinv = inv; st->wmax = wmax;
-            st->pmax_time = pmax_time; st->iter = iter; st->done = done; st->first = iter == 0; st->pad = 0;
+            st->pmax_time = pmax_time; st->iter = iter; st->done = done; st->first = iter == 0; st->lo_bits = lob;
         }
     }
     __syncthreads();
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
 }
 
 // The whole CG solve in one launch (wave-layout graphs whose grid is co-resident: n_wg <= compute units).
-// x_c [C][3], x_t [T][3]: solution; slab: n_wg * 3C 64-bit words; ws: vican_cg_resident_ws_doubles doubles (the barrier counter
+// x_c [C][3], x_t [T][3]: solution; slab: n_wg * 6C 64-bit words (double-word camera partials); ws: vican_cg_resident_ws_doubles doubles (the barrier counter
 // in it is zeroed in-stream by every call); rows_per_wg: max rows of one workgroup's chunk range [n_chunk b / n_wg,
 // n_chunk (b + 1) / n_wg); st: receives the final state (iter, done, rho, bnorm2, ...).
 extern "C" int vican_cg_resident(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c, const double* b_c,
@@ -384,15 +392,16 @@ extern "C" int vican_cg_resident(const vican_graph_t* g, const double* w, const 
     hipStream_t s = (hipStream_t)stream;
     // the barrier counter (behind the [3C] sums and the [n_wg][4] partials): armed here, so that a launch that was torn down
     // cannot make the next one pass its barriers early
-    if (hipMemsetAsync(ws + 3 * (size_t)g->n_cam + 4 * (size_t)g->n_wg, 0, 8, s) != hipSuccess)
+    if (hipMemsetAsync(ws + 9 * (size_t)g->n_cam + 4 * (size_t)g->n_wg, 0, 8, s) != hipSuccess)
         return set_err(VICAN_ERR_LAUNCH, "vican_cg_resident: memset failed");
 #define CGR_LAUNCH(E_, T_)                                                                                                \
     do {                                                                                                                  \
         auto kern = cg_resident_kernel<E_, T_>;                                                                           \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
+        if (int rc_ = vican_coresident_ok((const void*)kern, CGR_THREADS, lds, g->n_wg, "vican_cg_resident")) return rc_;  \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(CGR_THREADS), lds, s, *g, w, deg_t, deg_c, b_c, b_t, x_c, x_t, (u64*)slab, ws,  \
-                           rtol, (int)max_iter, n_add, wmax, (int)rows_per_wg, st);                                       \
+                           rtol, (int)max_iter, n_add, wmax, (int)rows_per_wg, st, g_vican_abort_word, g_vican_sync_ticks); \
     } while (0)
     if (epl == 4) { if (trips <= 1) CGR_LAUNCH(4, 1); else if (trips == 2) CGR_LAUNCH(4, 2); else CGR_LAUNCH(4, 3); }
     else          { if (trips <= 1) CGR_LAUNCH(2, 1); else if (trips == 2) CGR_LAUNCH(2, 2); else CGR_LAUNCH(2, 3); }

@@ -50,7 +50,58 @@ extern thread_local hipEvent_t g_vican_ev_start, g_vican_ev_stop;
         }                                                                                                          \
     } while (0)
 static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 96LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 144) + 256; }
-static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 48LL * n_cam + (int64_t)max_rows * (48LL * n_copy + 96) + 256; }
+// (double-word camera sums [2][3][C] + p_c planes; double-buffered double-word row stripes + two staging arrays)
+static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 72LL * n_cam + (int64_t)max_rows * (96LL * n_copy + 96) + 256; }
+// ---------------------------------------------------------------------------
+// Grid barriers of the cooperative kernels (lanczos_cam_coop_kernel, cg_resident_kernel, lanczos_resident_kernel)
+// ---------------------------------------------------------------------------
+// These kernels spin on a device counter, which only terminates if every workgroup of the grid is resident.  Three
+// layers make that safe:
+//   1. the launchers refuse grids that cannot be co-resident on an idle device (vican_coresident_ok: occupancy query x
+//      compute units), so the host falls back to the launch-sequence paths;
+//   2. every spin is BOUNDED: after `limit` ticks of the 100 MHz real-time counter (vican_set_barrier_abort, default 2 s) a
+//      workgroup raises the abort word and leaves; every other workgroup sees the word in its own spin loop (or at its
+//      first barrier if it was dispatched late) and leaves too - a grid that shares the device with something that keeps
+//      its workgroups out (another process's resident kernel, a CU mask) ends with an error instead of hanging the queue;
+//   3. the abort word lives in host-visible memory: the host polls it for free, re-runs on the launch-sequence path and
+//      stops using the cooperative kernels (device.HipBackend.barrier_aborted).
+// `fenced`: agent-scope RELEASE before the arrival / ACQUIRE after the exit (the portable ordering; costs an L2 write-back,
+// 0.4-0.8 us with little dirty data).  Without it the callers' cross-workgroup data must travel as agent-scope atomics.
+extern thread_local uint32_t* g_vican_abort_word;          // vican_sweep.hip (vican_set_barrier_abort)
+extern thread_local unsigned long long g_vican_sync_ticks;
+struct vican_sync_t { unsigned int* counter; uint32_t* abort_word; unsigned long long limit; };
+static inline vican_sync_t vican_sync_args(unsigned int* counter) { return vican_sync_t{counter, g_vican_abort_word, g_vican_sync_ticks}; }
+int vican_coresident_ok(const void* kernel, int block_threads, size_t lds_bytes, int grid, const char* who);   // vican_sweep.hip
+
+// returns true when the barrier was passed, false when the launch is aborted (the caller returns from the kernel)
+__device__ __forceinline__ bool vican_grid_sync(const vican_sync_t& sy, unsigned int target, bool fenced) {
+    __shared__ int s_pass;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(sy.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int pass = 1;
+        if (__hip_atomic_load(sy.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned int spins = 0;
+            while (__hip_atomic_load(sy.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 && sy.abort_word) {           // (host memory: looked at every ~1000 polls only)
+                    if (__hip_atomic_load(sy.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { pass = 0; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > sy.limit) {
+                        __hip_atomic_store(sy.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        pass = 0; break;
+                    }
+                }
+            }
+        }
+        if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_pass = pass;
+    }
+    __syncthreads();
+    return s_pass != 0;
+}
+
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------

@@ -543,14 +543,8 @@ __device__ __forceinline__ double ld_agent(const double* p) {
 // 18 MB of slabs included, ~10 us per barrier.  The reliance on this ISA behaviour is pinned by
 // tests/test_kernels_gpu.py::test_cooperative_step_repeats_bit_identically (3000 repetitions, bit-identical), and the
 // counter is zeroed at the start of every eigen-solve (by the seed kernel, vican_lanczos_seed(coop_sync)).
-__device__ __forceinline__ void coop_grid_sync(unsigned int* counter, unsigned int target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
+// Graphs with few slabs (<= 64 workgroups in the sweep, i.e. little dirty data in L2) take the fenced form of the barrier
+// anyway (`fenced`: +0.4-0.8 us per barrier there); the spin itself is bounded (vican_grid_sync, vican_common.h).
 // partial H = V[:, :ka]^T R over this workgroup's rows, to part[ka*3]; vs: this workgroup's rows of the basis, staged in
 // LDS as [ka][COOP_ROWS].  8 lanes per element: strided rows, then a DPP sum over the 8 lanes.  (The first version gave a
 // wavefront to each basis vector and reduced three sums over 64 lanes with shuffles - 36 ds_bpermute per vector, ~1.2 us,
@@ -623,8 +617,10 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
                                                                double* __restrict__ x_out, double pivot_floor,
                                                                unsigned int* sync, const long long* __restrict__ zpart,
                                                                int n_slab, const double* __restrict__ pa,
-                                                               const double* __restrict__ pb) {
-    extern __shared__ double vs[];                       // [ka][COOP_ROWS]: this workgroup's rows of the basis,
+                                                               const double* __restrict__ pb, uint32_t* abort_word,
+                                                               unsigned long long spin_limit, int fenced) {
+    extern __shared__ double vs[];
+    const vican_sync_t sy = {sync, abort_word, spin_limit};                       // [ka][COOP_ROWS]: this workgroup's rows of the basis,
     __shared__ double rs[3][COOP_ROWS];                  // read from global memory ONCE for all four uses
     __shared__ double h[KA_MAX * 3], h2[KA_MAX * 3];
     __shared__ double g6[4][6], G6s[6];
@@ -709,7 +705,7 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         CSTAMP();
         coop_gram(vs, ka, nsl, rs, part, nwg, wg);
         CSTAMP();
-        coop_grid_sync(&sync[0], (unsigned)((pass + 1) * nwg));
+        if (!vican_grid_sync(sy, (unsigned)((pass + 1) * nwg), fenced != 0)) return;
         CSTAMP();
         coop_reduce(part, hs, nwg, stage, hh);
         if (tid < nsl) {
@@ -739,7 +735,7 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         if (tid < 6) st_agent(partG + (size_t)tid * nwg + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
     }
     CSTAMP();
-    coop_grid_sync(&sync[0], (unsigned)(3 * nwg));
+    if (!vican_grid_sync(sy, (unsigned)(3 * nwg), fenced != 0)) return;
     CSTAMP();
     coop_reduce(partG, 6, nwg, stage, G6s);
     // upper Cholesky G = beta^T beta, Q = R beta^-1  (same pivot rule as chol_qr3_kernel)
@@ -784,7 +780,7 @@ extern "C" int64_t vican_lanczos_coop_ws_doubles(int32_t n_cam) {
 extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j, const double* z,
                                       double* ws, double* Hcol, double* beta, double* x_out, double pivot_floor,
                                       uint32_t* sync_ws, const void* zpart, int32_t n_slab, const double* pa, const double* pb,
-                                      void* stream) {
+                                      int32_t fenced, void* stream) {
     if (n_cam <= 0 || n_cam > 32 * COOP_CAMS || !lamC || !V || (!z && !zpart) || (zpart && n_slab <= 0) || !ws || !Hcol || !beta ||
         !x_out || !sync_ws || j < 0 ||
         3 * (j + 1) > 128 || ld < 3 * n_cam)                 // basis slice in LDS: 128 x 96 doubles = 96 KB
@@ -797,8 +793,16 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
             return set_err(VICAN_ERR_LAUNCH, "vican_lanczos_cam_coop: cannot raise dynamic LDS limit");
         configured = 128 * COOP_ROWS * 8;
     }
+    {   // co-residency of the grid on an idle device (checked once per LDS size class; <= 32 workgroups of 256 threads)
+        static size_t checked = 0;
+        if (lds > checked || checked == 0) {
+            if (int rc = vican_coresident_ok((const void*)lanczos_cam_coop_kernel, 256, lds, nwg, "vican_lanczos_cam_coop")) return rc;
+            checked = lds > 0 ? lds : 1;
+        }
+    }
     hipLaunchKernelGGL(lanczos_cam_coop_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, ws, Hcol,
-                       beta, x_out, pivot_floor, sync_ws, (const long long*)zpart, n_slab, pa, pb);
+                       beta, x_out, pivot_floor, sync_ws, (const long long*)zpart, n_slab, pa, pb, g_vican_abort_word,
+                       g_vican_sync_ticks, (int)fenced);
     LAUNCH_CHECK("vican_lanczos_cam_coop");
     return VICAN_OK;
 }

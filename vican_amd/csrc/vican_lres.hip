@@ -34,18 +34,8 @@ __device__ __forceinline__ double lr_ld(const double* p) {
 __device__ __forceinline__ void lr_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 lr_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// grid barrier: a counter that only grows during a launch, agent-scope RELEASE before the arrival and ACQUIRE after the exit
-// (0.8 us per barrier on a capture-sized graph; see cgr_grid_sync in vican_cgres.hip)
-__device__ __forceinline__ void lr_grid_sync(unsigned int* counter, unsigned int target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
+// grid barrier: vican_grid_sync (vican_common.h), fenced form, bounded spin (0.8 us per barrier on a capture-sized graph;
+// see vican_cgres.hip)
 
 // partial H = V[:, :ka]^T R over this workgroup's rows -> part[3 ka][ncw]: 8 lanes per element (strided rows, then a
 // DPP sum over the 8 lanes) - the same order as coop_gram in vican_kernels.hip, so both paths agree to the bit
@@ -115,7 +105,7 @@ template <typename S, int CP, int TRIPS>
 __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
     const int32_t* __restrict__ gate, vican_graph_t g, const double* __restrict__ lamT_inv, const double* __restrict__ lamC, double* V,
     int ld, int j0, int j1, double* xrow, double* HB, int hb_stride, int hw, u64* zpart, double* ws, unsigned int* sync,
-    const double* __restrict__ fx, double pivot_floor) {
+    const double* __restrict__ fx, double pivot_floor, uint32_t* abort_word, unsigned long long spin_limit) {
     GATE_RETURN(gate);
     constexpr int EPL = Vec<S>::N;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -155,7 +145,8 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
     double* part2 = ws + (size_t)ncw * hs_cap;
     double* partG = ws + (size_t)2 * ncw * hs_cap;
     unsigned int nbar = 0;
-    auto gsync = [&]() { ++nbar; lr_grid_sync(sync, nbar * (unsigned)nwg); };
+    const vican_sync_t sy = {sync, abort_word, spin_limit};
+    auto gsync = [&]() -> bool { ++nbar; return vican_grid_sync(sy, nbar * (unsigned)nwg, true); };
 #ifdef VICAN_LRSTAMP    /* diagnostic build: wall clock (100 MHz ticks) per phase and step of workgroup 0 -> ws tail [step][12] */
     unsigned long long st_t = __builtin_amdgcn_s_memrealtime();
     double* st_out = ws + (size_t)ncw * (2 * hs_cap + 8);
@@ -339,7 +330,7 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
                 for (int c = tid; c < C; c += LR_THREADS) lr_st(zp + q * C + c, (u64)fix_total<S>((long long)zs[q * CP + c]));
         }
         LSTAMP(2);
-        gsync();
+        if (!gsync()) return;
         LSTAMP(3);
 
         // ---- camera side (lanczos_cam_coop_kernel on the first ncw workgroups; its scratch overlays the sweep tables)
@@ -390,7 +381,7 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
             lr_gram(vs, ka, nsl, rs, part1, ncw, wg);
         }
         LSTAMP(4);
-        gsync();
+        if (!gsync()) return;
         LSTAMP(5);
         if (is_cam) {
             lr_reduce(part1, hs, ncw, stage, h);
@@ -406,7 +397,7 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
             lr_gram(vs, ka, nsl, rs, part2, ncw, wg);
         }
         LSTAMP(6);
-        gsync();
+        if (!gsync()) return;
         LSTAMP(7);
         if (is_cam) {
             lr_reduce(part2, hs, ncw, stage, h2);
@@ -434,7 +425,7 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
             if (tid < 6) lr_st(partG + (size_t)tid * ncw + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
         }
         LSTAMP(8);
-        gsync();
+        if (!gsync()) return;
         LSTAMP(9);
         if (is_cam) {
             lr_reduce(partG, 6, ncw, stage, G6s);
@@ -462,7 +453,7 @@ __global__ __launch_bounds__(LR_THREADS) void lanczos_resident_kernel(
             }
         }
         LSTAMP(10);
-        gsync();
+        if (!gsync()) return;
         LSTAMP(11);
     }
     // the last workgroup out re-arms the barrier counter for the next launch
@@ -508,8 +499,10 @@ extern "C" int vican_lanczos_resident(const vican_graph_t* g, const double* lamT
                 return set_err(VICAN_ERR_LAUNCH, "vican_lanczos_resident: cannot raise dynamic LDS limit");               \
             conf = lds;                                                                                                   \
         }                                                                                                                 \
+        if (int rc_ = vican_coresident_ok((const void*)kern, LR_THREADS, lds, g->n_wg, "vican_lanczos_resident")) return rc_; \
         hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(LR_THREADS), lds, s, g_vican_gate, *g, lamT_inv, lamC, V, (int)ld, (int)j0, \
-                           (int)j1, xrow, HB, (int)hb_stride, (int)hw, (u64*)zpart, ws, sync_ws, fx, pivot_floor);                 \
+                           (int)j1, xrow, HB, (int)hb_stride, (int)hw, (u64*)zpart, ws, sync_ws, fx, pivot_floor,         \
+                           g_vican_abort_word, g_vican_sync_ticks);                                                       \
     } while (0)
 #define LR_PICK2(S_, CP_) do { if (trips <= 1) LR_LAUNCH(S_, CP_, 1); else if (trips == 2) LR_LAUNCH(S_, CP_, 2); else LR_LAUNCH(S_, CP_, 3); } while (0)
 #define LR_PICK(S_) do { if (g->n_cam <= 256) LR_PICK2(S_, 256); else LR_PICK2(S_, 512); } while (0)

@@ -32,6 +32,43 @@ thread_local char g_vican_err[512] = "";
 extern "C" const char* vican_last_error(void) { return g_vican_err; }
 extern "C" int vican_abi_version(void) { return VICAN_ABI_VERSION; }
 
+thread_local uint32_t* g_vican_abort_word = nullptr;
+thread_local unsigned long long g_vican_sync_ticks = 200000000ull;          // 2 s of the 100 MHz real-time counter
+extern "C" int vican_set_barrier_abort(uint32_t* abort_word, int64_t timeout_us) {
+    g_vican_abort_word = abort_word;
+    g_vican_sync_ticks = timeout_us > 0 ? (unsigned long long)timeout_us * 100ull : 200000000ull;
+    return VICAN_OK;
+}
+// Can `grid` workgroups of this kernel be resident at once on an idle device?  (Necessary for its grid barriers; the
+// bounded spin of vican_grid_sync covers a device that is NOT idle.)
+int vican_coresident_ok(const void* kernel, int block_threads, size_t lds_bytes, int grid, const char* who) {
+    int dev = 0, n_cu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, lds_bytes) != hipSuccess)
+        return set_err(VICAN_ERR_LAUNCH, "%s: cannot query the occupancy of a cooperative kernel", who);
+    if ((long long)per_cu * n_cu < grid)
+        return set_err(VICAN_ERR_CAPACITY, "%s: the grid of this cooperative kernel cannot be co-resident on the device", who);
+    return VICAN_OK;
+}
+
+// diagnostic: workgroups that only stay resident (tests of the bounded grid barriers)
+__global__ void occupy_kernel(unsigned long long ticks, int lds_words) {
+    extern __shared__ unsigned int occ_lds[];
+    if (lds_words > 0) occ_lds[threadIdx.x % lds_words] = threadIdx.x;          // (keeps the allocation)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int vican_test_occupy(int32_t n_wg, int32_t threads, int32_t lds_bytes, int64_t microseconds, void* stream) {
+    if (n_wg <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || microseconds < 0)
+        return set_err(VICAN_ERR_ARG, "vican_test_occupy: bad argument");
+    static int conf = 0;
+    if (lds_bytes > conf) { hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); conf = lds_bytes; }
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull, lds_bytes / 4);
+    LAUNCH_CHECK("vican_test_occupy");
+    return VICAN_OK;
+}
+
 thread_local const int32_t* g_vican_gate = nullptr;
 extern "C" int vican_set_gate(const int32_t* gate) { g_vican_gate = gate; return VICAN_OK; }
 thread_local hipEvent_t g_vican_ev_start = nullptr, g_vican_ev_stop = nullptr;

@@ -124,6 +124,58 @@ __device__ __host__ inline double fix_scale(double c, double n_add, double* inv,
     return ldexp(1.0, e);
 }
 
+// ---- double-word fixed point (translation stage: CG product, right-hand side) ----------------------------------------
+// The reference's translation solve is scipy's f64 CSR product: every TERM w p keeps 53 bits.  One 64-bit accumulator
+// resolves 49 bits below a GLOBAL bound on max |w p| - rows whose terms are far below that bound (mild weights already
+// span 2^14, the CG direction varies over the graph) lose exactly those bits, and the loosely converged CG (rtol 1e-5 on a
+// singular Laplacian) shows it: 111 iterations on the large_shop-scale golden where the reference's own window is 101-106.
+// Contributions are therefore split into two integers that are accumulated separately:
+//     v * scale = hi + lo * 2^-lob ,   hi = rint(v * scale)  (|hi| < 2^51),   lo = rint((v * scale - hi) * 2^lob)
+// hi through the magic-number conversion as before; the residual v * scale - hi is EXACT (fma; scale is a power of two),
+// so the pair carries v to 49 + lob bits below the bound (lob = 48 unless an accumulator takes more than 2^14 adds) - a
+// term 2^-44 below the bound still has its 53 bits.  Sums of hi and of lo are exact integer sums (associative: bit-
+// reproducible whatever the order), and (sum hi, sum lo) is rounded to f64 ONCE per output (fix2_value).
+struct Fix2 { u64 hi, lo; };
+__device__ __forceinline__ Fix2 to_fix2(double v, double scale, double lo_scale) {
+    const double magic = 6755399441055744.0;          // 1.5 * 2^52
+    const double t = fma(v, scale, magic);
+    const double h = t - magic;                       // rint(v * scale), exact
+    Fix2 f;
+    f.hi = (u64)(__double_as_longlong(t) - __double_as_longlong(magic));
+    f.lo = to_fix(fma(v, scale, -h), lo_scale);       // exact residual in [-1/2, 1/2] -> integer below 2^(lob-1)
+    return f;
+}
+// bits of the lo word for accumulators that take up to n_add contributions: |sum lo| <= n_add 2^(lob-1) < 2^62
+__device__ __host__ inline int fix2_lo_bits(double n_add) {
+    const int h = (int)ceil(log2(n_add > 1 ? n_add : 1));
+    const int b = 62 - h;
+    return b > 48 ? 48 : (b < 8 ? 8 : b);
+}
+// (sum hi + sum lo 2^-lob) / scale as one double: lo's carry moves into hi, the fraction is added last
+__device__ __forceinline__ double fix2_value(long long hi, long long lo, int lob, double inv) {
+    const long long carry = lo >> lob;                // floor
+    hi += carry; lo -= carry << lob;                  // 0 <= lo < 2^lob
+    return ((double)hi + ldexp((double)lo, -lob)) * inv;
+}
+
+// Sums over the slabs of many workgroups: the lo word of every slab is normalised into [0, 2^lob) first (its carry moves
+// to hi) and hi is summed in two halves (hi >> 32, hi & 0xFFFFFFFF), so that no sum can overflow whatever the number of
+// slabs and however close to the bound the terms are.  (top, bot, lo) -> double, rounded once: the two integer parts are
+// exact doubles, the rounding error of their sum is recovered (two-sum) and joins the fraction.
+struct Fix3 { long long top, bot, lo; };
+__device__ __forceinline__ void fix3_add(Fix3& a, long long h, long long l, int lob) {
+    const long long c = l >> lob;
+    h += c; l -= c << lob;
+    a.top += h >> 32; a.bot += h & 0xFFFFFFFFll; a.lo += l;
+}
+__device__ __forceinline__ double fix3_value(long long top, long long bot, long long lo, int lob, double inv) {
+    const long long c = lo >> lob;
+    bot += c; lo -= c << lob;
+    const double x = (double)top * 4294967296.0, y = (double)bot;
+    const double sxy = x + y, bb = sxy - x, err = (x - (sxy - bb)) + (y - bb);
+    return (sxy + (err + ldexp((double)lo, -lob))) * inv;
+}
+
 // Sum of a 64-bit value over the aligned group of `ncopy` (power of two <= 32) neighbouring lanes, in every lane of the
 // group: DPP quad permutes (lane ^ 1, lane ^ 2), mirrors inside 8 and 16 lanes, one cross-row shuffle for 32.  Used to
 // fold the lane-striped fixed-point row accumulators with one LDS read per lane instead of ncopy dependent ones.

@@ -257,7 +257,7 @@ __global__ void cg_init_finish_kernel(int n_cam, const double* __restrict__ b_c,
         st->rho = 0; st->rho_prev = 0; st->pq = 0; st->alpha = 0; st->beta = 0; st->bnorm2 = 0; st->atol2 = 0;
         st->rr_cam = rc; st->pq_time = 0; st->rr_time = t;
         st->rmax_cam = mc; st->rmax_time = mt; st->pmax = 0; st->qscale = 1; st->qinv = 1; st->wmax = wmax;
-        st->iter = 0; st->done = 0; st->first = 1; st->pad = 0;
+        st->iter = 0; st->done = 0; st->first = 1; st->lo_bits = 48;
     }
 }
 extern "C" int vican_cg_init(int32_t n_cam, int32_t n_time, const double* b_c, const double* b_t, double* x_c,
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
         st->rho = rho;
         int go = 1;
         if (sqrt(rho) < sqrt(st->atol2) || rho == 0.0) { st->done = 1; go = 0; }    // scipy: norm(r) < atol
+        else if (!(rho == rho)) { st->done = -2; go = 0; }                          // NaN: scipy would spin to maxiter; stop and report
         double beta = 0.0;
         if (go && !st->first) beta = rho / st->rho_prev;
         st->beta = beta;
@@ -331,19 +332,19 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // Fixed-point scale of this iteration's sweep: 49 bits below a bound on max |w p| (a lane pre-sums up to four
-        // same-row contributions: 4 * 2^49 < 2^51, the range of the magic-number conversion).  The bound uses the
-        // cameras' exact max |p_c| and, for the timestep side (updated inside the sweep), |p_new| <= max|r_t| +
-        // beta * max|p_t| with the MEASURED max |p_t| of the current iterate (cg_step): the earlier running bound
-        // pmax <- rmax + beta pmax compounded its slack to 8-16x over a hundred iterations, and with 47 bits the
-        // quantisation of q = A p - a Laplacian product, i.e. differences of nearly equal terms - delayed convergence
-        // on the large_shop-scale golden from scipy's 102-106 iterations to 118 (reproduced on the host with a
-        // quantised matvec: 47 bits below the compounding bound 118, 49 below the tight one ~108, exact 103).
+        // Fixed-point scale of this iteration's sweep: the hi word sits 49 bits below a bound on max |w p| (a lane pre-sums up
+        // to four same-row contributions: 4 * 2^49 < 2^51, the range of the magic-number conversion), the lo word carries
+        // lo_bits more (to_fix2, vican_sweep_common.h).  The bound uses the cameras' exact max |p_c| and, for the timestep
+        // side (updated inside the sweep), |p_new| <= max|r_t| + beta * max|p_t| with the MEASURED max |p_t| of the current
+        // iterate (cg_step).  History: one accumulator 47 bits below a compounding bound stopped the large_shop-scale
+        // golden at 118 iterations, 49 bits below this tight bound at 111, scipy's own window is 101-106 (a Laplacian
+        // product is a difference of nearly equal terms, and terms far below the global bound lose their bits): hence two words.
         const double pc = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         const double pt = st->first ? st->rmax_time : st->rmax_time + beta * st->pmax_time;
         st->pmax = fmax(pc, pt);
         double inv;
         st->qscale = fix_scale(st->wmax * st->pmax, n_add, &inv, 49);
+        st->lo_bits = fix2_lo_bits(n_add);
         st->qinv = inv;
     }
 }
@@ -374,9 +375,9 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if (st->done) return;
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
-    u64* qc = (u64*)lds_raw;                               // [3][C] planes
-    u64* qt = qc + 3 * C;                                  // [2][max_rows*3][ncopy]
-    double* pcs = (double*)(qt + (size_t)2 * mr3 * ncopy); // [3][C] planes
+    u64* qc = (u64*)lds_raw;                               // [2][3][C] planes: hi words, lo words
+    u64* qt = qc + 6 * C;                                  // [2 buffers][2 words][max_rows*3][ncopy]
+    double* pcs = (double*)(qt + (size_t)4 * mr3 * ncopy); // [3][C] planes
     double* pts = pcs + 3 * C;                             // [2][max_rows*3]   p of the chunk's rows
     double* dps = pts + 2 * mr3;                           // [2][max_rows*3]   deg * p
     double* red = dps + 2 * mr3;                           // [16]
@@ -384,8 +385,11 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero weight
     const bool upd = !st->first;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
-    for (int i = tid; i < 3 * C; i += BLOCK) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; }
-    for (int i = tid; i < 2 * mr3 * ncopy; i += BLOCK) qt[i] = 0ull;
+    const int lob = st->lo_bits;
+    const double lo_scale = ldexp(1.0, lob);
+    const int lo_c = 3 * C, lo_t = mr3 * ncopy;            // offsets of the lo planes behind the hi planes
+    for (int i = tid; i < 3 * C; i += BLOCK) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; qc[lo_c + i] = 0ull; }
+    for (int i = tid; i < 4 * mr3 * ncopy; i += BLOCK) qt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 
@@ -449,15 +453,15 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
 
     auto fold = [&](const int k, const int buf) {
         const int r0 = g.chunk_row0[k], nrows = g.chunk_row0[k + 1] - r0;
-        u64* q = qt + (size_t)buf * mr3 * ncopy;
+        u64* q = qt + (size_t)buf * 2 * lo_t;
         for (int i = tid; i < 3 * nrows; i += BLOCK) {
-            long long sum = 0;
+            long long sum = 0, slo = 0;
             for (int c = 0; c < ncopy; ++c) {
                 const int a = i * ncopy + ((c + i) & cmask);
-                sum += (long long)q[a];
-                q[a] = 0ull;
+                sum += (long long)q[a]; slo += (long long)q[lo_t + a];
+                q[a] = 0ull; q[lo_t + a] = 0ull;
             }
-            const double qv = dps[buf * mr3 + i] - (double)sum * inv;
+            const double qv = dps[buf * mr3 + i] - fix2_value(sum, slo, lob, inv);
             q_t[(size_t)r0 * 3 + i] = qv;
             pq += pts[buf * mr3 + i] * qv;
         }
@@ -467,29 +471,34 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
         load_edges(nxt, k + 1 < k1 ? k + 1 : k);                               // in flight during this chunk (unconditional: exact vmcnt waits)
         if (k + 2 < k1) load_rows(ry, k + 2);
         const double* pt = pts + buf * mr3;
-        u64* qtb = qt + (size_t)buf * mr3 * ncopy;
+        u64* qtb = qt + (size_t)buf * 2 * lo_t;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
+        auto flush_row = [&](const uint32_t r) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const Fix2 f = to_fix2(acc[i], scale, lo_scale);
+                u64* a = &qtb[(r * 3 + i) * ncopy + lane_copy];
+                lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+            }
+        };
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
             const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
             const double wj = pad ? 0.0 : cur.w[j];
             if (row != prow) {
-                if (prow != 0xFFFFFFFFu)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&qtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+                if (prow != 0xFFFFFFFFu) flush_row(prow);
                 prow = row; acc[0] = acc[1] = acc[2] = 0.0;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 acc[i] += wj * pcs[i * C + cam];
-                lds_add_fix(&qc[i * C + cam], to_fix(wj * pt[row * 3 + i], scale));
+                const Fix2 f = to_fix2(wj * pt[row * 3 + i], scale, lo_scale);
+                lds_add_fix(&qc[i * C + cam], f.hi); lds_add_fix(&qc[lo_c + i * C + cam], f.lo);
             }
         }
-        if (prow != 0xFFFFFFFFu)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) lds_add_fix(&qtb[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+        if (prow != 0xFFFFFFFFu) flush_row(prow);
         // previous chunk's fold, then the next chunk's rows into the staging buffer the fold has just read
         // (same index -> same thread in both loops, so no cross-thread hazard on that buffer)
         if (k > k0) fold(k - 1, buf ^ 1);
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     }
     if (k0 < k1) fold(k1 - 1, (k1 - 1 - k0) & 1);
     __syncthreads();
-    for (int i = tid; i < 3 * C; i += BLOCK) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
+    for (int i = tid; i < 6 * C; i += BLOCK) qc_part[(size_t)blockIdx.x * 6 * C + i] = qc[i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
 }
@@ -736,28 +745,29 @@ extern "C" int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_stat
     return VICAN_OK;
 }
 
-// fold of one CG sweep in ONE launch: qcpq[0:3C] = qinv * sum_wg qc_part (planes [3][C] -> row-major
-// [C][3]) and qcpq[3C] = sum_wg pq_part (block 0).  Same fixed summation orders as
-// vican_slab_reduce_fx + vican_cg_reduce_pq.
+// fold of one CG sweep in ONE launch: qcpq[0:3C] = sum_wg qc_part (double-word planes [2][3][C] per workgroup -> row-major
+// [C][3] doubles, rounded once) and qcpq[3C] = sum_wg pq_part (block 0).  Integer sums: exact, any order, overflow-proof
+// (fix3_add / fix3_value, vican_sweep_common.h).
 __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
                                                        const double* __restrict__ pq_part, double* __restrict__ qcpq,
                                                        const vican_cg_state_t* __restrict__ st) {
-    __shared__ long long sh[1024];
+    __shared__ long long sh[3][1024];
     if (st->done) return;
     const long long n = 3LL * n_cam;
+    const int lob = st->lo_bits;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
-    long long s = 0;
+    Fix3 a = {0, 0, 0};
     if (i < n)
-        for (int k = grp; k < n_slab; k += 16) s += part[(size_t)k * n + i];
-    sh[threadIdx.x] = s;
+        for (int k = grp; k < n_slab; k += 16) fix3_add(a, part[(size_t)k * 2 * n + i], part[(size_t)k * 2 * n + n + i], lob);
+    sh[0][threadIdx.x] = a.top; sh[1][threadIdx.x] = a.bot; sh[2][threadIdx.x] = a.lo;
     __syncthreads();
     if (grp == 0 && i < n) {
-        long long t = 0;
+        long long t = 0, b = 0, l = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += sh[k * 64 + e];
+        for (int k = 0; k < 16; ++k) { t += sh[0][k * 64 + e]; b += sh[1][k * 64 + e]; l += sh[2][k * 64 + e]; }
         const long long q = i / n_cam, cam = i % n_cam;
-        qcpq[cam * 3 + q] = (double)t * st->qinv;
+        qcpq[cam * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
     }
     if (blockIdx.x == 0) {                   // p.q partials: loaded in parallel, summed in a fixed order
         __shared__ double pq[1024];
@@ -777,6 +787,16 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
     }
 }
 
+extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
+                             const vican_cg_state_t* st, void* stream) {
+    if (!qc_part || n_slab <= 0 || n_cam <= 0 || !pq_part || !qcpq || !st) return set_err(VICAN_ERR_ARG, "vican_cg_fold: bad argument");
+    const long long n = 3LL * n_cam;
+    hipLaunchKernelGGL(cg_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                       (const long long*)qc_part, n_slab, n_cam, pq_part, qcpq, st);
+    LAUNCH_CHECK("vican_cg_fold");
+    return VICAN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // composites: one CG iteration as two host calls (local half up to the point where a sharded
 // run all-reduces [q_c | p.q]; finishing half).  qcpq: [3C + 1] doubles.
@@ -788,11 +808,7 @@ extern "C" int vican_cg_iter_local(const vican_graph_t* g, const double* w, cons
     int rc;
     if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, stream)) < 0) return rc;
     if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
-    const long long n = 3LL * g->n_cam;
-    hipLaunchKernelGGL(cg_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
-                       (const long long*)qc_part, g->n_wg, g->n_cam, pq_part, qcpq, st);
-    LAUNCH_CHECK("vican_cg_iter_local");
-    return VICAN_OK;
+    return vican_cg_fold(qc_part, g->n_wg, g->n_cam, pq_part, qcpq, st, stream);
 }
 extern "C" int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, const double* qcpq,
                                     const double* p_c, double* x_c, double* r_c, const double* p_t, const double* q_t,

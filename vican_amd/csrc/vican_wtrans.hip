@@ -1,8 +1,9 @@
 // vican_wtrans.hip - the CG Laplacian product q = A p (reference bipgo.py:476-478, one application per scipy cg
 // iteration) on graphs in the WAVE layout: one wavefront per chunk, no workgroup barrier in the loop.
 //
-// Same arithmetic as cg_sweep_kernel (vican_trans.hip): contributions w p in f64, exact 64-bit fixed-point accumulation
-// (camera sums in the workgroup's LDS table, row sums in the wavefront's own LDS region), q_t = deg_t p_t - sum_c w p_c,
+// Same arithmetic as cg_sweep_kernel (vican_trans.hip): contributions w p in f64, exact DOUBLE-WORD fixed-point accumulation
+// (to_fix2, vican_sweep_common.h: hi and lo words in separate planes, so both keep the bank pattern of the slot order;
+// camera sums in the workgroup's LDS table, row sums in the wavefront's own LDS region), q_t = deg_t p_t - sum_c w p_c,
 // the timestep part of p.q, and the update p_t <- r_t + beta p_t folded into the row loads.  What changes is the
 // schedule: the block kernel's 12 wavefronts share a 3072-slot chunk and meet at a barrier per chunk; here a wavefront
 // owns a 256-slot chunk (whole rows), stages its rows' p and deg p in its private LDS region and folds its own row sums -
@@ -13,8 +14,8 @@
 #include "vican_sweep_common.h"
 
 extern "C" int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
-    const int64_t per_wave = (((int64_t)max_rows * 3 * (8LL * n_copy + 16)) + 15) & ~15LL;
-    return 48LL * n_cam + (int64_t)n_waves * per_wave + 256;
+    const int64_t per_wave = (((int64_t)max_rows * 3 * (16LL * n_copy + 16)) + 15) & ~15LL;
+    return 72LL * n_cam + (int64_t)n_waves * per_wave + 256;
 }
 
 #ifdef VICAN_CGWSTAMP   /* diagnostic build (tools/cgsweep_time.py --stamp): wall-clock structure of the launch, per wavefront */
@@ -49,18 +50,21 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
     const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    u64* qc = (u64*)lds_raw;                                   // [3][C] planes, shared by the workgroup
-    double* pcs = (double*)(qc + 3 * C);                       // [3][C] planes
-    const size_t per_wave = (((size_t)RW * 3 * (8 * ncopy + 16)) + 15) & ~(size_t)15;
+    u64* qc = (u64*)lds_raw;                                   // [2][3][C] planes (hi words, lo words), shared by the workgroup
+    double* pcs = (double*)(qc + 6 * C);                       // [3][C] planes
+    const size_t per_wave = (((size_t)RW * 3 * (16 * ncopy + 16)) + 15) & ~(size_t)15;
     unsigned char* wbase = (unsigned char*)(pcs + 3 * C) + (size_t)wave * per_wave;
-    u64* qt = (u64*)wbase;                                     // [RW * 3][ncopy] striped row accumulators (this wave's)
-    double* pts = (double*)(qt + (size_t)RW * 3 * ncopy);      // [RW * 3] p of the chunk's rows
+    u64* qt = (u64*)wbase;                                     // [2][RW * 3][ncopy] striped row accumulators (this wave's): hi, lo
+    double* pts = (double*)(qt + (size_t)2 * RW * 3 * ncopy);  // [RW * 3] p of the chunk's rows
     double* dps = pts + RW * 3;                                // [RW * 3] deg * p
     const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
     const bool upd = !st->first;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
-    for (int i = tid; i < 3 * C; i += NW * 64) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; }
-    for (int i = lane; i < 3 * RW * ncopy; i += 64) qt[i] = 0ull;
+    const int lob = st->lo_bits;
+    const double lo_scale = ldexp(1.0, lob);
+    const int lo_c = 3 * C, lo_t = 3 * RW * ncopy;             // offsets of the lo planes behind the hi planes
+    for (int i = tid; i < 3 * C; i += NW * 64) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; qc[lo_c + i] = 0ull; }
+    for (int i = lane; i < 2 * lo_t; i += 64) qt[i] = 0ull;
     const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
     const int kmax = g.n_chunk - 1;
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
                 for (int i = 0; i < 3; ++i) pr[j][i] = pr[j - 1][i];
             }
         }
-        u64 fc[EPL][3], fr[EPL][3];
+        Fix2 fc[EPL][3];
+        double ar[EPL][3];                                       // the lane's running row sum after edge j
         {
             double acc[3] = {0, 0, 0};
 #pragma unroll
@@ -173,8 +178,8 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     acc[i] += wj[j] * pc[j][i];
-                    fc[j][i] = to_fix(wj[j] * pr[j][i], scale);
-                    fr[j][i] = to_fix(acc[i], scale);            // used where the lane's run of this row ends
+                    fc[j][i] = to_fix2(wj[j] * pr[j][i], scale, lo_scale);
+                    ar[j][i] = acc[i];                           // converted only where the lane's run of this row ends
                 }
             }
         }
@@ -184,14 +189,21 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
-                asm volatile("" :: "v"(fc[j][i]));
+                asm volatile("" :: "v"(fc[j][i].hi), "v"(fc[j][i].lo));
 #else
-                lds_add_fix(&qc[i * C + cam[j]], fc[j][i]);
+                lds_add_fix(&qc[i * C + cam[j]], fc[j][i].hi);
+#if !defined(VICAN_CGWABLATE) || VICAN_CGWABLATE != 3     /* 3: hi words only (cost of the second word) */
+                lds_add_fix(&qc[lo_c + i * C + cam[j]], fc[j][i].lo);
+#endif
 #endif
             }
             if (j == EPL - 1 || row[j] != row[j + 1]) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) lds_add_fix(&qt[(row[j] * 3 + i) * ncopy + lane_copy], fr[j][i]);
+                for (int i = 0; i < 3; ++i) {
+                    const Fix2 f = to_fix2(ar[j][i], scale, lo_scale);
+                    u64* a = &qt[(row[j] * 3 + i) * ncopy + lane_copy];
+                    lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -201,12 +213,12 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         for (int base = 0; base < n3 * ncopy; base += 64) {
             const int a = base + lane;
             const bool live = a < n3 * ncopy;
-            u64 sum = 0ull;
-            if (live) { sum = qt[a]; qt[a] = 0ull; }
-            sum = stripe_sum(sum, ncopy);
+            u64 sum = 0ull, slo = 0ull;
+            if (live) { sum = qt[a]; slo = qt[lo_t + a]; qt[a] = 0ull; qt[lo_t + a] = 0ull; }
+            sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
             if (live && (a & cmask) == 0) {
                 const int i = a / ncopy;
-                const double qv = dps[i] - (double)(long long)sum * inv;
+                const double qv = dps[i] - fix2_value((long long)sum, (long long)slo, lob, inv);
                 q_t[(size_t)r0 * 3 + i] = qv;
                 pq += pts[i] * qv;
             }
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
-    for (int i = tid; i < 3 * C; i += NW * 64) qc_part[(size_t)blockIdx.x * 3 * C + i] = qc[i];
+    for (int i = tid; i < 6 * C; i += NW * 64) qc_part[(size_t)blockIdx.x * 6 * C + i] = qc[i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
 #ifdef VICAN_CGWSTAMP

@@ -31,6 +31,24 @@ def n_cu():
     return _N_CU
 
 
+# -- grid barriers of the cooperative kernels (include/vican_hip.h: vican_set_barrier_abort) ------------------------------
+# One abort word per process in PINNED HOST memory: a workgroup whose barrier spin exceeds its time limit writes it, the
+# host polls it for free (no copy, no synchronisation).
+_ABORT = None
+
+
+def barrier_abort_word(timeout_us=None):
+    """The process-wide abort word (a pinned int32 tensor); registers it with the library on first use.
+    timeout_us: spin limit of every grid barrier (default VICAN_BARRIER_TIMEOUT_US or 2 s)."""
+    global _ABORT
+    if _ABORT is None or timeout_us is not None:
+        if _ABORT is None:
+            _ABORT = torch.zeros(4, dtype=torch.int32).pin_memory()
+        us = int(timeout_us if timeout_us is not None else os.environ.get("VICAN_BARRIER_TIMEOUT_US", 0))
+        _lib.check(_lib.load().vican_set_barrier_abort(C.c_void_p(_ABORT.data_ptr()), us), "vican_set_barrier_abort")
+    return _ABORT
+
+
 STREAM_NT_BYTES = 192 << 20       # edge streams above this are read with non-temporal loads (LocalGraph, vican_sweep_common.h)
 X_BOUND = math.sqrt(3.0)      # |x_c|_F of every sweep input: orthonormal columns / stacked rotations
 
@@ -173,7 +191,7 @@ class LocalGraph:
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None, n_copy=None, layout=None, wg_waves=None):
+                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None):
         import os
         lib = _lib.load()
         if not torch.cuda.is_available():
@@ -266,6 +284,13 @@ class LocalGraph:
             _lib.check(lib.vican_edge_sums(gref_t, _ptr(self.w), 1, self.wmax, _ptr(self.row_sum_w), _ptr(self.cam_sum_w),
                                            _ptr(cam_ws), st), "vican_edge_sums")
             self.gmax = float((u.norm(dim=1) + v.norm(dim=1)).max()) if self.n_edges else 1.0
+            # diagonal of the translation system when the caller knows it better than "sum of the weights": the front-end
+            # passes the reference's own J^T J diagonal (float32-accumulated for dtype=float32, frontend.flatten_arrays);
+            # deg_c is this RANK's share (the solver all-reduces it: rank 0 carries the vector, the others zeros)
+            if deg_t is not None:
+                self.row_sum_w[: self.n_time].copy_(deg_t.to(dev, torch.float64))
+            if deg_c is not None:
+                self.cam_sum_w.copy_(deg_c.to(dev, torch.float64))
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
 
     # algorithmic HBM bytes of one operator sweep (B_op)
@@ -301,8 +326,10 @@ class HipBackend:
         # adds into one fixed-point accumulator by one workgroup: its rows (cameras), a chunk (rows)
         self.n_add = float(max(graph.tl.rows_per_wg_max, graph.tl.slots) + 1)
         self._status_host = {}
-        self.coop_cam_step = True               # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
+        self.coop_cam_step = os.environ.get("VICAN_COOP", "1") != "0"   # one cooperative kernel per camera-side Lanczos step (False: launch sequence)
         self._coop_ws, self._coop_sync, self._gram_ws = None, None, None
+        self.coop_failures = []
+        barrier_abort_word()
         self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w_cg, getattr(graph, "wmax", None)
         # layout the CG sweep runs on: the rotation layout if it is a wave layout, else the translation block layout
         cgl = graph.rot if graph.layout == "wave" else graph.tl
@@ -325,6 +352,27 @@ class HipBackend:
 
     def synchronize(self):
         torch.cuda.current_stream().synchronize()
+
+    # -- cooperative kernels: bounded grid barriers (vican_common.h vican_grid_sync) -------------------------------------
+    def barrier_aborted(self):
+        """True when a grid barrier of a cooperative kernel gave up since the last cooperative_failed(): the outputs of
+        that launch (and everything computed from them) are undefined."""
+        return bool(barrier_abort_word()[0].item())
+
+    def cooperative_failed(self, which):
+        """Stop using the cooperative kernels on this backend (the launch-sequence paths compute the same thing) and
+        re-arm the barrier words; called after an aborted barrier or a launcher's co-residency refusal."""
+        import warnings
+        warnings.warn("%s: the grid of a cooperative kernel could not run co-resident (device shared or partly masked); "
+                      "continuing on the launch-sequence path" % which, RuntimeWarning, stacklevel=3)
+        self.synchronize()
+        self.coop_failures.append(which)
+        self.coop_cam_step, self._cgres_ok, self.fold_in_step_ok = False, False, False
+        barrier_abort_word().zero_()
+        if self._coop_sync is not None:
+            self._coop_sync.zero_()
+        if getattr(self, "_cgres_ws", None) is not None:
+            self._cgres_ws.zero_()
 
     def _ck(self, rc, what):
         return _lib.check(rc, what)
@@ -415,10 +463,15 @@ class HipBackend:
                 self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
             fxp = self.g.fx.data_ptr()
             slabs = (_ptr(self.zpart), self.g.n_wg, C.c_void_p(fxp + 24), C.c_void_p(fxp + 56)) if from_slabs else (None, 0, None, None)
-            self._ck(self.lib.vican_lanczos_cam_coop(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(self._coop_ws), _ptr(Hcol),
-                                                     _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), *slabs,
-                                                     _stream()), "vican_lanczos_cam_coop")
-            return
+            # fenced barriers where the sweeps leave little dirty data in L2 (few slabs): 0.4-0.8 us each there, ~10 us with
+            # the stress graph's 256 slabs (which relies on the kernel's agent-scope atomics alone)
+            rc = self.lib.vican_lanczos_cam_coop(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(self._coop_ws), _ptr(Hcol),
+                                                 _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), *slabs,
+                                                 int(self.g.n_wg <= 64), _stream())
+            if rc != _lib.ERR_CAPACITY:
+                self._ck(rc, "vican_lanczos_cam_coop")
+                return
+            self.cooperative_failed("vican_lanczos_cam_coop")        # grid not co-resident even on an idle device
         if from_slabs:
             self.fold_z(z)
         ws = self._gram_workspace(3 * n_nodes)
@@ -456,7 +509,7 @@ class HipBackend:
                  "vican_lanczos_resident")
 
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
-        part = self.zpart[: self.cgl.n_wg * 3 * self.C]
+        part = self.zpart[: self.cgl.n_wg * 6 * self.C]            # double-word camera partials: (hi, lo) planes per workgroup
         self._ck(self.lib.vican_cg_iter_local(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
                                               _ptr(p_t), _ptr(q_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq), float(rtol),
                                               _ptr(self.rr_part), int(n_rr_part), self.n_add_cg, _ptr(st), _stream()),
@@ -631,10 +684,14 @@ class HipBackend:
         if getattr(self, "_cgres_ws", None) is None:
             n = int(self.lib.vican_cg_resident_ws_doubles(self.C, self.cgl.n_wg))
             self._cgres_ws = torch.zeros(n, dtype=torch.float64, device=self.dev)       # zeroed once: holds the barrier counter
-        self._ck(self.lib.vican_cg_resident(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(b_c), _ptr(b_t), _ptr(x_c),
-                                            _ptr(x_t), _ptr(self.zpart), _ptr(self._cgres_ws), float(rtol),
-                                            int(min(maxiter, 2 ** 31 - 1)), self.n_add_cg, float(self._cg_wmax),
-                                            int(self.cgl.rows_per_wg_max), _ptr(st), _stream()), "vican_cg_resident")
+        rc = self.lib.vican_cg_resident(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(b_c), _ptr(b_t), _ptr(x_c),
+                                        _ptr(x_t), _ptr(self.zpart), _ptr(self._cgres_ws), float(rtol),
+                                        int(min(maxiter, 2 ** 31 - 1)), self.n_add_cg, float(self._cg_wmax),
+                                        int(self.cgl.rows_per_wg_max), _ptr(st), _stream())
+        if rc == _lib.ERR_CAPACITY:               # grid not co-resident even on an idle device: report as an aborted launch
+            st.view(torch.int32)[_lib.CG_I["done"]] = -1
+            return
+        self._ck(rc, "vican_cg_resident")
 
     def cg_begin(self, r_c, p_c, rtol, st, n_rr_part=0):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part),
@@ -643,13 +700,10 @@ class HipBackend:
     def cg_sweep(self, deg_t, p_c, r_t, p_t, q_t, qcpq, st):
         """qcpq[0:3C] = local sum_t w p_t (slab-reduced), qcpq[3C] = local p_t.q_t."""
         nwg = self.cgl.n_wg
-        part = self.zpart[: nwg * 3 * self.C]
+        part = self.zpart[: nwg * 6 * self.C]
         self._ck(self.lib.vican_cg_sweep(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(p_c), _ptr(r_t), _ptr(p_t), _ptr(q_t),
                                          _ptr(part), _ptr(self.pq_part), _ptr(st), _stream()), "vican_cg_sweep")
-        self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, 1.0, C.c_void_p(st.data_ptr() + 8 * _lib.CG_F["qinv"]),
-                                               None, _ptr(qcpq), _stream()), "vican_slab_reduce_fx")
-        self._ck(self.lib.vican_cg_reduce_pq(_ptr(self.pq_part), nwg, C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C),
-                                             _ptr(st), _stream()), "vican_cg_reduce_pq")
+        self._ck(self.lib.vican_cg_fold(_ptr(part), nwg, self.C, _ptr(self.pq_part), _ptr(qcpq), _ptr(st), _stream()), "vican_cg_fold")
 
     def cg_cam_step(self, deg_c, qcpq, p_c, x_c, r_c, st):
         self._ck(self.lib.vican_cg_cam_step(self.C, _ptr(deg_c), _ptr(qcpq), C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C),
@@ -727,7 +781,7 @@ class TiledGraph:
     them at 1024 cameras.  Beyond that the operator z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) is evaluated tile by
     tile (TiledBackend): every edge block is read twice per application instead of once."""
 
-    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, tile=None):
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, tile=None, deg_t=None, deg_c=None):
         import os
         lib = _lib.load()
         tile = int(tile or os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
@@ -757,6 +811,10 @@ class TiledGraph:
         if have_t:
             self.row_sum_w = torch.stack([t.row_sum_w for t in self.tiles]).sum(0)
             self.cam_sum_w = torch.cat([t.cam_sum_w for t in self.tiles])
+            if deg_t is not None:                           # the caller's diagonal (LocalGraph)
+                self.row_sum_w[: T].copy_(deg_t.to(dev, torch.float64))
+            if deg_c is not None:
+                self.cam_sum_w.copy_(deg_c.to(dev, torch.float64))
             self.wmax = max(t.wmax for t in self.tiles)
             # weights-only layout over all cameras for the CG sweep
             storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
@@ -764,11 +822,11 @@ class TiledGraph:
             deg = rp_host[1:] - rp_host[:-1]
             deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
             lim, n_copy = int(lib.vican_lds_limit_bytes()), 8
-            cg_rows = lambda nc: (lim - 256 - 48 * self.n_cam) // (48 * nc + 96)
+            cg_rows = lambda nc: (lim - 256 - 72 * self.n_cam) // (96 * nc + 96)     # cg_lds_bytes (vican_common.h)
             while n_copy > 1 and cg_rows(n_copy) < 8:
                 n_copy //= 2
             if cg_rows(n_copy) < 1:
-                raise _lib.VicanError("camera vectors of the CG sweep (C=%d) do not fit in LDS (limit about 3300 cameras)" % self.n_cam)
+                raise _lib.VicanError("camera vectors of the CG sweep (C=%d) do not fit in LDS (limit about 2200 cameras)" % self.n_cam)
             cgl = _Layout.__new__(_Layout)
             epl = 4 if storage == _lib.STORE_F32 else 2
             bt = 768 if self.n_edges >= 768 * epl * n_cu() else 256
@@ -826,6 +884,7 @@ class TiledBackend(HipBackend):
         self.tiles = [HipBackend(t) for t in graph.tiles]
         self.fold_in_step_ok, self.coop_cam_step, self.layout = False, False, "tiled"
         self._status_host, self._coop_ws, self._coop_sync, self._gram_ws = {}, None, None, None
+        self.coop_failures = []
         self.rr_part = torch.zeros(1536, dtype=torch.float64, device=self.dev)
         self.ws = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         T1, nt = max(self.T, 1), len(self.tiles)
@@ -837,7 +896,7 @@ class TiledBackend(HipBackend):
             self._gref_cg, self.cgl = C.byref(graph.desc_cg), graph.cgl
             self.n_add_cg = float(max(graph.cgl.rows_per_wg_max, graph.cgl.slots) + 1)
             self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w_cg, graph.wmax
-            self.zpart = torch.empty(graph.cgl.n_wg * 3 * self.C, dtype=torch.float64, device=self.dev)
+            self.zpart = torch.empty(graph.cgl.n_wg * 6 * self.C, dtype=torch.float64, device=self.dev)
             self.pq_part = torch.empty(graph.cgl.n_wg, dtype=torch.float64, device=self.dev)
             self.rhs_part = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)
 
@@ -908,12 +967,14 @@ class TiledBackend(HipBackend):
     lsqr_init_u = lsqr_u_step = lsqr_v_step = _unsupported
 
 
-def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None):
-    """(graph, backend) for one rank's rows: the fused layouts up to TILE_CAMS cameras, camera tiles beyond."""
+def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None, deg_c=None):
+    """(graph, backend) for one rank's rows: the fused layouts up to TILE_CAMS cameras, camera tiles beyond.
+    deg_t / deg_c: diagonal of the translation system for this rank's rows / this rank's share of the camera diagonal
+    (default: sums of w)."""
     import os
     tile = int(os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
     if n_cam > tile:
-        g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile)
+        g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c)
         return g, TiledBackend(g)
-    g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v)
+    g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v, deg_t=deg_t, deg_c=deg_c)
     return g, HipBackend(g)

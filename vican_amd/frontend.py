@@ -14,7 +14,7 @@ import numpy as np
 class Problem:
     """Flattened, merged problem (all float64 on the host)."""
     __slots__ = ("cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "root",
-                 "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v",
+                 "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v", "deg_c", "deg_t",
                  "src_cam", "src_time", "src_t", "src_qtau", "src_kt")
 
     @property
@@ -110,8 +110,19 @@ def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, d
     np.cumsum(np.bincount(rows, minlength=T), out=p.row_ptr[1:])
     p.blk = seg(wR).reshape(E, 9)
     p.a = seg(kr)
-    w = seg(kf * kf)
-    p.w = w.astype(dtype).astype(np.float64)
+    # Entries of the reference's normal matrix J^T J (bipgo.py:477) AS SCIPY FORMS THEM: csr_matmat accumulates the products
+    # k k of the incidence entries in the matrix dtype, sequentially in source-edge order - for dtype=float32 that is float32
+    # products summed in float32, for the merged off-diagonal entries w_ct and for the DIAGONAL deg_n = sum over ALL source
+    # edges at node n alike.  In float32 the diagonal therefore differs from the sum of the (rounded) off-diagonal entries
+    # by ~1e-7 relative - the reference's matrix is not an exact Laplacian, and a CG that used sum_c w_ct instead would run on
+    # a matrix perturbed eight orders above rounding (rounds 1-2: 109 of 975 f32 campaign scenes beyond 1e-4 m).
+    # np.add.at adds unbuffered, in index order, in the array's dtype: exactly that accumulation.
+    kd = kt.astype(dtype)
+    prod = kd * kd
+    w = np.zeros(E, dtype=dtype); np.add.at(w, inv, prod)
+    deg_c = np.zeros(C, dtype=dtype); np.add.at(deg_c, ci, prod)
+    deg_t = np.zeros(T, dtype=dtype); np.add.at(deg_t, ti, prod)
+    p.w, p.deg_c, p.deg_t = w.astype(np.float64), deg_c.astype(np.float64), deg_t.astype(np.float64)
     kk = (kf * kt)[:, None]
     p.u = seg(kk * t)
     p.v = seg(kk * qtau[mk_idx])

@@ -67,13 +67,15 @@ class Comm:
         nmax = max(bounds[r + 1] - bounds[r] for r in range(self.world))
         send = torch.zeros(nmax, width, dtype=loc.dtype, device=loc.device)
         send[:n_local] = loc[:n_local]
-        recv = torch.empty(self.world * nmax, width, dtype=loc.dtype, device=loc.device)
-        try:
+        # the path is chosen by the backend's NAME, never by catching an error (a failing RCCL collective must surface):
+        # RCCL gathers device tensors in place; gloo has no all-gather for device tensors, so its blocks travel through host memory
+        if torch.distributed.get_backend(self.group) == "nccl" or not loc.is_cuda:
+            recv = torch.empty(self.world * nmax, width, dtype=loc.dtype, device=loc.device)
             torch.distributed.all_gather_into_tensor(recv, send, group=self.group)
-        except RuntimeError:              # (a backend without all-gather for this device type: gloo on GPU tensors)
-            recv.zero_()
-            recv[self.rank * nmax: (self.rank + 1) * nmax] = send
-            torch.distributed.all_reduce(recv, group=self.group)
+        else:
+            parts = [torch.empty(nmax, width, dtype=loc.dtype) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, send.cpu(), group=self.group)
+            recv = torch.cat(parts, 0).to(loc.device)
         self.n_allgather = getattr(self, "n_allgather", 0) + 1
         return torch.cat([recv[r * nmax: r * nmax + bounds[r + 1] - bounds[r]] for r in range(self.world)], 0)
 
@@ -439,10 +441,14 @@ class TranslationSolver:
             # four dependent launches of a few microseconds each - launch latency only)
             K.cg_resident(self.deg_t, self.deg_c, self.b_c, self.b_t, self.x_c, self.x_t, self.rtol, maxiter, st)
             s = self._state()
-            self._n_solves += 1
-            self.info = dict(cg_iters=s["iter"], converged=bool(s["done"]), resident=True,
-                             relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
-            return self.x_c, self.x_t
+            if s["done"] != -1:
+                self._n_solves += 1
+                self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1, resident=True,
+                                 relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+                return self.x_c, self.x_t
+            # done == -1: a grid barrier of the cooperative kernel was not passed within its time limit (the device is shared
+            # with something that kept part of the grid out): nothing was lost, the launch sequence below solves the system
+            K.cooperative_failed("vican_cg_resident")
         K.cg_init(self.b_c, self.b_t, self.x_c, self.x_t, self.r_c, self.r_t, self.p_c, self.p_t, st)
         if multi:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
@@ -500,8 +506,8 @@ class TranslationSolver:
             if s["done"] or it_launched > maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
-        self._last_iters = int(s["iter"]) if s["done"] else None
-        self.info = dict(cg_iters=s["iter"], converged=bool(s["done"]),
+        self._last_iters = int(s["iter"]) if s["done"] == 1 else None
+        self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1,
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
         return self.x_c, self.x_t
 
@@ -543,11 +549,42 @@ class TightTranslationSolver(TranslationSolver):
         return self.x_c, self.x_t
 
 
+def with_cooperative_fallback(K, comm, fn):
+    """Run ``fn()`` (stages that may launch cooperative kernels) and wait for it; if a grid barrier gave up meanwhile
+    (bounded spins, include/vican_hip.h: vican_set_barrier_abort - the device is shared with something that kept part of a
+    cooperative grid out) the results are undefined: the backend stops using the cooperative kernels and ``fn()`` runs
+    again on the launch-sequence paths.  Sharded runs cannot re-run one rank alone (the other ranks sit in collectives):
+    there the abort is an error."""
+    aborted = getattr(K, "barrier_aborted", None)
+    if aborted is None:                                      # stand-in backends (tests/numpy_backend.py)
+        return fn()
+    try:
+        out = fn()
+        K.synchronize()
+    except Exception:
+        if not aborted():
+            raise
+        out = None
+    if aborted():
+        if comm is not None and comm.world > 1:
+            raise RuntimeError("a grid barrier of a cooperative kernel timed out on rank %d (device shared with another resident "
+                               "kernel?); set VICAN_COOP=0 to run sharded solves without cooperative kernels" % comm.rank)
+        K.cooperative_failed("grid barrier timeout")
+        out = fn()
+        K.synchronize()
+    return out
+
+
 def solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol=1e-10, rtol=1e-5, lsqr_solver="conjugate_gradient",
                      bnorm2_fn=None, tight=False):
     """Rotation stage then translation stage on one rank's backend ``K``.
     Returns (rc [3C,3] node<-world stacked, Rt_local [T,9], x_c [C,3], x_t [T,3], stats).
     ``bnorm2_fn(rc, Rt_local) -> |b|^2`` of the reference's un-merged system (LSQR stopping tests)."""
+    return with_cooperative_fallback(K, comm, lambda: _solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol, rtol, lsqr_solver,
+                                                                        bnorm2_fn, tight))
+
+
+def _solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol, rtol, lsqr_solver, bnorm2_fn, tight):
     rot = RotationSolver(K, comm, eig_tol=eig_tol)
     rc, Rt_loc = rot.run(maxiter)
     K.synchronize()
