@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="storage type of the 3x3 blocks")
     ap.add_argument("--maxiter", type=int, default=4)
     ap.add_argument("--no-large-shop", action="store_true", help="skip the large_shop wall-clock measurement")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-capture measurement (detail.sparse) of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
     ap.add_argument("--n-copy", type=int, default=None)
@@ -170,8 +171,15 @@ def large_shop_wall_clock(args, dev, tdt, comm):
         src = synth.edges_to_dict(flat, SE3)
         cons = synth.constraints_from_scene(scene, SE3)
         unit, keep = (lambda e: 1.0), (lambda e: True)
+        from vican_amd.device import merge_edges
         t0 = time.perf_counter()
         prob = frontend.flatten(src, cons, unit, unit, keep, np.float32)
+        res["t_flatten_host_ms"] = (time.perf_counter() - t0) * 1e3
+        frontend.flatten(src, cons, unit, unit, keep, np.float32, merge=merge_edges)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frontend.flatten(src, cons, unit, unit, keep, np.float32, merge=merge_edges)       # what the drop-in call does
+        torch.cuda.synchronize()
         res["t_flatten_ms"] = (time.perf_counter() - t0) * 1e3
         res["flatten_source_edges"] = int(prob.n_src)
         # the same detections handed over as arrays (bipartite_se3sync_arrays: no edge dict, no per-edge callables)
@@ -180,7 +188,19 @@ def large_shop_wall_clock(args, dev, tdt, comm):
         ones = np.ones(len(cams))
         t0 = time.perf_counter()
         frontend.flatten_arrays(cams, tm[:, 0], tm[:, 2], flat["R"], flat["t"], ones, ones, cons, np.float32)
-        res["t_flatten_arrays_ms"] = (time.perf_counter() - t0) * 1e3
+        res["t_flatten_arrays_host_ms"] = (time.perf_counter() - t0) * 1e3
+        # ... what the drop-in does: string ids -> indices on the host, everything numeric on the device (vican_merge.hip)
+        ix = frontend.index_edges(cams, tm[:, 0], tm[:, 2], cons)
+        merge_edges(ix, flat["R"], flat["t"], ones, ones, np.float32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix = frontend.index_edges(cams, tm[:, 0], tm[:, 2], cons)
+        t1 = time.perf_counter()
+        merge_edges(ix, flat["R"], flat["t"], ones, ones, np.float32)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res["t_index_ms"], res["t_merge_device_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        res["t_flatten_arrays_ms"] = (t2 - t0) * 1e3
     except Exception as exc:
         res["t_flatten_ms"] = None
         res["flatten_error"] = repr(exc)
@@ -194,7 +214,8 @@ def large_shop_wall_clock(args, dev, tdt, comm):
 
 def launch_ranks(args):
     """`--gpus N` without a launcher: start N fresh rank processes (this process has not touched the GPU and never
-    does), relay rank 0's output, fail if any rank fails.  Never re-executes the current process."""
+    does), relay rank 0's output, fail if any rank fails.  Never re-executes the current process.  (Profilers: put
+    rocprofv3 in front of SINGLE-rank invocations only - its preloaded library initialises the GPU in the launcher.)"""
     import socket
     import subprocess
     n = args.gpus
@@ -215,12 +236,185 @@ def launch_ranks(args):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # supervise ALL ranks: if one dies at start-up the others would sit in init_process_group / a collective until the
+    # torch timeout - on the first non-zero exit (or after the overall limit) the rest are terminated
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("VICAN_BENCH_TIMEOUT_S", 3600))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = "rank %s failed" % bad if bad else "timeout"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    sys.stdout.write(b"".join(out_chunks).decode())
     sys.stdout.flush()
-    if any(rcs):
-        sys.exit("bench.py: rank exit codes %s" % rcs)
+    if failed or any(rcs):
+        sys.exit("bench.py: %s; rank exit codes %s" % (failed or "a rank failed", rcs))
+
+
+def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, steps, warmup, backend):
+    """Build the synthetic graph of one workload in HBM, run `warmup` + `steps` full solves between barriers, and return
+    value / ms_per_step / config / roofline / detail of it (the JSON line's fields)."""
+    from vican_amd import synth
+    from vican_amd.bipgo import _shard_rows
+    from vican_amd.device import HipBackend, LocalGraph
+    from vican_amd.solver import RotationSolver, TranslationSolver
+    if scaling == "weak":
+        T_total, r0, Tl = Tn * world, rank * Tn, Tn
+    else:                                               # one graph of Tn rows, split like solve_problem does
+        T_total = Tn
+        r0, r1 = _shard_rows(Tn, world, rank)
+        Tl = r1 - r0
+    gr = synth.make_merged_graph_torch(C, Tl, cpt, dev, tdt, seed=0, t_offset=r0)
+    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"],
+                   block_threads=args.block_threads, n_copy=args.n_copy)
+    E_local = g.n_edges
+    g._csr_t = None                                     # (no LSQR here: let the CSR-order inputs go)
+    del gr
+    torch.cuda.empty_cache()
+
+    class TimedBackend(HipBackend):
+        """HIP events bound to every launch of the dominant kernel (vican_set_launch_events: start / stop of the
+        dispatch itself on the launch stream - no event command sits in the stream next to the kernel, so the
+        5-8 us of queue idle that an event pair recorded around a launch adds are not part of the measurement)."""
+        events, timers = [], []
+        record = False
+
+        def block_op_raw(self, lamT_inv, x):
+            if self.record and self.timers:
+                pair = self.timers.pop()
+                self.time_next_sweep(pair)
+                self.events.append(pair)
+            return super().block_op_raw(lamT_inv, x)
+
+        def block_op(self, lamT_inv, x, z_out):
+            if not self.record:
+                return super().block_op(lamT_inv, x, z_out)
+            self.block_op_raw(lamT_inv, x)                 # the sweep kernel alone ...
+            self.fold_z(z_out)                             # ... then the slab fold
+
+    K = TimedBackend(g)
+    K.events, K.timers = [], []
+    rot = RotationSolver(K, comm)
+    tr = TranslationSolver(K, comm)
+    n_unknowns = 3 * (C + T_total)
+
+    def step(split=False):
+        """One full solve.  split=True also syncs between the rotation and the translation stage to time them
+        separately (costs a ~40 us pipeline bubble: done in the instrumented step only)."""
+        rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+        tr.poll_every = 8
+        t0 = time.perf_counter()
+        rc, Rt = rot.run(args.maxiter)
+        if split:
+            K.synchronize()
+        t1 = time.perf_counter()
+        tr.setup(rc, Rt)
+        tr.solve(n_unknowns)
+        K.synchronize()
+        return t1 - t0, time.perf_counter() - t1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    n_ar0 = comm.n_allreduce
+    for _ in range(warmup):
+        step()
+    K.timers = K.make_launch_timers(64)
+    barrier()
+    # HIP events are bound to every launch of the dominant kernel of the LAST timed step (its sync between the two
+    # stages, for the stage split, costs a pipeline bubble - one instrumented step is enough).
+    t_rot = t_tr = 0.0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        K.record = (i == steps - 1)
+        a, b = step(split=K.record)
+        if K.record:
+            t_rot, t_tr = a, b
+    K.record = False
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if K.barrier_aborted() or K.coop_failures:
+        print("bench.py: a cooperative kernel's grid barrier gave up during the run (%s): device shared?" % K.coop_failures, file=sys.stderr)
+
+    kern_ms = np.array([a.elapsed_time(b) for a, b in K.events])
+    # a speculative launch that the Ritz gate cancelled on the device exits at its first instruction (a few
+    # microseconds): not a sweep, so not part of the average (none occur once the step prediction has settled)
+    n_cancelled = int((kern_ms < 0.1 * np.median(kern_ms)).sum()) if len(kern_ms) else 0
+    if n_cancelled:
+        kern_ms = kern_ms[kern_ms >= 0.1 * np.median(kern_ms)]
+    op_bytes = g.op_bytes()
+    achieved = op_bytes / (kern_ms.mean() * 1e-3) / 1e9 if len(kern_ms) else 0.0
+    n_allreduce_total = comm.n_allreduce - n_ar0
+    cnt = torch.tensor([float(E_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(cnt)
+    E_total = int(cnt[0].item())
+    value = E_total * args.maxiter * steps / elapsed
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
+    # (profiles/<tag>_sweep_counters.json, written by tools/collect_profiles.py); null if none matches
+    traffic = None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+            if pj.get("traffic") and pj.get("bytes_per_launch_algorithmic") == op_bytes:
+                traffic = pj["traffic"]["hbm_bytes"]
+                break
+        except Exception:
+            pass
+    res = {
+        "value": value, "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": "%s: %d cameras x %d timesteps (%s) x %d cams/timestep, %d merged edges in total "
+                               "(%d on rank 0), maxiter=%d + CG translation solve, blocks stored %s" % (
+                                   workload, C, T_total, "%d per GPU" % Tn if scaling == "weak" else "split over the GPUs",
+                                   cpt, E_total, E_local, args.maxiter, args.dtype),
+                   "arithmetic": "%s block products, exact 64-bit fixed-point accumulation (double-word in the translation stage), "
+                                 "f64 camera side and CG" % args.dtype,
+                   "parallelism": "timestep-sharded x%d, camera side replicated" % world,
+                   "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
+        "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
+                     "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
+                     "padded_slots_over_edges": g.padded_slots() / max(E_local, 1)},
+        "detail": {"rot_loop_ms_per_step": t_rot * 1e3, "cg_ms_per_step": t_tr * 1e3,     # split of the last (instrumented) step
+                   "sweeps_per_step": rot.stats["sweeps"], "lanczos_steps": rot.stats["lanczos_steps"],
+                   "eig_resid": rot.stats["resid"], "cg_iters": tr.info.get("cg_iters"),
+                   "lanczos_checks": rot.stats.get("n_check"),
+                   "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
+                   "layout": g.layout, "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
+                   "rot_edges_per_s": E_total * args.maxiter / t_rot if t_rot else None,
+                   "edges_rank0": E_local, "rows_rank0": Tl,
+                   "n_allreduce_per_solve": n_allreduce_total / max(steps + warmup, 1)},
+    }
+    del K, g, rot, tr
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -248,11 +442,7 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
-    from vican_amd import synth
-    from vican_amd.device import HipBackend, LocalGraph
-    from vican_amd.solver import Comm, RotationSolver, TranslationSolver
-
-    from vican_amd.bipgo import _shard_rows
+    from vican_amd.solver import Comm
     if args.workload == "stress":
         C, Tn, cpt = args.cams or 1000, args.timesteps or 100000, args.cams_per_t or 250
     elif args.workload == "sparse":
@@ -260,150 +450,37 @@ def main():
     else:
         C, Tn, cpt = args.cams or 340, args.timesteps or 10000, args.cams_per_t or 4
     scaling = args.scaling or ("strong" if args.workload == "large_shop" else "weak")
-    if scaling == "weak":
-        T_total, r0, Tl = Tn * world, rank * Tn, Tn
-    else:                                               # one graph of Tn rows, split like solve_problem does
-        T_total = Tn
-        r0, r1 = _shard_rows(Tn, world, rank)
-        Tl = r1 - r0
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
-    gr = synth.make_merged_graph_torch(C, Tl, cpt, dev, tdt, seed=0, t_offset=r0)
-    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"],
-                   block_threads=args.block_threads, n_copy=args.n_copy)
-    E_local = g.n_edges
-    del gr
-    torch.cuda.empty_cache()
-
-    class TimedBackend(HipBackend):
-        """HIP events bound to every launch of the dominant kernel (vican_set_launch_events: start / stop of the
-        dispatch itself on the launch stream - no event command sits in the stream next to the kernel, so the
-        5-8 us of queue idle that an event pair recorded around a launch adds are not part of the measurement)."""
-        events, timers = [], []
-        record = False
-
-        def block_op_raw(self, lamT_inv, x):
-            if self.record and self.timers:
-                pair = self.timers.pop()
-                self.time_next_sweep(pair)
-                self.events.append(pair)
-            return super().block_op_raw(lamT_inv, x)
-
-        def block_op(self, lamT_inv, x, z_out):
-            if not self.record:
-                return super().block_op(lamT_inv, x, z_out)
-            self.block_op_raw(lamT_inv, x)                 # the sweep kernel alone ...
-            self.fold_z(z_out)                             # ... then the slab fold
-
-    K = TimedBackend(g)
     comm = Comm()
-    rot = RotationSolver(K, comm)
-    tr = TranslationSolver(K, comm)
-    n_unknowns = 3 * (C + T_total)
-
-    def step(split=False):
-        """One full solve.  split=True also syncs between the rotation and the translation stage to time them
-        separately (costs a ~40 us pipeline bubble: done in the instrumented step only)."""
-        rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
-        tr.poll_every = 8
-        t0 = time.perf_counter()
-        rc, Rt = rot.run(args.maxiter)
-        if split:
-            K.synchronize()
-        t1 = time.perf_counter()
-        tr.setup(rc, Rt)
-        tr.solve(n_unknowns)
-        K.synchronize()
-        return t1 - t0, time.perf_counter() - t1
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    K.timers = K.make_launch_timers(64)
-    barrier()
-    # HIP events are bound to every launch of the dominant kernel of the LAST timed step (its sync between the two
-    # stages, for the stage split, costs a pipeline bubble - one instrumented step is enough).
-    t_rot = t_tr = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        K.record = (i == args.steps - 1)
-        a, b = step(split=K.record)
-        if K.record:
-            t_rot, t_tr = a, b
-    K.record = False
-    barrier()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(el.item())
-
-    kern_ms = np.array([a.elapsed_time(b) for a, b in K.events])
-    # a speculative launch that the Ritz gate cancelled on the device exits at its first instruction (a few
-    # microseconds): not a sweep, so not part of the average (none occur once the step prediction has settled)
-    n_cancelled = int((kern_ms < 0.1 * np.median(kern_ms)).sum()) if len(kern_ms) else 0
-    if n_cancelled:
-        kern_ms = kern_ms[kern_ms >= 0.1 * np.median(kern_ms)]
-    op_bytes = g.op_bytes()
-    achieved = op_bytes / (kern_ms.mean() * 1e-3) / 1e9 if len(kern_ms) else 0.0
-    cnt = torch.tensor([float(E_local), float(comm.n_allreduce)], dtype=torch.float64, device=dev)
-    n_allreduce_total = comm.n_allreduce
-    if world > 1:
-        torch.distributed.all_reduce(cnt)
-    E_total = int(cnt[0].item())
-    value = E_total * args.maxiter * args.steps / elapsed
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
-    # (profiles/<tag>_sweep_counters.json, written by tools/collect_profiles.py); null if none matches
-    traffic = None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sweep_counters.json")), reverse=True):
-        try:
-            pj = json.load(open(f))
-            if pj.get("traffic") and pj.get("bytes_per_launch_algorithmic") == op_bytes:
-                traffic = pj["traffic"]["hbm_bytes"]
-                break
-        except Exception:
-            pass
+    m = measure(args, dev, tdt, comm, args.workload, C, Tn, cpt, scaling, world, rank, args.steps, args.warmup, backend)
     out = {
         "metric": "edges/sec through bipartite_se3sync primal-dual iter",
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "value": m["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s: %d cameras x %d timesteps (%s) x %d cams/timestep, %d merged edges in total "
-                               "(%d on rank 0), maxiter=%d + CG translation solve, blocks stored %s" % (
-                                   args.workload, C, T_total, "%d per GPU" % Tn if scaling == "weak" else "split over the GPUs",
-                                   cpt, E_total, E_local, args.maxiter, args.dtype),
-                   "arithmetic": "%s block products, exact 64-bit fixed-point accumulation, f64 camera side and CG" % args.dtype,
-                   "parallelism": "timestep-sharded x%d, camera side replicated" % world,
-                   "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
-        "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
-                     "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
-                     "padded_slots_over_edges": g.padded_slots() / max(E_local, 1)},
-        "detail": {"rot_loop_ms_per_step": t_rot * 1e3, "cg_ms_per_step": t_tr * 1e3,     # split of the last (instrumented) step
-                   "sweeps_per_step": rot.stats["sweeps"], "lanczos_steps": rot.stats["lanczos_steps"],
-                   "eig_resid": rot.stats["resid"], "cg_iters": tr.info.get("cg_iters"),
-                   "lanczos_checks": rot.stats.get("n_check"),
-                   "cg_converged": tr.info.get("converged"), "n_chunk": g.n_chunk, "n_wg": g.n_wg,
-                   "layout": g.layout, "block_threads": g.block_threads, "n_copy": g.n_copy, "max_rows": g.max_rows,
-                   "rot_edges_per_s": E_total * args.maxiter / t_rot if t_rot else None,
-                   "edges_rank0": E_local, "rows_rank0": Tl,
-                   "n_allreduce_per_solve": n_allreduce_total / max(args.steps + args.warmup, 1)},
+        "config": m["config"], "roofline": m["roofline"], "detail": m["detail"],
     }
     if rank == 0 and world == 1 and args.workload == "stress" and not args.no_large_shop:
         # second half of BASELINE.json's metric: wall-clock of a full solve of a large_shop-sized graph
         # (340 cameras x 10 000 timesteps x 4 cameras per timestep: cache-resident, latency-bound)
         try:
-            del K, g, rot, tr
-            torch.cuda.empty_cache()
             out["detail"]["large_shop_wall_clock"] = large_shop_wall_clock(args, dev, tdt, comm)
         except Exception as exc:
             out["detail"]["large_shop_wall_clock"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and args.workload == "stress" and not args.no_sparse:
+        # the regime real captures are in (2-8 cameras per timestep): a long sparse capture, 100 cameras x 2 M timesteps x
+        # 8 cameras per timestep = 16 M merged edges, the same measurement in short form (`--workload sparse` for the full one)
+        try:
+            ms = measure(args, dev, tdt, comm, "sparse", 100, 2000000, 8, "weak", 1, 0, 3, 1, backend)
+            out["detail"]["sparse"] = {"workload": ms["config"]["workload"], "frac": ms["roofline"]["frac"],
+                                       "achieved_GBps": ms["roofline"]["achieved"], "avg_launch_ms": ms["roofline"]["avg_launch_ms"],
+                                       "bytes_per_launch": ms["roofline"]["bytes_per_launch"], "traffic": ms["roofline"]["traffic"],
+                                       "ms_per_solve": ms["ms_per_step"], "value_edges_per_s": ms["value"],
+                                       "sweeps_per_step": ms["detail"]["sweeps_per_step"], "cg_iters": ms["detail"]["cg_iters"],
+                                       "cg_ms_per_step": ms["detail"]["cg_ms_per_step"], "layout": ms["detail"]["layout"],
+                                       "max_rows": ms["detail"]["max_rows"], "n_copy": ms["detail"]["n_copy"], "steps": 3, "warmup": 1}
+        except Exception as exc:
+            out["detail"]["sparse"] = {"error": repr(exc)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Ts = args.cpu_sample_timesteps or {"stress": 300, "sparse": 20000}.get(args.workload, 10000)
         try:

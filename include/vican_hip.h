@@ -232,7 +232,7 @@ int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, double* out
 /* out[c][q] = scale * (*pa) * (*pb) * sum_s part[s][q][c]: folds 64-bit fixed-point plane slabs
  * [n_slab][ncomp][n_cam] into a row-major camera vector [n_cam][ncomp] (exact integer sum).
  * pa / pb may be NULL (= 1).  vican_block_op slabs: ncomp 9, pa = fx+3, pb = fx+7;
- * vican_cg_sweep slabs: ncomp 3, pa = &state->qinv; vican_trans_rhs slabs: ncomp 3, scale = *inv_out. */
+ * (vican_trans_rhs and vican_cg_fold fold their double-word slabs themselves.) */
 int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_cam, int32_t ncomp, double scale,
                          const double* pa, const double* pb, double* out, void* stream);
 
@@ -370,17 +370,36 @@ int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, 
                double eig_tol, double floor_tol, double floor_level, double stall_ratio, double* Y,
                double* status, int32_t* gate, void* stream);
 
+/* ---- front-end on the device: constraint application + multi-marker merge (bipgo.py:203-221, 445-469) --------------------
+ * One entry per KEPT source edge (the host has evaluated edge_filter / noise_model_r / noise_model_t and mapped the string
+ * ids to indices - frontend.index_edges): cam / tim / marker [n] int32 indices, R [n][9] and t [n][3] the measured pose of
+ * the marker in the camera frame, kr / kt [n] the two weights; CmT [n_marker][9] = R_m^T R_root and qtau [n_marker][3] =
+ * (R_root^T R_m) trans(S_m^-1 S_root) per marker.  Output, all device arrays sized for n (the merged count E <= n comes back
+ * in *n_merged): the timestep-major CSR problem row_ptr [n_time+1], col [E] (ascending camera inside a row),
+ * blk [E][9] = sum k_r R~ R_m^T R_root, a [E] = sum k_r, w [E] = sum kf^2, u [E][3] = sum kf k_t t~, v [E][3] = sum kf k_t
+ * qtau_m (kf = k_t rounded to the matrix dtype `storage`), and deg_c [n_cam], deg_t [n_time] = the diagonal of the reference's
+ * J^T J, accumulated in the matrix dtype in source-edge order as scipy's csr_matmat does.  Every sum runs sequentially in
+ * source-edge order with unfused IEEE operations: bit-identical to frontend.merge_host.  ws: vican_merge_ws_bytes bytes.  */
+int64_t vican_merge_ws_bytes(int64_t n, int32_t n_cam, int32_t n_time);
+int vican_merge_edges(int64_t n, int32_t n_cam, int32_t n_time, int32_t n_marker, int32_t storage,
+                      const int32_t* cam, const int32_t* tim, const int32_t* marker, const double* R, const double* t,
+                      const double* kr, const double* kt, const double* CmT, const double* qtau, void* ws, int64_t ws_bytes,
+                      int32_t* n_merged, int32_t* row_ptr, int32_t* col, double* blk, double* a, double* w, double* u, double* v,
+                      double* deg_c, double* deg_t, void* stream);
+
 /* ---- translation stage ---------------------------------------------------
  * Unknowns p (cameras [C][3], timesteps [T][3], double).  Normal equations of
  * bipgo.py:463-477:  (weighted bipartite Laplacian (x) I3) p = J^T b.          */
 
 /* Right-hand side J^T b (bipgo.py:451-461 + J^T): g_ct = Rc_c^T u_ct + Rt_t^T v_ct;
- * rhs_t[t] = sum_c g_ct (written), rhs_c_part = fixed-point slabs [n_wg][3][C] of -sum_t g_ct
- * (fold with vican_slab_reduce_fx, scale = *inv_out).  gmax >= max_e (|u_e| + |v_e|) and
- * n_add >= the number of edges added into one accumulator by one workgroup size the scale.   */
+ * rhs_t[t] = sum_c g_ct, rhs_c[c] = -sum_t g_ct over this rank's rows (both written; rhs_c_part: scratch of n_wg * 6C
+ * 64-bit words for the double-word fixed-point camera slabs).  u, v: per-edge 3-vectors in the slot order of g
+ * [n_chunk][3][slots] - either layout (block: trans_rhs_kernel; wave: trans_wrhs_kernel, one wavefront per chunk).
+ * gmax >= max_e (|u_e| + |v_e|) and n_add >= the number of contributions one workgroup adds into one accumulator
+ * size the scale.  Sums are exact (double-word fixed point, to_fix2) and rounded to f64 once per output.   */
 int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v,
-                    const double* rc, const double* rt, double* rhs_t, void* rhs_c_part,
-                    double gmax, double n_add, double* inv_out, void* stream);
+                    const double* rc, const double* rt, double* rhs_t, double* rhs_c, void* rhs_c_part,
+                    double gmax, double n_add, void* stream);
 
 /* ---- Jacobi (diagonal) scaling for the tight translation solve ----------------------------
  * The normal equations A = [[D_c, -W], [-W^T, D_t]] (x) I3 scaled symmetrically by S = D^-1/2 are again a

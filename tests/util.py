@@ -117,6 +117,7 @@ class SelfMovement:
                 x, code = self._cg(A, bb, *a, callback=count, **k)
                 return x, code, n[0]
             x, code, n0 = run(b, cb)
+            self._system = (A, b, a, k, x)                  # kept for more_trials()
             rng = np.random.default_rng(self.seed)
             moves, iters = [], [n0]
             for _ in range(self.n_trials):
@@ -131,6 +132,19 @@ class SelfMovement:
     def __exit__(self, *exc):
         self.orc.cg = self._cg
         return False
+
+    def more_trials(self, rel, n_trials=None):
+        """Self-movement under right-hand sides perturbed by `rel` relative instead of 1e-15 - END-TO-END comparisons feed
+        the two translation stages rotations that differ by `rel` radians (two eigen-solvers: 1e-9 in f64, 1e-7 .. 1e-6 in
+        f32), which moves the right-hand side by that much, and the loosely converged CG amplifies that just like it
+        amplifies the 1e-15.  Returns the movements (m) of the oracle's own answer."""
+        A, b, a, k, x = self._system
+        rng = np.random.default_rng(self.seed + 1)
+        moves = []
+        for _ in range(n_trials or self.n_trials):
+            xt, _ = self._cg(A, b * (1.0 + rel * rng.standard_normal(b.shape)), *a, **k)
+            moves.append(float(np.linalg.norm((np.asarray(xt) - np.asarray(x)).reshape(-1, 3), axis=1).max()))
+        return np.array(moves)
 
     def bound(self, factor=4.0, floor=1e-6):
         """Translation tolerance (m): ``factor`` x the largest self-movement seen, floored where the oracle is

@@ -43,8 +43,8 @@ def stage_alone(src, cons, mode, fns, dt, ref):
     from vican_amd.device import make_backend
     from vican_amd.solver import Comm, TranslationSolver
     nr, nt, ff = fns
-    if mode == "object":          # (object scenes of make_case are all f64, where end to end IS stage-accurate; the wrapper returns markers only)
-        return None, None
+    if mode == "object":          # (the object wrapper returns markers only; object scenes are f64, where end to end IS stage-accurate)
+        return None, None, None, None
     prob = frontend.flatten(src, cons, nr, nt, ff, dt)
     dev = torch.device("cuda", torch.cuda.current_device())
     tdt = torch.float32 if dt == np.float32 else torch.float64
@@ -54,14 +54,21 @@ def stage_alone(src, cons, mode, fns, dt, ref):
     Rw = {str(k): np.asarray(v.R(), dtype=np.float64) for k, v in ref.items()}
     rc = np.stack([Rw[str(c)].T for c in prob.cam_names]).reshape(-1, 3)
     rt = np.stack([Rw[str(s) + "_0"].T for s in prob.time_names]).reshape(-1, 9)
-    tr = TranslationSolver(K, Comm.single())
-    tr.setup(K.from_numpy(rc), K.from_numpy(rt))
-    x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
-    pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
-    pos.update({str(s) + "_0": x_t.cpu().numpy()[i] for i, s in enumerate(prob.time_names)})
-    t = np.stack([pos[str(k)] for k in ref])
     tr_ = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
-    return float(np.linalg.norm(t - tr_, axis=1).max()), int(tr.info["cg_iters"])
+
+    def run(B):
+        tr = TranslationSolver(B, Comm.single())
+        tr.setup(B.from_numpy(rc), B.from_numpy(rt))
+        x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
+        pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
+        pos.update({str(s) + "_0": x_t.cpu().numpy()[i] for i, s in enumerate(prob.time_names)})
+        t = np.stack([pos[str(k)] for k in ref])
+        return float(np.linalg.norm(t - tr_, axis=1).max()), int(tr.info["cg_iters"])
+    # the same stage through the NumPy stand-in (tests/numpy_backend.py: plain f64 NumPy sums, no fixed point, no GPU) - an
+    # independent f64 implementation of the same recurrence: what IT does against the bound calibrates the bound
+    from numpy_backend import NumpyBackend
+    N = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=dt, deg_t=prob.deg_t, deg_c=prob.deg_c)
+    return run(K) + run(N)
 
 
 for seed in range(N):
@@ -99,13 +106,18 @@ for seed in range(N):
                 tr = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
                 rot, err = float(geodesic(R, Rr).max()), float(np.linalg.norm(t - tr, axis=1).max())
                 bound = sm.bound()                          # max(1e-6 m, 4 x the oracle's largest self-movement)
-                # f32 end to end: the rotation stages (two f32 eigen-solves) differ by `rot`, which moves the right-hand
-                # side by that much relative; first-order effect on positions of this scene's extent
-                bound_e2e = bound + (4.0 * rot * (1.0 + float(np.abs(tr).max())) if dt == np.float32 else 0.0)
-                stage_err, stage_cg = stage_alone(src, cons, mode, (nr, nt, ff), dt, ref)
-                row.update(rot_rad=rot, trans_m=err, stage_trans_m=stage_err, self_move_max=float(sm.self_move.max()),
-                           self_move_median=float(np.median(sm.self_move)), bound_m=bound, bound_e2e_m=bound_e2e, cg_stage=stage_cg,
-                           cg_oracle=oinfo.get("cg_iters"), cg_oracle_min=int(sm.iters.min()), cg_oracle_max=int(sm.iters.max()))
+                # end to end the two translation stages are fed rotations that differ by `rot` (two eigen-solvers: ~1e-9 rad in
+                # f64, 1e-7 .. 1e-6 in f32), i.e. right-hand sides that differ by that much relative: the yardstick there is the
+                # oracle's own movement under perturbations of THAT size (stage_trans_m, fed the oracle's rotations, keeps 1e-15)
+                move_rot = sm.more_trials(max(rot, 1e-15))
+                bound_e2e = max(bound, 4.0 * float(move_rot.max()))
+                stage_err, stage_cg, np_err, np_cg = stage_alone(src, cons, mode, (nr, nt, ff), dt, ref)
+                row.update(rot_rad=rot, trans_m=err, stage_trans_m=stage_err, stage_numpy_m=np_err, self_move_max=float(sm.self_move.max()),
+                           self_move_median=float(np.median(sm.self_move)), self_move_at_rot_max=float(move_rot.max()), bound_m=bound,
+                           bound_e2e_m=bound_e2e, cg_stage=stage_cg,
+                           cg_numpy=np_cg, cg_oracle=oinfo.get("cg_iters"), cg_oracle_min=int(sm.iters.min()), cg_oracle_max=int(sm.iters.max()),
+                           cg_oracle_trials=";".join(str(int(i)) for i in sm.iters[1:]),
+                           self_move_trials=";".join("%.2e" % m for m in sm.self_move))
                 if rot >= (1e-7 if dt == np.float64 else 5e-6):
                     row["outcome"] = "ROTATION MISMATCH"
                 elif err >= bound_e2e or (stage_err is not None and stage_err >= bound):
@@ -115,8 +127,9 @@ for seed in range(N):
     rows.append(row)
     if seed % 50 == 49:
         print("seed %d  %.0f s" % (seed, time.time() - t_start), flush=True)
-keys = ["seed", "mode", "dtype", "weights", "filter", "cameras", "timesteps", "source_edges", "rot_rad", "trans_m", "stage_trans_m",
-        "self_move_max", "self_move_median", "bound_m", "bound_e2e_m", "cg", "cg_stage", "cg_oracle", "cg_oracle_min", "cg_oracle_max", "outcome"]
+keys = ["seed", "mode", "dtype", "weights", "filter", "cameras", "timesteps", "source_edges", "rot_rad", "trans_m", "stage_trans_m", "stage_numpy_m",
+        "self_move_max", "self_move_median", "self_move_at_rot_max", "bound_m", "bound_e2e_m", "cg", "cg_stage", "cg_numpy", "cg_oracle", "cg_oracle_min", "cg_oracle_max",
+        "cg_oracle_trials", "self_move_trials", "outcome"]
 with open(os.path.join(out, "random_parity.csv"), "w", newline="") as f:
     wr_ = csv.DictWriter(f, fieldnames=keys)
     wr_.writeheader()
@@ -128,7 +141,9 @@ over = [r for r in cmp_rows if r["trans_m"] > 1e-4]
 summary = {
     "columns": "bound_m = max(1e-6, 4 x self_move_max); self_move = movement of the oracle's own answer under 8 right-hand sides perturbed "
                "by 1e-15 relative (tests/util.SelfMovement); stage_trans_m = translation stage alone with the oracle's rotations fed in "
-               "(camera mode); bound_e2e_m = bound_m (+ 4 rot (1 + max|t|) in f32, where the two f32 rotation stages differ by rot)",
+               "(camera mode); bound_e2e_m = max(bound_m, 4 x self_move_at_rot_max): the oracle's movement under right-hand sides perturbed by rot_rad "
+               "relative, the amount by which the two rotation stages differ; stage_numpy_m / cg_numpy = the same stage through the plain-f64 "
+               "NumPy stand-in (calibrates the bound)",
     "seeds": N, "compared": len(cmp_rows),
     "outcomes": {o: sum(1 for r in rows if r["outcome"] == o) for o in sorted(set(r["outcome"] for r in rows))},
     "max_rot_rad_f64": max((r["rot_rad"] for r in cmp_rows if r["dtype"] == "float64"), default=None),
@@ -142,7 +157,20 @@ summary = {
     "stage_over_1e-4_m": sum(1 for r in cmp_rows if (r.get("stage_trans_m") or 0) > 1e-4),
     "stage_over_1e-4_m_and_over_self_move_max": sum(1 for r in cmp_rows if (r.get("stage_trans_m") or 0) > 1e-4 and r["stage_trans_m"] > r["self_move_max"]),
     "self_move_max_over_1e-4_m": sum(1 for r in cmp_rows if r["self_move_max"] > 1e-4),
+    # calibration of the bound: the NumPy stand-in (independent plain-f64 implementation) against the SAME bound, and how often a
+    # 1e-15-perturbed run of the ORACLE ITSELF stops at another iteration than its unperturbed run
+    "stage_over_bound": sum(1 for r in cmp_rows if r.get("stage_trans_m") is not None and r["stage_trans_m"] >= r["bound_m"]),
+    "numpy_stand_in_over_bound": sum(1 for r in cmp_rows if r.get("stage_numpy_m") is not None and r["stage_numpy_m"] >= r["bound_m"]),
+    "stage_compared": sum(1 for r in cmp_rows if r.get("stage_trans_m") is not None),
+    "stage_iteration_differs_from_oracle": sum(1 for r in cmp_rows if r.get("cg_stage") is not None and r["cg_stage"] != r["cg_oracle"]),
+    "numpy_stand_in_iteration_differs_from_oracle": sum(1 for r in cmp_rows if r.get("cg_numpy") is not None and r["cg_numpy"] != r["cg_oracle"]),
+    "oracle_trials_with_other_iteration_count_fraction": (lambda tr: sum(1 for a, b in tr if a != b) / max(len(tr), 1))(
+        [(int(x), r["cg_oracle"]) for r in cmp_rows if r.get("cg_oracle_trials") for x in r["cg_oracle_trials"].split(";")]),
     "cg_iteration_difference_le_2_fraction": (sum(1 for a, b, _, _ in it if abs(a - b) <= 2) / len(it)) if it else None,
+    "numpy_stand_in_cg_iteration_difference_le_2_fraction": (lambda v: sum(1 for a, b in v if abs(a - b) <= 2) / max(len(v), 1))(
+        [(r["cg_numpy"], r["cg_oracle"]) for r in cmp_rows if r.get("cg_numpy") is not None]),
+    "stage_cg_iteration_difference_le_2_fraction": (lambda v: sum(1 for a, b in v if abs(a - b) <= 2) / max(len(v), 1))(
+        [(r["cg_stage"], r["cg_oracle"]) for r in cmp_rows if r.get("cg_stage") is not None]),
     "cg_inside_oracle_window_pm2_fraction": (sum(1 for a, _, lo, hi in it if lo - 2 <= a <= hi + 2) / len(it)) if it else None,
     "max_abs_cg_iteration_difference": max((abs(a - b) for a, b, _, _ in it), default=None),
     "seconds": time.time() - t_start,

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so")      # VICAN_LIB: diagnostic builds (tools/)
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
-           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip")]
+           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
 FX_DOUBLES = 20
@@ -104,7 +104,7 @@ PROTOTYPES = {
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
+    "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp]),
     "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_sweep": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -119,6 +119,9 @@ PROTOTYPES = {
     "vican_lanczos_resident_lds_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "vican_lanczos_resident_ws_doubles": (_i64, [_i32]),
     "vican_lanczos_resident": (C.c_int, [_G, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
+    "vican_merge_ws_bytes": (_i64, [_i64, _i32, _i32]),
+    "vican_merge_edges": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),

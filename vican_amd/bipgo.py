@@ -51,6 +51,17 @@ def _warn_if_disconnected(prob):
     return n
 
 
+def _device_merge():
+    """The numeric half of the front-end on the GPU (device.merge_edges); VICAN_HOST_MERGE=1 keeps it in NumPy."""
+    import os
+    if os.environ.get("VICAN_HOST_MERGE") == "1":
+        return None
+    if not torch.cuda.is_available():
+        raise VicanError("no GPU visible: vican_amd has no CPU fallback")
+    from .device import merge_edges
+    return merge_edges
+
+
 def _shard_rows(T, world, rank):
     return (T * rank) // world, (T * (rank + 1)) // world
 
@@ -74,15 +85,18 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     T = prob.n_time
     r0, r1 = _shard_rows(T, comm.world, comm.rank)
-    e0, e1 = int(prob.row_ptr[r0]), int(prob.row_ptr[r1])
+    rp_h = prob.host_csr()[0]
+    e0, e1 = int(rp_h[r0]), int(rp_h[r1])
     t0 = time.perf_counter()
-    to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
-    # diagonal of the reference's J^T J as scipy forms it (frontend.flatten_arrays); the camera part is all-reduced by the
+
+    def to(a, dt=torch.float64):          # host arrays of merge_host, or device tensors of device.merge_edges
+        return a.to(dev, dt) if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    # diagonal of the reference's J^T J as scipy forms it (frontend.merge_host); the camera part is all-reduced by the
     # solver, so rank 0 carries it and the other ranks contribute zeros
     deg_t = to(prob.deg_t[r0:r1]) if getattr(prob, "deg_t", None) is not None else None
     deg_c = None
     if getattr(prob, "deg_c", None) is not None:
-        deg_c = to(prob.deg_c if comm.rank == 0 else np.zeros_like(prob.deg_c))
+        deg_c = to(prob.deg_c) if comm.rank == 0 else torch.zeros(prob.n_cam, dtype=torch.float64, device=dev)
     g, K = make_backend(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
                         to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]),
                         deg_t=deg_t, deg_c=deg_c)
@@ -159,7 +173,7 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
     """SE(3) synchronisation of static cameras and a moving marker object
     (reference bipgo.py:353-490).  See module docstring."""
     t0 = time.perf_counter()
-    prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype)
+    prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge())
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
@@ -183,7 +197,7 @@ def bipartite_se3sync_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, cons
     is the caller's (drop the entries).  Skips the edge dict and its per-edge Python callables - the part of the
     drop-in call that dominates once the solve takes milliseconds."""
     t0 = time.perf_counter()
-    prob = frontend.flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype)
+    prob = frontend.flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype, merge=_device_merge())
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info

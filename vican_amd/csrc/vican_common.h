@@ -49,7 +49,8 @@ extern thread_local hipEvent_t g_vican_ev_start, g_vican_ev_stop;
             hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                           \
         }                                                                                                          \
     } while (0)
-static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 96LL * n_cam + (int64_t)max_rows * (24LL * n_copy + 144) + 256; }
+// (double-word camera sums [2][3][C] + R_c planes [9][C]; double-word row stripes + double-buffered R_t staging)
+static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 120LL * n_cam + (int64_t)max_rows * (48LL * n_copy + 144) + 256; }
 // (double-word camera sums [2][3][C] + p_c planes; double-buffered double-word row stripes + two staging arrays)
 static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 72LL * n_cam + (int64_t)max_rows * (96LL * n_copy + 96) + 256; }
 // ---------------------------------------------------------------------------

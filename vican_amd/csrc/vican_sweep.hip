@@ -115,8 +115,8 @@ extern "C" int32_t vican_max_rows_for(int32_t n_cam, int32_t storage, int32_t n_
     const int64_t lim = vican_lds_limit_bytes(), s = ssize(storage);
     if (n_cam > 1024) return 0;
     int64_t a = (lim - 256 - 9LL * plane_stride(n_cam) * (s + 8)) / (72 + 9 * s + 72LL * n_copy);
-    int64_t b = (lim - 256 - 96LL * n_cam) / (24LL * n_copy + 144);  // rhs kernel (vican_trans.hip; double-buffered R_t staging)
-    int64_t c = (lim - 256 - 48LL * n_cam) / (48LL * n_copy + 96);   // CG sweep (double-buffered rows + accumulators)
+    int64_t b = (lim - 256 - 120LL * n_cam) / (48LL * n_copy + 144); // rhs kernel (rhs_lds_bytes, vican_common.h)
+    int64_t c = (lim - 256 - 72LL * n_cam) / (96LL * n_copy + 96);   // CG sweep (cg_lds_bytes)
     int64_t m = a < b ? a : b; if (c < m) m = c; if (m > 65535) m = 65535;
     return (int32_t)m;
 }

@@ -20,6 +20,9 @@
 // ---------------------------------------------------------------------------
 // Software pipeline as in cg_sweep_kernel: the edge words of chunk k+1 (packed index + u + v: 52 B per edge)
 // and the R_t blocks of its rows are in flight while chunk k is processed; two barriers per chunk.
+// Sums in double-word fixed point (to_fix2): the reference forms J^T b in f64, and its loosely converged CG turns a
+// relative perturbation of the right-hand side of 1e-15 into 1e-5 .. 5e-4 m (tests/golden/cg_sensitivity.npz) - one
+// 64-bit word 47 bits below the global bound max (|u| + |v|) was a perturbation of that size on every small entry.
 template <int EPL>
 struct RhsRegs { double u[3][EPL], v[3][EPL]; uint32_t id[EPL]; };
 
@@ -27,18 +30,20 @@ template <int BLOCK, int EPL, int NR>
 __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const double* __restrict__ u,
                                                           const double* __restrict__ v, const double* __restrict__ rc,
                                                           const double* __restrict__ rt, double* __restrict__ rhs_t,
-                                                          u64* __restrict__ rhs_c_part, double scale, double inv) {
+                                                          u64* __restrict__ rhs_c_part, double scale, double inv, int lob) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr9 = 9 * g.max_rows;
-    u64* gc = (u64*)lds_raw;                          // [3][C] planes
-    u64* gt = gc + 3 * C;                             // [max_rows*3][ncopy]
-    double* rcs = (double*)(gt + (size_t)3 * g.max_rows * ncopy);   // [9][C] planes
+    const int lo_c = 3 * C, lo_t = 3 * g.max_rows * ncopy;
+    const double lo_scale = ldexp(1.0, lob);
+    u64* gc = (u64*)lds_raw;                          // [2][3][C] planes: hi words, lo words
+    u64* gt = gc + 6 * C;                             // [2][max_rows*3][ncopy]
+    double* rcs = (double*)(gt + (size_t)2 * lo_t);   // [9][C] planes
     double* rts = rcs + 9 * C;                        // [2][max_rows][9]
     const int tid = threadIdx.x, lane_copy = tid & cmask;
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero block
     for (int i = tid; i < 9 * C; i += BLOCK) rcs[(i % 9) * C + i / 9] = rc[i];
-    for (int i = tid; i < 3 * C; i += BLOCK) gc[i] = 0ull;
-    for (int i = tid; i < 3 * g.max_rows * ncopy; i += BLOCK) gt[i] = 0ull;
+    for (int i = tid; i < 6 * C; i += BLOCK) gc[i] = 0ull;
+    for (int i = tid; i < 2 * lo_t; i += BLOCK) gt[i] = 0ull;
     const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
 
@@ -82,14 +87,20 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
         const double* rtb = rts + buf * mr9;
         double acc[3] = {0, 0, 0};
         uint32_t prow = 0xFFFFFFFFu;
+        auto flush_row = [&](const uint32_t r) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const Fix2 f = to_fix2(acc[i], scale, lo_scale);
+                u64* a = &gt[(r * 3 + i) * ncopy + lane_copy];
+                lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+            }
+        };
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
             const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
             if (row != prow) {
-                if (prow != 0xFFFFFFFFu)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) lds_add_fix(&gt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+                if (prow != 0xFFFFFFFFu) flush_row(prow);
                 prow = row; acc[0] = acc[1] = acc[2] = 0.0;
             }
             const double* B = rtb + row * 9;
@@ -99,21 +110,20 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
                                   rcs[(2 * 3 + i) * C + cam] * cur.u[2][j] + B[0 * 3 + i] * cur.v[0][j] +
                                   B[1 * 3 + i] * cur.v[1][j] + B[2 * 3 + i] * cur.v[2][j];
                 acc[i] += gi;
-                lds_add_fix(&gc[i * C + cam], to_fix(-gi, scale));
+                const Fix2 f = to_fix2(-gi, scale, lo_scale);
+                lds_add_fix(&gc[i * C + cam], f.hi); lds_add_fix(&gc[lo_c + i * C + cam], f.lo);
             }
         }
-        if (prow != 0xFFFFFFFFu)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) lds_add_fix(&gt[(prow * 3 + i) * ncopy + lane_copy], to_fix(acc[i], scale));
+        if (prow != 0xFFFFFFFFu) flush_row(prow);
         __syncthreads();
         for (int i = tid; i < 3 * nrows; i += BLOCK) {
-            long long sum = 0;
+            long long sum = 0, slo = 0;
             for (int c = 0; c < ncopy; ++c) {
                 const int a = i * ncopy + ((c + i) & cmask);
-                sum += (long long)gt[a];
-                gt[a] = 0ull;
+                sum += (long long)gt[a]; slo += (long long)gt[lo_t + a];
+                gt[a] = 0ull; gt[lo_t + a] = 0ull;
             }
-            rhs_t[(size_t)r0 * 3 + i] = (double)sum * inv;
+            rhs_t[(size_t)r0 * 3 + i] = fix2_value(sum, slo, lob, inv);
         }
         if (k + 1 < k1) commit_rows(k + 1, buf ^ 1);
         __syncthreads();
@@ -123,28 +133,55 @@ __global__ __launch_bounds__(BLOCK) void trans_rhs_kernel(vican_graph_t g, const
         body(ea, eb, k, 0);
         if (k + 1 < k1) body(eb, ea, k + 1, 1);
     }
-    for (int i = tid; i < 3 * C; i += BLOCK) rhs_c_part[(size_t)blockIdx.x * 3 * C + i] = gc[i];
+    for (int i = tid; i < 6 * C; i += BLOCK) rhs_c_part[(size_t)blockIdx.x * 6 * C + i] = gc[i];
 }
 
+// fold of double-word slabs [n_slab][2][ncomp][C] -> out [C][ncomp] doubles, each rounded once (fix3_add / fix3_value)
+__global__ __launch_bounds__(1024) void fold2_kernel(const long long* __restrict__ part, int n_slab, int n_cam, int ncomp, int lob,
+                                                     double inv, double* __restrict__ out) {
+    __shared__ long long sh[3][1024];
+    const long long n = (long long)ncomp * n_cam;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    Fix3 a = {0, 0, 0};
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 16) fix3_add(a, part[(size_t)k * 2 * n + i], part[(size_t)k * 2 * n + n + i], lob);
+    sh[0][threadIdx.x] = a.top; sh[1][threadIdx.x] = a.bot; sh[2][threadIdx.x] = a.lo;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        long long t = 0, b = 0, l = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t += sh[0][k * 64 + e]; b += sh[1][k * 64 + e]; l += sh[2][k * 64 + e]; }
+        const long long q = i / n_cam, cam = i % n_cam;
+        out[cam * ncomp + q] = fix3_value(t, b, l, lob, inv);
+    }
+}
+
+extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
+                                                                      const double* rt, double* rhs_t, void* rhs_c_part, double scale,
+                                                                      double inv, int lob, void* stream);   // vican_wtrans.hip
 extern "C" int vican_trans_rhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
-                               const double* rt, double* rhs_t, void* rhs_c_part, double gmax, double n_add,
-                               double* inv_out, void* stream) {
-    if (int r = vican_check_block_graph(g, "vican_trans_rhs")) return r;
-    if (!u || !v || !rc || !rt || !rhs_t || !rhs_c_part || !inv_out || !(gmax >= 0))
+                               const double* rt, double* rhs_t, double* rhs_c, void* rhs_c_part, double gmax, double n_add,
+                               void* stream) {
+    if (int r = vican_check_graph(g, "vican_trans_rhs")) return r;
+    if (!u || !v || !rc || !rt || !rhs_t || !rhs_c || !rhs_c_part || !(gmax >= 0))
         return set_err(VICAN_ERR_ARG, "vican_trans_rhs: bad argument");
     double inv;
     const double scale = fix_scale(gmax, n_add, &inv);
-    *inv_out = inv;
+    const int lob = fix2_lo_bits(n_add);
+    hipStream_t st = (hipStream_t)stream;
+    if (g->layout == VICAN_LAYOUT_WAVE) {
+        if (int r = vican_trans_wrhs(g, u, v, rc, rt, rhs_t, rhs_c_part, scale, inv, lob, stream)) return r;
+    } else {
     const size_t lds = (size_t)rhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;
-    hipStream_t st = (hipStream_t)stream;
 const int nr = (9 * g->max_rows + g->block_threads - 1) / g->block_threads;        // R_t values per thread (<= 9 EPL)
 #define RHS_LAUNCH3(B, E, R)                                                                                     \
     do {                                                                                                         \
         auto kern = trans_rhs_kernel<B, E, R>;                                                                   \
         static size_t conf = 0;                                                                                  \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, st, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv); \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, st, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv, lob); \
     } while (0)
 #define RHS_LAUNCH(B, E)                                                                                         \
     do {                                                                                                         \
@@ -157,6 +194,10 @@ const int nr = (9 * g->max_rows + g->block_threads - 1) / g->block_threads;     
     else                              { if (epl == 4) RHS_LAUNCH(256, 4);  else RHS_LAUNCH(256, 2); }
 #undef RHS_LAUNCH3
 #undef RHS_LAUNCH
+    }
+    const long long n = 3LL * g->n_cam;
+    hipLaunchKernelGGL(fold2_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, (const long long*)rhs_c_part, g->n_wg,
+                       g->n_cam, 3, lob, inv, rhs_c);
     LAUNCH_CHECK("vican_trans_rhs");
     return VICAN_OK;
 }

@@ -257,6 +257,193 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// right-hand side J^T b on the wave layout (vican_trans_rhs, reference bipgo.py:451-461 + J^T):
+//   g_ct = Rc_c^T u_ct + Rt_t^T v_ct ;  rhs_t = sum_c g_ct ;  rhs_c = -sum_t g_ct
+// ---------------------------------------------------------------------------
+// A pure stream like the dual-update sweep: 52 B per edge (packed index + u + v, in the rotation layout's slot order),
+// one wavefront per chunk, the chunk's R_t blocks staged in the wavefront's own LDS region, R_c as planes shared by the
+// workgroup, sums in double-word fixed point (to_fix2).  Edge words and R_t values one chunk ahead, row bounds two.
+// 8 wavefronts per workgroup (4 on small graphs): two register sets of 24 doubles per lane do not fit 12.
+template <int EPL>
+struct RhsWRegs { double u[3][EPL], v[3][EPL]; uint32_t id[EPL]; };
+
+static inline int64_t wrhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
+    const int64_t per_wave = (((int64_t)max_rows * (48LL * n_copy + 72)) + 15) & ~15LL;
+    return 120LL * n_cam + (int64_t)n_waves * per_wave + 256;
+}
+
+template <int NW, int EPL, int TRIPS>
+__global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, const double* __restrict__ u, const double* __restrict__ v,
+                                                             const double* __restrict__ rc, const double* __restrict__ rt,
+                                                             double* __restrict__ rhs_t, u64* __restrict__ rhs_c_part, double scale,
+                                                             double inv, int lob) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
+    const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double lo_scale = ldexp(1.0, lob);
+    const int lo_c = 3 * C, lo_t = 3 * RW * ncopy;
+    u64* gc = (u64*)lds_raw;                                   // [2][3][C] planes (hi, lo), shared by the workgroup
+    double* rcs = (double*)(gc + 6 * C);                       // [9][C] planes
+    const size_t per_wave = (((size_t)RW * (48 * ncopy + 72)) + 15) & ~(size_t)15;
+    unsigned char* wbase = (unsigned char*)(rcs + 9 * C) + (size_t)wave * per_wave;
+    u64* gt = (u64*)wbase;                                     // [2][RW * 3][ncopy] striped row accumulators (this wave's)
+    double* rts = (double*)(gt + (size_t)2 * lo_t);            // [RW][9] R_t of the chunk's rows
+    const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
+    for (int i = tid; i < 9 * C; i += NW * 64) rcs[(i % 9) * C + i / 9] = rc[i];
+    for (int i = tid; i < 6 * C; i += NW * 64) gc[i] = 0ull;
+    for (int i = lane; i < 2 * lo_t; i += 64) gt[i] = 0ull;
+    const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    const int kmax = g.n_chunk - 1;
+
+    auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
+    auto load_edges = [&](RhsWRegs<EPL>& e, int k) {
+        k = k < kmax ? k : kmax;
+        const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
+        const bool nt = g.stream_nt != 0;
+        if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
+        else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const size_t o = ((size_t)k * 3 + p) * g.slots + (size_t)lane * EPL;
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2) {
+                const double2 a = nt ? stream_load((const double2*)(u + o + j)) : *(const double2*)(u + o + j);
+                const double2 b = nt ? stream_load((const double2*)(v + o + j)) : *(const double2*)(v + o + j);
+                e.u[p][j] = a.x; e.u[p][j + 1] = a.y; e.v[p][j] = b.x; e.v[p][j + 1] = b.y;
+            }
+        }
+    };
+    struct RowVals { double t[TRIPS]; };
+    auto load_rowvals = [&](RowVals& rv, const int2 vrow) {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n9 = 9 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            int i = lane + 64 * t;
+            i = i < n9 ? i : 0;
+            rv.t[t] = rt[(size_t)r0 * 9 + i];
+        }
+    };
+    __syncthreads();
+
+    int k = c0 + wave;
+    RhsWRegs<EPL> ea, eb;
+    RowVals ra, rb;
+    int2 v0 = load_rows(k), v1 = load_rows(k + NW), v2;
+    load_edges(ea, k);
+    load_rowvals(ra, v0);
+
+    auto body = [&](RhsWRegs<EPL>& cur, RhsWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int kk) -> int2 {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), nrows = __builtin_amdgcn_readfirstlane(vrow.y) - r0;
+        const int n9 = 9 * nrows, n3 = 3 * nrows;
+        const int2 vnn = load_rows(kk + 2 * NW);
+        load_rowvals(rvn, vnext);
+        __builtin_amdgcn_sched_barrier(0);
+        load_edges(nxt, kk + NW);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int i = lane + 64 * t;
+            if (i < n9) rts[i] = rv.t[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // all LDS reads and the arithmetic first, then nothing but atomics (LDS operations of a wavefront return in order)
+        uint32_t cam[EPL], row[EPL];
+        Fix2 fc[EPL][3];
+        double ar[EPL][3];
+        {
+            double acc[3] = {0, 0, 0}, B[9];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+                cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu); row[j] = pad ? 0u : (cur.id[j] >> 16);
+                const double uj[3] = {pad ? 0.0 : cur.u[0][j], pad ? 0.0 : cur.u[1][j], pad ? 0.0 : cur.u[2][j]};
+                const double vj[3] = {pad ? 0.0 : cur.v[0][j], pad ? 0.0 : cur.v[1][j], pad ? 0.0 : cur.v[2][j]};
+                if (j == 0 || row[j] != row[j - 1]) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) B[q] = rts[row[j] * 9 + q];
+                    acc[0] = acc[1] = acc[2] = 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {       // world<-node = transpose of the stored blocks
+                    const double gi = rcs[(0 * 3 + i) * C + cam[j]] * uj[0] + rcs[(1 * 3 + i) * C + cam[j]] * uj[1] +
+                                      rcs[(2 * 3 + i) * C + cam[j]] * uj[2] + B[0 * 3 + i] * vj[0] + B[1 * 3 + i] * vj[1] + B[2 * 3 + i] * vj[2];
+                    acc[i] += gi;
+                    fc[j][i] = to_fix2(-gi, scale, lo_scale);
+                    ar[j][i] = acc[i];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { lds_add_fix(&gc[i * C + cam[j]], fc[j][i].hi); lds_add_fix(&gc[lo_c + i * C + cam[j]], fc[j][i].lo); }
+            if (j == EPL - 1 || row[j] != row[j + 1]) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const Fix2 f = to_fix2(ar[j][i], scale, lo_scale);
+                    u64* a = &gt[(row[j] * 3 + i) * ncopy + lane_copy];
+                    lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < n3 * ncopy; base += 64) {
+            const int a = base + lane;
+            const bool live = a < n3 * ncopy;
+            u64 sum = 0ull, slo = 0ull;
+            if (live) { sum = gt[a]; slo = gt[lo_t + a]; gt[a] = 0ull; gt[lo_t + a] = 0ull; }
+            sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
+            if (live && (a & cmask) == 0) rhs_t[(size_t)r0 * 3 + a / ncopy] = fix2_value((long long)sum, (long long)slo, lob, inv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return vnn;
+    };
+#pragma unroll 1
+    while (k < c1) {
+        v2 = body(ea, eb, ra, rb, v0, v1, k);
+        k += NW;
+        if (k >= c1) break;
+        v0 = body(eb, ea, rb, ra, v1, v2, k);
+        k += NW;
+        const int2 tmp = v0; v0 = v2; v1 = tmp;
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * C; i += NW * 64) rhs_c_part[(size_t)blockIdx.x * 6 * C + i] = gc[i];
+}
+
+extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
+                                                                      const double* rt, double* rhs_t, void* rhs_c_part, double scale,
+                                                                      double inv, int lob, void* stream) {
+    int nw = g->wg_waves >= 8 ? 8 : 4;
+    if (wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw = 4;
+    const size_t lds = (size_t)wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
+    if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_trans_rhs (wave layout)");
+    const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
+    if (trips > 9) return set_err(VICAN_ERR_CAPACITY, "vican_trans_rhs: more than 64 rows per chunk");
+    // the grid of the rotation layout has one workgroup per 12 / 8 / 4 wavefronts' worth of chunks; this kernel has nw
+    hipStream_t s = (hipStream_t)stream;
+#define WRHS_LAUNCH(NW_, E_, T_)                                                                                          \
+    do {                                                                                                                  \
+        auto kern = trans_wrhs_kernel<NW_, E_, T_>;                                                                       \
+        static size_t conf = 0;                                                                                           \
+        if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv, lob); \
+    } while (0)
+#define WRHS_PICK(NW_)                                                                                                    \
+    do {                                                                                                                  \
+        if (epl == 4) { if (trips <= 1) WRHS_LAUNCH(NW_, 4, 1); else if (trips <= 3) WRHS_LAUNCH(NW_, 4, 3); else WRHS_LAUNCH(NW_, 4, 9); } \
+        else          { if (trips <= 1) WRHS_LAUNCH(NW_, 2, 1); else if (trips <= 3) WRHS_LAUNCH(NW_, 2, 3); else WRHS_LAUNCH(NW_, 2, 9); } \
+    } while (0)
+    if (nw == 8) WRHS_PICK(8); else WRHS_PICK(4);
+#undef WRHS_PICK
+#undef WRHS_LAUNCH
+    LAUNCH_CHECK("vican_trans_rhs");
+    return VICAN_OK;
+}
+
 // launcher: called by vican_cg_sweep for graphs in the wave layout
 extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,

@@ -226,9 +226,13 @@ class LocalGraph:
                 raise _lib.VicanError("the wave layout needs rows of at most %d edges and C <= 1024" % (64 * epl))
             rot = mk("block", block_threads=block_threads, n_wg=n_wg, n_copy=n_copy)
         have_t = w is not None
-        tl = rot if (rot.kind == "block" or not have_t) else mk("block")
+        # the translation arrays (w, u, v) live in the rotation layout's slot order, whichever layout that is: right-hand side
+        # and CG sweep have a kernel for each (vican_trans.hip / vican_wtrans.hip).  Only the LSQR kernels are block-layout
+        # only; a wave-layout graph builds that second layout on first use (lsqr_layout()).
+        tl = rot
         self.rot, self.tl = rot, tl
         self.layout = rot.kind
+        self._mk_block, self._storage = (lambda: mk("block")), storage
         # the rotation layout's numbers under the historical attribute names
         self.chunk_row0_host, self.max_rows, self.n_chunk, self.slots = rot.chunk_row0_host, rot.max_rows, rot.n_chunk, rot.slots
         self.block_threads, self.n_copy, self.n_wg, self.wg_waves = rot.block_threads, rot.n_copy, rot.n_wg, rot.wg_waves
@@ -239,12 +243,10 @@ class LocalGraph:
         self.w = torch.empty(tl.nslot, dtype=torch.float64, device=dev) if have_t else None
         self.u = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
         self.v = torch.empty(3 * tl.nslot, dtype=torch.float64, device=dev) if have_t else None
-        # the CG sweep runs on the rotation layout when that is a wave layout (vican_wtrans.hip): a second copy of the weights
-        # in its slot order (8 B per edge); u, v (right-hand side, LSQR) stay in the block layout
-        self.w_cg = self.w if tl is rot else (torch.empty(rot.nslot, dtype=torch.float64, device=dev) if have_t else None)
+        self.w_cg = self.w
         self.desc = rot.describe(self.n_cam, storage, self.blk)
-        self.desc_t = self.desc if tl is rot else tl.describe(self.n_cam, storage, None)
-        gref, gref_t = C.byref(self.desc), C.byref(self.desc_t)
+        self.desc_t = self.desc
+        gref = C.byref(self.desc)
         row_ptr = row_ptr.to(dev, torch.int32).contiguous()
         col = col.to(dev, torch.int32).contiguous()
         blk = blk.contiguous(); a = a.to(blk.dtype).contiguous()
@@ -258,15 +260,15 @@ class LocalGraph:
             if have_t:
                 w, u, v = (torch.zeros(k, dtype=torch.float64, device=dev) for k in (1, 3, 3))
         st = _stream()
-        perm_ws = torch.empty(max(rot.nslot, tl.nslot), dtype=torch.int32, device=dev)
-        same = tl is rot
+        perm_ws = torch.empty(rot.nslot, dtype=torch.int32, device=dev)
         _lib.check(lib.vican_pack_edges(gref, _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a), _ptr(w) if have_t else None,
-                                        _ptr(u) if same else None, _ptr(v) if same else None, _ptr(self.a),
-                                        _ptr(self.w_cg) if have_t else None, _ptr(self.u) if same else None,
-                                        _ptr(self.v) if same else None, _ptr(perm_ws), st), "vican_pack_edges")
-        if have_t and not same:
-            _lib.check(lib.vican_pack_edges(gref_t, _ptr(row_ptr), _ptr(col), None, None, _ptr(w), _ptr(u), _ptr(v), None,
-                                            _ptr(self.w), _ptr(self.u), _ptr(self.v), _ptr(perm_ws), st), "vican_pack_edges")
+                                        _ptr(u) if have_t else None, _ptr(v) if have_t else None, _ptr(self.a),
+                                        _ptr(self.w) if have_t else None, _ptr(self.u) if have_t else None,
+                                        _ptr(self.v) if have_t else None, _ptr(perm_ws), st), "vican_pack_edges")
+        # (kept for lsqr_layout(): CSR-order inputs of the translation arrays - references, no copies)
+        self._csr_t = (row_ptr, col, w, u, v) if (have_t and rot.kind == "wave") else None
+        self._lsqr_layout = None
+        gref_t = gref
         # graph constants
         T1 = max(self.n_time, 1)
         f64 = dict(dtype=torch.float64, device=dev)
@@ -292,6 +294,25 @@ class LocalGraph:
             if deg_c is not None:
                 self.cam_sum_w.copy_(deg_c.to(dev, torch.float64))
         torch.cuda.current_stream().synchronize()      # inputs may be freed by the caller
+
+    def lsqr_layout(self):
+        """(layout, desc, w, u, v) in a BLOCK layout for the LSQR kernels (vican_lsqr.hip): the graph's own arrays when the
+        rotation layout is a block layout, else a second layout packed on first use from the retained CSR-order inputs."""
+        if self.rot.kind == "block":
+            return self.rot, self.desc, self.w, self.u, self.v
+        if self._lsqr_layout is None:
+            lib = _lib.load()
+            row_ptr, col, w, u, v = self._csr_t
+            bl = self._mk_block()
+            desc = bl.describe(self.n_cam, self._storage, None)
+            wb = torch.empty(bl.nslot, dtype=torch.float64, device=self.device)
+            ub, vb = torch.empty(3 * bl.nslot, dtype=torch.float64, device=self.device), torch.empty(3 * bl.nslot, dtype=torch.float64, device=self.device)
+            perm_ws = torch.empty(bl.nslot, dtype=torch.int32, device=self.device)
+            _lib.check(lib.vican_pack_edges(C.byref(desc), _ptr(row_ptr), _ptr(col), None, None, _ptr(w), _ptr(u), _ptr(v), None,
+                                            _ptr(wb), _ptr(ub), _ptr(vb), _ptr(perm_ws), _stream()), "vican_pack_edges")
+            torch.cuda.current_stream().synchronize()
+            self._lsqr_layout = (bl, desc, wb, ub, vb)
+        return self._lsqr_layout
 
     # algorithmic HBM bytes of one operator sweep (SURVEY.md 8(d), B_op)
     def op_bytes(self, ncols=3):
@@ -637,13 +658,9 @@ class HipBackend:
         deg_c.copy_(self.g.cam_sum_w)
 
     def trans_rhs(self, rc, rt, rhs_t, rhs_c):
-        nwg = self.tl.n_wg
-        part = self.zpart[: nwg * 3 * self.C]
-        inv = C.c_double(0.0)
-        self._ck(self.lib.vican_trans_rhs(self._gref_t, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t),
-                                          _ptr(part), self.g.gmax, self.n_add, C.byref(inv), _stream()), "vican_trans_rhs")
-        self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(rhs_c), _stream()),
-                 "vican_slab_reduce_fx")
+        part = self.zpart[: self.tl.n_wg * 6 * self.C]              # double-word camera slabs
+        self._ck(self.lib.vican_trans_rhs(self._gref_t, _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt), _ptr(rhs_t), _ptr(rhs_c),
+                                          _ptr(part), self.g.gmax, self.n_add, _stream()), "vican_trans_rhs")
 
     # Jacobi scaling (tight translation solve): the CG entry points then run on the scaled weights
     def jacobi_scale(self, deg, s_out):
@@ -720,31 +737,36 @@ class HipBackend:
 # -- LSQR ("direct") wrappers, attached to HipBackend ------------------------------------------
 def _lsqr_alloc(self):
     if not hasattr(self, "_lsqr_u"):
-        nslot = max(1, self.tl.n_chunk) * self.tl.slots
+        # the LSQR kernels take block layouts only: the graph's own one, or (wave-layout graphs) a second one built here
+        self._ll, self._ldesc, self._lw, self._lu, self._lv = self.g.lsqr_layout()
+        self._lgref = C.byref(self._ldesc)
+        self._ln_add = float(max(self._ll.rows_per_wg_max, self._ll.slots) + 1)
+        self._lslab = torch.empty(max(self._ll.n_wg, 1) * 3 * self.C, dtype=torch.float64, device=self.dev)
+        nslot = max(1, self._ll.n_chunk) * self._ll.slots
         self._lsqr_u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
         self._lsqr_sw = torch.zeros(nslot, dtype=torch.float64, device=self.dev)       # sqrt(w), written by lsqr_init_u
-        self._lsqr_part = torch.zeros(max(self.tl.n_wg, 1024), dtype=torch.float64, device=self.dev)
+        self._lsqr_part = torch.zeros(max(self._ll.n_wg, 1024), dtype=torch.float64, device=self.dev)
 
 
 def _lsqr_init_u(self, rc, rt, nrm2_out):
     _lsqr_alloc(self)
-    self._ck(self.lib.vican_lsqr_init_u(self._gref_t, _ptr(self.g.w), _ptr(self.g.u), _ptr(self.g.v), _ptr(rc), _ptr(rt),
+    self._ck(self.lib.vican_lsqr_init_u(self._lgref, _ptr(self._lw), _ptr(self._lu), _ptr(self._lv), _ptr(rc), _ptr(rt),
                                         _ptr(self._lsqr_u), _ptr(self._lsqr_sw), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()),
              "vican_lsqr_init_u")
 
 
 def _lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
-    self._ck(self.lib.vican_lsqr_u_step(self._gref_t, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
+    self._ck(self.lib.vican_lsqr_u_step(self._lgref, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
                                         _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
 
 
 def _lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
     """v_t updated in place; acc_c[3C] = this rank's camera-side sums (all-reduce, then lsqr_cam_v)."""
-    nwg = self.tl.n_wg
-    part = self.zpart[: nwg * 3 * self.C]
+    nwg = self._ll.n_wg
+    part = self._lslab
     inv = C.c_double(0.0)
-    self._ck(self.lib.vican_lsqr_v_step(self._gref_t, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
-                                        _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self.n_add,
+    self._ck(self.lib.vican_lsqr_v_step(self._lgref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
+                                        _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self._ln_add,
                                         C.byref(inv), _stream()), "vican_lsqr_v_step")
     self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
              "vican_slab_reduce_fx")
@@ -965,6 +987,47 @@ class TiledBackend(HipBackend):
 
     dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = _unsupported
     lsqr_init_u = lsqr_u_step = lsqr_v_step = _unsupported
+
+
+def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
+    """frontend.merge_host ON THE DEVICE (vican_merge.hip; reference bipgo.py:203-221, 445-469): the per-edge arrays go to
+    HBM once (124 B per source edge), the merged timestep-major CSR problem never leaves it.  Same bits as merge_host
+    (tests/test_merge_gpu.py).  Returns a frontend.Problem whose numeric fields are device tensors (`on_device`)."""
+    from . import frontend
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.VicanError("vican_amd needs a GPU (MI355X); there is no CPU fallback")
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    n, C_, T_ = int(ix.n), len(ix.cam_names), len(ix.time_names)
+    f64 = lambda x, shape: torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(shape))).to(dev, non_blocking=True)
+    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.int32))).to(dev, non_blocking=True)
+    t_h = np.asarray(t, dtype=np.float64).reshape(n, 3)
+    kt_h = np.asarray(k_t, dtype=np.float64)
+    cam, tim, mk = i32(ix.ci), i32(ix.ti), i32(ix.mi)
+    Rd, td, krd, ktd = f64(R, (n, 9)), f64(t_h, (n, 3)), f64(k_r, (n,)), f64(kt_h, (n,))
+    CmT, qtau = f64(ix.CmT, (-1, 9)), f64(ix.qtau, (-1, 3))
+    wsb = int(lib.vican_merge_ws_bytes(n, C_, T_))
+    if wsb < 0:
+        raise _lib.VicanError("vican_merge_ws_bytes failed")
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    e = lambda *shape, dt=torch.float64: torch.empty(*shape, dtype=dt, device=dev)
+    nm, row_ptr, col = e(1, dt=torch.int32), e(T_ + 1, dt=torch.int32), e(n, dt=torch.int32)
+    blk, a, w, u, v, deg_c, deg_t = e(n, 9), e(n), e(n), e(n, 3), e(n, 3), e(C_), e(T_)
+    storage = _lib.STORE_F32 if np.dtype(dtype) == np.float32 else _lib.STORE_F64
+    _lib.check(lib.vican_merge_edges(n, C_, T_, int(CmT.shape[0]), storage, _ptr(cam), _ptr(tim), _ptr(mk), _ptr(Rd), _ptr(td), _ptr(krd),
+                                     _ptr(ktd), _ptr(CmT), _ptr(qtau), _ptr(ws), wsb, _ptr(nm), _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a),
+                                     _ptr(w), _ptr(u), _ptr(v), _ptr(deg_c), _ptr(deg_t), _stream()), "vican_merge_edges")
+    E = int(nm.item())                                           # (the one synchronisation: sizes the outputs)
+    p = frontend.Problem()
+    p.on_device = True
+    p.root, p.n_src = ix.root, n
+    p.cam_names, p.time_names, p.tnodes = ix.cam_names, ix.time_names, ix.tnodes
+    p.tnode_of_cam, p.tnode_of_time = ix.tnode_of_cam, ix.tnode_of_time
+    p.row_ptr, p.col, p.blk, p.a, p.w, p.u, p.v = row_ptr, col[:E], blk[:E], a[:E], w[:E], u[:E], v[:E]
+    p.deg_c, p.deg_t = deg_c, deg_t
+    p.row_ptr_host, p.col_host = row_ptr.cpu().numpy(), p.col.cpu().numpy()
+    p.src_cam, p.src_time, p.src_t, p.src_qtau, p.src_kt = ix.ci, ix.ti, t_h, ix.qtau[ix.mi], kt_h
+    return p
 
 
 def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None, deg_c=None):

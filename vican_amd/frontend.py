@@ -15,7 +15,13 @@ class Problem:
     """Flattened, merged problem (all float64 on the host)."""
     __slots__ = ("cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "root",
                  "n_src", "row_ptr", "col", "blk", "a", "w", "u", "v", "deg_c", "deg_t",
-                 "src_cam", "src_time", "src_t", "src_qtau", "src_kt")
+                 "src_cam", "src_time", "src_t", "src_qtau", "src_kt", "on_device", "row_ptr_host", "col_host")
+
+    def host_csr(self):
+        """(row_ptr, col) as NumPy arrays - the problem's own arrays, or copies of the device arrays of a device merge."""
+        if getattr(self, "on_device", False):
+            return self.row_ptr_host, self.col_host
+        return self.row_ptr, self.col
 
     @property
     def n_cam(self):
@@ -30,8 +36,9 @@ class Problem:
         return len(self.col)
 
 
-def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype=np.float32) -> Problem:
-    """Filter, weight, apply marker constraints and merge multi-marker edges.
+def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype=np.float32, merge=None) -> Problem:
+    """Filter, weight, apply marker constraints and merge multi-marker edges.  `merge`: the numeric half - None =
+    merge_host (NumPy), or a callable (ix, R, t, k_r, k_t, dtype) -> Problem such as device.merge_edges.
 
     Per kept source edge e = (c, "t_m") (bipgo.py:203-221, 445-468):
         M_ct += k_r * R~_e R_m^T R_root,   a_ct += k_r
@@ -52,63 +59,111 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
         raise ValueError("no edge passes edge_filter")
     R = np.stack([np.asarray(p.R(), dtype=np.float64) for p in poses])
     t = np.stack([np.asarray(p.t(), dtype=np.float64).reshape(3) for p in poses])
-    return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype)
+    return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype, merge)
 
 
-def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype=np.float32) -> Problem:
-    """The array form of ``flatten`` (everything after the per-edge Python loop; vectorised NumPy): one entry per KEPT
-    source edge - camera id, timestamp and marker id (strings, as in the reference's keys ``(cam, "<t>_<marker>")``),
-    measured rotation R [n,3,3] and translation t [n,3] of the marker in the camera frame, and the two weights the
-    reference obtains from ``noise_model_r`` / ``noise_model_t``.  Callers that already hold their detections as
-    arrays (or evaluate their weight functions vectorised) skip the edge dict and its per-edge callables altogether:
-    80 000 source edges flatten in ~90 ms instead of ~180 ms through the dict (and ~13 s in the reference's loops)."""
-    n = len(cam_ids)
-    if n == 0:
+def sorted_codes(ids, prefix=""):
+    """(sorted unique strings, index of every entry into them) - what ``np.unique(prefix + ids, return_inverse=True)``
+    returns (bipgo.py:225-229: node order = string sort order), without sorting 80 000 UCS-4 strings by comparison: ASCII
+    ids of at most 8 characters are packed into big-endian 64-bit integers, whose numeric order IS their string order
+    (shorter strings are zero-padded, so a prefix sorts first), and sorted as integers.  A common prefix does not change
+    the order of the strings, only their spelling.  Anything else falls back to ``np.unique``."""
+    a = np.asarray(ids)
+    if a.dtype.kind != "U":
+        a = a.astype(str)
+    width = a.dtype.itemsize // 4
+    if 0 < width <= 8 and a.ndim == 1 and len(a):
+        cp = np.ascontiguousarray(a).view(np.uint32).reshape(len(a), width)      # UCS-4 code points, zero-padded
+        if int(cp.max()) < 128:
+            keys = np.zeros(len(a), dtype=np.uint64)
+            for k in range(width):
+                keys |= cp[:, k].astype(np.uint64) << np.uint64(8 * (7 - k))
+            uk, inv = np.unique(keys, return_inverse=True)
+            names = np.array([prefix + int(v).to_bytes(8, "big").rstrip(b"\0").decode("ascii") for v in uk])
+            return names, inv.astype(np.int64)
+    names, inv = np.unique(np.char.add(prefix, a) if prefix else a, return_inverse=True)
+    return names, inv.astype(np.int64)
+
+
+class EdgeIndex:
+    """Host half of the front-end: string ids -> node / marker indices, node orderings, the
+    per-marker constraint tables.  Everything per-edge and numeric happens in ``merge_host`` (NumPy) or on the device
+    (``device.merge_edges``, vican_merge.hip) from these indices."""
+    __slots__ = ("n", "root", "cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "ci", "ti", "mi", "CmT", "qtau")
+
+
+def index_edges(cam_ids, time_ids, marker_ids, constraints) -> EdgeIndex:
+    ix = EdgeIndex()
+    ix.n = len(cam_ids)
+    if ix.n == 0:
         raise ValueError("no edge passes edge_filter")
-    root = str(min(list(constraints.keys())))                      # bipgo.py:196,411 (string min)
-    r_root = np.asarray(constraints[root].R(), dtype=np.float64)
+    ix.root = str(min(list(constraints.keys())))                   # bipgo.py:196,411 (string min)
+    r_root = np.asarray(constraints[ix.root].R(), dtype=np.float64)
     # per-marker constraint tables (KeyError for an unknown marker id, as bipgo.py:209)
-    mk_names, mk_idx = np.unique(np.asarray(marker_ids, dtype=str), return_inverse=True)
-    CmT = np.empty((len(mk_names), 3, 3)); Q = np.empty((len(mk_names), 3, 3)); tau = np.empty((len(mk_names), 3))
+    mk_names, ix.mi = sorted_codes(marker_ids)
+    M = len(mk_names)
+    ix.CmT = np.empty((M, 3, 3)); Q = np.empty((M, 3, 3)); tau = np.empty((M, 3))
     for i, m in enumerate(mk_names):
         cm = constraints[str(m)]
         r_m = np.asarray(cm.R(), dtype=np.float64)
-        CmT[i] = r_m.T @ r_root                                    # bipgo.py:213
+        ix.CmT[i] = r_m.T @ r_root                                 # bipgo.py:213
         Q[i] = r_root.T @ r_m                                      # bipgo.py:451
-        tau[i] = np.asarray((cm.inv() @ constraints[root]).t(), dtype=np.float64)   # bipgo.py:452
-    qtau = np.einsum("mij,mj->mi", Q, tau)
+        tau[i] = np.asarray((cm.inv() @ constraints[ix.root]).t(), dtype=np.float64)   # bipgo.py:452
+    ix.qtau = np.einsum("mij,mj->mi", Q, tau)
+    # bipgo.py:225-229 sorts 'c' + id / 't' + id: a common prefix changes the spelling, not the order
+    ix.cam_names, ix.ci = sorted_codes(cam_ids)
+    ix.time_names, ix.ti = sorted_codes(time_ids)
+    # translation unknowns: cameras and "<t>_0" nodes in ONE string-sorted list (bipgo.py:426-430)
+    t0 = np.char.add(ix.time_names, "_0")
+    ix.tnodes = np.unique(np.concatenate([ix.cam_names, t0]))
+    ix.tnode_of_cam = np.searchsorted(ix.tnodes, ix.cam_names).astype(np.int64)
+    ix.tnode_of_time = np.searchsorted(ix.tnodes, t0).astype(np.int64)
+    return ix
+
+
+def weighted_rotations(kr, R, CmT_e):
+    """(k_r R~_e) (R_m^T R_root) per edge with every rounding spelled out - products and sums in index order, no fused
+    multiply-add, no BLAS - so that the device kernel (vican_merge.hip, same order, contraction off) reproduces it to the bit
+    on any machine: out[e,i,j] = ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j), a = k_r R."""
+    A = kr[:, None, None] * R
+    out = np.empty_like(A)
+    for i in range(3):
+        for j in range(3):
+            out[:, i, j] = (A[:, i, 0] * CmT_e[:, 0, j] + A[:, i, 1] * CmT_e[:, 1, j]) + A[:, i, 2] * CmT_e[:, 2, j]
+    return out
+
+
+def merge_host(ix: EdgeIndex, R, t, k_r, k_t, dtype=np.float32) -> Problem:
+    """Numeric half of the front-end on the host (bipgo.py:203-221, 445-469): per kept source edge
+        M_ct += k_r R~_e R_m^T R_root,   a_ct += k_r,   w_ct += kf^2,   u_ct += kf k_t t~_e,   v_ct += kf k_t (R_root^T R_m) tau_m
+    summed SEQUENTIALLY in source-edge order (np.add.at: unbuffered, in index order) - the order scipy's csr_matmat uses for
+    J^T J and the order the device merge uses, so both produce the same bits."""
+    n = ix.n
     R = np.asarray(R, dtype=np.float64).reshape(n, 3, 3)
     t = np.asarray(t, dtype=np.float64).reshape(n, 3)
     kr = np.asarray(k_r, dtype=np.float64); kt = np.asarray(k_t, dtype=np.float64)
     kf = kt.astype(dtype).astype(np.float64)
-    wR = (kr[:, None, None] * R) @ CmT[mk_idx]
-
-    cam_s, time_s = np.asarray(cam_ids, dtype=str), np.asarray(time_ids, dtype=str)
-    cam_nodes, ci = np.unique(np.char.add("c", cam_s), return_inverse=True)      # bipgo.py:225-229
-    time_nodes, ti = np.unique(np.char.add("t", time_s), return_inverse=True)
-    C, T = len(cam_nodes), len(time_nodes)
-    key = ti.astype(np.int64) * C + ci                              # timestep-major merged-edge key
+    ci, ti = ix.ci, ix.ti
+    C, T = len(ix.cam_names), len(ix.time_names)
+    key = ti * C + ci                                               # timestep-major merged-edge key
     ukey, inv = np.unique(key, return_inverse=True)
     E = len(ukey)
-    order = np.argsort(inv, kind="stable")                          # source edges grouped by merged edge
-    starts = np.searchsorted(inv[order], np.arange(E))
 
     def seg(x):
-        return np.add.reduceat(x[order], starts, axis=0)
+        out = np.zeros((E,) + x.shape[1:], dtype=x.dtype)
+        np.add.at(out, inv, x)
+        return out
 
     p = Problem()
-    p.root, p.n_src = root, n
-    p.cam_names = np.array([c[1:] for c in cam_nodes])
-    p.time_names = np.array([s[1:] for s in time_nodes])
-    p.tnodes = np.unique(np.concatenate([cam_s, np.char.add(time_s, "_0")]))     # bipgo.py:426-430
-    pos = {s: i for i, s in enumerate(p.tnodes)}
-    p.tnode_of_cam = np.array([pos[c] for c in p.cam_names], dtype=np.int64)
-    p.tnode_of_time = np.array([pos[s + "_0"] for s in p.time_names], dtype=np.int64)
+    p.on_device = False
+    p.root, p.n_src = ix.root, n
+    p.cam_names, p.time_names, p.tnodes = ix.cam_names, ix.time_names, ix.tnodes
+    p.tnode_of_cam, p.tnode_of_time = ix.tnode_of_cam, ix.tnode_of_time
     p.col = (ukey % C).astype(np.int32)
     rows = (ukey // C).astype(np.int64)
     p.row_ptr = np.zeros(T + 1, dtype=np.int32)
     np.cumsum(np.bincount(rows, minlength=T), out=p.row_ptr[1:])
-    p.blk = seg(wR).reshape(E, 9)
+    p.blk = seg(weighted_rotations(kr, R, ix.CmT[ix.mi])).reshape(E, 9)
     p.a = seg(kr)
     # Entries of the reference's normal matrix J^T J (bipgo.py:477) AS SCIPY FORMS THEM: csr_matmat accumulates the products
     # k k of the incidence entries in the matrix dtype, sequentially in source-edge order - for dtype=float32 that is float32
@@ -125,11 +180,21 @@ def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, d
     p.w, p.deg_c, p.deg_t = w.astype(np.float64), deg_c.astype(np.float64), deg_t.astype(np.float64)
     kk = (kf * kt)[:, None]
     p.u = seg(kk * t)
-    p.v = seg(kk * qtau[mk_idx])
+    p.v = seg(kk * ix.qtau[ix.mi])
     # per-source-edge data of the un-merged right-hand side b (bipgo.py:451-461); only its norm is
     # needed (LSQR stopping tests), see bnorm2()
-    p.src_cam, p.src_time, p.src_t, p.src_qtau, p.src_kt = ci, ti, t, qtau[mk_idx], kt
+    p.src_cam, p.src_time, p.src_t, p.src_qtau, p.src_kt = ci, ti, t, ix.qtau[ix.mi], kt
     return p
+
+
+def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype=np.float32, merge=None) -> Problem:
+    """The array form of ``flatten`` (everything after the per-edge Python loop): one entry per KEPT source edge - camera
+    id, timestamp and marker id (strings, as in the reference's keys ``(cam, "<t>_<marker>")``), measured rotation R
+    [n,3,3] and translation t [n,3] of the marker in the camera frame, and the two weights the reference obtains from
+    ``noise_model_r`` / ``noise_model_t``.  Callers that already hold their detections as arrays (or evaluate their
+    weight functions vectorised) skip the edge dict and its per-edge callables altogether.  = index_edges + merge_host;
+    the drop-in API on a GPU box runs index_edges on the host and the merge on the device (device.merge_edges)."""
+    return (merge or merge_host)(index_edges(cam_ids, time_ids, marker_ids, constraints), R, t, k_r, k_t, dtype)
 
 
 def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
@@ -178,7 +243,8 @@ def count_components(prob: Problem) -> int:
     pointer jumping).  More than one means more than three near-null eigenvectors: the reference then returns an
     arbitrary mixture of the components' gauges without any diagnostic ('disconnected graph
     silently yields garbage'); the drop-in API warns."""
-    C, col, row_ptr = prob.n_cam, prob.col.astype(np.int64), prob.row_ptr.astype(np.int64)
+    row_ptr, col = prob.host_csr()
+    C, col, row_ptr = prob.n_cam, col.astype(np.int64), row_ptr.astype(np.int64)
     rows = np.repeat(np.arange(prob.n_time), np.diff(row_ptr))
     order = np.argsort(col, kind="stable")                          # edges grouped by camera
     rows_by_cam = rows[order]
