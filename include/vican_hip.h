@@ -468,10 +468,23 @@ int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
                    const double* p_c, const double* r_t, double* p_t, double* q_t,
                    void* qc_part, double* pq_part, const vican_cg_state_t* st, void* stream);
 /* Fold of one sweep: qcpq[0:3C] = sum over the n_slab workgroup slabs of qc_part (double-word fixed point -> [C][3] doubles,
- * each rounded once; exact, order-independent, overflow-proof integer sums) and qcpq[3C] = sum pq_part in a fixed order:
- * the message a sharded run all-reduces per CG iteration.                          */
+ * each rounded once; exact, order-independent, overflow-proof integer sums) and qcpq[3C] = sum pq_part in a fixed order
+ * (pq_part = NULL: the camera part only):  the message a sharded run all-reduces per CG iteration.          */
 int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                   const vican_cg_state_t* st, void* stream);
+/* Camera-tiled graphs (more cameras than one LDS table holds; the reference has no camera limit, bipgo.py:225-232): the
+ * product q = A p one camera tile at a time.  vican_cg_update_pt: p_t <- r_t + beta p_t (skipped on the first iteration) -
+ * what vican_cg_sweep does while it loads its rows.  vican_cg_sweep_partial (g = ONE tile's block-layout graph, w its
+ * weights, p_c the tile's slice of the camera vector): acc_t [T][3] = sum_{c in tile} w_ct p_c and the double-word slabs of
+ * sum_t w_ct p_t for the tile's cameras (complete: fold them with vican_cg_fold(pq_part = NULL) into the tile's slice of
+ * qcpq).  vican_cg_combine_rows: q_t = deg_t p_t - sum_tiles acc (tile order), pq_part[b] = partial p_t.q_t; returns the
+ * number of partials (sum them with vican_cg_reduce_pq).  acc: [n_tile][tile_stride] doubles, tile_stride >= 3 n_time.   */
+int vican_cg_update_pt(int32_t n_time, const double* r_t, double* p_t, const vican_cg_state_t* st, void* stream);
+int vican_cg_sweep_partial(const vican_graph_t* g, const double* w, const double* p_c, const double* p_t, double* acc_t,
+                           void* qc_part, const vican_cg_state_t* st, void* stream);
+int vican_cg_combine_rows(int32_t n_time, int32_t n_tile, int64_t tile_stride, const double* deg_t, const double* p_t,
+                          const double* acc, double* q_t, double* pq_part, int32_t part_cap, const vican_cg_state_t* st,
+                          void* stream);
 /* *out = sum pq_part (the timestep part of p.q); `out` is normally the slot right
  * behind the reduced q_c vector so that ONE all-reduce carries both.           */
 int vican_cg_reduce_pq(const double* pq_part, int32_t n_part, double* out,

@@ -49,8 +49,8 @@ def test_tiled_operator_and_dual_update_match_numpy(C, T, tile):
 
 def test_full_solve_with_1500_cameras_matches_numpy():
     """A consistent synthetic scene (1500 cameras, 2500 timesteps, 4 cameras per timestep, 1e-3 noise) through the whole
-    solve - block Lanczos on 4500-row vectors, tiled operator and dual updates, tiled right-hand side, CG on the
-    weights-only layout - against the NumPy restatement of the same solver."""
+    solve - block Lanczos on 4500-row vectors, tiled operator and dual updates, tiled right-hand side, tiled CG product
+    - against the NumPy restatement of the same solver."""
     from vican_amd import synth
     from vican_amd.device import TiledBackend, TiledGraph
     C, T = 1500, 2500
@@ -94,3 +94,26 @@ def test_dropin_on_forced_tiles_matches_reference(name, dt, monkeypatch):
     from vican_amd._lib import VicanError
     with pytest.raises(VicanError, match="direct"):
         bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "direct", np.dtype(dt).type)
+
+
+@pytest.mark.parametrize("C,T,tile", [(4000, 3000, 1024), (70, 500, 16)])
+def test_tiled_translation_stage_has_no_camera_limit(C, T, tile):
+    """The CG product tile by tile (vican_cg_sweep_partial + vican_cg_combine_rows): right-hand side and CG on 4000
+    cameras - beyond what any single LDS table holds (round 2 stopped at ~3300) - against the NumPy restatement, plain
+    and in tight (Jacobi-scaled) mode."""
+    from vican_amd.solver import TightTranslationSolver, TranslationSolver
+    rp, col, blk, a, w, u, v = random_graph(C, T, 3, 9, 11, False)
+    g, K = _tiled(C, rp, col, blk, a, w, u, v, np.float64, tile)
+    N = NumpyBackend(C, rp, col, blk, a, w, u, v, storage=np.float64)
+    rng = np.random.default_rng(2)
+    rc = np.linalg.qr(rng.standard_normal((C, 3, 3)))[0].reshape(3 * C, 3)
+    rt = np.linalg.qr(rng.standard_normal((T, 3, 3)))[0].reshape(T, 9)
+    for cls, rtol, tol in ((TranslationSolver, 1e-9, 1e-6), (TightTranslationSolver, 1e-10, 1e-6)):
+        th, tn = cls(K, Comm.single(), rtol=rtol), cls(N, Comm.single(), rtol=rtol)
+        th.setup(K.from_numpy(rc), K.from_numpy(rt)); tn.setup(N.from_numpy(rc), N.from_numpy(rt))
+        assert np.abs(th.b_c.cpu().numpy() - tn.b_c.numpy()).max() <= 1e-11 * np.abs(tn.b_c.numpy()).max()
+        xh = [x.cpu().numpy().copy() for x in th.solve(3 * (C + T))]
+        xn = [x.numpy().copy() for x in tn.solve(3 * (C + T))]
+        assert th.info["converged"] and abs(th.info["cg_iters"] - tn.info["cg_iters"]) <= 2
+        scale = max(np.abs(xn[0]).max(), 1.0)
+        assert np.abs(xh[0] - xn[0]).max() < tol * scale and np.abs(xh[1][:T] - xn[1][:T]).max() < tol * scale

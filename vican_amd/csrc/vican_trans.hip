@@ -412,7 +412,10 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
                                                          const double* __restrict__ p_c, const double* __restrict__ r_t,
                                                          double* __restrict__ p_t, double* __restrict__ q_t,
                                                          u64* __restrict__ qc_part, double* __restrict__ pq_part,
-                                                         const vican_cg_state_t* __restrict__ st) {
+                                                         const vican_cg_state_t* __restrict__ st, const int partial) {
+    // partial != 0 (camera-tiled graphs, vican_cg_sweep_partial): g holds the edges of ONE camera tile; p_t is read as it is
+    // (already updated), q_t receives the tile's row sums sum_{c in tile} w p_c alone and no p.q partial is formed - the
+    // caller combines the tiles (vican_cg_combine_rows).  The camera sums of the tile's cameras are complete either way.
     extern __shared__ __align__(16) unsigned char lds_raw[];
     if (st->done) return;
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     double* red = dps + 2 * mr3;                           // [16]
     const int tid = threadIdx.x, lane_copy = tid & cmask;
     const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);   // padding slots: a valid camera, zero weight
-    const bool upd = !st->first;
+    const bool upd = !st->first && !partial;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
     const int lob = st->lo_bits;
     const double lo_scale = ldexp(1.0, lob);
@@ -502,7 +505,8 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
                 sum += (long long)q[a]; slo += (long long)q[lo_t + a];
                 q[a] = 0ull; q[lo_t + a] = 0ull;
             }
-            const double qv = dps[buf * mr3 + i] - fix2_value(sum, slo, lob, inv);
+            const double acc_ = fix2_value(sum, slo, lob, inv);
+            const double qv = partial ? acc_ : dps[buf * mr3 + i] - acc_;
             q_t[(size_t)r0 * 3 + i] = qv;
             pq += pts[buf * mr3 + i] * qv;
         }
@@ -555,19 +559,22 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
     __syncthreads();
     for (int i = tid; i < 6 * C; i += BLOCK) qc_part[(size_t)blockIdx.x * 6 * C + i] = qc[i];
     const double t = block_sum(pq, red);
-    if (tid == 0) pq_part[blockIdx.x] = t;
+    if (tid == 0 && !partial) pq_part[blockIdx.x] = t;
 }
 extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,
                                                                      void* qc_part, double* pq_part, const vican_cg_state_t* st,
                                                                      void* stream);       // vican_wtrans.hip
-extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
-                              const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
-                              const vican_cg_state_t* st, void* stream) {
+static int cg_sweep_launch(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
+                           const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
+                           const vican_cg_state_t* st, void* stream, const int partial) {
     if (int r = vican_check_graph(g, "vican_cg_sweep")) return r;
     if (!w || !deg_t || !p_c || !r_t || !p_t || !q_t || !qc_part || !pq_part || !st)
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
-    if (g->layout == VICAN_LAYOUT_WAVE) return vican_cg_wsweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream);
+    if (g->layout == VICAN_LAYOUT_WAVE) {
+        if (partial) return set_err(VICAN_ERR_ARG, "vican_cg_sweep_partial: camera tiles are block layouts");
+        return vican_cg_wsweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream);
+    }
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;
     const int nr = (3 * g->max_rows + g->block_threads - 1) / g->block_threads;   // row values per thread (<= 3 EPL)
@@ -577,7 +584,7 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
         auto kern = cg_sweep_kernel<B, E, R>;                                                                    \
         static size_t conf = 0;                                                                                  \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(B), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st, partial); \
     } while (0)
 #define CG_LAUNCH(B, E)                                                                                          \
     do {                                                                                                         \
@@ -592,6 +599,67 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
 #undef CG_LAUNCH3
     LAUNCH_CHECK("vican_cg_sweep");
     return VICAN_OK;
+}
+extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
+                              const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
+                              const vican_cg_state_t* st, void* stream) {
+    return cg_sweep_launch(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream, 0);
+}
+
+// ---- camera-tiled graphs (more cameras than one LDS table holds): the product q = A p tile by tile ----------------------
+// p_t <- r_t + beta p_t (not on the first iteration): the update the untiled sweep performs while it loads its rows
+__global__ void cg_update_pt_kernel(long long n, const double* __restrict__ r_t, double* __restrict__ p_t, const vican_cg_state_t* __restrict__ st) {
+    if (st->done || st->first) return;
+    const double beta = st->beta;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p_t[i] = r_t[i] + beta * p_t[i];
+}
+extern "C" int vican_cg_update_pt(int32_t n_time, const double* r_t, double* p_t, const vican_cg_state_t* st, void* stream) {
+    if (n_time < 0 || !r_t || !p_t || !st) return set_err(VICAN_ERR_ARG, "vican_cg_update_pt: bad argument");
+    const long long n = 3LL * n_time;
+    if (n == 0) return VICAN_OK;
+    long long nb = (n + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(cg_update_pt_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, n, r_t, p_t, st);
+    LAUNCH_CHECK("vican_cg_update_pt");
+    return VICAN_OK;
+}
+// one camera tile: acc_t [T][3] = sum_{c in tile} w_ct p_c (exact double-word sums, rounded once), qc_part = the
+// double-word slabs of sum_t w_ct p_t for the tile's cameras (complete: every edge of a camera lies in its tile; fold with
+// vican_cg_fold(pq_part = NULL)).  p_c: the tile's slice of the camera vector; p_t: already updated (vican_cg_update_pt).
+extern "C" int vican_cg_sweep_partial(const vican_graph_t* g, const double* w, const double* p_c, const double* p_t, double* acc_t,
+                                      void* qc_part, const vican_cg_state_t* st, void* stream) {
+    if (!acc_t) return set_err(VICAN_ERR_ARG, "vican_cg_sweep_partial: null pointer");
+    // (deg_t, r_t and pq_part are not touched in partial mode: any valid pointers)
+    return cg_sweep_launch(g, w, p_t, p_c, p_t, const_cast<double*>(p_t), acc_t, qc_part, acc_t, st, stream, 1);
+}
+// q_t = deg_t p_t - sum over the tiles of acc (tile order: deterministic), pq_part[block] = partial p_t.q_t
+__global__ __launch_bounds__(256) void cg_combine_rows_kernel(long long n, int n_tile, long long tile_stride, const double* __restrict__ deg_t,
+                                                              const double* __restrict__ p_t, const double* __restrict__ acc,
+                                                              double* __restrict__ q_t, double* __restrict__ pq_part,
+                                                              const vican_cg_state_t* __restrict__ st) {
+    __shared__ double red[8];
+    if (st->done) return;
+    double pq = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double s = 0.0;
+        for (int k = 0; k < n_tile; ++k) s += acc[(size_t)k * tile_stride + i];
+        const double p = p_t[i], q = deg_t[i / 3] * p - s;
+        q_t[i] = q;
+        pq += p * q;
+    }
+    const double t = block_sum(pq, red);
+    if (threadIdx.x == 0) pq_part[blockIdx.x] = t;
+}
+extern "C" int vican_cg_combine_rows(int32_t n_time, int32_t n_tile, int64_t tile_stride, const double* deg_t, const double* p_t,
+                                     const double* acc, double* q_t, double* pq_part, int32_t part_cap, const vican_cg_state_t* st,
+                                     void* stream) {
+    if (n_time < 0 || n_tile <= 0 || !deg_t || !p_t || !acc || !q_t || !pq_part || part_cap < 1 || !st)
+        return set_err(VICAN_ERR_ARG, "vican_cg_combine_rows: bad argument");
+    const long long n = 3LL * n_time;
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > part_cap) nb = part_cap; if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(cg_combine_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, (int)n_tile, (long long)tile_stride, deg_t, p_t,
+                       acc, q_t, pq_part, st);
+    LAUNCH_CHECK("vican_cg_combine_rows");
+    return nb;
 }
 
 __global__ void cg_reduce_pq_kernel(const double* __restrict__ pq_part, int n_part, double* __restrict__ out,
@@ -810,7 +878,7 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
         const long long q = i / n_cam, cam = i % n_cam;
         qcpq[cam * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
     }
-    if (blockIdx.x == 0) {                   // p.q partials: loaded in parallel, summed in a fixed order
+    if (blockIdx.x == 0 && pq_part != nullptr) {   // p.q partials: loaded in parallel, summed in a fixed order
         __shared__ double pq[1024];
         __syncthreads();
         for (int k0 = 0; k0 < n_slab; k0 += 1024) {
@@ -830,7 +898,7 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
 
 extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                              const vican_cg_state_t* st, void* stream) {
-    if (!qc_part || n_slab <= 0 || n_cam <= 0 || !pq_part || !qcpq || !st) return set_err(VICAN_ERR_ARG, "vican_cg_fold: bad argument");
+    if (!qc_part || n_slab <= 0 || n_cam <= 0 || !qcpq || !st) return set_err(VICAN_ERR_ARG, "vican_cg_fold: bad argument");
     const long long n = 3LL * n_cam;
     hipLaunchKernelGGL(cg_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
                        (const long long*)qc_part, n_slab, n_cam, pq_part, qcpq, st);

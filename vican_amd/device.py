@@ -796,8 +796,8 @@ TILE_CAMS = 1024
 
 class TiledGraph:
     """The edge set cut by camera range into tiles of at most `tile` cameras, each a block-layout ``LocalGraph`` over ALL
-    timestep rows (camera indices local to the tile), plus one weights-only layout over the full camera set for the CG
-    sweep (its LDS budget is 48 B per camera: C <= ~3300).
+    timestep rows (camera indices local to the tile); the translation CG runs tile by tile as well, so there is no limit
+    on the number of cameras (the reference has none, bipgo.py:225-232).
 
     The reference has no camera limit (bipgo.py:225-232); the fused sweeps keep the camera tables in LDS, which caps
     them at 1024 cameras.  Beyond that the operator z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) is evaluated tile by
@@ -838,51 +838,7 @@ class TiledGraph:
             if deg_c is not None:
                 self.cam_sum_w.copy_(deg_c.to(dev, torch.float64))
             self.wmax = max(t.wmax for t in self.tiles)
-            # weights-only layout over all cameras for the CG sweep
-            storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
-            rp_host = row_ptr.to("cpu", torch.int32).contiguous()
-            deg = rp_host[1:] - rp_host[:-1]
-            deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
-            lim, n_copy = int(lib.vican_lds_limit_bytes()), 8
-            cg_rows = lambda nc: (lim - 256 - 72 * self.n_cam) // (96 * nc + 96)     # cg_lds_bytes (vican_common.h)
-            while n_copy > 1 and cg_rows(n_copy) < 8:
-                n_copy //= 2
-            if cg_rows(n_copy) < 1:
-                raise _lib.VicanError("camera vectors of the CG sweep (C=%d) do not fit in LDS (limit about 2200 cameras)" % self.n_cam)
-            cgl = _Layout.__new__(_Layout)
-            epl = 4 if storage == _lib.STORE_F32 else 2
-            bt = 768 if self.n_edges >= 768 * epl * n_cu() else 256
-            if deg_max > 256 * epl:
-                bt = 768
-            if deg_max > 768 * epl:
-                bt = 1024
-            slots = bt * epl
-            max_rows = int(min(cg_rows(n_copy), max(1, int(math.ceil(1.25 * slots / deg_avg)) + 1), 65535))
-            cap = T + 2
-            c0a = np.empty(cap, dtype=np.int32)
-            nchunk = _lib.check(lib.vican_plan_chunks(T, C.c_void_p(rp_host.data_ptr()), slots, max_rows, C.c_void_p(c0a.ctypes.data), cap),
-                                "vican_plan_chunks")
-            cgl.kind, cgl.n_time, cgl.chunk_row0_host = "block", T, c0a[: nchunk + 1].copy()
-            cgl.max_rows = int(np.diff(cgl.chunk_row0_host).max()) if nchunk else 1
-            cgl.n_chunk, cgl.slots, cgl.block_threads, cgl.n_copy, cgl.wg_waves = int(nchunk), slots, bt, n_copy, 0
-            cgl.n_wg = max(1, min(cgl.n_chunk, n_cu()))
-            b = (np.arange(cgl.n_wg + 1, dtype=np.int64) * cgl.n_chunk) // cgl.n_wg
-            cgl.rows_per_wg_max = int(np.diff(cgl.chunk_row0_host[b]).max()) if nchunk else 1
-            cgl.wg_chunk_cap, cgl.rows_per_wg_sweep = 0, cgl.rows_per_wg_max
-            cgl.chunk_row0 = torch.from_numpy(cgl.chunk_row0_host).to(dev)
-            cgl.nslot = max(1, cgl.n_chunk) * slots
-            cgl.idx = torch.empty(cgl.nslot, dtype=torch.int32, device=dev)
-            self.cgl = cgl
-            self.desc_cg = cgl.describe(self.n_cam, storage, None)
-            self.w_cg = torch.empty(cgl.nslot, dtype=torch.float64, device=dev)
-            perm_ws = torch.empty(cgl.nslot, dtype=torch.int32, device=dev)
-            # (the converted inputs are held in variables until the pack has run: a temporary freed inside the argument
-            #  list is handed to the NEXT conversion by the caching allocator and overwritten before the kernel reads it)
-            rp32, col32, w64 = row_ptr.to(torch.int32).contiguous(), col.to(torch.int32).contiguous(), w.to(dev, torch.float64).contiguous()
-            _lib.check(lib.vican_pack_edges(C.byref(self.desc_cg), _ptr(rp32), _ptr(col32), None, None, _ptr(w64), None, None, None,
-                                            _ptr(self.w_cg), None, None, _ptr(perm_ws), _stream()), "vican_pack_edges")
-            torch.cuda.current_stream().synchronize()
-            del rp32, col32, w64
+            # (the CG product runs tile by tile on the tiles' own weight arrays - TiledBackend.cg_iter_local: no camera limit)
 
     def op_bytes(self, ncols=3):
         return sum(t.op_bytes(ncols) for t in self.tiles) * 2
@@ -896,7 +852,8 @@ class TiledBackend(HipBackend):
     operator (sweep MODE 2: y_t = sum_c M_ct^T x_c and z_c = sum_t M_ct x_t in one pass over a tile's blocks), the
     per-row partials of the tiles are summed in tile order by ``vican_sum_apply3``; everything camera-sided (Lanczos
     step, Ritz, gauge, polar) is the launch-sequence path of the untiled backend, which has no camera limit; the CG
-    runs on the weights-only layout over all cameras.  No fused dual update, no LSQR (``lsqr_solver="direct"`` raises)."""
+    product runs tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows): no limit on the number of cameras.
+    No fused dual update, no LSQR (``lsqr_solver="direct"`` raises)."""
     fused_dual_ok = False
 
     def __init__(self, graph: TiledGraph):
@@ -914,12 +871,13 @@ class TiledBackend(HipBackend):
         self.wrow = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)           # phase-3 operand of the second pass
         self.zero_rows = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)
         self.scratch_c = [torch.zeros(3 * (b1 - b0), 3, dtype=torch.float64, device=self.dev) for b0, b1 in zip(graph.bounds[:-1], graph.bounds[1:])]
-        if hasattr(graph, "cgl"):
-            self._gref_cg, self.cgl = C.byref(graph.desc_cg), graph.cgl
-            self.n_add_cg = float(max(graph.cgl.rows_per_wg_max, graph.cgl.slots) + 1)
-            self._w_scaled, self._cg_w, self._cg_wmax = None, graph.w_cg, graph.wmax
-            self.zpart = torch.empty(graph.cgl.n_wg * 6 * self.C, dtype=torch.float64, device=self.dev)
-            self.pq_part = torch.empty(graph.cgl.n_wg, dtype=torch.float64, device=self.dev)
+        if graph.tiles[0].w is not None:
+            self.n_add_cg = float(max(max(t.tl.rows_per_wg_max, t.tl.slots) for t in graph.tiles) + 1)
+            self._cg_wmax = graph.wmax
+            self._cg_w = [t.w for t in graph.tiles]                                     # per tile, in the tile's slot order
+            self._w_scaled = None
+            self.pq_part = torch.empty(1024, dtype=torch.float64, device=self.dev)
+            self.acc_t = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)   # per-tile row sums of the CG product
             self.rhs_part = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)
 
     def _tile_rows(self, k):
@@ -982,10 +940,44 @@ class TiledBackend(HipBackend):
         self._ck(self.lib.vican_sum_apply3(self.T, 3, None, _ptr(self.rhs_part), len(self.tiles), self.rhs_part.stride(0), _ptr(rhs_t), _stream()),
                  "vican_sum_apply3")
 
+    # The CG product q = A p one camera tile at a time (vican_cg_sweep_partial): a tile's sweep yields its row sums
+    # sum_{c in tile} w p_c and the complete camera sums of its own cameras; the rows are combined in tile order.
+    cg_resident_ok = False
+
+    def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
+        b = self.g.bounds
+        self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part), self.n_add_cg,
+                                         _ptr(st), _stream()), "vican_cg_begin")
+        self._ck(self.lib.vican_cg_update_pt(self.T, _ptr(r_t), _ptr(p_t), _ptr(st), _stream()), "vican_cg_update_pt")
+        for k, K in enumerate(self.tiles):
+            part = K.zpart[: K.tl.n_wg * 6 * K.C]
+            self._ck(self.lib.vican_cg_sweep_partial(K._gref_t, _ptr(self._cg_w[k]), _ptr(p_c[b[k]: b[k + 1]]), _ptr(p_t), _ptr(self.acc_t[k]),
+                                                     _ptr(part), _ptr(st), _stream()), "vican_cg_sweep_partial")
+            self._ck(self.lib.vican_cg_fold(_ptr(part), K.tl.n_wg, K.C, None, C.c_void_p(qcpq.data_ptr() + 8 * 3 * b[k]), _ptr(st), _stream()),
+                     "vican_cg_fold")
+        nb = self._ck(self.lib.vican_cg_combine_rows(self.T, len(self.tiles), self.acc_t.stride(0), _ptr(deg_t), _ptr(p_t), _ptr(self.acc_t),
+                                                     _ptr(q_t), _ptr(self.pq_part), self.pq_part.numel(), _ptr(st), _stream()),
+                      "vican_cg_combine_rows")
+        self._ck(self.lib.vican_cg_reduce_pq(_ptr(self.pq_part), nb, C.c_void_p(qcpq.data_ptr() + 8 * 3 * self.C), _ptr(st), _stream()),
+                 "vican_cg_reduce_pq")
+
+    def set_cg_scaling(self, s_c, s_t):
+        """CG sweeps use w~ = w s_c s_t (<= 1) until clear_cg_scaling() - per tile."""
+        b = self.g.bounds
+        if self._w_scaled is None:
+            self._w_scaled = [torch.empty_like(t.w) for t in self.g.tiles]
+        for k, K in enumerate(self.tiles):
+            self._ck(self.lib.vican_scale_weights(K._gref_t, _ptr(self.g.tiles[k].w), _ptr(s_c[b[k]: b[k + 1]]), _ptr(s_t), _ptr(self._w_scaled[k]),
+                                                  _stream()), "vican_scale_weights")
+        self._cg_w, self._cg_wmax = self._w_scaled, 1.0
+
+    def clear_cg_scaling(self):
+        self._cg_w, self._cg_wmax = [t.w for t in self.g.tiles], self.g.wmax
+
     def _unsupported(self, *a, **k):
         raise _lib.VicanError("not available on camera-tiled graphs (more than %d cameras)" % TILE_CAMS)
 
-    dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = _unsupported
+    dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = cg_sweep = cg_resident = _unsupported
     lsqr_init_u = lsqr_u_step = lsqr_v_step = _unsupported
 
 
