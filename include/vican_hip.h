@@ -559,6 +559,43 @@ int vican_lsqr_cam_v(int32_t n_cam, const double* acc, double beta, double* v_c,
 int vican_lsqr_update(int64_t n, double inv_alfa, double t1, double t2, double* v, double* w,
                       double* x, double* part, double* nrm2_w_out, void* stream);
 
+/* Device-resident LSQR iteration: every scalar of scipy's loop lives in this struct (initialised by the caller after the
+ * first bidiagonalisation step), the host only polls `done`.  The edge vector is stored UNNORMALISED (u~_i = beta_i u_i). */
+typedef struct vican_lsqr_state {
+    double alfa, beta, rhobar, phibar, anorm, ddnorm, xxnorm, z, cs2, sn2;   /* scipy's variables of the same names */
+    double c2;         /* |b|^2 - |b~|^2: added back to the residual norms of the merged system */
+    double bnorm, atol, btol, ctol;
+    double coef;       /* alfa_i / beta_i: factor of the stored u~ in the next step */
+    double inv_alfa, t1, t2;   /* coefficients of the pending v / x / w update */
+    double rnorm, arnorm, acond, xnorm;   /* scipy's estimates after the last completed iteration */
+    double qscale, qinv;       /* fixed-point scale of the next step's sums */
+    double smax;       /* max sqrt(w_e) */
+    double n_add;      /* contributions one workgroup adds into one accumulator */
+    double reserved;
+    int32_t itn, istop, done, iter_lim;   /* istop: scipy's codes 1..7; 8 = NaN */
+    int32_t lo_bits, update, pad0, pad1;  /* update: 1 while the x / w update of iteration itn is still to run */
+} vican_lsqr_state_t;
+/* One fused pass over the edges (block layout): u^ = J~ v - coef u~ written over u~, z_t [T][3] = row sums of J~^T u^, the camera
+ * sums as double-word slabs (zc_part: n_wg * 6C words) folded into acc[0:3C] ([C][3]), acc[3C] = |u^|^2 = beta_{i+1}^2 - this
+ * rank's part: all-reduce acc[0 : 3C+1] when sharded.  part: >= max(n_wg, 1024) doubles of scratch.                       */
+int vican_lsqr_step(const vican_graph_t* g, const double* sw, double* u, const double* v_c, const double* v_t, double* z_t,
+                    void* zc_part, double* part, double* acc, const vican_lsqr_state_t* st, void* stream);
+/* v_t <- z_t / beta' - beta' v_t, v_c <- acc_c / beta' - beta' v_c with beta' = sqrt(acc[3C]); part2[0:ret] = partials of |v_t|^2,
+ * part2[1024] = |v_c|^2 (part2: >= 1025 doubles); returns the number of partials.                                            */
+int vican_lsqr_nodes(int32_t n_cam, int32_t n_time, const double* z_t, const double* acc, double* v_t, double* v_c, double* part2,
+                     const vican_lsqr_state_t* st, void* stream);
+/* The scalars of the iteration (Givens rotation, norm estimates, scipy's stopping tests -> istop / done, the update
+ * coefficients, coef and the fixed-point scale of the next step).  |v~_t|^2 = sum part2[0:n_part], or *tsum when the caller
+ * all-reduced it; |w|^2 = sum wpart_t[0:n_wt] (or *wsum_t) + sum wpart_c[0:n_wc] from the previous vican_lsqr_update_st calls. */
+int vican_lsqr_scalars(int32_t n_cam, const double* acc, const double* part2, int32_t n_part, const double* tsum,
+                       const double* wpart_t, int32_t n_wt, const double* wpart_c, int32_t n_wc, const double* wsum_t,
+                       vican_lsqr_state_t* st, void* stream);
+/* vican_lsqr_update with the coefficients of the state; runs iff state.update (set by vican_lsqr_scalars: scipy updates x
+ * before it tests), `last` != 0 clears that flag behind the kernel; returns the number of |w|^2 partials written to part.  */
+int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* part, int32_t last, vican_lsqr_state_t* st,
+                         void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,6 +267,14 @@ def test_lsqr_kernels(cfg):
     assert ih["istop"] == inn["istop"] and abs(ih["lsqr_iters"] - inn["lsqr_iters"]) <= max(1, inn["lsqr_iters"] // 20)
     scale = max(np.abs(xt_n).max(), 1.0)
     assert np.abs(xc_h - xc_n).max() < 1e-6 * scale and np.abs(xt_h - xt_n).max() < 1e-6 * scale
+    # the HIP run above kept every scalar on the device and made one fused pass over the edges per iteration (vican_lsqr_step);
+    # the round-2 path - Golub-Kahan scalars on the host, two passes - must stop at the same iteration with the same answer
+    assert ih.get("device_scalars")
+    H.lsqr_host_scalars = True
+    ls = LsqrTranslationSolver(H, Comm(), atol=1e-10, btol=1e-10)
+    x_c, x_t = ls.solve(H.from_numpy(rc), H.from_numpy(rt), 3 * (C + T))
+    assert not ls.info.get("device_scalars") and ls.info["istop"] == ih["istop"] and abs(ls.info["lsqr_iters"] - ih["lsqr_iters"]) <= 1
+    assert np.abs(x_c.cpu().numpy() - xc_h).max() < 1e-8 * scale and np.abs(x_t.cpu().numpy() - xt_h).max() < 1e-8 * scale
 
 
 @pytest.mark.parametrize("C,j", [(5, 0), (60, 3), (333, 7), (1000, 5), (1024, 20)])

@@ -18,4 +18,10 @@ for (C, T, k) in ((340, 10000, 4), (1000, 100000, 250)):
         torch.cuda.synchronize(); t1 = time.perf_counter()
         ls = LsqrTranslationSolver(K, Comm()); ls.solve(rc, Rt, 3 * (C + T), None)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        print("C=%d T=%d E=%d: CG %.2f ms (%d it)   LSQR %.2f ms (%s it, istop %s)" % (C, T, g.n_edges, (t1 - t0) * 1e3, tr.info["cg_iters"], (t2 - t1) * 1e3, ls.info.get("lsqr_iters"), ls.info.get("istop")))
+        K.lsqr_host_scalars = True                  # the round-2 path: Golub-Kahan scalars on the host, two edge passes per iteration
+        lh = LsqrTranslationSolver(K, Comm()); lh.solve(rc, Rt, 3 * (C + T), None)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        K.lsqr_host_scalars = False
+        print("C=%d T=%d E=%d: CG %.2f ms (%d it)   LSQR device scalars + fused pass %.2f ms (%s it, istop %s: %.3f ms / it)   host scalars %.2f ms (%s it: %.3f ms / it)" % (
+            C, T, g.n_edges, (t1 - t0) * 1e3, tr.info["cg_iters"], (t2 - t1) * 1e3, ls.info.get("lsqr_iters"), ls.info.get("istop"),
+            (t2 - t1) * 1e3 / max(ls.info.get("lsqr_iters"), 1), (t3 - t2) * 1e3, lh.info.get("lsqr_iters"), (t3 - t2) * 1e3 / max(lh.info.get("lsqr_iters"), 1)))

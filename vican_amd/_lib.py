@@ -51,6 +51,12 @@ CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=
             rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15, pmax_time=16)
 CG_I = dict(iter=34, done=35, first=36, lo_bits=37)     # int32 index into the same buffer viewed as int32
 
+# vican_lsqr_state_t: 28 doubles then 8 int32 (256 bytes = 32 doubles)
+LSQR_STATE_DOUBLES = 32
+LSQR_F = dict(alfa=0, beta=1, rhobar=2, phibar=3, anorm=4, ddnorm=5, xxnorm=6, z=7, cs2=8, sn2=9, c2=10, bnorm=11, atol=12, btol=13,
+              ctol=14, coef=15, inv_alfa=16, t1=17, t2=18, rnorm=19, arnorm=20, acond=21, xnorm=22, qscale=23, qinv=24, smax=25, n_add=26)
+LSQR_I = dict(itn=56, istop=57, done=58, iter_lim=59, lo_bits=60, update=61)     # int32 index into the same buffer viewed as int32
+
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _G = C.POINTER(Graph)
 
@@ -130,6 +136,10 @@ PROTOTYPES = {
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
     "vican_lsqr_cam_v": (C.c_int, [_i32, _vp, _f64, _vp, _vp, _vp]),
     "vican_lsqr_update": (C.c_int, [_i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_step": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_nodes": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_scalars": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "vican_lsqr_update_st": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
     auto load_edges = [&](CgrEdges<EPL>& e, const int kc) {
         const size_t sl = (size_t)kc * g.slots + (size_t)lane * EPL;
         if constexpr (EPL == 4) {
-            const uint4 a = *(const uint4*)(g.idx + sl); const double2 b0 = *(const double2*)(w + sl), b1 = *(const double2*)(w + sl + 2);
+            const double* wk = w + (size_t)kc * g.slots + (size_t)lane * 2;          // permuted storage of w (slot_pos8)
+            const uint4 a = *(const uint4*)(g.idx + sl); const double2 b0 = *(const double2*)wk, b1 = *(const double2*)(wk + 128);
             e.id[0] = a.x; e.id[1] = a.y; e.id[2] = a.z; e.id[3] = a.w; e.w[0] = b0.x; e.w[1] = b0.y; e.w[2] = b1.x; e.w[3] = b1.y;
         } else {
             const uint2 a = *(const uint2*)(g.idx + sl); const double2 b0 = *(const double2*)(w + sl);

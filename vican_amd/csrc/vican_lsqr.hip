@@ -9,7 +9,7 @@
 // the host (two small device->host reads per iteration); everything O(E) runs here:
 //   u-step   u <- s (v_t - v_c) - coef * u          (12 + 2*24 algorithmic bytes / edge)
 //   v-step   v <- J~^T (u / beta) - beta v           (12 + 24 bytes / edge, fixed-point sums)
-#include "vican_common.h"
+#include "vican_sweep_common.h"
 #include <type_traits>
 
 #define LSQR_PARTS 1024
@@ -375,4 +375,322 @@ extern "C" int vican_lsqr_update(int64_t n, double inv_alfa, double t1, double t
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, nb, nrm2_w_out);
     LAUNCH_CHECK("vican_lsqr_update");
     return VICAN_OK;
+}
+
+// ===========================================================================================================================
+// Device-resident LSQR iteration (no host read on the critical path; one pass over the edges per iteration)
+// ===========================================================================================================================
+// scipy's loop (bidiagonalisation  beta u = A v - alfa u,  alfa v = A^T u - beta v,  then the QR / norm / stopping-test
+// scalars) with every scalar in a device struct (vican_lsqr_state_t) and the two edge passes of an iteration FUSED: the edge
+// vector is stored UNNORMALISED (u~_i = beta_i u_i), a pass forms  u^ = J~ v_i - (alfa_i / beta_i) u~_i  (= beta_{i+1} u_{i+1}),
+// writes it, and in the same pass accumulates |u^|^2 and z = J~^T u^ (row sums written out, camera sums as double-word
+// fixed-point slabs); the node-side kernel then finishes  v~ = z / beta_{i+1} - beta_{i+1} v_i.  60 bytes per edge and
+// iteration (packed index 4, sqrt(w) 8, u~ read 24 + written 24) instead of 60 + 36 in two passes.  (J~^T u^) / beta and
+// J~^T (u^ / beta) differ by rounding only; iterates agree with scipy's to ~1e-15 relative per iteration.
+static_assert(sizeof(vican_lsqr_state_t) == 8 * 28 + 4 * 8, "vican_lsqr_state_t layout");
+
+template <int BLOCK, int EPL, int NR>
+__global__ __launch_bounds__(BLOCK) void lsqr_step_kernel(vican_graph_t g, const double* __restrict__ sw, double* __restrict__ u,
+                                                          const double* __restrict__ v_c, const double* __restrict__ v_t,
+                                                          double* __restrict__ z_t, u64* __restrict__ zc_part,
+                                                          double* __restrict__ part, const vican_lsqr_state_t* __restrict__ st) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    if (st->done) return;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, mr3 = 3 * g.max_rows;
+    const int lo_c = 3 * C, lo_t = mr3 * ncopy;
+    u64* zc = (u64*)lds_raw;                               // [2][3][C] planes: hi, lo
+    u64* zt = zc + 6 * C;                                  // [2 buffers][2][max_rows*3][ncopy]
+    double* vcs = (double*)(zt + (size_t)4 * lo_t);        // [3][C] planes
+    double* vts = vcs + 3 * C;                             // [2][max_rows*3]
+    double* red = vts + 2 * mr3;                           // [16]
+    const int tid = threadIdx.x, lane_copy = tid & cmask;
+    const uint32_t pad_cam = (uint32_t)((tid & 31) < g.n_cam ? (tid & 31) : 0);
+    const double coef = st->coef, scale = st->qscale, inv = st->qinv;
+    const int lob = st->lo_bits;
+    const double lo_scale = ldexp(1.0, lob);
+    for (int i = tid; i < 3 * C; i += BLOCK) { vcs[(i % 3) * C + i / 3] = v_c[i]; zc[i] = 0ull; zc[lo_c + i] = 0ull; }
+    for (int i = tid; i < 4 * lo_t; i += BLOCK) zt[i] = 0ull;
+    const int k0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int k1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    double rv[NR];
+    auto load_rows = [&](int k) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; rv[m] = i < n3 ? v_t[(size_t)r0 * 3 + i] : 0.0; }
+    };
+    auto commit_rows = [&](int k, int buf) {
+        const int n3 = 3 * (g.chunk_row0[k + 1] - g.chunk_row0[k]);
+#pragma unroll
+        for (int m = 0; m < NR; ++m) { const int i = tid + m * BLOCK; if (i < n3) vts[buf * mr3 + i] = rv[m]; }
+    };
+    auto fold = [&](const int k, const int buf) {
+        const int r0 = g.chunk_row0[k], n3 = 3 * (g.chunk_row0[k + 1] - r0);
+        u64* q = zt + (size_t)buf * 2 * lo_t;
+        for (int i = tid; i < n3; i += BLOCK) {
+            long long sum = 0, slo = 0;
+            for (int c = 0; c < ncopy; ++c) {
+                const int a = i * ncopy + ((c + i) & cmask);
+                sum += (long long)q[a]; slo += (long long)q[lo_t + a];
+                q[a] = 0ull; q[lo_t + a] = 0ull;
+            }
+            z_t[(size_t)r0 * 3 + i] = fix2_value(sum, slo, lob, inv);
+        }
+    };
+    LsqrRegs<EPL> ea, eb;
+    double nrm = 0.0;
+    if (k0 < k1) { lsqr_load_edges<EPL>(ea, g, sw, u, k0, tid); load_rows(k0); commit_rows(k0, 0); }
+    __syncthreads();
+    auto body = [&](LsqrRegs<EPL>& cur, LsqrRegs<EPL>& nxt, const int k, const int buf) {
+        if (k + 1 < k1) { lsqr_load_edges<EPL>(nxt, g, sw, u, k + 1, tid); load_rows(k + 1); }
+        const double* vt = vts + buf * mr3;
+        u64* ztb = zt + (size_t)buf * 2 * lo_t;
+        double un[3][EPL], acc[3] = {0, 0, 0};
+        uint32_t prow = 0xFFFFFFFFu;
+        auto flush_row = [&](const uint32_t r) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const Fix2 f = to_fix2(acc[i], scale, lo_scale);
+                u64* a = &ztb[(r * 3 + i) * ncopy + lane_copy];
+                lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            const uint32_t cam = pad ? pad_cam : (cur.id[j] & 0xFFFFu), row = pad ? 0u : (cur.id[j] >> 16);
+            const double sj = pad ? 0.0 : cur.s[j];
+            if (row != prow) {
+                if (prow != 0xFFFFFFFFu) flush_row(prow);
+                prow = row; acc[0] = acc[1] = acc[2] = 0.0;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const double uh = pad ? 0.0 : sj * (vt[row * 3 + p] - vcs[p * C + cam]) - coef * cur.u[p][j];
+                un[p][j] = uh;
+                nrm += uh * uh;
+                const double a = sj * uh;
+                acc[p] += a;
+                const Fix2 f = to_fix2(-a, scale, lo_scale);
+                lds_add_fix(&zc[p * C + cam], f.hi); lds_add_fix(&zc[lo_c + p * C + cam], f.lo);
+            }
+        }
+        if (prow != 0xFFFFFFFFu) flush_row(prow);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            double* o = u + ((size_t)k * 3 + p) * g.slots + (size_t)tid * EPL;
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2) *(double2*)(o + j) = make_double2(un[p][j], un[p][j + 1]);
+        }
+        if (k > k0) fold(k - 1, buf ^ 1);                  // deferred: overlaps with everybody's edge work
+        if (k + 1 < k1) commit_rows(k + 1, buf ^ 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int k = k0; k < k1; k += 2) {
+        body(ea, eb, k, 0);
+        if (k + 1 < k1) body(eb, ea, k + 1, 1);
+    }
+    if (k0 < k1) fold(k1 - 1, (k1 - 1 - k0) & 1);
+    __syncthreads();
+    for (int i = tid; i < 6 * C; i += BLOCK) zc_part[(size_t)blockIdx.x * 6 * C + i] = zc[i];
+    const double t = block_sum(nrm, red);
+    if (tid == 0) part[blockIdx.x] = t;
+}
+static inline int64_t lsqr_step_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) {
+    return 72LL * n_cam + (int64_t)max_rows * (96LL * n_copy + 48) + 256;
+}
+
+// camera slabs [n_slab][2][3][C] -> acc[0 : 3C] ([C][3], exact sums rounded once); acc[3C] = sum of the |u^|^2 partials
+__global__ __launch_bounds__(1024) void lsqr_fold_kernel(const long long* __restrict__ slab, int n_slab, int n_cam, const double* __restrict__ part,
+                                                         double* __restrict__ acc, const vican_lsqr_state_t* __restrict__ st) {
+    __shared__ long long sh[3][1024];
+    if (st->done) return;
+    const long long n = 3LL * n_cam;
+    const int lob = st->lo_bits;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    Fix3 a = {0, 0, 0};
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 16) fix3_add(a, slab[(size_t)k * 2 * n + i], slab[(size_t)k * 2 * n + n + i], lob);
+    sh[0][threadIdx.x] = a.top; sh[1][threadIdx.x] = a.bot; sh[2][threadIdx.x] = a.lo;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        long long t = 0, b = 0, l = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t += sh[0][k * 64 + e]; b += sh[1][k * 64 + e]; l += sh[2][k * 64 + e]; }
+        const long long q = i / n_cam, cam = i % n_cam;
+        acc[cam * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
+    }
+    if (blockIdx.x == 0) {
+        __shared__ double pp[1024];
+        __syncthreads();
+        double tot = 0.0;
+        for (int k0 = 0; k0 < n_slab; k0 += 1024) {
+            const int k = k0 + threadIdx.x;
+            pp[threadIdx.x] = k < n_slab ? part[k] : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) { const int m = n_slab - k0 < 1024 ? n_slab - k0 : 1024; for (int j = 0; j < m; ++j) tot += pp[j]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc[n] = tot;
+    }
+}
+
+// node side of the fused step: beta' = sqrt(acc[3C]) (all-reduced by the caller when sharded);
+// v_t <- z_t / beta' - beta' v_t, v_c <- acc_c / beta' - beta' v_c (block 0); part2[b] = partial |v_t|^2, part2[LSQR_PARTS] = |v_c|^2
+__global__ __launch_bounds__(256) void lsqr_nodes_kernel(long long n_t, int n_c, const double* __restrict__ z_t, const double* __restrict__ acc,
+                                                         double* __restrict__ v_t, double* __restrict__ v_c, double* __restrict__ part2,
+                                                         const vican_lsqr_state_t* __restrict__ st) {
+    __shared__ double red[8];
+    if (st->done) return;
+    const double b2 = acc[n_c];
+    const double beta = sqrt(b2), ib = beta > 0.0 ? 1.0 / beta : 0.0;
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_t; i += (long long)gridDim.x * 256) {
+        const double vn = z_t[i] * ib - beta * v_t[i];
+        v_t[i] = vn; s += vn * vn;
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) part2[blockIdx.x] = t;
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        double sc = 0.0;
+        for (int i = threadIdx.x; i < n_c; i += 256) { const double vn = acc[i] * ib - beta * v_c[i]; v_c[i] = vn; sc += vn * vn; }
+        const double tc = block_sum(sc, red);
+        if (threadIdx.x == 0) part2[LSQR_PARTS] = tc;
+    }
+}
+
+__device__ __forceinline__ void lsqr_sym_ortho(double a, double b, double& c, double& s, double& r) {
+    if (b == 0.0) { c = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0); s = 0.0; r = fabs(a); return; }
+    if (a == 0.0) { c = 0.0; s = b > 0 ? 1.0 : -1.0; r = fabs(b); return; }
+    if (fabs(b) > fabs(a)) { const double tau = a / b; s = (b > 0 ? 1.0 : -1.0) / sqrt(1.0 + tau * tau); c = s * tau; r = b / s; }
+    else { const double tau = b / a; c = (a > 0 ? 1.0 : -1.0) / sqrt(1.0 + tau * tau); s = c * tau; r = a / c; }
+}
+// the scalars of one iteration (scipy.sparse.linalg.lsqr's loop body after the bidiagonalisation step) + stopping tests.
+// nv2 = |v~|^2 timestep part = sum of part2[0:n_part] (or *tsum when the caller all-reduced it) + part2[LSQR_PARTS];
+// wn2 = |w|^2 of the current direction = sum wpart_t[0:n_wt] + sum wpart_c[0:n_wc] (or *wsum_t when all-reduced).
+__global__ __launch_bounds__(256) void lsqr_scalars_kernel(const double* __restrict__ acc_beta2, const double* __restrict__ part2, int n_part,
+                                                           const double* __restrict__ tsum, const double* __restrict__ wpart_t, int n_wt,
+                                                           const double* __restrict__ wpart_c, int n_wc, const double* __restrict__ wsum_t,
+                                                           vican_lsqr_state_t* st) {
+    __shared__ double red[8];
+    if (st->done) return;
+    double a = 0.0, b = 0.0;
+    if (!tsum) for (int i = threadIdx.x; i < n_part; i += 256) a += part2[i];
+    if (!wsum_t) for (int i = threadIdx.x; i < n_wt; i += 256) b += wpart_t[i];
+    for (int i = threadIdx.x; i < n_wc; i += 256) b += wpart_c[i];
+    const double sa = block_sum(a, red);
+    const double sb = block_sum(b, red);
+    if (threadIdx.x != 0) return;
+    const double eps = 2.220446049250313e-16;
+    const double beta = sqrt(*acc_beta2);
+    const double nv2 = (tsum ? *tsum : sa) + part2[LSQR_PARTS];
+    const double wnorm2 = sb + (wsum_t ? *wsum_t : 0.0);
+    double alfa = st->alfa, anorm = st->anorm;
+    if (beta > 0.0) { anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta); alfa = sqrt(nv2); }
+    double cs, sn, rho;
+    lsqr_sym_ortho(st->rhobar, beta, cs, sn, rho);
+    const double theta = sn * alfa;
+    const double rhobar = -cs * alfa, phi = cs * st->phibar, phibar = sn * st->phibar, tau = sn * phi;
+    const double t1 = phi / rho, t2 = -theta / rho;
+    const double ddnorm = st->ddnorm + wnorm2 / (rho * rho);
+    const double delta = st->sn2 * rho, gambar = -st->cs2 * rho, rhs = phi - delta * st->z, zbar = rhs / gambar;
+    const double xnorm = sqrt(st->xxnorm + zbar * zbar);
+    const double gamma = sqrt(gambar * gambar + theta * theta);
+    const double z = rhs / gamma;
+    const double acond = anorm * sqrt(ddnorm);
+    const double rnorm = sqrt(phibar * phibar + st->c2), arnorm = alfa * fabs(tau);
+    const double test1 = rnorm / st->bnorm, test2 = arnorm / (anorm * rnorm + eps), test3 = 1.0 / (acond + eps);
+    const double tt1 = test1 / (1.0 + anorm * xnorm / st->bnorm), rtol = st->btol + st->atol * anorm * xnorm / st->bnorm;
+    const int itn = st->itn + 1;
+    int istop = 0;
+    if (itn >= st->iter_lim) istop = 7;
+    if (1.0 + test3 <= 1.0) istop = 6;
+    if (1.0 + test2 <= 1.0) istop = 5;
+    if (1.0 + tt1 <= 1.0) istop = 4;
+    if (test3 <= st->ctol) istop = 3;
+    if (test2 <= st->atol) istop = 2;
+    if (test1 <= rtol) istop = 1;
+    if (!(rnorm == rnorm)) istop = 8;                      // NaN: stop and report (scipy would run to iter_lim)
+    st->coef = beta > 0.0 ? alfa / beta : 0.0;             // next step: u^ = J~ v - (alfa / beta) u~
+    st->inv_alfa = alfa > 0.0 ? 1.0 / alfa : 1.0; st->t1 = t1; st->t2 = t2;
+    st->alfa = alfa; st->beta = beta; st->anorm = anorm; st->rhobar = rhobar; st->phibar = phibar; st->ddnorm = ddnorm;
+    st->cs2 = gambar / gamma; st->sn2 = theta / gamma; st->z = z; st->xxnorm = st->xxnorm + z * z;
+    st->rnorm = rnorm; st->arnorm = arnorm; st->acond = acond; st->xnorm = xnorm;
+    // fixed-point scale of the next step's sums: |s u^| <= smax (2 smax |v|_max + alfa |u|_max) <= smax (2 smax + alfa)   (|v| = |u| = 1)
+    double qi;
+    st->qscale = fix_scale(st->smax * (2.0 * st->smax + alfa), st->n_add, &qi, 49);
+    st->qinv = qi;
+    st->itn = itn; st->istop = istop;
+    st->update = 1;                                        // this iteration's x / w update is still to run
+    if (istop) st->done = 1;
+}
+
+// v *= inv_alfa ; x += t1 w ; w = v + t2 w ; partial |w_new|^2 - coefficients from the state; runs for the iteration whose
+// scalars were just computed even if that iteration raised `done` (scipy updates x before it tests)
+__global__ __launch_bounds__(256) void lsqr_update_st_kernel(long long n, double* v, double* w, double* x, double* __restrict__ part,
+                                                             const vican_lsqr_state_t* __restrict__ st) {
+    __shared__ double red[8];
+    if (!st->update) return;
+    const double inv_alfa = st->inv_alfa, t1 = st->t1, t2 = st->t2;
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double vn = v[i] * inv_alfa, wo = w[i];
+        v[i] = vn;
+        x[i] += t1 * wo;
+        const double wn = vn + t2 * wo;
+        w[i] = wn;
+        s += wn * wn;
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void lsqr_clear_update_kernel(vican_lsqr_state_t* st) { st->update = 0; }
+
+extern "C" int vican_lsqr_step(const vican_graph_t* g, const double* sw, double* u, const double* v_c, const double* v_t, double* z_t,
+                               void* zc_part, double* part, double* acc, const vican_lsqr_state_t* state, void* stream) {
+    const vican_lsqr_state_t* st = state;
+    if (int r = vican_check_block_graph(g, "vican_lsqr_step")) return r;
+    if (!sw || !u || !v_c || !v_t || !z_t || !zc_part || !part || !acc || !st) return set_err(VICAN_ERR_ARG, "vican_lsqr_step: null pointer");
+    if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_step: more than 4 rows per lane in a chunk");
+    hipStream_t st_ = (hipStream_t)stream;
+    const size_t lds = (size_t)lsqr_step_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
+    if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_step: camera tables / row staging do not fit in LDS");
+    {
+        hipStream_t st = st_;                               // (the dispatch macro launches on `st`)
+        LSQR_DISPATCH_NR(lsqr_step_kernel, lds, *g, sw, u, v_c, v_t, z_t, (u64*)zc_part, part, state);
+    }
+    const long long n = 3LL * g->n_cam;
+    hipLaunchKernelGGL(lsqr_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st_, (const long long*)zc_part, g->n_wg, g->n_cam, part, acc, st);
+    LAUNCH_CHECK("vican_lsqr_step");
+    return VICAN_OK;
+}
+extern "C" int vican_lsqr_nodes(int32_t n_cam, int32_t n_time, const double* z_t, const double* acc, double* v_t, double* v_c, double* part2,
+                                const vican_lsqr_state_t* st, void* stream) {
+    if (n_cam <= 0 || n_time < 0 || !z_t || !acc || !v_t || !v_c || !part2 || !st) return set_err(VICAN_ERR_ARG, "vican_lsqr_nodes: bad argument");
+    const long long n = 3LL * n_time;
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > LSQR_PARTS) nb = LSQR_PARTS;
+    hipLaunchKernelGGL(lsqr_nodes_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, 3 * n_cam, z_t, acc, v_t, v_c, part2, st);
+    LAUNCH_CHECK("vican_lsqr_nodes");
+    return nb;
+}
+extern "C" int vican_lsqr_scalars(int32_t n_cam, const double* acc, const double* part2, int32_t n_part, const double* tsum,
+                                  const double* wpart_t, int32_t n_wt, const double* wpart_c, int32_t n_wc, const double* wsum_t,
+                                  vican_lsqr_state_t* st, void* stream) {
+    if (n_cam <= 0 || !acc || !part2 || !wpart_c || (!wpart_t && !wsum_t) || !st) return set_err(VICAN_ERR_ARG, "vican_lsqr_scalars: bad argument");
+    hipLaunchKernelGGL(lsqr_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc + 3 * (size_t)n_cam, part2, (int)n_part, tsum, wpart_t,
+                       (int)n_wt, wpart_c, (int)n_wc, wsum_t, st);
+    LAUNCH_CHECK("vican_lsqr_scalars");
+    return VICAN_OK;
+}
+extern "C" int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* part, int32_t last, vican_lsqr_state_t* st,
+                                    void* stream) {
+    if (n < 0 || !v || !w || !x || !part || !st) return set_err(VICAN_ERR_ARG, "vican_lsqr_update_st: bad argument");
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > LSQR_PARTS) nb = LSQR_PARTS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lsqr_update_st_kernel, dim3(nb), dim3(256), 0, s, (long long)n, v, w, x, part, st);
+    if (last) hipLaunchKernelGGL(lsqr_clear_update_kernel, dim3(1), dim3(1), 0, s, st);
+    LAUNCH_CHECK("vican_lsqr_update_st");
+    return nb;
 }

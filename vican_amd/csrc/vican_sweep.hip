@@ -262,6 +262,8 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
     S* blk = blk_csr ? (S*)g.blk : nullptr;      // a layout that only carries the translation arrays has no block planes
     uint32_t* idx = (uint32_t*)g.idx;
     const size_t base = (size_t)k * g.slots + s;
+    const int s8 = slot_pos8(g, s);                 // position in the 8-byte-per-slot arrays (w, planes of u / v)
+    const size_t base8 = (size_t)k * g.slots + s8;
     const int e = perm[base];
     if (e >= 0) {
         int lo = r0, hi = r1;           // row_ptr[lo] <= e < row_ptr[hi]
@@ -275,11 +277,11 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
             for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = blk_csr[(size_t)e * 9 + p];
         }
         if (a_out) a_out[base] = a_csr[e];
-        if (w_out) w_out[base] = w_csr[e];
+        if (w_out) w_out[base8] = w_csr[e];
         if (u_out)
-            for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = u_csr[(size_t)e * 3 + p];
+            for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s8] = u_csr[(size_t)e * 3 + p];
         if (v_out)
-            for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = v_csr[(size_t)e * 3 + p];
+            for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s8] = v_csr[(size_t)e * 3 + p];
     } else {
         idx[base] = VICAN_PAD_SLOT;
         if (blk) {
@@ -287,9 +289,9 @@ __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ r
             for (int p = 0; p < 9; ++p) blk[((size_t)k * 9 + p) * g.slots + s] = (S)0;
         }
         if (a_out) a_out[base] = (S)0;
-        if (w_out) w_out[base] = 0.0;
-        if (u_out) for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
-        if (v_out) for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s] = 0.0;
+        if (w_out) w_out[base8] = 0.0;
+        if (u_out) for (int p = 0; p < 3; ++p) u_out[((size_t)k * 3 + p) * g.slots + s8] = 0.0;
+        if (v_out) for (int p = 0; p < 3; ++p) v_out[((size_t)k * 3 + p) * g.slots + s8] = 0.0;
     }
 }
 
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(256) void edge_sums_kernel(vican_graph_t g, const S
         for (int s = threadIdx.x; s < g.slots; s += blockDim.x) {
             const uint32_t id = g.idx[base + s];
             if (id == VICAN_PAD_SLOT) continue;
-            const u64 f = to_fix((double)val[base + s], scale);
+            // (an 8-byte array on a 4-slots-per-lane wave layout is the weights w in their permuted order, slot_pos8)
+            const u64 f = to_fix((double)val[base + (sizeof(S) == 8 ? slot_pos8(g, s) : s)], scale);
             lds_add_fix(&rows[id >> 16], f);
             lds_add_fix(&cams[id & 0xFFFFu], f);
         }

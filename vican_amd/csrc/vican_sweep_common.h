@@ -13,6 +13,17 @@ static inline int64_t ssize(int32_t storage) { return storage == VICAN_STORE_F32
 // component planes are reached with LDS immediate offsets instead of per-access address math
 static inline int64_t plane_stride(int32_t n_cam) { return n_cam <= 256 ? 256 : (n_cam <= 512 ? 512 : 1024); }
 
+// Position of slot s inside its chunk for the 8-BYTE-PER-SLOT arrays of the translation stage (w; the planes of u, v).
+// Wave layout with four slots per lane (f32 block storage, 256 slots): a lane's four doubles would be 32 contiguous bytes,
+// i.e. each of its two 16-byte loads would cover only every other 16 bytes of a 2 KB span.  Measured (tools/
+// stride_read_bench.hip, non-temporal loads, 12 wavefronts per workgroup): 5.74-5.81 TB/s that way against 6.60-6.93 TB/s
+// when every load instruction of a wavefront is dense - so these arrays are stored permuted: slots (4l+2h, 4l+2h+1) of lane
+// l at doubles [128 h + 2 l, +2).  Every other layout / storage keeps plain slot order (already dense).
+__host__ __device__ inline int slot_pos8(const vican_graph_t& g, int s) {
+    if (g.layout == VICAN_LAYOUT_WAVE && g.slots == 256) return ((s & 2) << 6) + ((s >> 2) << 1) + (s & 1);
+    return s;
+}
+
 template <typename S> struct Vec;
 template <> struct Vec<float>  { typedef float4  type; static constexpr int N = 4; };
 template <> struct Vec<double> { typedef double2 type; static constexpr int N = 2; };

@@ -236,9 +236,9 @@ __global__ void scale_weights_kernel(vican_graph_t g, const double* __restrict__
     const int k = blockIdx.y;
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= g.slots) return;
-    const size_t i = (size_t)k * g.slots + sl;
+    const size_t i = (size_t)k * g.slots + sl, i8 = (size_t)k * g.slots + slot_pos8(g, sl);
     const uint32_t id = g.idx[i];
-    w_out[i] = id == VICAN_PAD_SLOT ? 0.0 : w[i] * s_cam[id & 0xFFFFu] * s_row[g.chunk_row0[k] + (int)(id >> 16)];
+    w_out[i8] = id == VICAN_PAD_SLOT ? 0.0 : w[i8] * s_cam[id & 0xFFFFu] * s_row[g.chunk_row0[k] + (int)(id >> 16)];
 }
 extern "C" int vican_scale_weights(const vican_graph_t* g, const double* w, const double* s_cam, const double* s_row,
                                    double* w_out, void* stream) {

@@ -75,8 +75,9 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
         if (EPL == 4) {
             uint4 t; double2 a, b;
-            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)(w + s)); b = stream_load((const double2*)(w + s + 2)); }
-            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)(w + s); b = *(const double2*)(w + s + 2); }
+            const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
+            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
             e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
@@ -307,11 +308,13 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
         else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const size_t o = ((size_t)k * 3 + p) * g.slots + (size_t)lane * EPL;
+            // EPL 4: permuted storage (slot_pos8): slots (4l+j, 4l+j+1) at doubles [64 j + 2 l, +2) - dense 16-byte loads
+            const size_t o = ((size_t)k * 3 + p) * g.slots + (EPL == 4 ? (size_t)lane * 2 : (size_t)lane * EPL);
 #pragma unroll
             for (int j = 0; j < EPL; j += 2) {
-                const double2 a = nt ? stream_load((const double2*)(u + o + j)) : *(const double2*)(u + o + j);
-                const double2 b = nt ? stream_load((const double2*)(v + o + j)) : *(const double2*)(v + o + j);
+                const size_t oj = o + (EPL == 4 ? 64 * j : j);
+                const double2 a = nt ? stream_load((const double2*)(u + oj)) : *(const double2*)(u + oj);
+                const double2 b = nt ? stream_load((const double2*)(v + oj)) : *(const double2*)(v + oj);
                 e.u[p][j] = a.x; e.u[p][j + 1] = a.y; e.v[p][j] = b.x; e.v[p][j + 1] = b.y;
             }
         }
@@ -350,8 +353,7 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
         __builtin_amdgcn_wave_barrier();
         // all LDS reads and the arithmetic first, then nothing but atomics (LDS operations of a wavefront return in order)
         uint32_t cam[EPL], row[EPL];
-        Fix2 fc[EPL][3];
-        double ar[EPL][3];
+        double gn[EPL][3], ar[EPL][3];                       // -g of the edge (converted in the atomic phase), running row sum
         {
             double acc[3] = {0, 0, 0}, B[9];
 #pragma unroll
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
                     const double gi = rcs[(0 * 3 + i) * C + cam[j]] * uj[0] + rcs[(1 * 3 + i) * C + cam[j]] * uj[1] +
                                       rcs[(2 * 3 + i) * C + cam[j]] * uj[2] + B[0 * 3 + i] * vj[0] + B[1 * 3 + i] * vj[1] + B[2 * 3 + i] * vj[2];
                     acc[i] += gi;
-                    fc[j][i] = to_fix2(-gi, scale, lo_scale);
+                    gn[j][i] = -gi;
                     ar[j][i] = acc[i];
                 }
             }
@@ -379,7 +381,10 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { lds_add_fix(&gc[i * C + cam[j]], fc[j][i].hi); lds_add_fix(&gc[lo_c + i * C + cam[j]], fc[j][i].lo); }
+            for (int i = 0; i < 3; ++i) {
+                const Fix2 f = to_fix2(gn[j][i], scale, lo_scale);
+                lds_add_fix(&gc[i * C + cam[j]], f.hi); lds_add_fix(&gc[lo_c + i * C + cam[j]], f.lo);
+            }
             if (j == EPL - 1 || row[j] != row[j + 1]) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -417,11 +422,13 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
 extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
                                                                       const double* rt, double* rhs_t, void* rhs_c_part, double scale,
                                                                       double inv, int lob, void* stream) {
-    int nw = g->wg_waves >= 8 ? 8 : 4;
-    if (wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw = 4;
+    const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
+    // 12 wavefronts only where the two register sets fit without (much) scratch: 2 slots per lane, or 4 with one R_t trip
+    int nw = g->wg_waves >= 12 && (epl == 2 || trips <= 1) ? 12 : (g->wg_waves >= 8 ? 8 : 4);
+    if (const char* ev = getenv("VICAN_WRHS_WAVES")) { const int v = atoi(ev); if (v == 4 || v == 8 || v == 12) nw = v; }     // A/B
+    while (nw > 4 && wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw -= 4;
     const size_t lds = (size_t)wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_trans_rhs (wave layout)");
-    const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
     if (trips > 9) return set_err(VICAN_ERR_CAPACITY, "vican_trans_rhs: more than 64 rows per chunk");
     // the grid of the rotation layout has one workgroup per 12 / 8 / 4 wavefronts' worth of chunks; this kernel has nw
     hipStream_t s = (hipStream_t)stream;
@@ -437,7 +444,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
         if (epl == 4) { if (trips <= 1) WRHS_LAUNCH(NW_, 4, 1); else if (trips <= 3) WRHS_LAUNCH(NW_, 4, 3); else WRHS_LAUNCH(NW_, 4, 9); } \
         else          { if (trips <= 1) WRHS_LAUNCH(NW_, 2, 1); else if (trips <= 3) WRHS_LAUNCH(NW_, 2, 3); else WRHS_LAUNCH(NW_, 2, 9); } \
     } while (0)
-    if (nw == 8) WRHS_PICK(8); else WRHS_PICK(4);
+    if (nw == 12) WRHS_PICK(12); else if (nw == 8) WRHS_PICK(8); else WRHS_PICK(4);
 #undef WRHS_PICK
 #undef WRHS_LAUNCH
     LAUNCH_CHECK("vican_trans_rhs");

@@ -781,6 +781,40 @@ def _lsqr_update(self, inv_alfa, t1, t2, v, w, x, nrm2_w_out):
                                         _ptr(self._lsqr_part), _ptr(nrm2_w_out), _stream()), "vican_lsqr_update")
 
 
+def _lsqr_step(self, v_c, v_t, z_t, acc, st):
+    """One fused pass over the edges (vican_lsqr_step): u~ <- J~ v - coef u~, z_t, acc[0:3C] camera sums, acc[3C] = |u^|^2."""
+    self._ck(self.lib.vican_lsqr_step(self._lgref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), _ptr(v_c), _ptr(v_t), _ptr(z_t), _ptr(self._lslab2),
+                                      _ptr(self._lsqr_part), _ptr(acc), _ptr(st), _stream()), "vican_lsqr_step")
+
+
+def _lsqr_nodes(self, z_t, acc, v_t, v_c, part2, st):
+    return self._ck(self.lib.vican_lsqr_nodes(self.C, self.T, _ptr(z_t), _ptr(acc), _ptr(v_t), _ptr(v_c), _ptr(part2), _ptr(st), _stream()),
+                    "vican_lsqr_nodes")
+
+
+def _lsqr_scalars(self, acc, part2, n_part, tsum, wpart_t, n_wt, wpart_c, n_wc, wsum_t, st):
+    self._ck(self.lib.vican_lsqr_scalars(self.C, _ptr(acc), _ptr(part2), int(n_part), _ptr(tsum), _ptr(wpart_t), int(n_wt), _ptr(wpart_c),
+                                         int(n_wc), _ptr(wsum_t), _ptr(st), _stream()), "vican_lsqr_scalars")
+
+
+def _lsqr_update_st(self, v, w, x, part, last, st):
+    return self._ck(self.lib.vican_lsqr_update_st(v.numel(), _ptr(v), _ptr(w), _ptr(x), _ptr(part), int(last), _ptr(st), _stream()),
+                    "vican_lsqr_update_st")
+
+
+def _lsqr_device_params(self):
+    """(smax, n_add) of the fused step's fixed-point scale; allocates its slab buffer."""
+    _lsqr_alloc(self)
+    if not hasattr(self, "_lslab2"):
+        self._lslab2 = torch.empty(max(self._ll.n_wg, 1) * 6 * self.C, dtype=torch.float64, device=self.dev)
+    return math.sqrt(self.g.wmax), self._ln_add
+
+
+HipBackend.lsqr_step = _lsqr_step
+HipBackend.lsqr_nodes = _lsqr_nodes
+HipBackend.lsqr_scalars = _lsqr_scalars
+HipBackend.lsqr_update_st = _lsqr_update_st
+HipBackend.lsqr_device_params = _lsqr_device_params
 HipBackend.lsqr_init_u = _lsqr_init_u
 HipBackend.lsqr_u_step = _lsqr_u_step
 HipBackend.lsqr_v_step = _lsqr_v_step
@@ -978,7 +1012,7 @@ class TiledBackend(HipBackend):
         raise _lib.VicanError("not available on camera-tiled graphs (more than %d cameras)" % TILE_CAMS)
 
     dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = cg_sweep = cg_resident = _unsupported
-    lsqr_init_u = lsqr_u_step = lsqr_v_step = _unsupported
+    lsqr_init_u = lsqr_u_step = lsqr_v_step = lsqr_step = lsqr_device_params = _unsupported
 
 
 def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):

@@ -30,7 +30,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ._lib import CG_F, CG_I, CG_STATE_DOUBLES
+from ._lib import CG_F, CG_I, CG_STATE_DOUBLES, LSQR_F, LSQR_I, LSQR_STATE_DOUBLES
 
 
 class Comm:
@@ -575,6 +575,59 @@ def with_cooperative_fallback(K, comm, fn):
     return out
 
 
+def _lsqr_solve_device(self, alfa, beta, c2, bnorm, ctol, iter_lim, multi):
+    """The iterations with every scalar on the device (vican_lsqr_state_t) and ONE fused pass over the edges per iteration
+    (vican_lsqr_step): the host enqueues iterations in bursts and polls the state; nothing on the critical path is read back.
+    Entered after the first bidiagonalisation step (u~_1 = b~ stored unnormalised, v_1 and w_1 = v_1 in place, x = 0)."""
+    K, comm = self.K, self.comm
+    C3 = 3 * K.C
+    smax, n_add = K.lsqr_device_params()
+    h = np.zeros(LSQR_STATE_DOUBLES)
+    hi = h.view(np.int32)
+    for k, v in dict(alfa=alfa, beta=beta, rhobar=alfa, phibar=beta, cs2=-1.0, c2=c2, bnorm=bnorm, atol=self.atol, btol=self.btol, ctol=ctol,
+                     coef=alfa / beta, smax=smax, n_add=n_add).items():
+        h[LSQR_F[k]] = v
+    cb = smax * (2.0 * smax + alfa)                              # fix_scale(c, n_add, bits = 49) of vican_sweep_common.h
+    e = min(49 - int(np.ceil(np.log2(cb))), 61 - int(np.ceil(np.log2(cb * max(n_add, 1.0)))))
+    h[LSQR_F["qscale"]], h[LSQR_F["qinv"]] = np.ldexp(1.0, e), np.ldexp(1.0, -e)
+    hi[LSQR_I["iter_lim"]] = int(min(iter_lim, 2 ** 31 - 1))
+    hi[LSQR_I["lo_bits"]] = int(min(48, max(8, 62 - int(np.ceil(np.log2(max(n_add, 1.0)))))))
+    st = K.from_numpy(h)
+    z_t, acc = K.zeros(max(K.T, 1), 3), K.zeros(C3 + 2)          # acc: [camera sums | |u^|^2 | |w_t|^2 of the direction (sharded runs)]
+    part2, wp_c, wp_t = K.zeros(1025), K.zeros(1024), K.zeros(1024)
+    # |w_1|^2 from the initial update (s2[3] cameras, s2[1] timesteps)
+    wpart_t, n_wt, wpart_c, n_wc = self.s2[1:2], 1, self.s2[3:4], 1
+    if multi:
+        acc[C3 + 1:C3 + 2].copy_(self.s2[1:2])
+    burst, launched, state = 8, 0, None
+    while True:
+        for _ in range(burst):
+            K.lsqr_step(self.v_c, self.v_t, z_t, acc, st)
+            if multi:
+                comm.allreduce(acc)                              # one message: camera sums, |u^|^2 and the pending |w_t|^2
+            nb = K.lsqr_nodes(z_t, acc, self.v_t, self.v_c, part2, st)
+            tsum = None
+            if multi:
+                tsum = part2[:nb].sum().reshape(1)
+                comm.allreduce(tsum)
+            K.lsqr_scalars(acc, part2, nb, tsum, None if multi else wpart_t, n_wt, wpart_c, n_wc, acc[C3 + 1:] if multi else None, st)
+            n_wc = K.lsqr_update_st(self.v_c, self.w_c, self.x_c, wp_c, 0, st)
+            n_wt = K.lsqr_update_st(self.v_t, self.w_t, self.x_t, wp_t, 1, st)
+            wpart_t, wpart_c = wp_t, wp_c
+            if multi:
+                acc[C3 + 1:C3 + 2].copy_(wp_t[:n_wt].sum().reshape(1))
+            launched += 1
+        hs = st.cpu().numpy()
+        state = {**{k: float(hs[i]) for k, i in LSQR_F.items()}, **{k: int(hs.view(np.int32)[i]) for k, i in LSQR_I.items()}}
+        if state["done"] or launched >= iter_lim:
+            break
+        burst = min(2 * burst, 64)
+    self.info = dict(lsqr_iters=state["itn"], istop=state["istop"], converged=True, rnorm=state["rnorm"], arnorm=state["arnorm"],
+                     anorm=state["anorm"], acond=state["acond"], xnorm=state["xnorm"], device_scalars=True)
+    return self.x_c, self.x_t
+
+
+
 def solve_on_backend(K, comm, maxiter, n_unknowns_total, eig_tol=1e-10, rtol=1e-5, lsqr_solver="conjugate_gradient",
                      bnorm2_fn=None, tight=False):
     """Rotation stage then translation stage on one rank's backend ``K``.
@@ -673,6 +726,8 @@ class LsqrTranslationSolver:
         # v1 = v/alfa, w1 = v1, x = 0
         K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_c, self.w_c, self.x_c, self.s2[3:4])
         K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_t, self.w_t, self.x_t, self.s2[1:2])
+        if hasattr(K, "lsqr_step") and not getattr(K, "lsqr_host_scalars", False):
+            return self._solve_device(alfa, beta, c2, bnorm, ctol, iter_lim, multi)
         rhobar, phibar = alfa, beta
         anorm = acond = ddnorm = xnorm = xxnorm = z = 0.0
         cs2, sn2 = -1.0, 0.0
@@ -737,3 +792,6 @@ class LsqrTranslationSolver:
         self.info = dict(lsqr_iters=itn, istop=istop, converged=True, rnorm=float(rnorm), arnorm=float(arnorm),
                          anorm=float(anorm), acond=float(acond), xnorm=float(xnorm))
         return self.x_c, self.x_t
+
+
+LsqrTranslationSolver._solve_device = _lsqr_solve_device
