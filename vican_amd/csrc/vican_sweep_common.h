@@ -196,6 +196,33 @@ __device__ __forceinline__ u64 dpp_u64(u64 v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
     return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
 }
+// Sum of a double over the 64 lanes of a wavefront WITHOUT the LDS pipe, in a fixed order (deterministic): DPP inside the rows
+// of 16 lanes (lane ^ 1, lane ^ 2, half-row mirror, row mirror), then row_bcast15 / row_bcast31 carry the row totals
+// upwards; the total arrives in lane 63 and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((u64)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v += dpp_f64<0xB1, 0xF>(v);                     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);                     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v);                    // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v);                    // row_mirror: every lane of a row holds the row's total
+    v += dpp_f64<0x142, 0xA>(v);                    // row_bcast15 into rows 1 and 3 (other rows add the `old` value 0)
+    v += dpp_f64<0x143, 0xC>(v);                    // row_bcast31 into rows 2 and 3: lane 63 = total
+    const u64 b = (u64)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_bcast(double v, const int src_lane) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
 __device__ __forceinline__ u64 stripe_sum(u64 v, const int ncopy) {
     if (ncopy >= 2) v += dpp_u64<0xB1>(v);           // quad_perm [1,0,3,2]
     if (ncopy >= 4) v += dpp_u64<0x4E>(v);           // quad_perm [2,3,0,1]

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                     int done = 1, nb = 0, nl = 0;
                     if (taken < cap_units) {
                         // two units while the queue is long (fewer atomics), one towards its end (finer balance)
-                        const int want = (long long)(k + 2 * nwg * NW) * 8 < (long long)nchunk * 7 ? 2 : 1;
+                        // (never past the cap: the host sizes the fixed-point head-room of the z accumulators from exactly cap_units)
+                        int want = (long long)(k + 2 * nwg * NW) * 8 < (long long)nchunk * 7 ? 2 : 1;
+                        if (want > cap_units - taken) want = cap_units - taken;
                         unsigned int p = 0;
                         if (lane == 0) p = __hip_atomic_fetch_add(&sched[0], (unsigned)want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         p = (unsigned int)__builtin_amdgcn_readfirstlane((int)p);

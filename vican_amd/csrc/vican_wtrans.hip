@@ -134,6 +134,43 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         CSTAMP(1);
         ++n_done;
 #endif
+        if (n3 == 3) {
+            // ONE row in the chunk (dense rows: every lane's slots belong to it): no LDS staging, no row accumulators, no fold -
+            // lanes 0..2 hold p / r / deg of the row's three components, the row sum sum_c w p_c is a wave reduction of the
+            // lanes' partial sums (DPP, fixed order: deterministic; plain f64 like scipy's row sum), camera side as below
+            const double pn = upd ? rv.r[0] + beta * rv.p[0] : rv.p[0];
+            if (upd && lane < 3) p_t[(size_t)r0 * 3 + lane] = pn;
+            const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
+            CSTAMP(2);
+            uint32_t cam[EPL];
+            double wj[EPL], acc[3] = {0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+                cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
+                wj[j] = pad ? 0.0 : cur.w[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] += wj[j] * pcs[i * C + cam[j]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const Fix2 f = to_fix2(wj[j] * prow[i], scale, lo_scale);
+                    lds_add_fix(&qc[i * C + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * C + cam[j]], f.lo);
+                }
+            }
+            const double s0 = wave_total(acc[0]), s1 = wave_total(acc[1]), s2 = wave_total(acc[2]);
+            if (lane < 3) {
+                const double qv = rv.d[0] * pn - (lane == 0 ? s0 : (lane == 1 ? s1 : s2));
+                q_t[(size_t)r0 * 3 + lane] = qv;
+                pq += pn * qv;
+            }
+            CSTAMP(3);
+            CSTAMP(4);
+            return vnn;
+        }
         // commit this chunk's rows: p (updated), deg p into the wavefront's staging; the updated p back to memory
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
@@ -423,8 +460,8 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
                                                                       const double* rt, double* rhs_t, void* rhs_c_part, double scale,
                                                                       double inv, int lob, void* stream) {
     const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
-    // 12 wavefronts only where the two register sets fit without (much) scratch: 2 slots per lane, or 4 with one R_t trip
-    int nw = g->wg_waves >= 12 && (epl == 2 || trips <= 1) ? 12 : (g->wg_waves >= 8 ? 8 : 4);
+    // (measured: 8 wavefronts beat 12 even where 12 fit the register budget: stress 240 vs 253 us, sparse 207 vs 302 us)
+    int nw = g->wg_waves >= 8 ? 8 : 4;
     if (const char* ev = getenv("VICAN_WRHS_WAVES")) { const int v = atoi(ev); if (v == 4 || v == 8 || v == 12) nw = v; }     // A/B
     while (nw > 4 && wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw -= 4;
     const size_t lds = (size_t)wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
