@@ -1,0 +1,149 @@
+"""Host logic added in round 3, on CPU: string ids -> sorted node indices without a comparison sort, the explicit
+(machine-independent) arithmetic of the host merge against the reference-shaped formulation, scipy's J^T J entries, the
+cooperative-kernel fallback wrapper, and the self-movement recorder the parity bounds are built on."""
+import numpy as np
+import pytest
+
+import golden_cases as gc
+from util import SelfMovement, rebuild_inputs
+from vican_amd import frontend
+from vican_amd.solver import with_cooperative_fallback
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sorted_codes_is_np_unique(seed):
+    rng = np.random.default_rng(seed)
+    alphabet = np.array(list("0123456789abcXYZ_-"))
+    n = int(rng.integers(1, 400))
+    ids = ["".join(rng.choice(alphabet, int(rng.integers(0 if seed else 1, 9)))) for _ in range(n)]
+    if seed == 4:
+        ids += ["é1", "10", "9"]                      # non-ASCII: falls back to np.unique
+    if seed == 5:
+        ids += ["123456789", "12345678"]              # longer than 8 characters: falls back
+    for prefix in ("", "c"):
+        names, idx = frontend.sorted_codes(ids, prefix)
+        ref_names, ref_idx = np.unique(np.char.add(prefix, np.array(ids, dtype=str)), return_inverse=True)
+        assert list(names) == list(ref_names) and np.array_equal(idx, ref_idx)
+
+
+def test_node_order_is_the_string_order_of_the_reference():
+    """bipgo.py:225-229 sorts 'c' + id / 't' + timestamp as STRINGS ('t10' < 't2'); the translation nodes are one mixed
+    string-sorted list of camera ids and '<t>_0' (bipgo.py:426-430)."""
+    from vican_amd.geometry import SE3
+    ix = frontend.index_edges(["2", "10", "100", "2"], ["2", "10", "2", "10"], ["0", "0", "1", "1"],
+                              {"0": SE3(pose=np.eye(4)), "1": SE3(pose=np.eye(4))})
+    assert list(ix.cam_names) == ["10", "100", "2"] and list(ix.time_names) == ["10", "2"]
+    assert list(ix.tnodes) == sorted(["10", "100", "2", "10_0", "2_0"])
+    assert [ix.tnodes[i] for i in ix.tnode_of_cam] == ["10", "100", "2"] and [ix.tnodes[i] for i in ix.tnode_of_time] == ["10_0", "2_0"]
+    assert ix.root == "0" and list(ix.ci) == [2, 0, 1, 2] and list(ix.ti) == [1, 0, 1, 0]
+
+
+@pytest.mark.parametrize("name", ["g3_medium", "g4_illcond"])
+def test_host_merge_is_sequential_and_matches_a_per_edge_loop(name):
+    """merge_host against the reference-shaped per-edge loop (bipgo.py:203-221, 445-469 restated edge by edge): identical
+    blocks up to the association (k R) (R_m^T R_root) vs ((k R) R_m^T) R_root, and - the part scipy fixes - J^T J entries that
+    are float32 products summed in float32 in source order for dtype=float32."""
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name)
+    for dt in (np.float32, np.float64):
+        prob = frontend.flatten(src, cons, nr, nt, ff, dt)
+        root = str(min(cons.keys()))
+        C, T = prob.n_cam, prob.n_time
+        cpos = {c: i for i, c in enumerate(prob.cam_names)}; tpos = {t: i for i, t in enumerate(prob.time_names)}
+        M, w = {}, {}
+        dc, dtt = np.zeros(C, dtype=dt), np.zeros(T, dtype=dt)
+        for key, val in src.items():
+            if not ff(val):
+                continue
+            ts, mid = key[1].split("_")
+            c, t = cpos[key[0]], tpos[ts]
+            blk = nr(val) * np.asarray(val["pose"].R(), dtype=np.float64) @ np.asarray(cons[mid].R()).T @ np.asarray(cons[root].R())
+            M[(t, c)] = M.get((t, c), 0.0) + blk
+            k = dt(nt(val))
+            w[(t, c)] = dt(w.get((t, c), dt(0)) + k * k)
+            dc[c] = dc[c] + k * k; dtt[t] = dtt[t] + k * k
+        rows = np.repeat(np.arange(T), np.diff(prob.row_ptr))
+        for e in range(prob.n_edges):
+            key = (int(rows[e]), int(prob.col[e]))
+            assert np.abs(prob.blk[e].reshape(3, 3) - M[key]).max() < 1e-13 * max(1.0, np.abs(M[key]).max())
+            assert prob.w[e] == float(w[key])                      # bit for bit
+        assert np.array_equal(prob.deg_c, dc.astype(np.float64)) and np.array_equal(prob.deg_t, dtt.astype(np.float64))
+
+
+def test_weighted_rotations_rounding_is_spelled_out():
+    rng = np.random.default_rng(0)
+    kr, R, B = rng.uniform(0.1, 5, 50), rng.standard_normal((50, 3, 3)), rng.standard_normal((50, 3, 3))
+    out = frontend.weighted_rotations(kr, R, B)
+    A = kr[:, None, None] * R
+    for e in (0, 17, 49):
+        for i in range(3):
+            for j in range(3):
+                assert out[e, i, j] == (A[e, i, 0] * B[e, 0, j] + A[e, i, 1] * B[e, 1, j]) + A[e, i, 2] * B[e, 2, j]
+
+
+class _FakeBackend:
+    def __init__(self, abort_on):
+        self.abort_on, self.calls, self.failed, self.flag = set(abort_on), 0, [], False
+
+    def synchronize(self):
+        pass
+
+    def barrier_aborted(self):
+        return self.flag
+
+    def cooperative_failed(self, which):
+        self.failed.append(which); self.flag = False
+
+
+class _Comm:
+    def __init__(self, world):
+        self.world, self.rank = world, 0
+
+
+def test_cooperative_fallback_reruns_once_on_the_launch_sequence_path():
+    K = _FakeBackend(abort_on=[1])
+
+    def fn():
+        K.calls += 1
+        if K.calls in K.abort_on:
+            K.flag = True
+            raise ArithmeticError("garbage from the aborted launch")
+        return "result %d" % K.calls
+    assert with_cooperative_fallback(K, _Comm(1), fn) == "result 2" and K.failed == ["grid barrier timeout"]
+    # no abort: untouched; an error without an abort is the caller's error
+    assert with_cooperative_fallback(K, _Comm(1), fn) == "result 3" and len(K.failed) == 1
+    with pytest.raises(ZeroDivisionError):
+        with_cooperative_fallback(K, _Comm(1), lambda: 1 // 0)
+    # sharded runs cannot re-run one rank alone: loud error
+    K2 = _FakeBackend(abort_on=[1])
+
+    def fn2():
+        K2.calls += 1
+        K2.flag = True
+        return 0
+    with pytest.raises(RuntimeError, match="grid barrier"):
+        with_cooperative_fallback(K2, _Comm(2), fn2)
+    # stand-in backends without the hooks pass straight through
+    assert with_cooperative_fallback(object(), None, lambda: 7) == 7
+
+
+def test_self_movement_recorder_on_a_small_singular_system():
+    """SelfMovement around the oracle's cg: the unperturbed answer is what the oracle returns, the trials move it by a few
+    ulps on a well-conditioned graph, and more_trials(rel) scales with rel."""
+    import types
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import cg
+    n = 30
+    rng = np.random.default_rng(1)
+    i, j = rng.integers(0, n, 120), rng.integers(0, n, 120)
+    keep = i != j
+    W = sp.coo_matrix((np.ones(keep.sum()), (i[keep], j[keep])), shape=(n, n)); W = W + W.T
+    L = sp.kron(sp.diags(np.asarray(W.sum(1)).ravel()) - W, sp.eye(3)).tocsr()
+    b = L @ rng.standard_normal(3 * n)
+    orc = types.SimpleNamespace(cg=cg)
+    with SelfMovement(orc, n_trials=4) as sm:
+        x, code = orc.cg(L, b)
+    assert orc.cg is cg and code == 0 and np.allclose(x, cg(L, b)[0])
+    assert sm.self_move.shape == (4,) and sm.self_move.max() < 1e-9 and len(sm.iters) == 5
+    assert sm.bound() == 1e-6
+    big = sm.more_trials(1e-3, n_trials=3)
+    assert big.shape == (3,) and big.max() > 100 * max(sm.self_move.max(), 1e-16)

@@ -100,8 +100,6 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     g, K = make_backend(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
                         to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]),
                         deg_t=deg_t, deg_c=deg_c)
-    if lsqr_solver == "direct" and g.layout == "tiled":
-        raise VicanError("lsqr_solver='direct' is not available beyond %d cameras (camera-tiled graph); use 'conjugate_gradient'" % TILE_CAMS)
     t1 = time.perf_counter()
     nloc = r1 - r0
     bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]

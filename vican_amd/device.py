@@ -886,8 +886,8 @@ class TiledBackend(HipBackend):
     operator (sweep MODE 2: y_t = sum_c M_ct^T x_c and z_c = sum_t M_ct x_t in one pass over a tile's blocks), the
     per-row partials of the tiles are summed in tile order by ``vican_sum_apply3``; everything camera-sided (Lanczos
     step, Ritz, gauge, polar) is the launch-sequence path of the untiled backend, which has no camera limit; the CG
-    product runs tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows): no limit on the number of cameras.
-    No fused dual update, no LSQR (``lsqr_solver="direct"`` raises)."""
+    product and the LSQR steps run tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows; vican_lsqr_step per tile):
+    no limit on the number of cameras.  No fused dual update (a performance feature of the untiled sweeps)."""
     fused_dual_ok = False
 
     def __init__(self, graph: TiledGraph):
@@ -1008,11 +1008,51 @@ class TiledBackend(HipBackend):
     def clear_cg_scaling(self):
         self._cg_w, self._cg_wmax = [t.w for t in self.g.tiles], self.g.wmax
 
+    # LSQR (lsqr_solver="direct") tile by tile: every tile keeps its own edge vector u~; row sums of the tiles are added in
+    # tile order, camera sums are complete per tile, |u^|^2 is the sum of the tiles' parts
+    def _lsqr_tiles_alloc(self):
+        if not hasattr(self, "_ls_tmp"):
+            nt, T1 = len(self.tiles), max(self.T, 1)
+            self._ls_tmp = torch.zeros(nt + 1, dtype=torch.float64, device=self.dev)
+            self._ls_rows = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)
+            self._lsqr_part = torch.zeros(1024, dtype=torch.float64, device=self.dev)
+
+    def lsqr_init_u(self, rc, rt, nrm2_out):
+        self._lsqr_tiles_alloc()
+        b = self.g.bounds
+        for k, K in enumerate(self.tiles):
+            K.lsqr_init_u(rc[3 * b[k]: 3 * b[k + 1]], rt, self._ls_tmp[k: k + 1])
+        nrm2_out.copy_(self._ls_tmp[: len(self.tiles)].sum().reshape(1))
+
+    def lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
+        b = self.g.bounds
+        for k, K in enumerate(self.tiles):
+            self._ls_rows[k].zero_()
+            K.lsqr_v_step(inv_beta, 0.0, self._ls_rows[k], acc_c[3 * b[k]: 3 * b[k + 1]], self._ls_tmp[k: k + 1])
+        v_t.copy_(self._ls_rows.sum(0) - beta * v_t)
+        nrm2_t_out.copy_((v_t[: self.T] ** 2).sum().reshape(1))
+
+    def lsqr_device_params(self):
+        self._lsqr_tiles_alloc()
+        n_add = max(K.lsqr_device_params()[1] for K in self.tiles)
+        return math.sqrt(self.g.wmax), n_add
+
+    def lsqr_step(self, v_c, v_t, z_t, acc, st):
+        b, C3 = self.g.bounds, 3 * self.C
+        nt = len(self.tiles)
+        for k, K in enumerate(self.tiles):
+            # the tile writes its camera sums into its slice of acc and its part of |u^|^2 right behind the slice
+            K.lsqr_step(v_c[b[k]: b[k + 1]], v_t, self._ls_rows[k], acc[3 * b[k]:], st)
+            self._ls_tmp[k: k + 1].copy_(acc[3 * b[k + 1]: 3 * b[k + 1] + 1])
+        acc[C3: C3 + 1].copy_(self._ls_tmp[:nt].sum().reshape(1))
+        self._ck(self.lib.vican_sum_apply3(self.T, 3, None, _ptr(self._ls_rows), nt, self._ls_rows.stride(0), _ptr(z_t), _stream()),
+                 "vican_sum_apply3")
+
     def _unsupported(self, *a, **k):
         raise _lib.VicanError("not available on camera-tiled graphs (more than %d cameras)" % TILE_CAMS)
 
     dual_update_op = block_op_raw = fold_z = bip_apply = bip_scales = node_degrees = cg_sweep = cg_resident = _unsupported
-    lsqr_init_u = lsqr_u_step = lsqr_v_step = lsqr_step = lsqr_device_params = _unsupported
+    lsqr_u_step = _unsupported
 
 
 def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
