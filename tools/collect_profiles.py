@@ -5,7 +5,8 @@ import collections, csv, glob, json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/profile_%s" % tag
 os.makedirs("profiles", exist_ok=True)
-OURS = ("block_sweep", "wave_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs",
+OURS = ("block_sweep", "wave_sweep", "cg_", "slab_reduce", "tall_", "chol_qr3", "lap_apply", "polar_dual", "gauge_project", "trans_rhs", "trans_wrhs",
+        "fold2", "merge_", "occupy",
         "dual_svd", "edge_sums", "block_norms", "pack_edges", "plan_slots", "init_duals", "fx_finish", "duals_bound",
         "scaled_identity", "rows_to_cols", "lanczos_", "ritz_", "right_solve3", "lsqr_", "jacobi", "row_scale")
 
@@ -18,7 +19,12 @@ out = []
 f = first("stats/**/*kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f)))
+    others = [r for r in rows if not any(k in r["Name"] for k in OURS)]
     with open("profiles/%s_kernel_stats.csv" % tag, "w") as o:
+        # (comment row first: what is NOT listed - the synthetic-graph generator's torch kernels, outside bench.py's timed region)
+        o.write("# this project's kernels only; %d other kernels of the same trace are left out (%.1f ms in total: torch / Tensile / "
+                "rocPRIM kernels of synth.make_merged_graph_torch - batched 3x3 matmuls, sorts, elementwise - which build the "
+                "synthetic graph BEFORE bench.py's timed region)\n" % (len(others), sum(float(r["TotalDurationNs"]) for r in others) / 1e6))
         w = csv.writer(o); w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms"])
         for r in rows:
             if any(k in r["Name"] for k in OURS):
@@ -61,6 +67,37 @@ for name, title in (("timeline_stress.txt", "stress workload (bench.py default),
         tl.append("# %s  (tools/timeline.py)\n%s" % (title, open(fn).read()))
 if tl:
     open("profiles/%s_timeline.txt" % tag, "w").write("\n".join(tl))
+# 3. the sparse capture: kernel stats + traffic of its operator sweep
+fs = first("sparse_stats/**/*kernel_stats.csv")
+if fs:
+    rows = list(csv.DictReader(open(fs)))
+    with open("profiles/%s_sparse_kernel_stats.csv" % tag, "w") as o:
+        o.write("# bench.py --workload sparse (100 cameras x 2 M timesteps x 8 cameras per timestep); this project's kernels only\n")
+        w = csv.writer(o); w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for r in rows:
+            if any(k in r["Name"] for k in OURS):
+                w.writerow([r["Name"][:100], r["Calls"], "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (float(r["MinNs"]) / 1e3),
+                            "%.2f" % (float(r["MaxNs"]) / 1e3), "%.3f" % (float(r["TotalDurationNs"]) / 1e6)])
+    spm = {}
+    for sub in ("sparse_fetch", "sparse_write"):
+        c, n = counters(sub)
+        spm.update(c)
+    sb = None
+    bj2 = os.path.join(src, "bench_sparse.json")
+    if os.path.exists(bj2):
+        lines = [l for l in open(bj2) if l.startswith("{")]
+        if lines:
+            sb = json.loads(lines[-1])
+            json.dump(sb, open("profiles/%s_sparse_bench.json" % tag, "w"), indent=1)
+    st = None
+    if "FETCH_SIZE" in spm and "WRITE_SIZE" in spm:
+        st = dict(fetch_bytes=2.0 * spm["FETCH_SIZE"] * 1024, write_bytes=spm["WRITE_SIZE"] * 1024)
+        st["hbm_bytes"] = st["fetch_bytes"] + st["write_bytes"]
+    json.dump(dict(tag=tag, workload=sb["config"]["workload"] if sb else "sparse", counters_mean_per_dispatch=spm, traffic=st,
+                   bytes_per_launch_algorithmic=sb["roofline"]["bytes_per_launch"] if sb else None,
+                   kernel=sb["roofline"]["kernel"] if sb else None), open("profiles/%s_sparse_counters.json" % tag, "w"), indent=1)
+    out.append("sparse capture: profiles/%s_sparse_kernel_stats.csv, _sparse_counters.json, _sparse_bench.json" % tag)
+
 summary = dict(tag=tag, kernel=(bench["roofline"]["kernel"] if bench else "sweep kernel MODE 0 (vican_block_op)"), counters_mean_per_dispatch=pm, traffic=traffic,
                workload=bench["config"]["workload"] if bench else None,
                bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None)

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 O=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/bench_write.log 2>&1
@@ -17,6 +17,14 @@ cd $GRAFT_REPO_ROOT && python bench.py > $O/bench.json 2> $O/bench.err
 # busy/idle timelines of one solve per workload (second-to-last solve of each trace: not the one carrying HIP events)
 python tools/timeline.py $O/stats 2 > $O/timeline_stress.txt 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_trace_ls.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse --steps 2 --warmup 1 > $O/bench_trace_ls.log 2>&1
 cd $GRAFT_REPO_ROOT && python tools/timeline.py $O/trace_ls 2 > $O/timeline_large_shop.txt 2>&1
 rm -rf $O/trace_ls $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv
+# the sparse capture (100 cameras x 2 M timesteps x 8 cameras per timestep): kernel stats + HBM traffic counters of its operator sweep
+cd /tmp
+BS="python3 $GRAFT_REPO_ROOT/bench.py --workload sparse --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sparse_stats -- $BS > $O/bench_sparse_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/sparse_fetch -- $BS --steps 1 --warmup 0 > $O/bench_sparse_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/sparse_write -- $BS --steps 1 --warmup 0 > $O/bench_sparse_write.log 2>&1
+cd $GRAFT_REPO_ROOT && python bench.py --workload sparse --no-cpu-baseline > $O/bench_sparse.json 2> $O/bench_sparse.err
+rm -rf $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv
