@@ -41,6 +41,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
                                                             double* __restrict__ pq_part, const vican_cg_state_t* __restrict__ st) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red[16];
+    __shared__ int s_ticket;
     if (st->done) return;
 #ifdef VICAN_CGWSTAMP
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -99,25 +100,31 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             rv.p[t] = p_t[gi]; rv.r[t] = r_t[gi]; rv.d[t] = deg_t[r0 + i / 3];
         }
     };
+    if (tid == 0) s_ticket = c0 + 3 * NW;
     __syncthreads();
 
-    int k = c0 + wave;
+    // Chunks of the workgroup's range are handed to its wavefronts by an LDS ticket (the first three rounds are static):
+    // with a static interleaved assignment the wavefronts of a workgroup finished 64-84 us into an 86 us launch (the SIMD
+    // arbiter favours some), and the workgroup ends with its last wavefront.  A ticket is drawn two bodies before its chunk is
+    // processed (row bounds are requested two chunks ahead), its value is read at the end of the body that drew it.
+    int k = c0 + wave, kb = k + NW, kc = k + 2 * NW;
     CgWRegs<EPL> ea, eb;
     RowVals ra, rb;
-    int2 v0 = load_rows(k), v1 = load_rows(k + NW), v2;
+    int2 v0 = load_rows(k), v1 = load_rows(kb), v2;
     load_edges(ea, k);
     load_rowvals(ra, v0);
     double pq = 0.0;
 
     // body: chunk k (edges `cur`, row values `rv`, row bounds `vrow`); requests the edge words and row values of chunk
     // k + NW (row bounds `vnext`, loaded a body ago) and the row bounds of chunk k + 2 NW (returned)
-    auto body = [&](CgWRegs<EPL>& cur, CgWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int kk) -> int2 {
+    auto body = [&](CgWRegs<EPL>& cur, CgWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int k_next,
+                    const int k_after) -> int2 {
         CSTAMP0();
         const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
-        const int2 vnn = load_rows(kk + 2 * NW);
+        const int2 vnn = load_rows(k_after);
         load_rowvals(rvn, vnext);
         __builtin_amdgcn_sched_barrier(0);
-        load_edges(nxt, kk + NW);
+        load_edges(nxt, k_next);
 #if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
 #pragma unroll
         for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
@@ -268,14 +275,21 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #ifdef VICAN_CGWSTAMP
     const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    auto draw = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;                                              // (valid in lane 0; read with readfirstlane after the body)
+    };
 #pragma unroll 1
     while (k < c1) {
-        v2 = body(ea, eb, ra, rb, v0, v1, k);
-        k += NW;
+        int t = draw();
+        v2 = body(ea, eb, ra, rb, v0, v1, kb, kc);             // chunk k; v2 = row bounds of kc
+        k = kb; kb = kc; kc = __builtin_amdgcn_readfirstlane(t);
         if (k >= c1) break;
-        v0 = body(eb, ea, rb, ra, v1, v2, k);
-        k += NW;
-        // rotate the row-bound registers: (v0, v1, v2) now hold (k + NW, k, -) -> bring them back to (k, k + NW)
+        t = draw();
+        v0 = body(eb, ea, rb, ra, v1, v2, kb, kc);             // chunk k (the former kb); v0 = row bounds of the new kc
+        k = kb; kb = kc; kc = __builtin_amdgcn_readfirstlane(t);
+        // rotate the row-bound registers: (v0, v1, v2) hold the bounds of (kb, -, k) -> bring them back to (k, kb)
         const int2 tmp = v0; v0 = v2; v1 = tmp;
     }
 #ifdef VICAN_CGWSTAMP
