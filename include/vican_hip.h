@@ -575,7 +575,8 @@ typedef struct vican_lsqr_state {
     int32_t itn, istop, done, iter_lim;   /* istop: scipy's codes 1..7; 8 = NaN */
     int32_t lo_bits, update, pad0, pad1;  /* update: 1 while the x / w update of iteration itn is still to run */
 } vican_lsqr_state_t;
-/* One fused pass over the edges (block layout): u^ = J~ v - coef u~ written over u~, z_t [T][3] = row sums of J~^T u^, the camera
+/* One fused pass over the edges (either layout; on wave layouts u~ and sw are in the permuted 8-byte order of the layout,
+ * as vican_lsqr_init_u writes them): u^ = J~ v - coef u~ written over u~, z_t [T][3] = row sums of J~^T u^, the camera
  * sums as double-word slabs (zc_part: n_wg * 6C words) folded into acc[0:3C] ([C][3]), acc[3C] = |u^|^2 = beta_{i+1}^2 - this
  * rank's part: all-reduce acc[0 : 3C+1] when sharded.  part: >= max(n_wg, 1024) doubles of scratch.                       */
 int vican_lsqr_step(const vican_graph_t* g, const double* sw, double* u, const double* v_c, const double* v_t, double* z_t,

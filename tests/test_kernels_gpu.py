@@ -273,8 +273,9 @@ def test_lsqr_kernels(cfg):
     H.lsqr_host_scalars = True
     ls = LsqrTranslationSolver(H, Comm(), atol=1e-10, btol=1e-10)
     x_c, x_t = ls.solve(H.from_numpy(rc), H.from_numpy(rt), 3 * (C + T))
-    assert not ls.info.get("device_scalars") and ls.info["istop"] == ih["istop"] and abs(ls.info["lsqr_iters"] - ih["lsqr_iters"]) <= 1
-    assert np.abs(x_c.cpu().numpy() - xc_h).max() < 1e-8 * scale and np.abs(x_t.cpu().numpy() - xt_h).max() < 1e-8 * scale
+    assert not ls.info.get("device_scalars") and ls.info["istop"] == ih["istop"]
+    assert abs(ls.info["lsqr_iters"] - ih["lsqr_iters"]) <= max(1, ih["lsqr_iters"] // 20)      # (tolerance 1e-10: ~90 iterations)
+    assert np.abs(x_c.cpu().numpy() - xc_h).max() < 1e-7 * scale and np.abs(x_t.cpu().numpy() - xt_h).max() < 1e-7 * scale
 
 
 @pytest.mark.parametrize("C,j", [(5, 0), (60, 3), (333, 7), (1000, 5), (1024, 20)])

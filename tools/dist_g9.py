@@ -35,7 +35,7 @@ scene, flat = gc.build_flat(gc.LARGE_SHOP)
 src = synth.edges_to_dict(flat, SE3)
 cons = synth.constraints_from_scene(scene, SE3)
 nr, nt, ff = (gc.CALLABLES[gc.LARGE_SHOP[k]] for k in ("noise_r", "noise_t", "filt"))
-single = dist.new_group([rank])                             # every rank also solves the whole problem alone
+single = [dist.new_group([r]) for r in range(world)][rank]  # every rank also solves the whole problem alone (new_group is collective: same calls everywhere)
 report, bad = {"world": world, "backend": backend, "devices": min(ndev, world)}, 0
 for dt in ("float64", "float32"):
     exp = expected(g, "conjugate_gradient", dt)

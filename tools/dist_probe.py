@@ -15,6 +15,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)
 bad = 0
+# one-rank groups, created by EVERY rank in the same order (torch.distributed.new_group is collective)
+singles = [dist.new_group([r]) for r in range(world)]
 for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101)]):
     scene = synth.make_scene(n_cam=C, n_time=T, n_marker=3, seed=seed)
     flat = synth.make_camera_edges(scene, cpt=min(C, 3), mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=seed + 1)
@@ -24,7 +26,7 @@ for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101
         prob = frontend.flatten(src, cons, unit, unit, keep, dt)
         info = {}
         Rc, Rt, pc, pt = solve_problem(prob, 4, "conjugate_gradient", dt, group=dist.group.WORLD, info=info)
-        single = dist.new_group([rank])                 # every rank also solves the whole problem alone
+        single = singles[rank]                          # every rank also solves the whole problem alone
         Rc1, Rt1, pc1, pt1 = solve_problem(prob, 4, "conjugate_gradient", dt, group=single)
         rot = max(float(geodesic(Rc, Rc1).max()), float(geodesic(Rt, Rt1).max()))
         tr = max(float(np.abs(pc - pc1).max()), float(np.abs(pt - pt1).max()))

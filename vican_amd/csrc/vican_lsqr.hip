@@ -288,12 +288,24 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int n, doub
     }
 }
 
+extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_winit(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
+                                                                      const double* rc, const double* rt, double* u, double* sw, double* part,
+                                                                      void* stream);          // vican_wtrans.hip
+extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vican_graph_t* g, const double* sw, double* u, const double* v_c,
+                                                                      const double* v_t, double* z_t, void* zc_part, double* part,
+                                                                      const vican_lsqr_state_t* st, void* stream);
 extern "C" int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
                                  const double* rc, const double* rt, double* u, double* sw, double* part, double* nrm2_out,
                                  void* stream) {
-    if (int r = vican_check_block_graph(g, "vican_lsqr_init_u")) return r;
+    if (int r = vican_check_graph(g, "vican_lsqr_init_u")) return r;
     if (!w || !ue || !ve || !rc || !rt || !u || !sw || !part || !nrm2_out) return set_err(VICAN_ERR_ARG, "vican_lsqr_init_u: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (g->layout == VICAN_LAYOUT_WAVE) {
+        if (int r = vican_lsqr_winit(g, w, ue, ve, rc, rt, u, sw, part, stream)) return r;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, g->n_wg, nrm2_out);
+        LAUNCH_CHECK("vican_lsqr_init_u");
+        return VICAN_OK;
+    }
     const size_t lds = (size_t)8 * (9 * g->n_cam + 9 * g->max_rows + 16);
     LSQR_DISPATCH(lsqr_init_u_kernel, lds, *g, w, ue, ve, rc, rt, u, sw, part);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, part, g->n_wg, nrm2_out);
@@ -651,8 +663,16 @@ __global__ void lsqr_clear_update_kernel(vican_lsqr_state_t* st) { st->update = 
 extern "C" int vican_lsqr_step(const vican_graph_t* g, const double* sw, double* u, const double* v_c, const double* v_t, double* z_t,
                                void* zc_part, double* part, double* acc, const vican_lsqr_state_t* state, void* stream) {
     const vican_lsqr_state_t* st = state;
-    if (int r = vican_check_block_graph(g, "vican_lsqr_step")) return r;
+    if (int r = vican_check_graph(g, "vican_lsqr_step")) return r;
     if (!sw || !u || !v_c || !v_t || !z_t || !zc_part || !part || !acc || !st) return set_err(VICAN_ERR_ARG, "vican_lsqr_step: null pointer");
+    if (g->layout == VICAN_LAYOUT_WAVE) {
+        if (int r = vican_lsqr_wstep(g, sw, u, v_c, v_t, z_t, zc_part, part, st, stream)) return r;
+        const long long n = 3LL * g->n_cam;
+        hipLaunchKernelGGL(lsqr_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, (const long long*)zc_part, g->n_wg,
+                           g->n_cam, part, acc, st);
+        LAUNCH_CHECK("vican_lsqr_step");
+        return VICAN_OK;
+    }
     if (3 * g->max_rows > 12 * g->block_threads) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_step: more than 4 rows per lane in a chunk");
     hipStream_t st_ = (hipStream_t)stream;
     const size_t lds = (size_t)lsqr_step_lds_bytes(g->n_cam, g->max_rows, g->n_copy);

@@ -502,6 +502,301 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
     return VICAN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// LSQR on the wave layout (lsqr_solver="direct", reference bipgo.py:479-480; the block-layout kernels and the mathematics are in
+// vican_lsqr.hip): u~_1 = b~ and the fused step  u^ = J~ v - coef u~,  |u^|^2,  z = J~^T u^  - one wavefront per chunk, the edge
+// vector u~ and sqrt(w) in the rotation layout's slot order (dense permuted storage, slot_pos8), 60 B per edge and step.
+// ---------------------------------------------------------------------------
+template <int EPL>
+struct LsqrWRegs { double u[3][EPL], s[EPL]; uint32_t id[EPL]; };
+
+template <int EPL>
+__device__ __forceinline__ size_t wpos8(int lane, int j) { return EPL == 4 ? (size_t)(64 * (j & 2) + lane * 2 + (j & 1)) : (size_t)(lane * EPL + j); }
+
+// u~_1 = b~ = (Rc^T u_e + Rt^T v_e) / sqrt(w_e) per edge, sw = sqrt(w), part[block] = partial |b~|^2
+template <int NW, int EPL, int TRIPS>
+__global__ __launch_bounds__(NW * 64) void lsqr_winit_kernel(vican_graph_t g, const double* __restrict__ w, const double* __restrict__ ue,
+                                                             const double* __restrict__ ve, const double* __restrict__ rc,
+                                                             const double* __restrict__ rt, double* __restrict__ u, double* __restrict__ sw,
+                                                             double* __restrict__ part) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red[16];
+    const int C = g.n_cam, RW = g.max_rows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* rcs = (double*)lds_raw;                            // [9][C] planes
+    double* rts = rcs + 9 * C + (size_t)wave * RW * 9;         // [RW][9] this wavefront's rows
+    for (int i = tid; i < 9 * C; i += NW * 64) rcs[(i % 9) * C + i / 9] = rc[i];
+    __syncthreads();
+    const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    double nrm = 0.0;
+    for (int k = c0 + wave; k < c1; k += NW) {                 // (runs once per solve: not pipelined)
+        const int r0 = g.chunk_row0[k], n9 = 9 * (g.chunk_row0[k + 1] - r0);
+        for (int i = lane; i < n9; i += 64) rts[i] = rt[(size_t)r0 * 9 + i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const size_t e = (size_t)k * g.slots + (size_t)lane * EPL + j, e8 = (size_t)k * g.slots + wpos8<EPL>(lane, j);
+            const uint32_t id = g.idx[e];
+            double out[3] = {0, 0, 0}, sq = 0.0;
+            if (id != VICAN_PAD_SLOT) {
+                const uint32_t cam = id & 0xFFFFu, row = id >> 16;
+                sq = sqrt(w[e8]);
+                const double inv_s = 1.0 / sq;
+                double uu[3], vv[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { uu[p] = ue[((size_t)k * 3 + p) * g.slots + wpos8<EPL>(lane, j)]; vv[p] = ve[((size_t)k * 3 + p) * g.slots + wpos8<EPL>(lane, j)]; }
+                const double* B = rts + row * 9;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double gi = rcs[(0 * 3 + i) * C + cam] * uu[0] + rcs[(1 * 3 + i) * C + cam] * uu[1] + rcs[(2 * 3 + i) * C + cam] * uu[2] +
+                                      B[0 * 3 + i] * vv[0] + B[1 * 3 + i] * vv[1] + B[2 * 3 + i] * vv[2];
+                    out[i] = gi * inv_s;
+                    nrm += out[i] * out[i];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) u[((size_t)k * 3 + p) * g.slots + wpos8<EPL>(lane, j)] = out[p];
+            sw[e8] = sq;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double t = block_sum(nrm, red);
+    if (tid == 0) part[blockIdx.x] = t;
+}
+
+static inline int64_t lsqr_wstep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
+    const int64_t per_wave = (((int64_t)max_rows * 3 * (16LL * n_copy + 8)) + 15) & ~15LL;
+    return 72LL * n_cam + (int64_t)n_waves * per_wave + 256;
+}
+
+template <int NW, int EPL, int TRIPS>
+__global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, const double* __restrict__ sw, double* __restrict__ u,
+                                                             const double* __restrict__ v_c, const double* __restrict__ v_t,
+                                                             double* __restrict__ z_t, u64* __restrict__ zc_part, double* __restrict__ part,
+                                                             const vican_lsqr_state_t* __restrict__ st) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red[16];
+    __shared__ int s_ticket;
+    if (st->done) return;
+    const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
+    const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double coef = st->coef, scale = st->qscale, inv = st->qinv;
+    const int lob = st->lo_bits;
+    const double lo_scale = ldexp(1.0, lob);
+    const int lo_c = 3 * C, lo_t = 3 * RW * ncopy;
+    u64* zc = (u64*)lds_raw;                                   // [2][3][C] planes (hi, lo), shared by the workgroup
+    double* vcs = (double*)(zc + 6 * C);                       // [3][C] planes
+    const size_t per_wave = (((size_t)RW * 3 * (16 * ncopy + 8)) + 15) & ~(size_t)15;
+    unsigned char* wbase = (unsigned char*)(vcs + 3 * C) + (size_t)wave * per_wave;
+    u64* zt = (u64*)wbase;                                     // [2][RW * 3][ncopy] striped row accumulators (this wave's)
+    double* vts = (double*)(zt + (size_t)2 * lo_t);            // [RW * 3] v_t of the chunk's rows
+    const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
+    for (int i = tid; i < 3 * C; i += NW * 64) { vcs[(i % 3) * C + i / 3] = v_c[i]; zc[i] = 0ull; zc[lo_c + i] = 0ull; }
+    for (int i = lane; i < 2 * lo_t; i += 64) zt[i] = 0ull;
+    const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    const int kmax = g.n_chunk - 1;
+    if (tid == 0) s_ticket = c0 + 3 * NW;
+
+    auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
+    auto load_edges = [&](LsqrWRegs<EPL>& e, int k) {
+        k = k < kmax ? k : kmax;
+        const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
+        const bool nt = g.stream_nt != 0;
+        if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
+        else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+#pragma unroll
+        for (int j = 0; j < EPL; j += 2) {
+            const double* a = sw + (size_t)k * g.slots + wpos8<EPL>(lane, j);
+            const double2 t = nt ? stream_load((const double2*)a) : *(const double2*)a;
+            e.s[j] = t.x; e.s[j + 1] = t.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2) {
+                const double* a = u + ((size_t)k * 3 + p) * g.slots + wpos8<EPL>(lane, j);
+                const double2 t = *(const double2*)a;          // (plain load: the stream is written back and re-read next step)
+                e.u[p][j] = t.x; e.u[p][j + 1] = t.y;
+            }
+    };
+    struct RowVals { double v[TRIPS]; };
+    auto load_rowvals = [&](RowVals& rv, const int2 vrow) {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            int i = lane + 64 * t;
+            i = i < n3 ? i : 0;
+            rv.v[t] = v_t[(size_t)r0 * 3 + i];
+        }
+    };
+    __syncthreads();
+
+    int k = c0 + wave, kb = k + NW, kc = k + 2 * NW;
+    LsqrWRegs<EPL> ea, eb;
+    RowVals ra, rb;
+    int2 v0 = load_rows(k), v1 = load_rows(kb), v2;
+    load_edges(ea, k);
+    load_rowvals(ra, v0);
+    double nrm = 0.0;
+
+    auto body = [&](LsqrWRegs<EPL>& cur, LsqrWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int kcur,
+                    const int k_next, const int k_after) -> int2 {
+        const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
+        const int2 vnn = load_rows(k_after);
+        load_rowvals(rvn, vnext);
+        __builtin_amdgcn_sched_barrier(0);
+        load_edges(nxt, k_next);
+        const bool single = n3 == 3;                           // one row in the chunk: its v_t broadcast from lanes 0..2, row sums by DPP
+        double vrow1[3] = {0, 0, 0};
+        if (single) {
+            vrow1[0] = lane_bcast(rv.v[0], 0); vrow1[1] = lane_bcast(rv.v[0], 1); vrow1[2] = lane_bcast(rv.v[0], 2);
+        } else {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) { const int i = lane + 64 * t; if (i < n3) vts[i] = rv.v[t]; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t cam[EPL], row[EPL];
+        double un[3][EPL], sa[EPL][3], ar[EPL][3];
+        {
+            double acc[3] = {0, 0, 0}, vt3[3] = {vrow1[0], vrow1[1], vrow1[2]};
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+                cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu); row[j] = pad ? 0u : (cur.id[j] >> 16);
+                const double sj = pad ? 0.0 : cur.s[j];
+                if (!single && (j == 0 || row[j] != row[j - 1])) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) vt3[p] = vts[row[j] * 3 + p];
+                    acc[0] = acc[1] = acc[2] = 0.0;
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const double uh = pad ? 0.0 : sj * (vt3[p] - vcs[p * C + cam[j]]) - coef * cur.u[p][j];
+                    un[p][j] = uh;
+                    nrm += uh * uh;
+                    const double a = sj * uh;
+                    acc[p] += a;
+                    sa[j][p] = -a;
+                    ar[j][p] = acc[p];
+                }
+            }
+        }
+        // the new edge vector back to memory (dense permuted positions)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < EPL; j += 2)
+                *(double2*)(u + ((size_t)kcur * 3 + p) * g.slots + wpos8<EPL>(lane, j)) = make_double2(un[p][j], un[p][j + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const Fix2 f = to_fix2(sa[j][p], scale, lo_scale);
+                lds_add_fix(&zc[p * C + cam[j]], f.hi); lds_add_fix(&zc[lo_c + p * C + cam[j]], f.lo);
+            }
+            if (!single && (j == EPL - 1 || row[j] != row[j + 1])) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const Fix2 f = to_fix2(ar[j][p], scale, lo_scale);
+                    u64* a = &zt[(row[j] * 3 + p) * ncopy + lane_copy];
+                    lds_add_fix(a, f.hi); lds_add_fix(a + lo_t, f.lo);
+                }
+            }
+        }
+        if (single) {
+            const double s0 = wave_total(ar[EPL - 1][0]), s1 = wave_total(ar[EPL - 1][1]), s2 = wave_total(ar[EPL - 1][2]);
+            if (lane < 3) z_t[(size_t)r0 * 3 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < n3 * ncopy; base += 64) {
+                const int a = base + lane;
+                const bool live = a < n3 * ncopy;
+                u64 sum = 0ull, slo = 0ull;
+                if (live) { sum = zt[a]; slo = zt[lo_t + a]; zt[a] = 0ull; zt[lo_t + a] = 0ull; }
+                sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
+                if (live && (a & cmask) == 0) z_t[(size_t)r0 * 3 + a / ncopy] = fix2_value((long long)sum, (long long)slo, lob, inv);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return vnn;
+    };
+    auto draw = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;
+    };
+#pragma unroll 1
+    while (k < c1) {
+        int t = draw();
+        v2 = body(ea, eb, ra, rb, v0, v1, k, kb, kc);
+        k = kb; kb = kc; kc = __builtin_amdgcn_readfirstlane(t);
+        if (k >= c1) break;
+        t = draw();
+        v0 = body(eb, ea, rb, ra, v1, v2, k, kb, kc);
+        k = kb; kb = kc; kc = __builtin_amdgcn_readfirstlane(t);
+        const int2 tmp = v0; v0 = v2; v1 = tmp;
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * C; i += NW * 64) zc_part[(size_t)blockIdx.x * 6 * C + i] = zc[i];
+    const double t = block_sum(nrm, red);
+    if (tid == 0) part[blockIdx.x] = t;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_winit(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
+                                                                      const double* rc, const double* rt, double* u, double* sw, double* part,
+                                                                      void* stream) {
+    const int nw = g->wg_waves >= 8 ? 8 : 4;
+    const size_t lds = (size_t)8 * (9 * g->n_cam + (size_t)nw * 9 * g->max_rows) + 256;
+    if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_lsqr_init_u (wave layout)");
+    const int epl = g->slots / 64;
+    hipStream_t s = (hipStream_t)stream;
+#define WINIT_LAUNCH(NW_, E_)                                                                                             \
+    do {                                                                                                                  \
+        auto kern = lsqr_winit_kernel<NW_, E_, 1>;                                                                        \
+        static size_t conf = 0;                                                                                           \
+        if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, ue, ve, rc, rt, u, sw, part);             \
+    } while (0)
+    if (nw == 8) { if (epl == 4) WINIT_LAUNCH(8, 4); else WINIT_LAUNCH(8, 2); }
+    else         { if (epl == 4) WINIT_LAUNCH(4, 4); else WINIT_LAUNCH(4, 2); }
+#undef WINIT_LAUNCH
+    LAUNCH_CHECK("vican_lsqr_init_u");
+    return VICAN_OK;
+}
+extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vican_graph_t* g, const double* sw, double* u, const double* v_c,
+                                                                      const double* v_t, double* z_t, void* zc_part, double* part,
+                                                                      const vican_lsqr_state_t* st, void* stream) {
+    int nw = g->wg_waves >= 8 ? 8 : 4;
+    while (nw > 4 && lsqr_wstep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw -= 4;
+    const size_t lds = (size_t)lsqr_wstep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
+    if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_lsqr_step (wave layout)");
+    const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64;
+    if (trips > 3) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_step: more than 64 rows per chunk");
+    hipStream_t s = (hipStream_t)stream;
+#define WSTEP_LAUNCH(NW_, E_, T_)                                                                                         \
+    do {                                                                                                                  \
+        auto kern = lsqr_wstep_kernel<NW_, E_, T_>;                                                                       \
+        static size_t conf = 0;                                                                                           \
+        if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
+        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, sw, u, v_c, v_t, z_t, (u64*)zc_part, part, st); \
+    } while (0)
+#define WSTEP_PICK(NW_)                                                                                                   \
+    do {                                                                                                                  \
+        if (epl == 4) { if (trips <= 1) WSTEP_LAUNCH(NW_, 4, 1); else if (trips == 2) WSTEP_LAUNCH(NW_, 4, 2); else WSTEP_LAUNCH(NW_, 4, 3); } \
+        else          { if (trips <= 1) WSTEP_LAUNCH(NW_, 2, 1); else if (trips == 2) WSTEP_LAUNCH(NW_, 2, 2); else WSTEP_LAUNCH(NW_, 2, 3); } \
+    } while (0)
+    if (nw == 8) WSTEP_PICK(8); else WSTEP_PICK(4);
+#undef WSTEP_PICK
+#undef WSTEP_LAUNCH
+    LAUNCH_CHECK("vican_lsqr_step");
+    return VICAN_OK;
+}
+
 // launcher: called by vican_cg_sweep for graphs in the wave layout
 extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,

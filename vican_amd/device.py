@@ -735,40 +735,54 @@ class HipBackend:
 
 
 # -- LSQR ("direct") wrappers, attached to HipBackend ------------------------------------------
-def _lsqr_alloc(self):
-    if not hasattr(self, "_lsqr_u"):
-        # the LSQR kernels take block layouts only: the graph's own one, or (wave-layout graphs) a second one built here
-        self._ll, self._ldesc, self._lw, self._lu, self._lv = self.g.lsqr_layout()
-        self._lgref = C.byref(self._ldesc)
-        self._ln_add = float(max(self._ll.rows_per_wg_max, self._ll.slots) + 1)
-        self._lslab = torch.empty(max(self._ll.n_wg, 1) * 3 * self.C, dtype=torch.float64, device=self.dev)
-        nslot = max(1, self._ll.n_chunk) * self._ll.slots
-        self._lsqr_u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
-        self._lsqr_sw = torch.zeros(nslot, dtype=torch.float64, device=self.dev)       # sqrt(w), written by lsqr_init_u
-        self._lsqr_part = torch.zeros(max(self._ll.n_wg, 1024), dtype=torch.float64, device=self.dev)
+class _LsqrCtx:
+    pass
+
+
+def _lsqr_ctx(self):
+    """Arrays of the LSQR kernels.  The device-resident path (vican_lsqr_init_u / vican_lsqr_step) runs on the graph's own
+    layout, wave or block; the round-2 path with host scalars (vican_lsqr_u_step / vican_lsqr_v_step, `lsqr_host_scalars`)
+    is block-only: wave-layout graphs pack a second layout for it on first use (LocalGraph.lsqr_layout)."""
+    legacy = bool(getattr(self, "lsqr_host_scalars", False))
+    cache = self.__dict__.setdefault("_lsqr_ctxs", {})
+    if legacy not in cache:
+        c = _LsqrCtx()
+        if legacy or self.g.rot.kind == "block":
+            c.ll, c.desc, c.w, c.u_in, c.v_in = self.g.lsqr_layout()
+        else:
+            c.ll, c.desc, c.w, c.u_in, c.v_in = self.g.rot, self.g.desc, self.g.w, self.g.u, self.g.v
+        c.gref = C.byref(c.desc)
+        c.n_add = float(max(c.ll.rows_per_wg_max, c.ll.slots) + 1)
+        nslot = max(1, c.ll.n_chunk) * c.ll.slots
+        c.u = torch.zeros(3 * nslot, dtype=torch.float64, device=self.dev)
+        c.sw = torch.zeros(nslot, dtype=torch.float64, device=self.dev)       # sqrt(w), written by lsqr_init_u
+        c.part = torch.zeros(max(c.ll.n_wg, 1024), dtype=torch.float64, device=self.dev)
+        c.slab = torch.empty(max(c.ll.n_wg, 1) * 6 * self.C, dtype=torch.float64, device=self.dev)
+        cache[legacy] = c
+    return cache[legacy]
 
 
 def _lsqr_init_u(self, rc, rt, nrm2_out):
-    _lsqr_alloc(self)
-    self._ck(self.lib.vican_lsqr_init_u(self._lgref, _ptr(self._lw), _ptr(self._lu), _ptr(self._lv), _ptr(rc), _ptr(rt),
-                                        _ptr(self._lsqr_u), _ptr(self._lsqr_sw), _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()),
+    c = _lsqr_ctx(self)
+    self._ck(self.lib.vican_lsqr_init_u(c.gref, _ptr(c.w), _ptr(c.u_in), _ptr(c.v_in), _ptr(rc), _ptr(rt),
+                                        _ptr(c.u), _ptr(c.sw), _ptr(c.part), _ptr(nrm2_out), _stream()),
              "vican_lsqr_init_u")
 
 
 def _lsqr_u_step(self, v_c, v_t, coef, nrm2_out):
-    self._ck(self.lib.vican_lsqr_u_step(self._lgref, _ptr(self._lsqr_sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(self._lsqr_u),
-                                        _ptr(self._lsqr_part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
+    c = _lsqr_ctx(self)
+    self._ck(self.lib.vican_lsqr_u_step(c.gref, _ptr(c.sw), _ptr(v_c), _ptr(v_t), float(coef), _ptr(c.u),
+                                        _ptr(c.part), _ptr(nrm2_out), _stream()), "vican_lsqr_u_step")
 
 
 def _lsqr_v_step(self, inv_beta, beta, v_t, acc_c, nrm2_t_out):
     """v_t updated in place; acc_c[3C] = this rank's camera-side sums (all-reduce, then lsqr_cam_v)."""
-    nwg = self._ll.n_wg
-    part = self._lslab
+    c = _lsqr_ctx(self)
     inv = C.c_double(0.0)
-    self._ck(self.lib.vican_lsqr_v_step(self._lgref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), float(inv_beta), float(beta), _ptr(v_t),
-                                        _ptr(part), _ptr(self._lsqr_part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), self._ln_add,
+    self._ck(self.lib.vican_lsqr_v_step(c.gref, _ptr(c.sw), _ptr(c.u), float(inv_beta), float(beta), _ptr(v_t),
+                                        _ptr(c.slab), _ptr(c.part), _ptr(nrm2_t_out), math.sqrt(self.g.wmax), c.n_add,
                                         C.byref(inv), _stream()), "vican_lsqr_v_step")
-    self._ck(self.lib.vican_slab_reduce_fx(_ptr(part), nwg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
+    self._ck(self.lib.vican_slab_reduce_fx(_ptr(c.slab), c.ll.n_wg, self.C, 3, inv.value, None, None, _ptr(acc_c), _stream()),
              "vican_slab_reduce_fx")
 
 
@@ -777,14 +791,17 @@ def _lsqr_cam_v(self, acc_c, beta, v_c, nrm2_out):
 
 
 def _lsqr_update(self, inv_alfa, t1, t2, v, w, x, nrm2_w_out):
+    if not hasattr(self, "_lsqr_part"):
+        self._lsqr_part = torch.zeros(1024, dtype=torch.float64, device=self.dev)
     self._ck(self.lib.vican_lsqr_update(v.numel(), float(inv_alfa), float(t1), float(t2), _ptr(v), _ptr(w), _ptr(x),
                                         _ptr(self._lsqr_part), _ptr(nrm2_w_out), _stream()), "vican_lsqr_update")
 
 
 def _lsqr_step(self, v_c, v_t, z_t, acc, st):
     """One fused pass over the edges (vican_lsqr_step): u~ <- J~ v - coef u~, z_t, acc[0:3C] camera sums, acc[3C] = |u^|^2."""
-    self._ck(self.lib.vican_lsqr_step(self._lgref, _ptr(self._lsqr_sw), _ptr(self._lsqr_u), _ptr(v_c), _ptr(v_t), _ptr(z_t), _ptr(self._lslab2),
-                                      _ptr(self._lsqr_part), _ptr(acc), _ptr(st), _stream()), "vican_lsqr_step")
+    c = _lsqr_ctx(self)
+    self._ck(self.lib.vican_lsqr_step(c.gref, _ptr(c.sw), _ptr(c.u), _ptr(v_c), _ptr(v_t), _ptr(z_t), _ptr(c.slab),
+                                      _ptr(c.part), _ptr(acc), _ptr(st), _stream()), "vican_lsqr_step")
 
 
 def _lsqr_nodes(self, z_t, acc, v_t, v_c, part2, st):
@@ -803,11 +820,8 @@ def _lsqr_update_st(self, v, w, x, part, last, st):
 
 
 def _lsqr_device_params(self):
-    """(smax, n_add) of the fused step's fixed-point scale; allocates its slab buffer."""
-    _lsqr_alloc(self)
-    if not hasattr(self, "_lslab2"):
-        self._lslab2 = torch.empty(max(self._ll.n_wg, 1) * 6 * self.C, dtype=torch.float64, device=self.dev)
-    return math.sqrt(self.g.wmax), self._ln_add
+    """(smax, n_add) of the fused step's fixed-point scale."""
+    return math.sqrt(self.g.wmax), _lsqr_ctx(self).n_add
 
 
 HipBackend.lsqr_step = _lsqr_step

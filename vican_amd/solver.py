@@ -575,33 +575,64 @@ def with_cooperative_fallback(K, comm, fn):
     return out
 
 
-def _lsqr_solve_device(self, alfa, beta, c2, bnorm, ctol, iter_lim, multi):
+def _lsqr_solve_device(self, beta, c2, bnorm, ctol, iter_lim, multi):
     """The iterations with every scalar on the device (vican_lsqr_state_t) and ONE fused pass over the edges per iteration
     (vican_lsqr_step): the host enqueues iterations in bursts and polls the state; nothing on the critical path is read back.
-    Entered after the first bidiagonalisation step (u~_1 = b~ stored unnormalised, v_1 and w_1 = v_1 in place, x = 0)."""
+    Entered after vican_lsqr_init_u (u~_1 = b~ stored unnormalised, |b~| = beta known, v = w = x = 0).  The first
+    bidiagonalisation step alfa_1 v_1 = J~^T u_1 is the same fused pass with coef = -1 on v = 0 (u^ = u~, z = J~^T u~)."""
     K, comm = self.K, self.comm
     C3 = 3 * K.C
     smax, n_add = K.lsqr_device_params()
     h = np.zeros(LSQR_STATE_DOUBLES)
     hi = h.view(np.int32)
+    lo_bits = int(min(48, max(8, 62 - int(np.ceil(np.log2(max(n_add, 1.0)))))))
+
+    def scale_for(bound):                                            # fix_scale(c, n_add, bits = 49) of vican_sweep_common.h
+        cb = max(bound, 1e-300)
+        e = min(49 - int(np.ceil(np.log2(cb))), 61 - int(np.ceil(np.log2(cb * max(n_add, 1.0)))))
+        e = max(-1000, min(1000, e))
+        return np.ldexp(1.0, e), np.ldexp(1.0, -e)
+    z_t, acc = K.zeros(max(K.T, 1), 3), K.zeros(C3 + 2)          # acc: [camera sums | |u^|^2 | |w_t|^2 of the direction (sharded runs)]
+    part2, wp_c, wp_t = K.zeros(1025), K.zeros(1024), K.zeros(1024)
+    self.info = dict(lsqr_iters=0, istop=0, converged=True, device_scalars=True)
+    if beta == 0.0:
+        return self.x_c, self.x_t
+    # ---- first step: |s u^| <= smax |u~| <= smax beta
+    h[LSQR_F["coef"]], h[LSQR_F["smax"]], h[LSQR_F["n_add"]] = -1.0, smax, n_add
+    h[LSQR_F["qscale"]], h[LSQR_F["qinv"]] = scale_for(smax * beta)
+    hi[LSQR_I["lo_bits"]] = lo_bits
+    st = K.from_numpy(h)
+    K.lsqr_step(self.v_c, self.v_t, z_t, acc, st)
+    if multi:
+        comm.allreduce(acc[: C3 + 1])
+    nb = K.lsqr_nodes(z_t, acc, self.v_t, self.v_c, part2, st)      # v~ = J~^T u~ / beta
+    nv2 = part2[:nb].sum().reshape(1)
+    if multi:
+        comm.allreduce(nv2)
+    alfa = float(np.sqrt(float(nv2.cpu()[0]) + float(part2[1024].cpu())))
+    if alfa == 0.0:
+        return self.x_c, self.x_t
+    # v1 = v/alfa, w1 = v1, x = 0
+    K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_c, self.w_c, self.x_c, self.s2[3:4])
+    K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_t, self.w_t, self.x_t, self.s2[1:2])
+    # ---- the state of scipy's loop
+    h[:] = 0.0
     for k, v in dict(alfa=alfa, beta=beta, rhobar=alfa, phibar=beta, cs2=-1.0, c2=c2, bnorm=bnorm, atol=self.atol, btol=self.btol, ctol=ctol,
                      coef=alfa / beta, smax=smax, n_add=n_add).items():
         h[LSQR_F[k]] = v
-    cb = smax * (2.0 * smax + alfa)                              # fix_scale(c, n_add, bits = 49) of vican_sweep_common.h
-    e = min(49 - int(np.ceil(np.log2(cb))), 61 - int(np.ceil(np.log2(cb * max(n_add, 1.0)))))
-    h[LSQR_F["qscale"]], h[LSQR_F["qinv"]] = np.ldexp(1.0, e), np.ldexp(1.0, -e)
+    h[LSQR_F["qscale"]], h[LSQR_F["qinv"]] = scale_for(smax * (2.0 * smax + alfa))
     hi[LSQR_I["iter_lim"]] = int(min(iter_lim, 2 ** 31 - 1))
-    hi[LSQR_I["lo_bits"]] = int(min(48, max(8, 62 - int(np.ceil(np.log2(max(n_add, 1.0)))))))
-    st = K.from_numpy(h)
-    z_t, acc = K.zeros(max(K.T, 1), 3), K.zeros(C3 + 2)          # acc: [camera sums | |u^|^2 | |w_t|^2 of the direction (sharded runs)]
-    part2, wp_c, wp_t = K.zeros(1025), K.zeros(1024), K.zeros(1024)
+    hi[LSQR_I["lo_bits"]] = lo_bits
+    st.copy_(K.from_numpy(h))
     # |w_1|^2 from the initial update (s2[3] cameras, s2[1] timesteps)
     wpart_t, n_wt, wpart_c, n_wc = self.s2[1:2], 1, self.s2[3:4], 1
     if multi:
         acc[C3 + 1:C3 + 2].copy_(self.s2[1:2])
     burst, launched, state = 8, 0, None
+    if getattr(self, "_last_iters", None):                      # the same system was solved before: launch exactly that many first
+        burst = max(1, min(self._last_iters, 256))
     while True:
-        for _ in range(burst):
+        for _ in range(min(burst, max(iter_lim - launched, 1))):
             K.lsqr_step(self.v_c, self.v_t, z_t, acc, st)
             if multi:
                 comm.allreduce(acc)                              # one message: camera sums, |u^|^2 and the pending |w_t|^2
@@ -622,6 +653,7 @@ def _lsqr_solve_device(self, alfa, beta, c2, bnorm, ctol, iter_lim, multi):
         if state["done"] or launched >= iter_lim:
             break
         burst = min(2 * burst, 64)
+    self._last_iters = state["itn"] if state["done"] else None
     self.info = dict(lsqr_iters=state["itn"], istop=state["istop"], converged=True, rnorm=state["rnorm"], arnorm=state["arnorm"],
                      anorm=state["anorm"], acond=state["acond"], xnorm=state["xnorm"], device_scalars=True)
     return self.x_c, self.x_t
@@ -713,6 +745,8 @@ class LsqrTranslationSolver:
         beta = float(np.sqrt(self._get(self.s2)[0]))
         c2 = 0.0 if bnorm2_true is None else max(bnorm2_true - beta * beta, 0.0)
         bnorm = np.sqrt(beta * beta + c2)
+        if hasattr(K, "lsqr_step") and not getattr(K, "lsqr_host_scalars", False):
+            return self._solve_device(beta, c2, bnorm, ctol, iter_lim, multi)
         alfa = 0.0
         if beta > 0:
             K.lsqr_v_step(1.0 / beta, 0.0, self.v_t, self.acc[: 3 * K.C], self.acc[3 * K.C:])
@@ -726,8 +760,6 @@ class LsqrTranslationSolver:
         # v1 = v/alfa, w1 = v1, x = 0
         K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_c, self.w_c, self.x_c, self.s2[3:4])
         K.lsqr_update(1.0 / alfa, 0.0, 0.0, self.v_t, self.w_t, self.x_t, self.s2[1:2])
-        if hasattr(K, "lsqr_step") and not getattr(K, "lsqr_host_scalars", False):
-            return self._solve_device(alfa, beta, c2, bnorm, ctol, iter_lim, multi)
         rhobar, phibar = alfa, beta
         anorm = acond = ddnorm = xnorm = xxnorm = z = 0.0
         cs2, sn2 = -1.0, 0.0
