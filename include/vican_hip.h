@@ -82,7 +82,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 11            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 12            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -514,6 +514,29 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
                          const double* p_c, double* x_c, double* r_c, const double* p_t,
                          const double* q_t, double* x_t, double* r_t, double* rr_part,
                          int32_t part_cap, vican_cg_state_t* st, void* stream);
+
+/* ONE message per CG iteration for timestep-sharded solves (replaces the two reductions per iteration of the pair above;
+ * scipy.sparse.linalg.cg at bipgo.py:476-478 on a sharded graph): the Chronopoulos-Gear arrangement - the product is formed
+ * on the RESIDUAL (s = A r), gamma = r.r and delta = r.s travel together, beta = gamma/gamma_prev,
+ * alpha = gamma / (delta - beta gamma / alpha_prev), p = r + beta p, q = s + beta q, x += alpha p, r -= alpha q.  Same
+ * iterates in exact arithmetic and scipy's stopping test (|r_k| < rtol |b|, r.r formed directly, before iteration k's update);
+ * roundings differ from scipy's recurrence (q by recurrence, alpha from delta).  Start from vican_cg_init (x = 0, r = b).
+ *   vican_cg1_iter_local : msg[0:3C] = sum_t w r_t over THIS rank's rows ([C][3]), msg[3C] = r_t.s_t, msg[3C+1] = r_t.r_t of
+ *     this rank; s_t [T][3] = deg_t r_t - sum_c w r_c written.  rr_part / n_part: the partials the previous
+ *     vican_cg1_iter_finish returned (n_part = 0 before the first iteration).  sw: a scratch vican_cg_state_t (the sweep's
+ *     view of the state).  All-reduce msg[0:3C+2] over the ranks, then
+ *   vican_cg1_iter_finish(k = 0, 1, 2, ...): the scalars, the stopping test (st->done, st->iter = completed iterations) and
+ *     the vector updates; the updated camera residual goes to r_c_new (another buffer than r_c: pass it as r_c to the next
+ *     vican_cg1_iter_local and swap the two); q_c [C][3]; sc: 4 doubles of scratch kept between the calls; rr_part >= 1024
+ *     doubles; returns the number of partials written.  Both calls do nothing once st->done != 0.                                            */
+int vican_cg1_iter_local(const vican_graph_t* g, const double* w, const double* deg_t, const double* r_c,
+                         const double* r_t, double* s_t, void* qc_part, double* pq_part, double* msg,
+                         const double* rr_part, int32_t n_part, double n_add, const vican_cg_state_t* st,
+                         vican_cg_state_t* sw, void* stream);
+int vican_cg1_iter_finish(int32_t n_cam, int32_t n_time, int32_t k, double rtol, const double* deg_c, const double* msg,
+                          const double* r_c, double* r_c_new, double* p_c, double* q_c, double* x_c, double* r_t, const double* s_t,
+                          double* p_t, double* q_t, double* x_t, double* rr_part, int32_t part_cap, double* sc,
+                          vican_cg_state_t* st, void* stream);
 
 /* The whole CG solve as ONE cooperative launch (vican_cgres.hip) for wave-layout graphs whose n_wg workgroups are
  * co-resident (n_wg <= compute units, <= 256) and whose per-workgroup rows fit in LDS: replaces the vican_cg_init /

@@ -440,6 +440,57 @@ class NumpyBackend:
         self.cg_cam_step(deg_c, qcpq, p_c, x_c, r_c, st)
         return self.cg_time_step(p_t, q_t, x_t, r_t, st)
 
+    # one message per CG iteration (include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)
+    def cg1_iter_local(self, deg_t, r_c, r_t, s_t, msg, st, n_rr_part):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return
+        T, C3 = self.T, 3 * self.C
+        rt, rc = r_t.numpy(), r_c.numpy()
+        acc = np.zeros((max(T, 1), 3)); np.add.at(acc, self.row, self.w[:, None] * rc[self.col])
+        s = deg_t.numpy()[:, None] * rt - acc
+        s_t.numpy()[:] = s
+        qc = np.zeros((self.C, 3)); np.add.at(qc, self.col, self.w[:, None] * rt[self.row])
+        out = msg.numpy()
+        out[:C3] = qc.reshape(-1)
+        out[C3] = float((rt[:T] * s[:T]).sum())
+        out[C3 + 1] = float((rt[:T] ** 2).sum())
+
+    def cg1_iter_finish(self, k, deg_c, msg, r_c, r_c_new, p_c, q_c, x_c, r_t, s_t, p_t, q_t, x_t, rtol, st):
+        f, i = self._st(st)
+        if i[CG_I["done"]]:
+            return 1
+        T, C3 = self.T, 3 * self.C
+        m = msg.numpy()
+        r_c_new.numpy()[:] = r_c.numpy()
+        rc = r_c_new.numpy()
+        sc = deg_c.numpy()[:, None] * rc - m[:C3].reshape(self.C, 3)
+        gamma = float((rc ** 2).sum()) + m[C3 + 1]
+        delta = float((rc * sc).sum()) + m[C3]
+        if k == 0:
+            f[CG_F["bnorm2"]] = gamma; f[CG_F["atol2"]] = rtol * rtol * gamma
+        f[CG_F["rho_prev"]] = f[CG_F["rho"]]; f[CG_F["rho"]] = gamma
+        if np.sqrt(gamma) < np.sqrt(f[CG_F["atol2"]]) or gamma == 0.0:
+            i[CG_I["done"]] = 1
+            return 1
+        if k == 0:
+            beta, alpha = 0.0, gamma / delta
+        else:
+            beta = gamma / self._cg1_gamma
+            alpha = gamma / (delta - beta * gamma / self._cg1_alpha)
+        self._cg1_gamma, self._cg1_alpha = gamma, alpha
+        f[CG_F["alpha"]] = alpha; f[CG_F["beta"]] = beta
+        i[CG_I["iter"]] = k + 1; i[CG_I["first"]] = 0
+        for r, s_, p, q, x, n in ((r_t.numpy(), s_t.numpy(), p_t.numpy(), q_t.numpy(), x_t.numpy(), T),
+                                  (rc, sc, p_c.numpy(), q_c.numpy(), x_c.numpy(), self.C)):
+            if k:
+                p[:n] = r[:n] + beta * p[:n]; q[:n] = s_[:n] + beta * q[:n]
+            else:
+                p[:n] = r[:n]; q[:n] = s_[:n]
+            x[:n] += alpha * p[:n]
+            r[:n] -= alpha * q[:n]
+        return 1
+
     def cg_end(self, n_part, st):
         f, i = self._st(st)
         if i[CG_I["done"]]:

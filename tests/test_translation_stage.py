@@ -37,9 +37,21 @@ def reference_rotations(prob, exp):
     return rc, rt
 
 
-def run_stage(K, prob, exp):
+class LoneShardComm(Comm):
+    """A "sharded" run whose other ranks hold no rows: world = 2 as far as the solver's choice of path goes, every all-reduce
+    is the identity.  Drives the sharded code (ONE message per CG iteration: vican_cg1_iter_local / _finish) in one process."""
+
+    def __init__(self):
+        self.group, self.world, self.rank, self.n_allreduce = None, 2, 0, 0
+
+    def allreduce(self, t):
+        self.n_allreduce += 1
+        return t
+
+
+def run_stage(K, prob, exp, comm=None):
     rc, rt = reference_rotations(prob, exp)
-    tr = TranslationSolver(K, Comm.single())
+    tr = TranslationSolver(K, comm or Comm.single())
     tr.setup(K.from_numpy(rc), K.from_numpy(rt))
     x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
     pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
@@ -56,6 +68,21 @@ def test_translation_stage_alone_numpy_backend(name, dt):
     dist, info = run_stage(K, prob, exp)
     assert dist < stage_tol(name, dt), dist
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+
+
+@pytest.mark.parametrize("name,dt", CASES)
+def test_one_message_cg_numpy_backend(name, dt):
+    """The sharded arrangement (one all-reduce per iteration, Chronopoulos-Gear) against the same goldens and bounds as
+    scipy's recurrence, and the message count: set-up + one per launched iteration."""
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c)
+    comm = LoneShardComm()
+    dist, info = run_stage(K, prob, exp, comm)
+    assert info.get("one_message")
+    assert dist < stage_tol(name, dt), dist
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    assert comm.n_allreduce <= 1 + info["cg_iters"] + 1 + 64            # bursts: overshoot bounded
 
 
 def hip_backend(prob, dt):
@@ -81,11 +108,35 @@ def test_translation_stage_alone_on_gpu(name, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,dt", CASES)
+def test_one_message_cg_on_gpu(name, dt):
+    """vican_cg1_iter_local / vican_cg1_iter_finish (the sharded runs' CG, one message per iteration) on one rank that
+    holds every row: same goldens and bounds as scipy's recurrence; agreement with that recurrence on the same device."""
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    K = hip_backend(prob, dt)
+    dist, info = run_stage(K, prob, exp, LoneShardComm())
+    dist2, info2 = run_stage(K, prob, exp)
+    print("%s %s: one-message CG %.2e m from the reference's iterate (scipy's recurrence: %.2e), cg %d / %d vs %d" % (
+        name, dt, dist, dist2, info["cg_iters"], info2["cg_iters"], int(exp["cg_iters"])))
+    assert info.get("one_message") and not info2.get("one_message")
+    assert dist < stage_tol(name, dt), dist
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["float32", "float64"])
-def test_translation_stage_alone_at_large_shop_scale(dt):
-    """g9 (BASELINE configs[2] scale, ~105 CG iterations): with the reference's rotations fed in, the CG kernels stay
-    inside the band by which the reference's own answer moves under 1e-15 perturbations (up to 5.3e-4 m) and stop
-    within its own iteration spread."""
+def test_one_message_cg_at_large_shop_scale(dt):
+    """g9 through the one-message arrangement: inside the reference's own band and iteration window (as the test below)."""
+    dist, info, exp = large_shop_stage(dt, LoneShardComm())
+    print("g9 %s: one-message CG: %.2e m from the reference's iterate, cg %d vs %d" % (dt, dist, info["cg_iters"], int(exp["cg_iters"])))
+    assert info.get("one_message")
+    assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
+    lo, hi = reference_window("g9_large_shop", dt, int(exp["cg_iters"]))
+    assert lo - 1 <= info["cg_iters"] <= hi + 1, (info["cg_iters"], lo, hi)
+
+
+def large_shop_stage(dt, comm=None):
     from util import load_golden
     from vican_amd import frontend, synth
     from vican_amd.geometry import SE3
@@ -98,7 +149,17 @@ def test_translation_stage_alone_at_large_shop_scale(dt):
     cons = synth.constraints_from_scene(scene, SE3)
     nr, nt, ff = (gc.CALLABLES[gc.LARGE_SHOP[k]] for k in ("noise_r", "noise_t", "filt"))
     prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
-    dist, info = run_stage(hip_backend(prob, dt), prob, exp)
+    dist, info = run_stage(hip_backend(prob, dt), prob, exp, comm)
+    return dist, info, exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_translation_stage_alone_at_large_shop_scale(dt):
+    """g9 (BASELINE configs[2] scale, ~105 CG iterations): with the reference's rotations fed in, the CG kernels stay
+    inside the band by which the reference's own answer moves under 1e-15 perturbations (up to 5.3e-4 m) and stop
+    within its own iteration spread."""
+    dist, info, exp = large_shop_stage(dt)
     print("g9 %s: translation stage alone: %.2e m from the reference's iterate, cg %d vs %d" % (
         dt, dist, info["cg_iters"], int(exp["cg_iters"])))
     assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist

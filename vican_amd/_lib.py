@@ -110,6 +110,9 @@ PROTOTYPES = {
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "vican_cg1_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
+    "vican_cg1_iter_finish": (C.c_int, [_i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
+                                        _vp, _vp]),
     "vican_trans_rhs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp]),
     "vican_cg_init": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),

@@ -854,6 +854,165 @@ extern "C" int vican_cg_end(const double* rr_part, int32_t n_part, vican_cg_stat
     return VICAN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// ONE message per iteration for sharded solves: the Chronopoulos-Gear arrangement of CG.  scipy's recurrence needs two
+// reductions per iteration ([q_c | p.q] after the product, r.r after the update; the second one feeds the beta that the NEXT
+// product's p = r + beta p needs).  Forming s = A r instead of q = A p removes the dependency: with gamma = r.r and
+// delta = r.s of the SAME residual in one message,
+//     beta_k = gamma_k / gamma_{k-1},   alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}),
+//     p_k = r_k + beta_k p_{k-1},  q_k = s_k + beta_k q_{k-1} (= A p_k),  x += alpha_k p_k,  r -= alpha_k q_k
+// - the same iterates in exact arithmetic, other roundings (q by recurrence, alpha from delta): another trajectory inside
+// the band in which the reference's loosely converged CG moves anyway.  The stopping test is scipy's
+// (|r_k| < rtol |b| on the directly formed r.r, before iteration k's update).  The product is the same sweep kernel, run
+// on r with a "first iteration" view of the state (`sw`: no p update, its own fixed-point scale from the measured max |r|).
+//   cg1_prepare : close the previous update (r_t.r_t and max |r_t| of this rank from the step kernel's partials) -> msg[3C+1],
+//                 scale of the sweep -> sw
+//   sweep + fold: msg[0:3C] = sum_t w r_t (this rank), msg[3C] = r_t.s_t (this rank);  s_t = deg_t r_t - sum_c w r_c
+//   (all-reduce of msg[0:3C+2] by the caller)
+//   cg1_step    : every block derives gamma, delta, beta, alpha itself; vector updates; block 0 the camera side and the state
+// sc: 4 doubles, gamma and alpha of the last two iterations by parity of k (block 0 of launch k writes slot k & 1 while the
+// other blocks still read slot (k-1) & 1); for the same reason the camera residual is written to a second buffer (r_c_new):
+// every block reads r_c for its scalars, and blocks start whenever the device lets them (a shared device delays them by
+// whole kernels).
+__global__ __launch_bounds__(256) void cg1_prepare_kernel(const double* __restrict__ rr_part, int n_part, double n_add,
+                                                          const vican_cg_state_t* __restrict__ st, vican_cg_state_t* sw,
+                                                          double* msg_rr) {
+    __shared__ double red[8];
+    if (st->done) { if (threadIdx.x == 0) sw->done = st->done; return; }
+    double ps = 0.0, pm = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 256) { ps += rr_part[i]; pm = fmax(pm, rr_part[CG_PARTS + i]); }
+    const double tsum = block_sum(ps, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pm = fmax(pm, __shfl_down(pm, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double rr = n_part > 0 ? tsum : st->rr_time;                     // (before the first iteration: from cg_init)
+        const double rmax_t = n_part > 0 ? fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) : st->rmax_time;
+        *msg_rr = rr;
+        double inv;
+        sw->qscale = fix_scale(st->wmax * fmax(st->rmax_cam, rmax_t), n_add, &inv, 49);
+        sw->qinv = inv; sw->lo_bits = fix2_lo_bits(n_add);
+        sw->beta = 0.0; sw->first = 1; sw->done = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cg1_step_kernel(int n_cam, long long n, int k, double rtol, const double* __restrict__ deg_c,
+                                                       const double* __restrict__ msg, const double* __restrict__ r_c,
+                                                       double* __restrict__ r_c_new, double* p_c, double* q_c, double* x_c,
+                                                       double* __restrict__ r_t, const double* __restrict__ s_t, double* __restrict__ p_t,
+                                                       double* __restrict__ q_t, double* __restrict__ x_t, double* __restrict__ rr_part,
+                                                       double* sc, vican_cg_state_t* st) {
+    __shared__ double red[8];
+    __shared__ double sh_alpha, sh_beta;
+    __shared__ int sh_go;
+    if (st->done) return;
+    const int nc = 3 * n_cam;
+    double g = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const double r = r_c[i];
+        const double s = deg_c[i / 3] * r - msg[i];
+        g += r * r; d += r * s;
+    }
+    const double gc = block_sum(g, red);
+    const double dc = block_sum(d, red);
+    if (threadIdx.x == 0) {
+        const double gamma = gc + msg[nc + 1], delta = dc + msg[nc];
+        const double atol2 = k == 0 ? rtol * rtol * gamma : st->atol2;
+        int stop = 0;
+        if (sqrt(gamma) < sqrt(atol2) || gamma == 0.0) stop = 1;                 // scipy: norm(r) < atol, at the top of iteration k
+        else if (!(gamma == gamma)) stop = -2;
+        double beta = 0.0, alpha = 0.0;
+        if (!stop) {
+            if (k == 0) alpha = gamma / delta;
+            else { beta = gamma / sc[(k - 1) & 1]; alpha = gamma / (delta - beta * gamma / sc[2 + ((k - 1) & 1)]); }
+        }
+        sh_alpha = alpha; sh_beta = beta; sh_go = !stop;
+        if (blockIdx.x == 0) {
+            if (k == 0) { st->bnorm2 = gamma; st->atol2 = atol2; }
+            st->rho_prev = st->rho; st->rho = gamma; st->rr_cam = gc; st->rr_time = msg[nc + 1];
+            if (stop) st->done = stop;
+            else {
+                sc[k & 1] = gamma; sc[2 + (k & 1)] = alpha;
+                st->alpha = alpha; st->beta = beta; st->pq = gamma / alpha; st->iter = k + 1; st->first = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (!sh_go) return;
+    const double alpha = sh_alpha, beta = sh_beta;
+    double rr = 0.0, m = 0.0;
+#pragma unroll 4
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double p = r_t[i], q = s_t[i];
+        if (k) { p += beta * p_t[i]; q += beta * q_t[i]; }
+        p_t[i] = p; q_t[i] = q;
+        x_t[i] += alpha * p;
+        const double r = r_t[i] - alpha * q;
+        r_t[i] = r;
+        rr += r * r; m = fmax(m, fabs(r));
+    }
+    const double t = block_sum(rr, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); }
+    if (blockIdx.x != 0) return;
+    __syncthreads();
+    double mc = 0.0;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        const double rv = r_c[i];
+        const double s = deg_c[i / 3] * rv - msg[i];
+        double p = rv, q = s;
+        if (k) { p += beta * p_c[i]; q += beta * q_c[i]; }
+        p_c[i] = p; q_c[i] = q;
+        x_c[i] += alpha * p;
+        const double r = rv - alpha * q;
+        r_c_new[i] = r;               // (never in place: the other blocks derive gamma and delta from r_c, some of them later than this)
+        mc = fmax(mc, fabs(r));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mc;
+    __syncthreads();
+    if (threadIdx.x == 0) st->rmax_cam = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+extern "C" int vican_cg1_iter_local(const vican_graph_t* g, const double* w, const double* deg_t, const double* r_c,
+                                    const double* r_t, double* s_t, void* qc_part, double* pq_part, double* msg,
+                                    const double* rr_part, int32_t n_part, double n_add, const vican_cg_state_t* st,
+                                    vican_cg_state_t* sw, void* stream) {
+    if (!g || !w || !deg_t || !r_c || !r_t || !s_t || !qc_part || !pq_part || !msg || !st || !sw || (n_part > 0 && !rr_part) ||
+        n_part > CG_PARTS)
+        return set_err(VICAN_ERR_ARG, "vican_cg1_iter_local: bad argument");
+    hipLaunchKernelGGL(cg1_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rr_part, n_part, n_add, st, sw,
+                       msg + 3 * (size_t)g->n_cam + 1);
+    LAUNCH_CHECK("vican_cg1_iter_local");
+    int rc;
+    // the product on the residual: the sweep's "first iteration" form reads p_t and never writes it
+    if ((rc = vican_cg_sweep(g, w, deg_t, r_c, r_t, const_cast<double*>(r_t), s_t, qc_part, pq_part, sw, stream)) < 0) return rc;
+    return vican_cg_fold(qc_part, g->n_wg, g->n_cam, pq_part, msg, sw, stream);
+}
+
+extern "C" int vican_cg1_iter_finish(int32_t n_cam, int32_t n_time, int32_t k, double rtol, const double* deg_c, const double* msg,
+                                     const double* r_c, double* r_c_new, double* p_c, double* q_c, double* x_c, double* r_t, const double* s_t,
+                                     double* p_t, double* q_t, double* x_t, double* rr_part, int32_t part_cap, double* sc,
+                                     vican_cg_state_t* st, void* stream) {
+    if (n_cam <= 0 || n_time < 0 || k < 0 || !deg_c || !msg || !r_c || !r_c_new || r_c_new == r_c || !p_c || !q_c || !x_c || !r_t || !s_t || !p_t || !q_t ||
+        !x_t || !rr_part || part_cap < 2 * CG_PARTS || !sc || !st)
+        return set_err(VICAN_ERR_ARG, "vican_cg1_iter_finish: bad argument");
+    const long long n = 3LL * n_time;
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;
+    hipLaunchKernelGGL(cg1_step_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_cam, n, k, rtol, deg_c, msg, r_c, r_c_new, p_c, q_c,
+                       x_c, r_t, s_t, p_t, q_t, x_t, rr_part, sc, st);
+    LAUNCH_CHECK("vican_cg1_iter_finish");
+    return nb;
+}
+
 // fold of one CG sweep in ONE launch: qcpq[0:3C] = sum_wg qc_part (double-word planes [2][3][C] per workgroup -> row-major
 // [C][3] doubles, rounded once) and qcpq[3C] = sum_wg pq_part (block 0).  Integer sums: exact, any order, overflow-proof
 // (fix3_add / fix3_value, vican_sweep_common.h).

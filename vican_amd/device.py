@@ -541,6 +541,22 @@ class HipBackend:
                                                       _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
                                                       self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_iter_finish")
 
+    # one message per CG iteration (sharded solves; include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)
+    def cg1_iter_local(self, deg_t, r_c, r_t, s_t, msg, st, n_rr_part):
+        if getattr(self, "_cg1_sw", None) is None:
+            self._cg1_sw = torch.zeros(_lib.CG_STATE_DOUBLES, dtype=torch.float64, device=self.dev)     # the sweep's view of the state
+            self._cg1_sc = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        part = self.zpart[: self.cgl.n_wg * 6 * self.C]
+        self._ck(self.lib.vican_cg1_iter_local(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(r_t), _ptr(s_t), _ptr(part),
+                                               _ptr(self.pq_part), _ptr(msg), _ptr(self.rr_part), int(n_rr_part), self.n_add_cg,
+                                               _ptr(st), _ptr(self._cg1_sw), _stream()), "vican_cg1_iter_local")
+
+    def cg1_iter_finish(self, k, deg_c, msg, r_c, r_c_new, p_c, q_c, x_c, r_t, s_t, p_t, q_t, x_t, rtol, st):
+        return self._ck(self.lib.vican_cg1_iter_finish(self.C, self.T, int(k), float(rtol), _ptr(deg_c), _ptr(msg), _ptr(r_c), _ptr(r_c_new), _ptr(p_c),
+                                                       _ptr(q_c), _ptr(x_c), _ptr(r_t), _ptr(s_t), _ptr(p_t), _ptr(q_t), _ptr(x_t),
+                                                       _ptr(self.rr_part), self.rr_part.numel(), _ptr(self._cg1_sc), _ptr(st), _stream()),
+                        "vican_cg1_iter_finish")
+
     def fold_z(self, z_out):
         """Fold the fixed-point slabs of the last block_op_raw into z_out[3C,3]."""
         fxp = self.g.fx.data_ptr()
@@ -903,6 +919,7 @@ class TiledBackend(HipBackend):
     product and the LSQR steps run tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows; vican_lsqr_step per tile):
     no limit on the number of cameras.  No fused dual update (a performance feature of the untiled sweeps)."""
     fused_dual_ok = False
+    cg1_iter_local = None          # sharded tiled solves keep the two-message CG (the one-message product is an untiled sweep)
 
     def __init__(self, graph: TiledGraph):
         self.lib, self.g, self.dev = _lib.load(), graph, graph.device

@@ -27,6 +27,8 @@ CPU with gloo by the tests (which inject a NumPy backend).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -409,8 +411,10 @@ class TranslationSolver:
         self.K, self.comm = K, comm or Comm()
         self.rtol, self.poll_every = rtol, poll_every
         C, T = K.C, max(K.T, 1)
-        self.deg_t, self.deg_c = K.empty(T), K.empty(C)
-        self.b_c, self.b_t = K.empty(C, 3), K.empty(T, 3)
+        # the camera-side set-up quantities share one buffer: ONE all-reduce of [deg_c | b_c] in sharded runs
+        self._setup_msg = K.empty(4 * C)
+        self.deg_t, self.deg_c = K.empty(T), self._setup_msg[:C]
+        self.b_c, self.b_t = self._setup_msg[C:].view(C, 3), K.empty(T, 3)
         self.x_c, self.r_c, self.p_c = K.empty(C, 3), K.empty(C, 3), K.empty(C, 3)
         self.x_t, self.r_t, self.p_t, self.q_t = K.empty(T, 3), K.empty(T, 3), K.empty(T, 3), K.empty(T, 3)
         self.qcpq = K.zeros(3 * C + 1)
@@ -419,6 +423,8 @@ class TranslationSolver:
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges < 2_000_000
         self._graphs, self._n_solves, self._last_iters = {}, 0, None
+        self.one_message = os.environ.get("VICAN_CG_MESSAGES", "1") != "2"
+        self._cg1 = None
 
     def _state(self):
         h = self.st.cpu()
@@ -428,9 +434,8 @@ class TranslationSolver:
     def setup(self, rc, rt):
         K = self.K
         K.trans_degrees(self.deg_t, self.deg_c)
-        self.comm.allreduce(self.deg_c)
         K.trans_rhs(rc, rt, self.b_t, self.b_c)
-        self.comm.allreduce(self.b_c)
+        self.comm.allreduce(self._setup_msg)
 
     def solve(self, n_unknowns_total, maxiter=None):
         K, comm, st = self.K, self.comm, self.st
@@ -450,6 +455,8 @@ class TranslationSolver:
             # with something that kept part of the grid out): nothing was lost, the launch sequence below solves the system
             K.cooperative_failed("vican_cg_resident")
         K.cg_init(self.b_c, self.b_t, self.x_c, self.x_t, self.r_c, self.r_t, self.p_c, self.p_t, st)
+        if multi and self.one_message and getattr(K, "cg1_iter_local", None) is not None:
+            return self._solve_one_message(maxiter)
         if multi:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
         n_part, it_launched, s = 0, 0, None
@@ -508,6 +515,40 @@ class TranslationSolver:
             self.poll_every = min(self.poll_every * 2, 64)
         self._last_iters = int(s["iter"]) if s["done"] == 1 else None
         self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1,
+                         relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+        return self.x_c, self.x_t
+
+
+    def _solve_one_message(self, maxiter):
+        """Sharded solves: ONE all-reduce per iteration, [sum_t w r_t | r.s | r.r] (3C + 2 doubles) - the Chronopoulos-Gear
+        arrangement of the same CG (include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish; scipy's recurrence
+        needs two reductions per iteration because its beta depends on the r.r of the update that precedes the product).
+        Same iterates in exact arithmetic, scipy's stopping test on the directly formed r.r; other roundings.
+        VICAN_CG_MESSAGES=2 keeps scipy's recurrence (two messages per iteration) on sharded runs."""
+        K, comm, st = self.K, self.comm, self.st
+        if self._cg1 is None:
+            C, T = K.C, max(K.T, 1)
+            self._cg1 = dict(msg=K.zeros(3 * C + 2), s_t=K.empty(T, 3), q_c=K.empty(C, 3), r_c2=K.empty(C, 3))
+        msg, s_t, q_c = self._cg1["msg"], self._cg1["s_t"], self._cg1["q_c"]
+        r_c, r_c_new = self.r_c, self._cg1["r_c2"]          # the camera residual alternates between two buffers (vican_cg1_iter_finish)
+        n_part, k, s, poll = 0, 0, None, self.poll_every
+        burst = poll if self._last_iters is None else min(max(self._last_iters + 1, 1), 64)
+        while True:
+            for _ in range(min(burst, maxiter + 1 - k)):
+                K.cg1_iter_local(self.deg_t, r_c, self.r_t, s_t, msg, st, n_part)
+                comm.allreduce(msg)
+                n_part = K.cg1_iter_finish(k, self.deg_c, msg, r_c, r_c_new, self.p_c, q_c, self.x_c, self.r_t, s_t, self.p_t, self.q_t,
+                                           self.x_t, self.rtol, st)
+                r_c, r_c_new = r_c_new, r_c
+                k += 1
+            s = self._state()
+            if s["done"] or k > maxiter:
+                break
+            poll = min(poll * 2, 64)
+            burst = poll
+        self._n_solves += 1
+        self._last_iters = int(s["iter"]) if s["done"] == 1 else None
+        self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1, one_message=True,
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
         return self.x_c, self.x_t
 
