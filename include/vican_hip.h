@@ -75,7 +75,11 @@ typedef struct vican_graph {
     int32_t wg_waves;         /* wavefronts per workgroup of the wave layout: 4, 8 or 12 (0 in the block layout) */
     int32_t stream_nt;        /* 1: the sweeps read blk / idx with non-temporal loads (edge stream far larger than the
                                  256 MB Infinity Cache); 0: plain loads (cache-resident graphs are re-read from cache) */
-    int32_t reserved;
+    int32_t slot_order;       /* order of the edges inside a chunk, chosen at pack time (vican_pack_edges): 0 = bank-aware (lane l
+                                 holds edges of cameras = l mod 32: conflict-free camera-side LDS accesses; dense rows), 1 = row-major
+                                 (a lane holds consecutive edges of a row: few row flushes; short rows).  The order is part of the
+                                 layout: a lane pre-sums its same-row terms in floating point, so results of the two orders agree
+                                 to rounding, and each is bit-reproducible */
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */

@@ -11,6 +11,14 @@ from util import load_golden                            # noqa: E402
 from vican_amd import synth                             # noqa: E402
 
 
+@pytest.fixture(autouse=True, params=["banks", "rows"])
+def slot_order(request, monkeypatch):
+    """Every test of this file under both orders of the edges inside a chunk (vican_graph_t.slot_order: bank-aware /
+    row-major; LocalGraph picks one by the average row length, VICAN_SLOT_ORDER forces it)."""
+    monkeypatch.setenv("VICAN_SLOT_ORDER", request.param)
+    return request.param
+
+
 def random_graph(C, T, deg_lo, deg_hi, seed, empty_rows=False):
     rng = np.random.default_rng(seed)
     deg = rng.integers(deg_lo, min(deg_hi, C) + 1, T)
@@ -225,7 +233,9 @@ def test_cg_resident_matches_multikernel(cfg, dt):
             outs.append((x_c.clone(), x_t.clone(), ts.info["cg_iters"], ts.info["relres"]))
         H._cgres_ok = True
         scale = max(float(outs[1][1].abs().max()), 1.0)
-        assert abs(outs[0][2] - outs[1][2]) <= 1, (outs[0][2], outs[1][2])
+        # (the two paths round their floating-point partial sums differently - the multi-kernel sweep pre-sums a lane's same-row
+        #  terms in f64 - and the stopping test is a threshold: a few per cent of the iteration count, as against the NumPy stand-in)
+        assert abs(outs[0][2] - outs[1][2]) <= max(1, outs[1][2] // 20), (outs[0][2], outs[1][2])
         if outs[0][2] == outs[1][2]:
             # (both iterates satisfy |r| < rtol |b|; rounding differences of the recurrences are amplified towards that level)
             tol = 1e3 * rtol * scale

@@ -40,7 +40,7 @@ class Graph(C.Structure):
         ("n_cam", C.c_int32), ("n_time", C.c_int32), ("n_chunk", C.c_int32), ("slots", C.c_int32),
         ("max_rows", C.c_int32), ("storage", C.c_int32), ("block_threads", C.c_int32), ("n_wg", C.c_int32),
         ("n_copy", C.c_int32), ("wg_chunk_cap", C.c_int32), ("layout", C.c_int32), ("wg_waves", C.c_int32),
-        ("stream_nt", C.c_int32), ("reserved", C.c_int32),
+        ("stream_nt", C.c_int32), ("slot_order", C.c_int32),
         ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
     ]
 

@@ -247,6 +247,18 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
     }
 }
 
+// ROW-MAJOR slot order (vican_graph_t.slot_order == 1): the chunk's edges in CSR order, i.e. lane l holds EPL consecutive
+// edges of (mostly) ONE row.  For graphs of short rows: with a few edges per row a (row, camera class) pair holds at most one
+// edge, so the bank-aware order above has no pure lanes at all - every lane flushes EPL row sums (9 LDS atomics each) and
+// re-reads EPL row operands per chunk - while here a lane changes row about once; the price is that the camera-side
+// gathers and atomics hit random banks.
+__global__ void plan_slots_rows_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ perm) {
+    const int k = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.slots) return;
+    const int e0 = row_ptr[g.chunk_row0[k]], e1 = row_ptr[g.chunk_row0[k + 1]];
+    perm[(size_t)k * g.slots + s] = e0 + s < e1 ? e0 + s : -1;
+}
+
 template <typename S>
 __global__ void pack_edges_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr,
                                   const int32_t* __restrict__ col, const S* __restrict__ blk_csr,
@@ -305,7 +317,10 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
     dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
-    hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
+    if (g->slot_order == 1)
+        hipLaunchKernelGGL(plan_slots_rows_kernel, grid, block, 0, st, *g, row_ptr, perm_ws);
+    else
+        hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
     const int32_t* perm = perm_ws;
     if (g->storage == VICAN_STORE_F32)
         hipLaunchKernelGGL(pack_edges_kernel<float>, grid, block, 0, st, *g, row_ptr, col, (const float*)blk_csr,

@@ -311,14 +311,24 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #endif
 
         // ---- phase 2 (this wavefront's rows only; LDS operations of a wavefront execute in order)
+#if defined(VICAN_WABLATE) && VICAN_WABLATE == 6      /* no fold, no y round trip through LDS (timing only: wrong results) */
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) {
+                const int j = lane + 64 * t;
+                if (j < nrows * 3) {
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; ++b3)
+                        wv[j * 3 + b3] = pre_scale<S>(dot3<double>(L[t][0], L[t][1], L[t][1], L[t][2], L[t][2], L[t][0]), z_scale);
+                }
+            }
+        }
+#else
         for (int i = lane; i < nrows * 9; i += 64) {
             const int oo = i % 9;
             long long s = 0;
-            for (int c = 0; c < ncopy; ++c) {
-                const int a = i * ncopy + ((c + oo) & cmask);
-                s += (long long)ys[a];
-                ys[a] = 0ull;
-            }
+            for (int c = 0; c < ncopy; ++c)          // read and clear in ONE LDS operation (ds_wrxchg_rtn_b64)
+                s += (long long)__hip_atomic_exchange(&ys[i * ncopy + ((c + oo) & cmask)], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const double y = (double)fix_total<S>(s) * y_inv;
             yv[i] = y;
             if (MODE != 0) lamT_out[(size_t)r0 * 9 + i] = y;        // Z_t for dual_svd_kernel (contiguous over the chunk)
@@ -336,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                 }
             }
         }
+#endif
         if (MODE == 3) {
             for (int r = lane; r < nrows; r += 64) {
                 double R[9];

@@ -259,7 +259,10 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             const int a = base + lane;
             const bool live = a < n3 * ncopy;
             u64 sum = 0ull, slo = 0ull;
-            if (live) { sum = qt[a]; slo = qt[lo_t + a]; qt[a] = 0ull; qt[lo_t + a] = 0ull; }
+            if (live) {                                          // read and clear in one LDS operation each (ds_wrxchg_rtn_b64)
+                sum = __hip_atomic_exchange(&qt[a], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                slo = __hip_atomic_exchange(&qt[lo_t + a], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
             if (live && (a & cmask) == 0) {
                 const int i = a / ncopy;

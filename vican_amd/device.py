@@ -157,6 +157,13 @@ class _Layout:
             self.wg_chunk_cap = per + max(2, -(-per // 8))
             self.rows_per_wg_sweep = max(self.rows_per_wg_max, min(n_time, self.wg_chunk_cap * self.max_rows), 1)
         self.chunk_row0 = torch.from_numpy(self.chunk_row0_host).to(dev)
+        # order of the edges inside a chunk (include/vican_hip.h: vican_graph_t.slot_order)
+        # bank-aware (conflict-free camera-side LDS accesses; needs >= 32 * epl edges per row before a lane holds a whole
+        # run of one row) or row-major (few row flushes).  Measured on MI355X (operator sweep, f32, ps per edge): rows of 8 / 16 /
+        # 32 / 64 / 128 / 250 edges - bank-aware 9.9 / 11.5 / 10.5 / 8.1 / 8.2 / 6.8, row-major 8.4 / 8.4 / 8.3 / 7.5 / 7.6 / 7.2
+        import os
+        so = os.environ.get("VICAN_SLOT_ORDER")
+        self.slot_order = {"banks": 0, "rows": 1}[so] if so else int(deg_avg < 48 * epl)
         self.nslot = max(1, self.n_chunk) * slots
         self.idx = torch.empty(self.nslot, dtype=torch.int32, device=dev)
 
@@ -171,7 +178,7 @@ class _Layout:
             self.stream_nt = int(os.environ["VICAN_TL_NT"])
         self.desc = _lib.Graph(n_cam, self.n_time, self.n_chunk, self.slots, self.max_rows, storage, self.block_threads,
                                self.n_wg, self.n_copy, self.wg_chunk_cap, _lib.LAYOUT_WAVE if self.kind == "wave" else _lib.LAYOUT_BLOCK,
-                               self.wg_waves, self.stream_nt, 0, None if blk is None else blk.data_ptr(), self.idx.data_ptr(),
+                               self.wg_waves, self.stream_nt, self.slot_order, None if blk is None else blk.data_ptr(), self.idx.data_ptr(),
                                self.chunk_row0.data_ptr())
         return self.desc
 
