@@ -62,27 +62,45 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype, merge)
 
 
-def sorted_codes(ids, prefix=""):
+def _packed_keys(a):
+    """ASCII strings of at most 8 characters as big-endian 64-bit integers (zero-padded: numeric order = string order, a
+    prefix sorts first), or None."""
+    width = a.dtype.itemsize // 4
+    if a.dtype.kind != "U" or not (0 < width <= 8) or a.ndim != 1 or not len(a):
+        return None
+    cp = np.ascontiguousarray(a).view(np.uint32).reshape(len(a), width)          # UCS-4 code points, zero-padded
+    if int(cp.max()) >= 128:
+        return None
+    buf = np.zeros((len(a), 8), dtype=np.uint8)
+    buf[:, :width] = cp                                         # one byte per character
+    return buf.view(">u8").ravel().astype(np.uint64)
+
+
+def _key_names(uk):
+    """The strings of packed keys, without a Python loop: the big-endian bytes of a key ARE its characters ('S8' drops the padding)."""
+    return uk.astype(">u8").view("S8").astype("U8")
+
+
+def sorted_codes(ids, prefix="", with_keys=False):
     """(sorted unique strings, index of every entry into them) - what ``np.unique(prefix + ids, return_inverse=True)``
     returns (bipgo.py:225-229: node order = string sort order), without sorting 80 000 UCS-4 strings by comparison: ASCII
-    ids of at most 8 characters are packed into big-endian 64-bit integers, whose numeric order IS their string order
-    (shorter strings are zero-padded, so a prefix sorts first), and sorted as integers.  A common prefix does not change
-    the order of the strings, only their spelling.  Anything else falls back to ``np.unique``."""
+    ids of at most 8 characters are packed into big-endian 64-bit integers, whose numeric order IS their string order, and
+    sorted as integers.  A common prefix does not change the order of the strings, only their spelling.  Anything else falls
+    back to ``np.unique``.  with_keys: also return the packed keys of the unique strings (None on the fallback path)."""
     a = np.asarray(ids)
     if a.dtype.kind != "U":
         a = a.astype(str)
-    width = a.dtype.itemsize // 4
-    if 0 < width <= 8 and a.ndim == 1 and len(a):
-        cp = np.ascontiguousarray(a).view(np.uint32).reshape(len(a), width)      # UCS-4 code points, zero-padded
-        if int(cp.max()) < 128:
-            keys = np.zeros(len(a), dtype=np.uint64)
-            for k in range(width):
-                keys |= cp[:, k].astype(np.uint64) << np.uint64(8 * (7 - k))
-            uk, inv = np.unique(keys, return_inverse=True)
-            names = np.array([prefix + int(v).to_bytes(8, "big").rstrip(b"\0").decode("ascii") for v in uk])
-            return names, inv.astype(np.int64)
-    names, inv = np.unique(np.char.add(prefix, a) if prefix else a, return_inverse=True)
-    return names, inv.astype(np.int64)
+    keys = _packed_keys(a)
+    if keys is not None:
+        uk, inv = np.unique(keys, return_inverse=True)
+        names = _key_names(uk)
+        if prefix:
+            names = np.char.add(prefix, names)
+    else:
+        uk = None
+        names, inv = np.unique(np.char.add(prefix, a) if prefix else a, return_inverse=True)
+    inv = inv.astype(np.int64)
+    return (names, inv, uk) if with_keys else (names, inv)
 
 
 class EdgeIndex:
@@ -111,10 +129,24 @@ def index_edges(cam_ids, time_ids, marker_ids, constraints) -> EdgeIndex:
         tau[i] = np.asarray((cm.inv() @ constraints[ix.root]).t(), dtype=np.float64)   # bipgo.py:452
     ix.qtau = np.einsum("mij,mj->mi", Q, tau)
     # bipgo.py:225-229 sorts 'c' + id / 't' + id: a common prefix changes the spelling, not the order
-    ix.cam_names, ix.ci = sorted_codes(cam_ids)
-    ix.time_names, ix.ti = sorted_codes(time_ids)
+    ix.cam_names, ix.ci, kc = sorted_codes(cam_ids, with_keys=True)
+    ix.time_names, ix.ti, kt = sorted_codes(time_ids, with_keys=True)
     # translation unknowns: cameras and "<t>_0" nodes in ONE string-sorted list (bipgo.py:426-430)
     t0 = np.char.add(ix.time_names, "_0")
+    if kc is not None and kt is not None:
+        # on the packed keys: "<t>_0" = the key of <t> with '_' and '0' in its next two bytes (needs len(t) <= 6)
+        ln = (kt.astype(">u8").view(np.uint8).reshape(-1, 8) != 0).sum(1).astype(np.uint64)
+        if int(ln.max()) <= 6:
+            k0 = kt | (np.uint64(ord("_")) << (np.uint64(8) * (np.uint64(7) - ln))) | (np.uint64(ord("0")) << (np.uint64(8) * (np.uint64(6) - ln)))
+            allk = np.concatenate([kc, k0])
+            order = np.argsort(allk, kind="stable")
+            sk = allk[order]
+            if not (sk[1:] == sk[:-1]).any():                       # (a camera called "<t>_0": the general path merges them)
+                pos = np.empty(len(allk), dtype=np.int64)
+                pos[order] = np.arange(len(allk), dtype=np.int64)
+                ix.tnodes = np.concatenate([ix.cam_names, t0])[order]
+                ix.tnode_of_cam, ix.tnode_of_time = pos[: len(kc)], pos[len(kc):]
+                return ix
     ix.tnodes = np.unique(np.concatenate([ix.cam_names, t0]))
     ix.tnode_of_cam = np.searchsorted(ix.tnodes, ix.cam_names).astype(np.int64)
     ix.tnode_of_time = np.searchsorted(ix.tnodes, t0).astype(np.int64)
