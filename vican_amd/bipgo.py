@@ -115,7 +115,9 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         if info is not None:                   # phase timings wanted: costs a pipeline bubble between the two stages
             K.synchronize()
         tm["t2"] = time.perf_counter()
-        Rt_all = gather_rows(Rt_loc, 9)
+        # (the rotations of all rows are needed before the translation stage only by the LSQR branch - |b|^2 of the un-merged
+        #  system on the host; otherwise they travel with the translations in ONE all-gather at the end)
+        Rt_all = gather_rows(Rt_loc, 9) if lsqr_solver == "direct" and not tight else None
         if tight:                                                            # not in the reference (module docstring)
             tr = TightTranslationSolver(K, comm)
             tr.setup(rc, Rt_loc)
@@ -133,13 +135,17 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
             x_c, x_t = tr.solve(3 * (prob.n_cam + T))
             if not tr.info["converged"] and not K.barrier_aborted():
                 raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
-        return rot, tr, rc, Rt_all, x_c, x_t
+        return rot, tr, rc, Rt_all, Rt_loc, x_c, x_t
 
     # (a cooperative kernel whose grid barrier timed out - device shared - makes the stages run again on the launch sequences)
-    rot, tr, rc, Rt_all, x_c, x_t = with_cooperative_fallback(K, comm, stages)
+    rot, tr, rc, Rt_all, Rt_loc, x_c, x_t = with_cooperative_fallback(K, comm, stages)
     t2 = tm["t2"]
     t3 = time.perf_counter()
-    xt_all = gather_rows(x_t, 3)
+    if Rt_all is None:
+        both = gather_rows(torch.cat([Rt_loc.reshape(-1, 9)[:max(nloc, 1)], x_t.reshape(-1, 3)[:max(nloc, 1)]], 1), 12)
+        Rt_all, xt_all = both[:, :9].contiguous(), both[:, 9:].contiguous()
+    else:
+        xt_all = gather_rows(x_t, 3)
     Rc = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()          # bipgo.py:346
     Rt = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()                # bipgo.py:348
     if info is not None:
