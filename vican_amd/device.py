@@ -226,8 +226,15 @@ class LocalGraph:
                 rot = mk("wave", n_wg=n_wg, n_copy=n_copy, wg_waves=wg_waves)
             except _lib.VicanError:
                 rot = None
-            if rot is not None and layout is None and rot.nslot > 1.06 * max(self.n_edges, 1) + 64 * epl * 8:
-                rot = None                                   # rows pack badly into 64-lane chunks: the block layout pads less
+            # (capture-sized graphs are latency-bound, padding costs them nothing, and only the wave layout has the resident
+            #  CG kernel: ragged rows of 2-5 edges - what real captures look like - pad a 64-row chunk by 15 % and stay here)
+            if rot is not None and layout is None and self.n_edges >= 2_000_000 and rot.nslot > 1.06 * max(self.n_edges, 1) + 64 * epl * 8:
+                # rows pack badly into 64-lane chunks (very short rows: a chunk holds at most 64 of them; rows of ~200 edges: one
+                # per chunk): the block layout is taken where it pads LESS - with rows of 1-4 edges its chunks are limited by
+                # their row count too and it pads more (measured: 2.07x against 1.6x)
+                alt = mk("block", block_threads=block_threads, n_wg=n_wg, n_copy=n_copy)
+                if alt.nslot < rot.nslot:
+                    rot = alt
         if rot is None:
             if layout == "wave":
                 raise _lib.VicanError("the wave layout needs rows of at most %d edges and C <= 1024" % (64 * epl))
