@@ -160,14 +160,22 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
 
 
 def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
-    rot, pos = {}, {}
-    for i, c in enumerate(prob.cam_names):
-        rot[c], pos[c] = Rc[i], pc[i]
-    for i, s in enumerate(prob.time_names):
-        rot[s + "_0"], pos[s + "_0"] = Rt[i], pt[i]
+    """{node id: SE3(R in `dtype`, t float64)} in the reference's sorted node order (bipgo.py:485-487).  Ten thousand nodes:
+    the arrays are scattered into node order at once and the SE3 objects are filled attribute by attribute (same contents as
+    ``SE3(R=..., t=...)``: R and t as given, a float32 4x4 beside them) - one constructor call per node took 4 us."""
+    n = len(prob.tnodes)
+    R = np.empty((n, 3, 3), dtype=dtype)
+    t = np.empty((n, 3), dtype=np.float64)
+    R[prob.tnode_of_cam], t[prob.tnode_of_cam] = Rc, pc
+    R[prob.tnode_of_time], t[prob.tnode_of_time] = Rt, pt
+    pose = np.zeros((n, 4, 4), dtype=np.float32)
+    pose[:, :3, :3], pose[:, :3, 3], pose[:, 3, 3] = R, t, 1.0
     out = {}
-    for n in prob.tnodes:                                               # bipgo.py:485-487 (sorted node order)
-        out[n] = SE3(R=np.ascontiguousarray(rot[n]).astype(dtype), t=pos[n].copy())
+    new = SE3.__new__
+    for i, name in enumerate(prob.tnodes.tolist()):
+        s = new(SE3)
+        s._R, s._t, s._pose = R[i], t[i], pose[i]
+        out[name] = s
     return out
 
 

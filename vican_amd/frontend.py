@@ -47,18 +47,20 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     stores the incidence matrix in ``dtype`` but the measurements in float64,
     bipgo.py:434-439).
     """
-    cams, times, marks, poses, kr, kt = [], [], [], [], [], []
+    cams, times, marks, Rs, ts_, kr, kt = [], [], [], [], [], [], []
+    add_c, add_t, add_m, add_R, add_p, add_kr, add_kt = cams.append, times.append, marks.append, Rs.append, ts_.append, kr.append, kt.append
     for key, val in src_edges.items():                             # the only per-edge Python loop
         if not edge_filter(val):
             continue
         ts, mid = key[1].split("_")
-        cams.append(key[0]); times.append(ts); marks.append(mid)
-        poses.append(val["pose"])
-        kr.append(noise_model_r(val)); kt.append(noise_model_t(val))
+        add_c(key[0]); add_t(ts); add_m(mid)
+        pose = val["pose"]
+        add_R(pose.R()); add_p(pose.t())
+        add_kr(noise_model_r(val)); add_kt(noise_model_t(val))
     if len(cams) == 0:
         raise ValueError("no edge passes edge_filter")
-    R = _stack_f64([p.R() for p in poses], (3, 3))
-    t = _stack_f64([p.t() for p in poses], (3,))
+    R = _stack_f64(Rs, (3, 3))
+    t = _stack_f64(ts_, (3,))
     return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype, merge)
 
 
