@@ -70,7 +70,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                   group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
-    from .device import TILE_CAMS, make_backend      # needs the GPU + extension
+    from .device import TILE_CAMS, make_backend, upload      # needs the GPU + extension
 
     if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
@@ -89,17 +89,24 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     e0, e1 = int(rp_h[r0]), int(rp_h[r1])
     t0 = time.perf_counter()
 
-    def to(a, dt=torch.float64):          # host arrays of merge_host, or device tensors of device.merge_edges
-        return a.to(dev, dt) if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
-    # diagonal of the reference's J^T J as scipy forms it (frontend.merge_host); the camera part is all-reduced by the
-    # solver, so rank 0 carries it and the other ranks contribute zeros
-    deg_t = to(prob.deg_t[r0:r1]) if getattr(prob, "deg_t", None) is not None else None
-    deg_c = None
-    if getattr(prob, "deg_c", None) is not None:
-        deg_c = to(prob.deg_c) if comm.rank == 0 else torch.zeros(prob.n_cam, dtype=torch.float64, device=dev)
-    g, K = make_backend(prob.n_cam, to(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), to(prob.col[e0:e1], torch.int32),
-                        to(prob.blk[e0:e1], tdt), to(prob.a[e0:e1], tdt), to(prob.w[e0:e1]), to(prob.u[e0:e1]), to(prob.v[e0:e1]),
-                        deg_t=deg_t, deg_c=deg_c)
+    # this rank's rows of the problem: host arrays of merge_host (ONE upload through page-locked staging, device.upload) or
+    # device tensors of device.merge_edges.  The diagonal of the reference's J^T J as scipy forms it (frontend.merge_host)
+    # comes along; its camera part is all-reduced by the solver, so rank 0 carries it and the other ranks contribute zeros
+    f64 = torch.float64
+    parts = [(prob.row_ptr[r0:r1 + 1] - prob.row_ptr[r0], torch.int32), (prob.col[e0:e1], torch.int32), (prob.blk[e0:e1], tdt),
+             (prob.a[e0:e1], tdt), (prob.w[e0:e1], f64), (prob.u[e0:e1], f64), (prob.v[e0:e1], f64)]
+    have_deg = getattr(prob, "deg_t", None) is not None and getattr(prob, "deg_c", None) is not None
+    if have_deg:
+        parts += [(prob.deg_t[r0:r1], f64), (prob.deg_c, f64)]
+    if any(torch.is_tensor(a) for a, _ in parts):
+        parts = [a.to(dev, dt) if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt) for a, dt in parts]
+    else:
+        parts = upload(dev, parts)
+    deg_t = deg_c = None
+    if have_deg:
+        deg_t = parts[7]
+        deg_c = parts[8] if comm.rank == 0 else torch.zeros(prob.n_cam, dtype=f64, device=dev)
+    g, K = make_backend(prob.n_cam, *parts[:7], deg_t=deg_t, deg_c=deg_c)
     t1 = time.perf_counter()
     nloc = r1 - r0
     bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]
@@ -243,7 +250,7 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
     ArithmeticError is raised when the dual iterate makes the connection Laplacian strongly indefinite - the
     reference's shift-invert ``eigs(sigma=-1e-6)`` then returns INTERIOR eigenvectors (and a meaningless answer),
     which the matrix-free eigen-solver does not reproduce."""
-    from .device import HipBackend, LocalGraph
+    from .device import HipBackend, LocalGraph, upload
 
     if not torch.cuda.is_available():
         raise VicanError("no GPU visible: vican_amd has no CPU fallback")
@@ -257,9 +264,8 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
         raise UnboundLocalError("local variable 'r' referenced before assignment")      # bipgo.py:139
     dev = torch.device("cuda", torch.cuda.current_device())
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
-    to = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
     # (the one-pass operator of the non-eliminated variant - sweep MODE 2 - exists for the block layout)
-    g = LocalGraph(prob.n_cam, to(prob.row_ptr, torch.int32), to(prob.col, torch.int32), to(prob.blk, tdt), to(prob.a, tdt), layout="block")
+    g = LocalGraph(prob.n_cam, *upload(dev, [(prob.row_ptr, torch.int32), (prob.col, torch.int32), (prob.blk, tdt), (prob.a, tdt)]), layout="block")
     K = HipBackend(g)
     t1 = time.perf_counter()
     rot = GeneralRotationSolver(K, Comm.single(), eig_tol=eig_tol)

@@ -37,6 +37,49 @@ def n_cu():
 _ABORT = None
 
 
+_NP_OF = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
+_STAGE = {"buf": None, "event": None}
+
+
+def upload(dev, items):
+    """Host arrays -> device tensors through ONE page-locked staging buffer and ONE copy: ``items`` = [(array, torch dtype)],
+    returns the tensors (typed views of one device allocation, 256-byte aligned).  Conversions happen on the host in NumPy.
+    Why not ``torch.from_numpy(a).to(dev)`` per array: a pageable host-to-device copy of ~1 MB now and then takes 70-100 ms
+    on this platform (about one cold drop-in call in three: tools/dbg/upload2.py), a copy from page-locked memory never; the
+    staging buffer is allocated once per process and reused (an event guards it against the copy still in flight)."""
+    offs, total = [], 0
+    arrs = []
+    for a, dt in items:
+        a = np.asarray(a)
+        arrs.append(a)
+        offs.append(total)
+        total += (a.size * np.dtype(_NP_OF[dt]).itemsize + 255) // 256 * 256
+    total = max(total, 256)
+    st = _STAGE
+    if st["buf"] is None or st["buf"].numel() < total:
+        st["buf"] = torch.empty(int(total * 1.5) + 4096, dtype=torch.uint8).pin_memory()
+        st["event"] = None
+    if st["event"] is not None:
+        st["event"].synchronize()
+    host = st["buf"].numpy()
+    for a, (_, dt), o in zip(arrs, items, offs):
+        if a.size:
+            np.copyto(host[o:o + a.size * np.dtype(_NP_OF[dt]).itemsize].view(_NP_OF[dt]).reshape(a.shape), a, casting="unsafe")
+    d = torch.empty(total, dtype=torch.uint8, device=dev)
+    d.copy_(st["buf"][:total], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st["event"] = ev
+    out = []
+    for a, (_, dt), o in zip(arrs, items, offs):
+        nb = a.size * np.dtype(_NP_OF[dt]).itemsize
+        out.append(d[o:o + nb].view(dt).view(a.shape) if a.size else torch.empty(a.shape, dtype=dt, device=dev))
+    return out
+
+
+_STATUS_POOL = {}          # (device, doubles) -> free (pinned buffer, copy-done event, ready event, side stream) slots, see post_status
+
+
 def barrier_abort_word(timeout_us=None):
     """The process-wide abort word (a pinned int32 tensor); registers it with the library on first use.
     timeout_us: spin limit of every grid barrier (default VICAN_BARRIER_TIMEOUT_US or 2 s)."""
@@ -385,6 +428,15 @@ class HipBackend:
         """Page-locked host buffer for small asynchronous device<->host copies."""
         return torch.zeros(*shape, dtype=torch.float64, pin_memory=True)
 
+    def __del__(self):
+        try:                                        # status slots back to the pool (post_status)
+            for n, slot in getattr(self, "_status_host", {}).items():
+                slot[1].synchronize()
+                _STATUS_POOL.setdefault((str(self.dev), n), []).append(slot)
+            self._status_host = {}
+        except Exception:                           # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def synchronize(self):
         torch.cuda.current_stream().synchronize()
 
@@ -659,8 +711,11 @@ class HipBackend:
         """Asynchronous device->host copy of a small status vector; returns a handle for wait_status."""
         host = self._status_host.get(status.numel())
         if host is None:
-            host = self._status_host[status.numel()] = (self.pinned(status.numel()), torch.cuda.Event(), torch.cuda.Event(),
-                                                        torch.cuda.Stream())
+            # (page-locked buffer + side stream + events come from a process-wide pool and go back to it with the backend: a
+            #  one-shot drop-in call builds a fresh backend, and creating these cost it 1.3 ms of idle GPU in its first check)
+            free = _STATUS_POOL.setdefault((str(self.dev), status.numel()), [])
+            host = self._status_host[status.numel()] = free.pop() if (free and not os.environ.get("VICAN_NO_STATUS_POOL")) else (
+                self.pinned(status.numel()), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Stream())
         # the copy runs on a side stream: in the launch stream it would sit between the Ritz kernel and the
         # speculative continuation and cost ~20 us of copy-engine latency per primal-dual iteration
         buf, done, ready, side = host
@@ -1110,13 +1165,12 @@ def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
         raise _lib.VicanError("vican_amd needs a GPU (MI355X); there is no CPU fallback")
     dev = device or torch.device("cuda", torch.cuda.current_device())
     n, C_, T_ = int(ix.n), len(ix.cam_names), len(ix.time_names)
-    f64 = lambda x, shape: torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(shape))).to(dev, non_blocking=True)
-    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.int32))).to(dev, non_blocking=True)
     t_h = np.asarray(t, dtype=np.float64).reshape(n, 3)
     kt_h = np.asarray(k_t, dtype=np.float64)
-    cam, tim, mk = i32(ix.ci), i32(ix.ti), i32(ix.mi)
-    Rd, td, krd, ktd = f64(R, (n, 9)), f64(t_h, (n, 3)), f64(k_r, (n,)), f64(kt_h, (n,))
-    CmT, qtau = f64(ix.CmT, (-1, 9)), f64(ix.qtau, (-1, 3))
+    f64, i32 = torch.float64, torch.int32
+    cam, tim, mk, Rd, td, krd, ktd, CmT, qtau = upload(dev, [
+        (ix.ci, i32), (ix.ti, i32), (ix.mi, i32), (np.asarray(R).reshape(n, 9), f64), (t_h, f64), (np.asarray(k_r).reshape(n), f64),
+        (kt_h, f64), (np.asarray(ix.CmT).reshape(-1, 9), f64), (np.asarray(ix.qtau).reshape(-1, 3), f64)])
     wsb = int(lib.vican_merge_ws_bytes(n, C_, T_))
     if wsb < 0:
         raise _lib.VicanError("vican_merge_ws_bytes failed")
