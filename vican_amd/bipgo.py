@@ -70,7 +70,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                   group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
-    from .device import TILE_CAMS, make_backend, upload      # needs the GPU + extension
+    from .device import TILE_CAMS, download, make_backend, upload      # needs the GPU + extension
 
     if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
@@ -153,8 +153,8 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         Rt_all, xt_all = both[:, :9].contiguous(), both[:, 9:].contiguous()
     else:
         xt_all = gather_rows(x_t, 3)
-    Rc = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).cpu().numpy()          # bipgo.py:346
-    Rt = Rt_all.reshape(T, 3, 3).transpose(1, 2).cpu().numpy()                # bipgo.py:348
+    Rc, Rt, xc_h, xt_h = download([rc.reshape(prob.n_cam, 3, 3).transpose(1, 2),          # bipgo.py:346
+                                   Rt_all.reshape(T, 3, 3).transpose(1, 2), x_c, xt_all])  # bipgo.py:348
     if info is not None:
         info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
                     eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
@@ -163,7 +163,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                     lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T,
                     n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=getattr(g, "n_chunk", None), n_wg=getattr(g, "n_wg", None), layout=g.layout,
                     t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world)
-    return Rc, Rt, x_c.cpu().numpy(), xt_all.cpu().numpy()
+    return Rc, Rt, xc_h, xt_h
 
 
 def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
