@@ -106,7 +106,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     if have_deg:
         deg_t = parts[7]
         deg_c = parts[8] if comm.rank == 0 else torch.zeros(prob.n_cam, dtype=f64, device=dev)
-    g, K = make_backend(prob.n_cam, *parts[:7], deg_t=deg_t, deg_c=deg_c)
+    g, K = make_backend(prob.n_cam, *parts[:7], deg_t=deg_t, deg_c=deg_c, row_ptr_host=np.asarray(rp_h[r0:r1 + 1]) - int(rp_h[r0]))
     t1 = time.perf_counter()
     nloc = r1 - r0
     bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]

@@ -266,7 +266,7 @@ class LocalGraph:
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None):
+                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None, row_ptr_host=None):
         import os
         lib = _lib.load()
         if not torch.cuda.is_available():
@@ -281,7 +281,9 @@ class LocalGraph:
         epl = 4 if storage == _lib.STORE_F32 else 2
         if self.n_cam > 65535:
             raise _lib.VicanError("more than 65535 cameras are not supported by the packed edge index")
-        rp_host = row_ptr.to("cpu", torch.int32).contiguous()
+        # (row_ptr_host: the caller's host copy of row_ptr, if it has one - saves a device->host read)
+        rp_host = (torch.from_numpy(np.ascontiguousarray(row_ptr_host, dtype=np.int32)) if row_ptr_host is not None
+                   else row_ptr.to("cpu", torch.int32).contiguous())
         deg = (rp_host[1:] - rp_host[:-1]) if self.n_time else torch.zeros(1, dtype=torch.int32)
         deg_max, deg_avg = int(deg.max()), max(1.0, float(deg.float().mean()))
         layout = layout or os.environ.get("VICAN_LAYOUT") or None
@@ -357,17 +359,24 @@ class LocalGraph:
         self.row_sum_a, self.cam_sum_a = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
         self.rnorm, self.fx = torch.zeros(T1, **f64), torch.zeros(_lib.FX_DOUBLES, **f64)
         cam_ws = torch.empty(self.n_cam, dtype=torch.int64, device=dev)
-        amax_a = float(a.abs().max()) if self.n_edges else 1.0
+        # the three host scalars of the graph constants in ONE device->host read (max |a|; max w and max (|u| + |v|): the bounds
+        # that size the fixed-point scales of the translation stage)
+        amax_a, self.wmax, self.gmax = 1.0, 1.0, 1.0
+        if self.n_edges:
+            sc = [a.abs().max().to(torch.float64)]
+            if have_t:
+                sc += [w.max(), (u.norm(dim=1) + v.norm(dim=1)).max()]
+            sc = torch.stack(sc).tolist()
+            amax_a = float(sc[0])
+            if have_t:
+                self.wmax, self.gmax = float(sc[1]), float(sc[2])
         _lib.check(lib.vican_edge_sums(gref, _ptr(self.a), int(storage == _lib.STORE_F64), amax_a, _ptr(self.row_sum_a),
                                        _ptr(self.cam_sum_a), _ptr(cam_ws), st), "vican_edge_sums")
         _lib.check(lib.vican_block_norms(gref, _ptr(self.rnorm), _ptr(self.fx), st), "vican_block_norms")
         if have_t:
             self.row_sum_w, self.cam_sum_w = torch.zeros(T1, **f64), torch.zeros(self.n_cam, **f64)
-            # bounds that size the fixed-point scales of the translation stage (host scalars, once)
-            self.wmax = float(w.max()) if self.n_edges else 1.0
             _lib.check(lib.vican_edge_sums(gref_t, _ptr(self.w), 1, self.wmax, _ptr(self.row_sum_w), _ptr(self.cam_sum_w),
                                            _ptr(cam_ws), st), "vican_edge_sums")
-            self.gmax = float((u.norm(dim=1) + v.norm(dim=1)).max()) if self.n_edges else 1.0
             # diagonal of the translation system when the caller knows it better than "sum of the weights": the front-end
             # passes the reference's own J^T J diagonal (float32-accumulated for dtype=float32, frontend.flatten_arrays);
             # deg_c is this RANK's share (the solver all-reduces it: rank 0 carries the vector, the others zeros)
@@ -1220,7 +1229,7 @@ def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
     return p
 
 
-def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None, deg_c=None):
+def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None, deg_c=None, row_ptr_host=None):
     """(graph, backend) for one rank's rows: the fused layouts up to TILE_CAMS cameras, camera tiles beyond.
     deg_t / deg_c: diagonal of the translation system for this rank's rows / this rank's share of the camera diagonal
     (default: sums of w)."""
@@ -1229,5 +1238,5 @@ def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None
     if n_cam > tile:
         g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c)
         return g, TiledBackend(g)
-    g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v, deg_t=deg_t, deg_c=deg_c)
+    g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v, deg_t=deg_t, deg_c=deg_c, row_ptr_host=row_ptr_host)
     return g, HipBackend(g)
