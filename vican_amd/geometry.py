@@ -53,11 +53,13 @@ class SE3:
     # algebra -------------------------------------------------------------
     def inv(self) -> "SE3":
         rt = self._R.T
-        m = np.zeros_like(self._pose)
+        m = np.zeros((4, 4), dtype=np.float32)      # (= zeros_like(_pose): the 4x4 is always float32)
         m[:3, :3] = rt
         m[:3, 3] = -(rt @ self._t)
         m[3, 3] = 1
-        return SE3(pose=m)
+        out = SE3.__new__(SE3)                      # = SE3(pose=m) without its float32 copy of an array that is float32 already
+        out._pose, out._R, out._t = m, m[:3, :3], m[:3, 3]
+        return out
 
     def __matmul__(self, other: "SE3") -> "SE3":
         return SE3(pose=self._pose @ other._pose)
