@@ -748,7 +748,7 @@ class HipBackend:
             # (page-locked buffer + side stream + events come from a process-wide pool and go back to it with the backend: a
             #  one-shot drop-in call builds a fresh backend, and creating these cost it 1.3 ms of idle GPU in its first check)
             free = _STATUS_POOL.setdefault((str(self.dev), status.numel()), [])
-            host = self._status_host[status.numel()] = free.pop() if (free and not os.environ.get("VICAN_NO_STATUS_POOL")) else (
+            host = self._status_host[status.numel()] = free.pop() if free else (
                 self.pinned(status.numel()), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Stream())
         # the copy runs on a side stream: in the launch stream it would sit between the Ritz kernel and the
         # speculative continuation and cost ~20 us of copy-engine latency per primal-dual iteration
