@@ -18,3 +18,6 @@ done
 } 2>&1 | grep -v amdgpu > $O/translation_kernels.txt
 hipcc --offload-arch=gfx950 -O3 tools/stride_read_bench.hip -o /tmp/srb > /dev/null 2>&1 && /tmp/srb > $O/stride_read_bench.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/lds_atomic_bench.hip -o /tmp/ldsb > /dev/null 2>&1 && /tmp/ldsb > $O/lds_atomic_bench.txt 2>&1
+timeout 600 python tools/api_time.py --oracle 2>&1 | grep -v "amdgpu\|Warn" > $O/api_time.txt
+python tools/cold_trace.py 24 2>&1 | grep "^call" > $O/cold_calls.txt
+timeout 300 python tools/ragged_solve.py 2>&1 | grep -v "amdgpu\|Warn" > $O/ragged_solve.txt
