@@ -10,7 +10,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from vican_amd import synth                                     # noqa: E402
 from vican_amd.device import HipBackend, LocalGraph             # noqa: E402
+
+
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cams", type=int, default=100)
@@ -21,26 +24,15 @@ ap.add_argument("--reps", type=int, default=40)
 args = ap.parse_args()
 C, T, lo, hi = args.cams, args.timesteps, args.lo, args.hi
 dev = torch.device("cuda:0")
-g = torch.Generator(device=dev); g.manual_seed(0)
-deg = torch.randint(lo, hi + 1, (T,), generator=g, device=dev)
-idx = torch.rand(T, C, generator=g, device=dev).topk(hi, dim=1).indices                    # hi distinct random cameras per row
-idx = torch.where(torch.arange(hi, device=dev)[None, :] < deg[:, None], idx, torch.full_like(idx, C)).sort(1).values
-col = idx[idx < C].to(torch.int32)
-row_ptr = torch.zeros(T + 1, dtype=torch.int32, device=dev); row_ptr[1:] = deg.cumsum(0)
+row_ptr, col, blk, a32 = synth.make_ragged_graph_torch(C, T, lo, hi, dev)
 E = int(col.numel())
-q = torch.randn(E, 4, generator=g, device=dev, dtype=torch.float64); q = q / q.norm(dim=1, keepdim=True)
-w, x, y, z = q.unbind(1)
-R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
-                 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
-a = torch.rand(E, generator=g, device=dev, dtype=torch.float64) + 0.5
-blk = (R * a[:, None]).to(torch.float32)
 xq = torch.linalg.qr(torch.randn(3 * C, 3, dtype=torch.float64, device=dev))[0].contiguous()
 for so in ("banks", "rows", None):
     if so is None:
         os.environ.pop("VICAN_SLOT_ORDER", None)
     else:
         os.environ["VICAN_SLOT_ORDER"] = so
-    gr = LocalGraph(C, row_ptr, col, blk, a.to(torch.float32))
+    gr = LocalGraph(C, row_ptr, col, blk, a32)
     H = HipBackend(gr)
     lam, dg, zz = H.empty(T, 9), H.empty(C), H.empty(3 * C, 3)
     H.init_duals(lam, dg)

@@ -20,13 +20,19 @@ ap.add_argument("--timesteps", type=int, default=100000)
 ap.add_argument("--cpt", type=int, default=250)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--stamp", action="store_true")
+ap.add_argument("--ragged", default=None, help="lo:hi - every timestep is seen by a uniformly random number of cameras in [lo, hi] (f32)")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("variants", nargs="*", default=["wave", "block"])
 args = ap.parse_args()
 C, T, K = args.cams, args.timesteps, args.cpt
 dev = torch.device("cuda:0")
 tdt = torch.float32 if args.dtype == "f32" else torch.float64
-d = synth.make_merged_graph_torch(C, T, K, dev, tdt, seed=0)
+if args.ragged:
+    lo_, hi_ = (int(v) for v in args.ragged.split(":"))
+    rp_, col_, blk_, a_ = synth.make_ragged_graph_torch(C, T, lo_, hi_, dev)
+    d = dict(row_ptr=rp_, col=col_, blk=blk_.to(tdt), a=a_.to(tdt))
+else:
+    d = synth.make_merged_graph_torch(C, T, K, dev, tdt, seed=0)
 x = torch.linalg.qr(torch.randn(3 * C, 3, dtype=torch.float64, device=dev))[0].contiguous()
 for var in args.variants:
     f = var.split(":")

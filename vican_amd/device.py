@@ -161,6 +161,15 @@ class _Layout:
             fits = lambda rows, nc, nw: int(lib.vican_wsweep_lds_bytes(n_cam, rows, storage, nc, nw)) <= lim
             while not fits(rows_target, n_copy, wg_waves) and n_copy > 1:
                 n_copy //= 2
+            if not fits(rows_target, n_copy, wg_waves):
+                # before giving up wavefronts (occupancy): a row limit without the 25 % margin, if the chunks still fill their
+                # slots with it (ragged rows of 2-8 edges: 62 rows instead of 64 keep 12 wavefronts resident instead of 8;
+                # worth 1.5 % there - that sweep is bound by the LDS work per row, not by occupancy: tools/ragged_time.py)
+                r = rows_target
+                while r > 1 and not fits(r, n_copy, wg_waves):
+                    r -= 1
+                if fits(r, n_copy, wg_waves) and r * deg_avg >= 1.05 * slots:
+                    rows_target = r
             while not fits(rows_target, n_copy, wg_waves) and wg_waves > 4:
                 wg_waves -= 4
             while not fits(rows_target, n_copy, wg_waves) and rows_target > 1:

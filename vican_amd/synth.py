@@ -302,3 +302,21 @@ def make_merged_graph_torch(n_cam: int, n_time: int, cams_per_t: int, device,
         "R_cam": R_cam, "p_cam": p_cam, "R_obj": R_obj, "p_obj": p_obj,
         "n_cam": C, "n_time": T,
     }
+
+
+def make_ragged_graph_torch(C, T, lo, hi, dev, seed=0):
+    """(row_ptr, col, blk f32, a f32) of a graph whose timestep t is seen by a uniformly random number of cameras in [lo, hi]."""
+    import torch
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    deg = torch.randint(lo, hi + 1, (T,), generator=g, device=dev)
+    idx = torch.rand(T, C, generator=g, device=dev).topk(hi, dim=1).indices                    # hi distinct random cameras per row
+    idx = torch.where(torch.arange(hi, device=dev)[None, :] < deg[:, None], idx, torch.full_like(idx, C)).sort(1).values
+    col = idx[idx < C].to(torch.int32)
+    row_ptr = torch.zeros(T + 1, dtype=torch.int32, device=dev); row_ptr[1:] = deg.cumsum(0)
+    E = int(col.numel())
+    q = torch.randn(E, 4, generator=g, device=dev, dtype=torch.float64); q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
+    a = torch.rand(E, generator=g, device=dev, dtype=torch.float64) + 0.5
+    return row_ptr, col, (R * a[:, None]).to(torch.float32), a.to(torch.float32)
