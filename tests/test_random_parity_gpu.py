@@ -71,6 +71,11 @@ def test_random_scene_matches_oracle(seed):
     nr, nt, ff = gc.CALLABLES[wr], gc.CALLABLES[wt], gc.CALLABLES[filt]
     info, oinfo = {}, {}
     from util import SelfMovement
+
+    def rotations_agree(ref):
+        Rp = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res])
+        Rq = np.stack([np.asarray(ref[k].R(), dtype=np.float64) for k in ref])
+        return float(geodesic(Rp, Rq).max()) < (1e-7 if dt == np.float64 else 5e-6)
     with SelfMovement(orc) as sm:       # the oracle's cg call + 8 repeats on right-hand sides perturbed by one unit in the last place
         if mode == "camera":
             cons = synth.constraints_from_scene(scene, SE3)
@@ -95,6 +100,14 @@ def test_random_scene_matches_oracle(seed):
             res = object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, info=info)
             ref = orc.object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=True, info=oinfo)
     assert [str(k) for k in res] == [str(k) for k in ref]
+    if not rotations_agree(ref):
+        # the reference's eigs call starts ARPACK from a random vector and goes astray about once in a thousand runs (rotations
+        # 1e-4 rad off, fine on the next run of the same input: tools/dbg/seed_repeat.py): one more oracle run
+        with SelfMovement(orc) as sm:
+            if mode == "camera":
+                ref = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=True, info=oinfo)
+            else:
+                ref = orc.object_bipartite_se3sync(src, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=True, info=oinfo)
     R = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res])
     Rr = np.stack([np.asarray(ref[k].R(), dtype=np.float64) for k in ref])
     t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in res])
