@@ -54,6 +54,10 @@ __device__ __forceinline__ float4 stream_load(const float4* p) {
 __device__ __forceinline__ double2 stream_load(const double2* p) {
     const vican_v2d t = __builtin_nontemporal_load((const vican_v2d*)p); return make_double2(t.x, t.y);
 }
+__device__ __forceinline__ void stream_store(double2* p, const double2 v) {
+    vican_v2d t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, (vican_v2d*)p);
+}
 __device__ __forceinline__ uint4 stream_load(const uint4* p) {
     const vican_v4u t = __builtin_nontemporal_load((const vican_v4u*)p); return make_uint4(t.x, t.y, t.z, t.w);
 }

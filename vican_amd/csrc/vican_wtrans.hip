@@ -603,6 +603,9 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
     const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
     const int kmax = g.n_chunk - 1;
     if (tid == 0) s_ticket = c0 + 3 * NW;
+    // the edge vector u~ (24 B per edge, read AND written every step): streamed past the caches when the graph's streams are
+    // (a vector of more than the 256 MB Infinity Cache cannot be found there again a step later; it only evicts what could)
+    const bool nt_u = g.stream_nt != 0;
 
     auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
     auto load_edges = [&](LsqrWRegs<EPL>& e, int k) {
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
 #pragma unroll
             for (int j = 0; j < EPL; j += 2) {
                 const double* a = u + ((size_t)k * 3 + p) * g.slots + wpos8<EPL>(lane, j);
-                const double2 t = *(const double2*)a;          // (plain load: the stream is written back and re-read next step)
+                const double2 t = nt_u ? stream_load((const double2*)a) : *(const double2*)a;
                 e.u[p][j] = t.x; e.u[p][j + 1] = t.y;
             }
     };
@@ -693,7 +696,8 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < EPL; j += 2)
-                *(double2*)(u + ((size_t)kcur * 3 + p) * g.slots + wpos8<EPL>(lane, j)) = make_double2(un[p][j], un[p][j + 1]);
+                if (nt_u) stream_store((double2*)(u + ((size_t)kcur * 3 + p) * g.slots + wpos8<EPL>(lane, j)), make_double2(un[p][j], un[p][j + 1]));
+                else *(double2*)(u + ((size_t)kcur * 3 + p) * g.slots + wpos8<EPL>(lane, j)) = make_double2(un[p][j], un[p][j + 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
