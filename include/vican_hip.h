@@ -619,7 +619,8 @@ int vican_lsqr_scalars(int32_t n_cam, const double* acc, const double* part2, in
                        const double* wpart_t, int32_t n_wt, const double* wpart_c, int32_t n_wc, const double* wsum_t,
                        vican_lsqr_state_t* st, void* stream);
 /* vican_lsqr_update with the coefficients of the state; runs iff state.update (set by vican_lsqr_scalars: scipy updates x
- * before it tests), `last` != 0 clears that flag behind the kernel; returns the number of |w|^2 partials written to part.  */
+ * before it tests; cleared by the first vican_lsqr_scalars call after `done`), `last` is ignored (kept for callers of ABI 11);
+ * returns the number of |w|^2 partials written to part.  */
 int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* part, int32_t last, vican_lsqr_state_t* st,
                          void* stream);
 

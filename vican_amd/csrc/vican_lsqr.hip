@@ -587,7 +587,10 @@ __global__ __launch_bounds__(256) void lsqr_scalars_kernel(const double* __restr
                                                            const double* __restrict__ wpart_c, int n_wc, const double* __restrict__ wsum_t,
                                                            vican_lsqr_state_t* st) {
     __shared__ double red[8];
-    if (st->done) return;
+    if (st->done) {                                        // (the update of the iteration that raised `done` has run: no more updates)
+        if (threadIdx.x == 0) st->update = 0;
+        return;
+    }
     double a = 0.0, b = 0.0;
     if (!tsum) for (int i = threadIdx.x; i < n_part; i += 256) a += part2[i];
     if (!wsum_t) for (int i = threadIdx.x; i < n_wt; i += 256) b += wpart_t[i];
@@ -658,7 +661,6 @@ __global__ __launch_bounds__(256) void lsqr_update_st_kernel(long long n, double
     const double t = block_sum(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-__global__ void lsqr_clear_update_kernel(vican_lsqr_state_t* st) { st->update = 0; }
 
 extern "C" int vican_lsqr_step(const vican_graph_t* g, const double* sw, double* u, const double* v_c, const double* v_t, double* z_t,
                                void* zc_part, double* part, double* acc, const vican_lsqr_state_t* state, void* stream) {
@@ -710,7 +712,7 @@ extern "C" int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, 
     int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > LSQR_PARTS) nb = LSQR_PARTS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(lsqr_update_st_kernel, dim3(nb), dim3(256), 0, s, (long long)n, v, w, x, part, st);
-    if (last) hipLaunchKernelGGL(lsqr_clear_update_kernel, dim3(1), dim3(1), 0, s, st);
+    (void)last;          // (the flag is cleared by the next vican_lsqr_scalars call once `done` is up: no extra launch)
     LAUNCH_CHECK("vican_lsqr_update_st");
     return nb;
 }
