@@ -53,10 +53,37 @@ def _eigs(*a, **k):
 def _cg(A, b, *a, **k):
     n = [0]
 
+    keep = _rec.get("keep_iterates")
+    early, last = {}, []
+
     def cb(_xk):
         n[0] += 1
+        if keep is not None:                          # (scipy hands over its working array: copy)
+            if n[0] in keep[0]:
+                early[n[0]] = np.array(_xk, dtype=np.float64)
+            last.append((n[0], np.array(_xk, dtype=np.float64)))
+            del last[:-keep[1]]
     x, info = _orig_cg(A, b, *a, callback=cb, **k)
     _rec["cg_iters"] = n[0]
+    if keep is not None:
+        _rec["iterates"] = {**early, **dict(last)}
+        _rec["x_final"] = np.array(x, dtype=np.float64)
+        # the reference's OWN iterate-matched reproducibility: the same call on right-hand sides perturbed by one unit in
+        # the last place, forced to run exactly as many iterations (no stopping test: rtol = 0) - how far ITERATE k moves
+        rng = np.random.default_rng(12345)
+        ks = sorted(_rec["iterates"])
+        move = np.zeros((8, len(ks)))
+        for trial in range(8):
+            got, cnt = {}, [0]
+
+            def cb2(_xk):
+                cnt[0] += 1
+                if cnt[0] in _rec["iterates"]:
+                    got[cnt[0]] = np.array(_xk, dtype=np.float64)
+            _orig_cg(A, b * (1.0 + 1e-15 * rng.standard_normal(b.shape)), *a, rtol=0.0, atol=0.0, maxiter=n[0], callback=cb2,
+                     **{kk: vv for kk, vv in k.items() if kk not in ("rtol", "atol", "maxiter", "tol")})
+            move[trial] = [float(np.linalg.norm((got[kk] - _rec["iterates"][kk]).reshape(-1, 3), axis=1).max()) for kk in ks]
+        _rec["self_dx"] = move
     _rec["cg_relres"] = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
     # the fully converged solution of the SAME system (x0 = 0 => same gauge): lets the tests
     # state how far the reference's loosely converged answer is from it
@@ -302,6 +329,81 @@ def large_shop_case():
     np.savez_compressed(os.path.join(HERE, "g9_large_shop.npz"), **out)
 
 
+def _run_reference(case, solver, dt):
+    scene, flat = gc.build_flat(case)
+    src = synth.edges_to_dict(flat, ref_geometry.SE3)
+    cons = synth.constraints_from_scene(scene, ref_geometry.SE3)
+    nr, nt, ff = (gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
+    import time
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        res = ref_bipgo.bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff,
+                                          maxiter=gc.MAXITER, lsqr_solver=solver, dtype=np.dtype(dt).type)
+    return flat, res, time.time() - t0
+
+
+def cg_iterates_case():
+    """G10: the reference's CG iterates x_k (scipy's callback on its own cg call, bipgo.py:477) for the k in
+    golden_cases.ITERATE_EARLY and the last ITERATE_LAST iterations of each run, stored as float32 differences to the
+    run's final iterate (which is stored in float64, like the rotations that produced the right-hand side), in the order
+    of the reference's output dict (= its node order).  One reference run per case and dtype: everything in a tag is
+    consistent with everything else in it."""
+    out = {}
+    for name, case in gc.ITERATE_CASES.items():
+        for solver, dt in case["runs"]:
+            if solver != "conjugate_gradient":
+                continue
+            _rec.update(evals=[], cg_iters=None, keep_iterates=(set(gc.ITERATE_EARLY), gc.ITERATE_LAST))
+            flat, res, wall = _run_reference(case, solver, dt)
+            _rec["keep_iterates"] = None
+            tag = "%s_%s_" % (name, dt)
+            keys = list(res.keys())
+            t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in keys])
+            assert np.array_equal(t.reshape(-1), _rec["x_final"]), "output translations are the CG vector in node order"
+            Rs = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in keys])
+            ks = sorted(_rec["iterates"])
+            out[tag + "digest"] = input_digest(flat)
+            out[tag + "keys"] = np.array([str(k) for k in keys])
+            out[tag + "R"] = Rs.astype(np.float32) if dt == "float32" else Rs
+            out[tag + "t"] = t
+            out[tag + "cg_iters"] = np.int64(_rec["cg_iters"])
+            out[tag + "k"] = np.array(ks, dtype=np.int64)
+            out[tag + "dx"] = np.stack([(_rec["iterates"][k] - _rec["x_final"]).reshape(-1, 3) for k in ks]).astype(np.float32)
+            out[tag + "self_dx"] = _rec["self_dx"]              # [8 trials, len(k)]: movement of the reference's own iterate k
+            step = [float(np.linalg.norm((_rec["iterates"][b] - _rec["iterates"][a]).reshape(-1, 3), axis=1).max())
+                    for a, b in zip(ks[-gc.ITERATE_LAST:-1], ks[-gc.ITERATE_LAST + 1:])]
+            print("  g10_iterates %-14s %-8s cg_iters=%d kept k=%s  last steps move %s m  (%.1f s)" % (
+                name, dt, _rec["cg_iters"], ks, " ".join("%.1e" % v for v in step), wall))
+            print("      iterate-matched self-movement under 1e-15 perturbations (max of 8): %s" % " ".join(
+                "%d:%.1e" % (k, v) for k, v in zip(ks, _rec["self_dx"].max(0))))
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__, "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, "g10_cg_iterates.npz"), **out)
+
+
+def unit_scale_case():
+    """G11: the reference on UNIT-weight scenes of large_shop and small_room size (golden_cases.UNIT_SCALE)."""
+    out = {}
+    for name, case in gc.UNIT_SCALE.items():
+        for solver, dt in case["runs"]:
+            _rec.update(evals=[], cg_iters=None, cg_relres=None, t_tight=None)
+            flat, res, wall = _run_reference(case, solver, dt)
+            tag = "%s_%s_" % (name, dt)
+            keys = list(res.keys())
+            Rs = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in keys])
+            out[name + "_digest"] = input_digest(flat)
+            out[tag + "keys"] = np.array([str(k) for k in keys])
+            out[tag + "R"] = Rs.astype(np.float32) if dt == "float32" else Rs
+            out[tag + "t"] = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in keys])
+            out[tag + "evals"] = np.stack(_rec["evals"])
+            out[tag + "cg_iters"] = np.int64(_rec["cg_iters"])
+            out[tag + "dist_tight"] = np.float64(np.linalg.norm(out[tag + "t"] - _rec["t_tight"][:len(keys)], axis=1).max())
+            out[tag + "ref_wall_s"] = np.float64(wall)
+            print("  g11_unit     %-22s %-8s nodes=%d src_edges=%d cg_iters=%d dist_tight=%.2e m  reference wall %.1f s" % (
+                name, dt, len(keys), len(flat["cam_key"]), _rec["cg_iters"], out[tag + "dist_tight"], wall))
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__, "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, "g11_unit_scale.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -318,3 +420,7 @@ if __name__ == "__main__":
         so3_case()
     if "g9_large_shop" in only:               # minutes of reference time: only on request
         large_shop_case()
+    if "g10_cg_iterates" in only:
+        cg_iterates_case()
+    if "g11_unit_scale" in only:
+        unit_scale_case()

@@ -162,9 +162,10 @@ def hipcc_path() -> str:
 def build_library(force: bool = False, verbose: bool = False, out: str = None, extra_flags=()) -> str:
     """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so`` (or ``out``).
 
-    One hipcc per translation unit, in parallel, then a link step.  Objects are cached in-tree
-    (``csrc/_build_cache/<sha1 of flags + source + headers>.o``), so diagnostic variants (``extra_flags``) and
-    rebuilds after a one-file edit only recompile what changed; ``force`` ignores the cache."""
+    One hipcc per translation unit, in parallel, then a link step.  Objects are cached OUTSIDE the tree
+    (``$VICAN_BUILD_CACHE`` or ``<tmp>/vican_amd_build_cache/<sha1 of flags + source + headers>.o`` - only the linked
+    library travels with a repository snapshot), so diagnostic variants (``extra_flags``) and rebuilds after a one-file
+    edit only recompile what changed; ``force`` ignores the cache."""
     out = out or LIB_PATH
     deps = SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")]
     if not force and not extra_flags and os.path.exists(out):
@@ -183,7 +184,8 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT", "-DVICAN_WSWEEP_PART=%d" % m]) for m in (0, 1, 3)]
     jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT"])]
     jobs += [(src, []) for src in SOURCES[1:]]
-    cache = os.path.join(CSRC, "_build_cache")
+    import tempfile
+    cache = os.environ.get("VICAN_BUILD_CACHE") or os.path.join(tempfile.gettempdir(), "vican_amd_build_cache")
     os.makedirs(cache, exist_ok=True)
     hdr = b"".join(open(p, "rb").read() for p in sorted(set(HEADERS) - {WSWEEP}) + [os.path.join(INCLUDE, "vican_hip.h")])
     # the compiler is part of the key: a toolchain upgrade must not reuse objects

@@ -18,6 +18,8 @@ Extra keyword-only arguments (defaults reproduce the reference):
               reproducing the reference's loosely converged scipy answer (rtol 1e-5, up to metres away
               from the solution of its own system on heavy-tailed weights); `lsqr_solver` is then only
               validated.  Off by default: it deliberately breaks parity.
+    cg_stop_at  (diagnostic) run exactly this many CG iterations instead of scipy's stopping test: lets a test compare
+              iterate k with the reference's iterate k (tests/test_cg_iterates.py)
 """
 from __future__ import annotations
 
@@ -67,7 +69,7 @@ def _shard_rows(T, world, rank):
 
 
 def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=np.float32,
-                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False):
+                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False, cg_stop_at=None):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
     from .device import TILE_CAMS, download, make_backend, upload      # needs the GPU + extension
@@ -139,8 +141,8 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         else:                                                                # bipgo.py:476-478
             tr = TranslationSolver(K, comm)
             tr.setup(rc, Rt_loc)
-            x_c, x_t = tr.solve(3 * (prob.n_cam + T))
-            if not tr.info["converged"] and not K.barrier_aborted():
+            x_c, x_t = tr.solve(3 * (prob.n_cam + T), stop_at=cg_stop_at)
+            if not tr.info["converged"] and not K.barrier_aborted() and cg_stop_at is None:
                 raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
         return rot, tr, rc, Rt_all, Rt_loc, x_c, x_t
 
@@ -188,7 +190,8 @@ def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
 
 def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callable, noise_model_t: Callable,
                       edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
-                      info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False) -> dict:
+                      info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False,
+                      cg_stop_at: Optional[int] = None) -> dict:
     """SE(3) synchronisation of static cameras and a moving marker object
     (reference bipgo.py:353-490).  See module docstring."""
     t0 = time.perf_counter()
@@ -196,7 +199,7 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
-    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight, cg_stop_at=cg_stop_at)
     local["t_flatten"] = t1 - t0
     out = _pose_dict(prob, Rc, Rt, pc, pt, dtype)
     if verbose:

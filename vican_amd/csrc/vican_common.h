@@ -35,7 +35,8 @@ int vican_check_block_graph(const vican_graph_t* g, const char* who);   // ... a
 // unless *gate == 1 at execution time (speculatively enqueued work that a device-side decision cancels).
 extern thread_local const int32_t* g_vican_gate;
 #define GATE_RETURN(gate) do { if ((gate) != nullptr && *(gate) != 1) return; } while (0)
-// Launch timer (vican_set_launch_events, per host thread, defined in vican_sweep.hip): the NEXT edge-sweep launch binds
+// Launch timer (vican_set_launch_events, per host thread, defined in vican_sweep.hip): the NEXT edge-kernel launch (operator /
+// dual-update sweeps, and on the wave layout the CG product, the right-hand side and the fused LSQR pass) binds
 // these two HIP events to its own dispatch (hipExtLaunchKernelGGL: start / stop = begin / end of the kernel on the
 // device, the timestamps a kernel trace shows) and clears them.  An event pair recorded around a launch instead also
 // times the 5-8 us the queue idles between an event command and the next dispatch.

@@ -221,6 +221,45 @@ __device__ __forceinline__ double wave_total(double v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
     return __longlong_as_double((long long)(((u64)hi << 32) | lo));
 }
+// Sums of THREE doubles over the 64 lanes of a wavefront in one butterfly (the row sums of a one-row chunk: vican_wtrans.hip).
+// Three wave_total() calls cost ~100 VALU instructions (six DPP steps of two moves and an add each, the `old` operands of the
+// masked row_bcast steps) - a third of the CG product's instruction count, and that kernel is bound by VALU issue (rocprofv3
+// counters, profiles/r04_cg_counters.json).  Here the three streams share the butterfly: after the first exchange (lane ^ 1) even
+// lanes carry a, odd lanes b; after the second (lane ^ 2) lanes = 0, 1 (mod 4) carry the quad's sums of a, b and lanes = 2, 3
+// (mod 4) the quad's sum of c; row_ror:4 / row_ror:8 add the four quads of a row of 16 lanes without moving a stream off its
+// lanes, v_permlane16_swap / v_permlane32_swap (gfx950) add the four rows.  Result: lane l holds the total of stream
+// min(l mod 4, 2) - lanes 0, 1, 2 the totals of a, b, c.  Fixed order: deterministic.  ~35 VALU instructions.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_all(double v) {        // every lane has a valid source lane: no `old` operand
+    const u64 b = (u64)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((u64)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ double rows_total(double v) {         // v + the same lane of the other three rows of 16 lanes
+    {
+        const u64 b = (u64)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)b, (uint32_t)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+        v = __longlong_as_double((long long)(((u64)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((u64)hi[1] << 32) | lo[1]));
+    }
+    {
+        const u64 b = (u64)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)b, (uint32_t)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+        v = __longlong_as_double((long long)(((u64)hi[0] << 32) | lo[0])) + __longlong_as_double((long long)(((u64)hi[1] << 32) | lo[1]));
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_total3(const double a, const double b, const double c, const int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double x = (b0 ? b : a) + dpp_f64_all<0xB1>(b0 ? a : b);       // quad_perm [1,0,3,2]: even lanes a, odd lanes b
+    const double c1 = c + dpp_f64_all<0xB1>(c);
+    double y = (b1 ? c1 : x) + dpp_f64_all<0x4E>(b1 ? x : c1);           // quad_perm [2,3,0,1]: lanes 0, 1 (mod 4) a, b; lanes 2, 3 c
+    y += dpp_f64_all<0x124>(y);                                           // row_ror:4
+    y += dpp_f64_all<0x128>(y);                                           // row_ror:8: the row's four quads
+    return rows_total(y);
+}
 __device__ __forceinline__ double lane_bcast(double v, const int src_lane) {
     const u64 b = (u64)__double_as_longlong(v);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);

@@ -15,7 +15,7 @@
 
 extern "C" int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy, int32_t n_waves) {
     const int64_t per_wave = (((int64_t)max_rows * 3 * (16LL * n_copy + 16)) + 15) & ~15LL;
-    return 72LL * n_cam + (int64_t)n_waves * per_wave + 256;
+    return 72LL * plane_stride(n_cam) + (int64_t)n_waves * per_wave + 256;       // nine camera planes of compile-time stride
 }
 
 #ifdef VICAN_CGWSTAMP   /* diagnostic build (tools/cgsweep_time.py --stamp): wall-clock structure of the launch, per wavefront */
@@ -33,7 +33,11 @@ extern "C" int vican_cgw_stamp_buffer(double* buf) {
 template <int EPL>
 struct CgWRegs { double w[EPL]; uint32_t id[EPL]; };
 
-template <int NW, int EPL, int TRIPS>
+// CP: stride of the camera planes in LDS (plane_stride(): 256 / 512 / 1024 entries) - a compile-time constant, so that the
+// nine planes (hi and lo words of the three sums, the three components of p_c) are reached with IMMEDIATE offsets from one
+// address register per edge: the kernel is bound by VALU issue (310 instructions per wavefront and chunk before, of which ~35
+// were plane address arithmetic and ~100 the three separate wave reductions of the one-row path - wave_total3).
+template <int NW, int EPL, int TRIPS, int CP>
 __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, const double* __restrict__ w,
                                                             const double* __restrict__ deg_t, const double* __restrict__ p_c,
                                                             const double* __restrict__ r_t, double* __restrict__ p_t,
@@ -51,10 +55,10 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
     const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    u64* qc = (u64*)lds_raw;                                   // [2][3][C] planes (hi words, lo words), shared by the workgroup
-    double* pcs = (double*)(qc + 6 * C);                       // [3][C] planes
+    u64* qc = (u64*)lds_raw;                                   // [2][3][CP] planes (hi words, lo words), shared by the workgroup
+    double* pcs = (double*)(qc + 6 * CP);                      // [3][CP] planes
     const size_t per_wave = (((size_t)RW * 3 * (16 * ncopy + 16)) + 15) & ~(size_t)15;
-    unsigned char* wbase = (unsigned char*)(pcs + 3 * C) + (size_t)wave * per_wave;
+    unsigned char* wbase = (unsigned char*)(pcs + 3 * CP) + (size_t)wave * per_wave;
     u64* qt = (u64*)wbase;                                     // [2][RW * 3][ncopy] striped row accumulators (this wave's): hi, lo
     double* pts = (double*)(qt + (size_t)2 * RW * 3 * ncopy);  // [RW * 3] p of the chunk's rows
     double* dps = pts + RW * 3;                                // [RW * 3] deg * p
@@ -63,8 +67,10 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
     const int lob = st->lo_bits;
     const double lo_scale = ldexp(1.0, lob);
-    const int lo_c = 3 * C, lo_t = 3 * RW * ncopy;             // offsets of the lo planes behind the hi planes
-    for (int i = tid; i < 3 * C; i += NW * 64) { pcs[(i % 3) * C + i / 3] = p_c[i]; qc[i] = 0ull; qc[lo_c + i] = 0ull; }
+    constexpr int lo_c = 3 * CP;                               // offset of the lo planes behind the hi planes
+    const int lo_t = 3 * RW * ncopy;
+    for (int i = tid; i < 3 * C; i += NW * 64) pcs[(i % 3) * CP + i / 3] = p_c[i];
+    for (int i = tid; i < 6 * CP; i += NW * 64) qc[i] = 0ull;
     for (int i = lane; i < 2 * lo_t; i += 64) qt[i] = 0ull;
     const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
     const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
                 cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
                 wj[j] = pad ? 0.0 : cur.w[j];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[i] += wj[j] * pcs[i * C + cam[j]];
+                for (int i = 0; i < 3; ++i) acc[i] += wj[j] * pcs[i * CP + cam[j]];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -165,12 +171,12 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const Fix2 f = to_fix2(wj[j] * prow[i], scale, lo_scale);
-                    lds_add_fix(&qc[i * C + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * C + cam[j]], f.lo);
+                    lds_add_fix(&qc[i * CP + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * CP + cam[j]], f.lo);
                 }
             }
-            const double s0 = wave_total(acc[0]), s1 = wave_total(acc[1]), s2 = wave_total(acc[2]);
+            const double srow = wave_total3(acc[0], acc[1], acc[2], lane);     // lanes 0, 1, 2: the row sums of the three components
             if (lane < 3) {
-                const double qv = rv.d[0] * pn - (lane == 0 ? s0 : (lane == 1 ? s1 : s2));
+                const double qv = rv.d[0] * pn - srow;
                 q_t[(size_t)r0 * 3 + lane] = qv;
                 pq += pn * qv;
             }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu); row[j] = pad ? 0u : (cur.id[j] >> 16);
             wj[j] = pad ? 0.0 : cur.w[j];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pc[j][i] = pcs[i * C + cam[j]];
+            for (int i = 0; i < 3; ++i) pc[j][i] = pcs[i * CP + cam[j]];
         }
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -236,9 +242,9 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 #if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
                 asm volatile("" :: "v"(fc[j][i].hi), "v"(fc[j][i].lo));
 #else
-                lds_add_fix(&qc[i * C + cam[j]], fc[j][i].hi);
+                lds_add_fix(&qc[i * CP + cam[j]], fc[j][i].hi);
 #if !defined(VICAN_CGWABLATE) || VICAN_CGWABLATE != 3     /* 3: hi words only (cost of the second word) */
-                lds_add_fix(&qc[lo_c + i * C + cam[j]], fc[j][i].lo);
+                lds_add_fix(&qc[lo_c + i * CP + cam[j]], fc[j][i].lo);
 #endif
 #endif
             }
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
-    for (int i = tid; i < 6 * C; i += NW * 64) qc_part[(size_t)blockIdx.x * 6 * C + i] = qc[i];
+    for (int pl = 0; pl < 6; ++pl)                             // the slab keeps planes of stride C ([2][3][C]: cg_fold_kernel)
+        for (int i = tid; i < C; i += NW * 64) qc_part[((size_t)blockIdx.x * 6 + pl) * C + i] = qc[pl * CP + i];
     const double t = block_sum(pq, red);
     if (tid == 0) pq_part[blockIdx.x] = t;
 #ifdef VICAN_CGWSTAMP
@@ -310,6 +317,143 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         o[9] = (double)n_done;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// The same product on graphs whose chunks hold exactly ONE row each (n_chunk == n_time: dense rows - the stress graph, 250
+// cameras per timestep).  Round-4 counters (profiles/r04_cg_counters.json) showed the general kernel bound by VALU issue and
+// memory latency, not by the LDS atomic pipe: 310 VALU wave-instructions per chunk, 70 % VALU-busy at three wavefronts per SIMD,
+// removing every camera atomic gained 2 %.  This variant has no row accumulators, no staging, no fold and no row bounds
+// (chunk k is row k), takes the three row sums through ONE shared butterfly (wave_total3), reaches the nine camera planes with
+// immediate offsets, and prefetches TWO chunks ahead (three register sets of 12 + 6 VGPRs; the wait for a chunk's data was
+// 950 of 3700 cycles per chunk with one).  Same arithmetic and summation structure as the one-row path of cg_wsweep_kernel
+// (exact double-word camera sums; the row sum a fixed-order f64 wave reduction).
+template <int NW, int EPL, int CP>
+__global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, const double* __restrict__ w,
+                                                             const double* __restrict__ deg_t, const double* __restrict__ p_c,
+                                                             const double* __restrict__ r_t, double* __restrict__ p_t,
+                                                             double* __restrict__ q_t, u64* __restrict__ qc_part,
+                                                             double* __restrict__ pq_part, const vican_cg_state_t* __restrict__ st) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red[16];
+    __shared__ int s_ticket;
+    if (st->done) return;
+    const int C = g.n_cam;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u64* qc = (u64*)lds_raw;                                   // [2][3][CP] planes (hi words, lo words)
+    double* pcs = (double*)(qc + 6 * CP);                      // [3][CP] planes
+    constexpr int lo_c = 3 * CP;
+    const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
+    const bool upd = !st->first;
+    const double beta = st->beta, scale = st->qscale;
+    const double lo_scale = ldexp(1.0, st->lo_bits);
+    for (int i = tid; i < 3 * C; i += NW * 64) pcs[(i % 3) * CP + i / 3] = p_c[i];
+    for (int i = tid; i < 6 * CP; i += NW * 64) qc[i] = 0ull;
+    const int c0 = (int)(((long long)blockIdx.x * g.n_chunk) / gridDim.x);
+    const int c1 = (int)(((long long)(blockIdx.x + 1) * g.n_chunk) / gridDim.x);
+    const int kmax = g.n_chunk - 1;
+    const int l3 = lane < 3 ? lane : 0;
+    // deg_t[k] has a wave-uniform address: left alone it becomes a SCALAR load, which under a saturated memory system takes
+    // thousands of cycles and shares lgkmcnt with the LDS operations (returning out of order, it turns every LDS wait into
+    // lgkmcnt(0)) - an opaque per-lane zero keeps it a vector load
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+
+    struct RowVals { double p, r, d; };                        // lanes 0..2: component `lane` of the row's p_t, r_t; deg_t
+    auto load_edges = [&](CgWRegs<EPL>& e, int k) {
+        k = k < kmax ? k : kmax;
+        const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
+        if (EPL == 4) {
+            uint4 t; double2 a, b;
+            const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
+            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
+            e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
+            e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
+        } else {
+            uint2 t; double2 a;
+            if (g.stream_nt) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
+            else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
+            e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
+        }
+    };
+    auto load_rowvals = [&](RowVals& rv, int k) {
+        k = k < kmax ? k : kmax;
+        const size_t gi = (size_t)k * 3 + l3;
+        rv.p = p_t[gi]; rv.r = r_t[gi]; rv.d = deg_t[k + vzero];
+    };
+    if (tid == 0) s_ticket = c0 + 4 * NW;
+    __syncthreads();
+
+    // chunks of the workgroup's range by LDS ticket (the first four rounds are static); a ticket is drawn three bodies before
+    // its chunk is processed and read at the end of the body that drew it
+    int q0 = c0 + wave, q1 = q0 + NW, q2 = q1 + NW, q3 = q2 + NW;
+    CgWRegs<EPL> ea, eb, ec;
+    RowVals ra, rb, rc;
+    load_edges(ea, q0); load_rowvals(ra, q0);
+    load_edges(eb, q1); load_rowvals(rb, q1);
+    double pq = 0.0;
+
+    auto body = [&](const CgWRegs<EPL>& cur, const RowVals& rv, CgWRegs<EPL>& fill, RowVals& rvf, const int k, const int k_fill) {
+        load_rowvals(rvf, k_fill);
+        load_edges(fill, k_fill);
+        __builtin_amdgcn_sched_barrier(0);
+        const double pn = upd ? rv.r + beta * rv.p : rv.p;
+        if (upd && lane < 3) p_t[(size_t)k * 3 + lane] = pn;
+        const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
+        uint32_t cam[EPL];
+        double wj[EPL], acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool pad = cur.id[j] == VICAN_PAD_SLOT;
+            cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
+            wj[j] = pad ? 0.0 : cur.w[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] += wj[j] * pcs[i * CP + cam[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const Fix2 f = to_fix2(wj[j] * prow[i], scale, lo_scale);
+                lds_add_fix(&qc[i * CP + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * CP + cam[j]], f.lo);
+            }
+        }
+        const double srow = wave_total3(acc[0], acc[1], acc[2], lane);         // lanes 0, 1, 2: the three row sums
+        if (lane < 3) {
+            const double qv = rv.d * pn - srow;
+            q_t[(size_t)k * 3 + lane] = qv;
+            pq += pn * qv;
+        }
+    };
+    auto draw = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t;
+    };
+#define CGW1_NEXT(t) do { q0 = q1; q1 = q2; q2 = q3; q3 = __builtin_amdgcn_readfirstlane(t); } while (0)
+#pragma unroll 1
+    while (q0 < c1) {
+        int t = draw();
+        body(ea, ra, ec, rc, q0, q2);
+        CGW1_NEXT(t);
+        if (q0 >= c1) break;
+        t = draw();
+        body(eb, rb, ea, ra, q0, q2);
+        CGW1_NEXT(t);
+        if (q0 >= c1) break;
+        t = draw();
+        body(ec, rc, eb, rb, q0, q2);
+        CGW1_NEXT(t);
+    }
+#undef CGW1_NEXT
+    __syncthreads();
+    for (int pl = 0; pl < 6; ++pl)
+        for (int i = tid; i < C; i += NW * 64) qc_part[((size_t)blockIdx.x * 6 + pl) * C + i] = qc[pl * CP + i];
+    const double t = block_sum(pq, red);
+    if (tid == 0) pq_part[blockIdx.x] = t;
 }
 
 // ---------------------------------------------------------------------------
@@ -491,7 +635,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
         auto kern = trans_wrhs_kernel<NW_, E_, T_>;                                                                       \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv, lob); \
+        VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv, lob); \
     } while (0)
 #define WRHS_PICK(NW_)                                                                                                    \
     do {                                                                                                                  \
@@ -716,8 +860,8 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
             }
         }
         if (single) {
-            const double s0 = wave_total(ar[EPL - 1][0]), s1 = wave_total(ar[EPL - 1][1]), s2 = wave_total(ar[EPL - 1][2]);
-            if (lane < 3) z_t[(size_t)r0 * 3 + lane] = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+            const double srow = wave_total3(ar[EPL - 1][0], ar[EPL - 1][1], ar[EPL - 1][2], lane);
+            if (lane < 3) z_t[(size_t)r0 * 3 + lane] = srow;
         } else {
             __builtin_amdgcn_wave_barrier();
             for (int base = 0; base < n3 * ncopy; base += 64) {
@@ -790,7 +934,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vica
         auto kern = lsqr_wstep_kernel<NW_, E_, T_>;                                                                       \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, sw, u, v_c, v_t, z_t, (u64*)zc_part, part, st); \
+        VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, sw, u, v_c, v_t, z_t, (u64*)zc_part, part, st); \
     } while (0)
 #define WSTEP_PICK(NW_)                                                                                                   \
     do {                                                                                                                  \
@@ -812,14 +956,41 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     const int nw = g->wg_waves >= 12 ? 12 : (g->wg_waves >= 8 ? 8 : 4);
     const size_t lds = (size_t)vican_cg_wsweep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > 160 * 1024) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_cg_sweep (wave layout)");
-    const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64;
+    const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64, cp = (int)plane_stride(g->n_cam);
     hipStream_t s = (hipStream_t)stream;
-#define CGW_LAUNCH(NW_, E_, T_)                                                                                           \
+    static const int one_row_ok = getenv("VICAN_CG_ONE_ROW") ? atoi(getenv("VICAN_CG_ONE_ROW")) : 1;      // (0: A/B against the general kernel)
+    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8) {
+        // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
+        const size_t lds1 = (size_t)72 * cp + 256;
+        static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;
+#define CGW1_LAUNCH(NW_, E_, CP_)                                                                                         \
+        do {                                                                                                              \
+            auto kern = cg_wsweep1_kernel<NW_, E_, CP_>;                                                                  \
+            static size_t conf = 0;                                                                                       \
+            if (lds1 > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); conf = lds1; } \
+            VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds1, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+        } while (0)
+#define CGW1_PICK(NW_)                                                                                                    \
+        do {                                                                                                              \
+            if (epl == 4) { if (cp == 256) CGW1_LAUNCH(NW_, 4, 256); else if (cp == 512) CGW1_LAUNCH(NW_, 4, 512); else CGW1_LAUNCH(NW_, 4, 1024); } \
+            else          { if (cp == 256) CGW1_LAUNCH(NW_, 2, 256); else if (cp == 512) CGW1_LAUNCH(NW_, 2, 512); else CGW1_LAUNCH(NW_, 2, 1024); } \
+        } while (0)
+        if (nw1 == 16) CGW1_PICK(16); else if (nw1 == 8) CGW1_PICK(8); else CGW1_PICK(12);
+#undef CGW1_PICK
+#undef CGW1_LAUNCH
+        LAUNCH_CHECK("vican_cg_sweep");
+        return VICAN_OK;
+    }
+#define CGW_LAUNCH_(NW_, E_, T_, CP_)                                                                                     \
     do {                                                                                                                  \
-        auto kern = cg_wsweep_kernel<NW_, E_, T_>;                                                                        \
+        auto kern = cg_wsweep_kernel<NW_, E_, T_, CP_>;                                                                   \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        hipLaunchKernelGGL(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+        VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+    } while (0)
+#define CGW_LAUNCH(NW_, E_, T_)                                                                                           \
+    do {                                                                                                                  \
+        if (cp == 256) CGW_LAUNCH_(NW_, E_, T_, 256); else if (cp == 512) CGW_LAUNCH_(NW_, E_, T_, 512); else CGW_LAUNCH_(NW_, E_, T_, 1024); \
     } while (0)
 #define CGW_PICK(NW_)                                                                                                     \
     do {                                                                                                                  \
@@ -829,6 +1000,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     if (nw == 12) CGW_PICK(12); else if (nw == 8) CGW_PICK(8); else CGW_PICK(4);
 #undef CGW_PICK
 #undef CGW_LAUNCH
+#undef CGW_LAUNCH_
     LAUNCH_CHECK("vican_cg_sweep");
     return VICAN_OK;
 }

@@ -437,16 +437,21 @@ class TranslationSolver:
         K.trans_rhs(rc, rt, self.b_t, self.b_c)
         self.comm.allreduce(self._setup_msg)
 
-    def solve(self, n_unknowns_total, maxiter=None):
+    def solve(self, n_unknowns_total, maxiter=None, stop_at=None):
+        """stop_at: run exactly this many iterations, whatever the residual (the state reports done = 0) - what an
+        iteration-matched comparison with scipy's iterates needs (tests/test_cg_iterates.py)."""
         K, comm, st = self.K, self.comm, self.st
         multi = comm.world > 1
         maxiter = 10 * n_unknowns_total if maxiter is None else maxiter       # scipy default
-        if not multi and self.small_graph and getattr(K, "cg_resident_ok", False):
+        rtol = self.rtol
+        if stop_at is not None:
+            return self._solve_fixed(int(stop_at))
+        if not multi and self.small_graph and getattr(K, "cg_resident_ok", False) and not K.barrier_aborted():
             # capture-sized graphs: the whole solve as one cooperative launch (an iteration of the multi-kernel path is
             # four dependent launches of a few microseconds each - launch latency only)
             K.cg_resident(self.deg_t, self.deg_c, self.b_c, self.b_t, self.x_c, self.x_t, self.rtol, maxiter, st)
             s = self._state()
-            if s["done"] != -1:
+            if s["done"] != -1 and not K.barrier_aborted():
                 self._n_solves += 1
                 self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1, resident=True,
                                  relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
@@ -518,6 +523,49 @@ class TranslationSolver:
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
         return self.x_c, self.x_t
 
+
+    def _solve_fixed(self, n_iter):
+        """Exactly n_iter iterations of the recurrence this solver would run (resident kernel, launch sequence or the
+        sharded runs' one-message arrangement), stopping test disabled (rtol = 0)."""
+        K, comm, st = self.K, self.comm, self.st
+        multi = comm.world > 1
+        if not multi and self.small_graph and getattr(K, "cg_resident_ok", False):
+            K.cg_resident(self.deg_t, self.deg_c, self.b_c, self.b_t, self.x_c, self.x_t, 0.0, n_iter, st)
+            s = self._state()
+            if s["done"] == -1:
+                raise RuntimeError("vican_cg_resident: grid barrier timed out")
+            self.info = dict(cg_iters=s["iter"], converged=False, resident=True, fixed=True,
+                             relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+            return self.x_c, self.x_t
+        K.cg_init(self.b_c, self.b_t, self.x_c, self.x_t, self.r_c, self.r_t, self.p_c, self.p_t, st)
+        if multi and self.one_message and getattr(K, "cg1_iter_local", None) is not None:
+            rtol, last = self.rtol, self._last_iters
+            self.rtol, self._last_iters = 0.0, None
+            try:
+                # (bursts of the polling loop overshoot: bound them to what is asked for)
+                self.poll_every, keep = n_iter, self.poll_every
+                out = self._solve_one_message(n_iter - 1)
+                self.poll_every = keep
+            finally:
+                self.rtol, self._last_iters = rtol, last
+            self.info["fixed"] = True
+            return out
+        if multi:
+            comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
+        n_part = 0
+        for _ in range(n_iter):
+            K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, 0.0, st, n_part)
+            if multi:
+                comm.allreduce(self.qcpq)
+            n_part = K.cg_iter_finish(self.deg_c, self.qcpq, self.p_c, self.x_c, self.r_c, self.p_t, self.q_t, self.x_t, self.r_t, st)
+            if multi:
+                K.cg_end(n_part, st)
+                comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
+                n_part = 0
+        s = self._state()
+        self.info = dict(cg_iters=n_iter, converged=False, fixed=True,
+                         relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+        return self.x_c, self.x_t
 
     def _solve_one_message(self, maxiter):
         """Sharded solves: ONE all-reduce per iteration, [sum_t w r_t | r.s | r.r] (3C + 2 doubles) - the Chronopoulos-Gear
