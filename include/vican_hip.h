@@ -109,9 +109,6 @@ int vican_set_gate(const int32_t* gate);
  * NULL: unbounded spins (no way to report).  After an abort the outputs of that launch are undefined and its barrier words
  * must be zeroed before they are used again.                                                                       */
 int vican_set_barrier_abort(uint32_t* abort_word, int64_t timeout_us);
-/* Diagnostic: n_wg workgroups of `threads` threads with lds_bytes of LDS each that do nothing but stay resident for
- * `microseconds` - stands in for "something else occupies the compute units" in the tests of the bounded barriers.  */
-int vican_test_occupy(int32_t n_wg, int32_t threads, int32_t lds_bytes, int64_t microseconds, void* stream);
 
 /* Launch timer (state of the calling host thread).  The NEXT launch of an edge sweep (vican_block_op(_z),
  * vican_dual_update(_op), vican_bip_apply) binds the two HIP events (hipEvent_t passed as void*, created by the caller
@@ -562,7 +559,8 @@ int vican_cg_resident(const vican_graph_t* g, const double* w, const double* deg
  * scipy.sparse.linalg.lsqr on the incidence matrix is reproduced on the MERGED system
  *   J~ p = b~ :  s_e (p_t - p_c) = g_e / s_e,  s_e = sqrt(w_e),  g_e = Rc_c^T u_e + Rt_t^T v_e
  * (same normal equations => same iterates; residual norms differ by the constant
- * |b|^2 - |b~|^2, added back by the host driver).  The Golub-Kahan scalars stay on the host.
+ * |b|^2 - |b~|^2, added back by the host driver).  (The round-2 two-pass steps with host-side Golub-Kahan scalars -
+ * vican_lsqr_u_step / _v_step / _cam_v - are kept for cross-checks only: include/vican_hip_test.h.)
  * u: per-edge 3-vectors in slot order [n_chunk][3][slots]; part: >= max(n_wg, 1024) doubles of
  * scratch; the *_out scalars are single device doubles (all-reduce them when sharded).        */
 /* u <- b~ (unnormalised);  *nrm2_out = |u|^2 over this rank's edges;  sw[slot] = s_e = sqrt(w_e) (slot order,
@@ -570,18 +568,6 @@ int vican_cg_resident(const vican_graph_t* g, const double* w, const double* deg
 int vican_lsqr_init_u(const vican_graph_t* g, const double* w, const double* ue, const double* ve,
                       const double* rc, const double* rt, double* u, double* sw, double* part,
                       double* nrm2_out, void* stream);
-/* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
-int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,
-                      double coef, double* u, double* part, double* nrm2_out, void* stream);
-/* v_t <- sum_c s u inv_beta - beta v_t (in place), *nrm2_t_out = |v_t|^2; camera side as
- * fixed-point slabs vc_part[n_wg][3][C] of -sum_t s u inv_beta (fold with
- * vican_slab_reduce_fx, scale = *inv_out, then vican_lsqr_cam_v).  smax >= max sqrt(w_e).      */
-int vican_lsqr_v_step(const vican_graph_t* g, const double* sw, const double* u, double inv_beta,
-                      double beta, double* v_t, void* vc_part, double* part, double* nrm2_t_out,
-                      double smax, double n_add, double* inv_out, void* stream);
-/* v_c <- acc - beta v_c ; *nrm2_out = |v_c|^2 */
-int vican_lsqr_cam_v(int32_t n_cam, const double* acc, double beta, double* v_c, double* nrm2_out,
-                     void* stream);
 /* v *= inv_alfa ; x += t1 w ; w <- v + t2 w ; *nrm2_w_out = |w_new|^2   (vectors of length n) */
 int vican_lsqr_update(int64_t n, double inv_alfa, double t1, double t2, double* v, double* w,
                       double* x, double* part, double* nrm2_w_out, void* stream);

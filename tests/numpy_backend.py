@@ -30,7 +30,13 @@ def svd_polar(mats, mode):
 
 
 class NumpyBackend:
-    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64, deg_t=None, deg_c=None):
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, storage=np.float64, deg_t=None, deg_c=None,
+                 sum_order="scipy"):
+        # sum_order (translation-stage sums only): "scipy" = sequential in edge order, the order scipy's CSR product adds a
+        # row's terms in (np.add.at); "reversed" = the same terms last to first; "exact" = accumulated in extended precision
+        # and rounded once (what the product's exact fixed-point sums do).  tools/standin_orders.py uses the variants to show
+        # what sharing scipy's order is worth against the reference's own reproducibility band.
+        self.sum_order = sum_order
         self.C = int(n_cam)
         self.storage_f64 = np.dtype(storage) == np.float64
         self.T = len(row_ptr) - 1
@@ -278,6 +284,16 @@ class NumpyBackend:
         self._cols(V, ld, n, col0, col0 + 3)[:] = X.numpy().T
 
     # translation stage
+    def _segsum(self, n, idx, vals):
+        if self.sum_order == "reversed":
+            out = np.zeros((n,) + vals.shape[1:]); np.add.at(out, idx[::-1], vals[::-1])
+            return out
+        if self.sum_order == "exact":
+            out = np.zeros((n,) + vals.shape[1:], dtype=np.longdouble); np.add.at(out, idx, vals.astype(np.longdouble))
+            return out.astype(np.float64)
+        out = np.zeros((n,) + vals.shape[1:]); np.add.at(out, idx, vals)
+        return out
+
     def trans_degrees(self, deg_t, deg_c):
         d = np.zeros(max(self.T, 1)); np.add.at(d, self.row, self.w)
         dc = np.zeros(self.C); np.add.at(dc, self.col, self.w)
@@ -305,8 +321,8 @@ class NumpyBackend:
         A = rc.numpy().reshape(self.C, 3, 3)[self.col]
         B = rt.numpy().reshape(-1, 3, 3)[self.row]
         g = np.einsum("eji,ej->ei", A, self.u) + np.einsum("eji,ej->ei", B, self.v)
-        bt = np.zeros((max(self.T, 1), 3)); np.add.at(bt, self.row, g)
-        bc = np.zeros((self.C, 3)); np.add.at(bc, self.col, -g)
+        bt = self._segsum(max(self.T, 1), self.row, g)
+        bc = self._segsum(self.C, self.col, -g)
         rhs_t.numpy()[:] = bt; rhs_c.numpy()[:] = bc
 
     @staticmethod
@@ -350,10 +366,10 @@ class NumpyBackend:
         if not i[CG_I["first"]]:
             pt[:T] = r_t.numpy()[:T] + f[CG_F["beta"]] * pt[:T]
         pc = p_c.numpy()
-        acc = np.zeros((max(T, 1), 3)); np.add.at(acc, self.row, self.w[:, None] * pc[self.col])
+        acc = self._segsum(max(T, 1), self.row, self.w[:, None] * pc[self.col])
         q = deg_t.numpy()[:, None] * pt - acc
         q_t.numpy()[:] = q
-        qc = np.zeros((self.C, 3)); np.add.at(qc, self.col, self.w[:, None] * pt[self.row])
+        qc = self._segsum(self.C, self.col, self.w[:, None] * pt[self.row])
         out = qcpq.numpy()
         out[: 3 * self.C] = qc.reshape(-1)
         out[3 * self.C] = float((pt[:T] * q[:T]).sum())

@@ -18,8 +18,8 @@ def lib():
     return _lib.load()
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "vican_hip.h")).read()
+def header_symbols(name="vican_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vican_[a-z0-9_]+)\s*\(", txt)))
 
@@ -32,6 +32,10 @@ def test_every_header_symbol_is_exported_and_bound(lib):
         assert s in _lib.PROTOTYPES, "ctypes table lacks %s" % s
     assert sorted(_lib.PROTOTYPES) == syms, "ctypes table and header disagree"
     assert lib.vican_abi_version() == _lib.ABI_VERSION
+    # diagnostics and superseded cross-check entry points live in their own header, outside the boundary
+    tsyms = header_symbols("vican_hip_test.h")
+    assert sorted(_lib.TEST_PROTOTYPES) == tsyms and not set(tsyms) & set(syms)
+    assert all(hasattr(lib, s) for s in tsyms)
 
 
 def test_struct_sizes():

@@ -43,22 +43,23 @@ def test_ranks_sharded_hip_solve_matches_single_rank(nranks):
     assert "dist probe: mismatches 0" in res.stdout
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_sharded_large_shop_golden_matches_the_reference(nranks):
     """BASELINE configs[3] CHECKED, not just run (tools/dist_g9.py): the large_shop-scale golden through the drop-in API with
-    its 10 000 timesteps sharded over 2 / 4 ranks - poses against the REAL reference's with the single-rank tolerances
+    its 10 000 timesteps sharded over 2 / 4 / 8 ranks (8 = the node size of configs[3]: 1250 rows per rank) - poses against the REAL reference's with the single-rank tolerances
     (rotations 1e-7 / 5e-6 rad, translations inside the reference's own reproducibility band, CG iterations inside its
     101..106 window +- 1), and against the single-rank solve of the same processes."""
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", "dist_g9.py")]
-    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     print(res.stdout[-3000:])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert "dist g9: mismatches 0" in res.stdout
 
 
-@pytest.mark.parametrize("workload,scaling,gpus", [("large_shop", "strong", 2), ("stress", "weak", 2), ("large_shop", "strong", 4)])
+@pytest.mark.parametrize("workload,scaling,gpus", [("large_shop", "strong", 2), ("stress", "weak", 2), ("large_shop", "strong", 4),
+                                                   ("large_shop", "strong", 8)])
 def test_bench_launches_its_own_ranks(workload, scaling, gpus):
     """`python bench.py --gpus N` without a launcher starts N ranks itself and reports n_gpus = N; large_shop is
     strong scaling (one graph of 10 000 rows split over the ranks), stress weak (rows per GPU)."""
@@ -74,6 +75,11 @@ def test_bench_launches_its_own_ranks(workload, scaling, gpus):
     assert out["detail"]["n_allreduce_per_solve"] > 0
     if scaling == "strong":
         assert out["detail"]["rows_rank0"] == 10000 // gpus
+        # collectives per solve: one all-reduce per operator application (propagated start + Lanczos steps + the tails'
+        # sweeps), ONE message per CG iteration, one set-up message - and nothing that grows with the number of ranks
+        d = out["detail"]
+        expect = d["sweeps_per_step"] + d["cg_iters"] + 1
+        assert expect - 2 <= d["n_allreduce_per_solve"] <= expect + 8, (d["n_allreduce_per_solve"], expect)
     else:
         assert out["detail"]["rows_rank0"] == 4000
 

@@ -6,7 +6,8 @@ import pytest
 
 import golden_cases as gc
 from util import SelfMovement, rebuild_inputs
-from vican_amd import frontend
+from vican_amd import frontend, synth
+from vican_amd.geometry import SE3
 from vican_amd.solver import with_cooperative_fallback
 
 
@@ -147,3 +148,65 @@ def test_self_movement_recorder_on_a_small_singular_system():
     assert sm.bound() == 1e-6
     big = sm.more_trials(1e-3, n_trials=3)
     assert big.shape == (3,) and big.max() > 100 * max(sm.self_move.max(), 1e-16)
+
+
+def _object_scene(n_time=60, n_marker=7, mpv=3, seed=5):
+    scene = synth.make_scene(n_cam=1, n_time=n_time, n_marker=n_marker, seed=seed)
+    flat = synth.make_object_edges(scene, mpv=mpv, sigma_r=1e-3, sigma_t=1e-3, seed=seed + 1)
+    return synth.edges_to_dict(flat, SE3)
+
+
+def _same_problem(p1, p2):
+    for f in ("row_ptr", "col", "blk", "a", "w", "u", "v", "deg_c", "deg_t", "cam_names", "time_names", "tnodes", "tnode_of_cam",
+              "tnode_of_time", "src_cam", "src_time", "src_t", "src_qtau", "src_kt"):
+        assert np.array_equal(getattr(p1, f), getattr(p2, f)), f
+    assert p1.root == p2.root and p1.n_src == p2.n_src
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_object_front_end_one_pass_equals_the_reference_shaped_path(dtype):
+    """flatten_object (one pass, batched float32 inversion - what object_bipartite_se3sync runs) against
+    invert_object_edges + flatten (a pose.inv() call and a dict copy per edge, as bipgo.py:523-531): the same Problem to the
+    bit - with trivial callables, with callables that look at the INVERTED pose / test membership / iterate the value dict,
+    with a filter that drops edges (the root is still the smallest id over ALL source edges), and with poses whose R / t
+    are float32 views (SE3(pose=...)) instead of float64 arrays."""
+    src = _object_scene()
+    unit, keep = (lambda e: 1.0), (lambda e: True)
+    w_pose = lambda e: 0.5 + float(np.abs(e["pose"].t()).sum())
+    f_pose = lambda e: ("pose" in e and e.get("pose") is not None and len(e) == 4 and sorted(e.keys()) == ["corners", "im_filename", "pose", "reprojected_err"]
+                        and e["pose"].R()[0, 0] > -0.95)
+    f_drop = lambda e: e["reprojected_err"] < np.median([v["reprojected_err"] for v in src.values()])
+    src32 = {k: dict(v, pose=SE3(pose=np.block([[v["pose"].R(), v["pose"].t()[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])))
+             for k, v in src.items()}
+    for edges, nr, nt, ff in ((src, unit, unit, keep), (src, w_pose, w_pose, f_pose), (src, unit, w_pose, f_drop), (src32, w_pose, unit, keep)):
+        root, re_keyed = frontend.invert_object_edges(edges)
+        p1 = frontend.flatten(re_keyed, {root: SE3(pose=np.eye(4))}, nr, nt, ff, dtype)
+        root2, p2 = frontend.flatten_object(edges, nr, nt, ff, dtype)
+        assert root == root2
+        _same_problem(p1, p2)
+
+
+def test_object_front_end_mixed_pose_dtypes_take_the_per_pose_path():
+    src = _object_scene(n_time=12)
+    keys = list(src)
+    v = src[keys[3]]
+    src[keys[3]] = dict(v, pose=SE3(pose=np.block([[v["pose"].R(), v["pose"].t()[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])))
+    assert frontend.inverted_poses([e["pose"].R() for e in src.values()], [e["pose"].t() for e in src.values()]) is None
+    unit, keep = (lambda e: 1.0), (lambda e: True)
+    root, re_keyed = frontend.invert_object_edges(src)
+    p1 = frontend.flatten(re_keyed, {root: SE3(pose=np.eye(4))}, unit, unit, keep, np.float64)
+    _, p2 = frontend.flatten_object(src, unit, unit, keep, np.float64)
+    _same_problem(p1, p2)
+
+
+def test_string_ids_sort_like_the_reference_on_the_fast_and_the_general_path():
+    """sorted_codes: packed-key path (ASCII ids of <= 8 characters, straight from a Python list) and np.unique fallback (longer /
+    non-ASCII ids) both reproduce np.unique's string order and inverse."""
+    rng = np.random.default_rng(3)
+    short = [str(int(x)) for x in rng.integers(0, 3000, 500)] + ["", "a", "Z9", "12345678"]
+    long_ = short + ["123456789", "camera-with-a-long-name"]
+    uni = short + ["caméra"]
+    for ids in (short, long_, uni, np.array(short), np.array(long_)):
+        names, inv = frontend.sorted_codes(ids)
+        ref_names, ref_inv = np.unique(np.asarray(ids).astype(str), return_inverse=True)
+        assert np.array_equal(names, ref_names) and np.array_equal(inv, ref_inv)

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import golden_cases as gc                                                   # noqa: E402
-from util import expected, iteration_slack, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
+from util import e2e_translation_tol, expected, iteration_slack, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
 
 CG_RUNS = [(n, d) for n, c in gc.CASES.items() for (s, d) in c["runs"] if s == "conjugate_gradient"]
 
@@ -30,7 +30,7 @@ def test_dropin_api_matches_reference(name, dt):
                                        maxiter=gc.MAXITER, lsqr_solver="conjugate_gradient", dtype=dtype, info=info)
     rot, tr = pose_errors(res, exp)
     assert rot < ROT_TOL[dt] <= 1e-4, rot
-    assert tr < translation_tol(name, dt), tr
+    assert tr < e2e_translation_tol(name, dt), tr
     if name == "g4_illcond" and info["cg_iters"] == int(exp["cg_iters"]):
         assert tr < 1e-3, tr          # stopped at the reference's iteration: then the iterate itself must match
     # iteration count: exact (+-1) on the well-conditioned cases.  On the heavy-tailed-weight case g4 (the

@@ -81,6 +81,16 @@ def translation_tol(name, dt):
     return base if move is None else max(base, 4.0 * float(move.max()))
 
 
+def e2e_translation_tol(name, dt):
+    """End-to-end bound: translation_tol, floored at 5e-6 m for float32 runs.  With dtype=float32 two correct eigen-solvers
+    (the reference's ARPACK on float32 matrices, the product's Lanczos iteration on float32 blocks) return rotations 2e-7 ..
+    4e-7 rad apart on every golden; the right-hand side b = R_c t~ + ... carries lever arms of ~10 m, so it moves by
+    micrometres and the answer with it (g2 float32: 0.6e-6 .. 1.2e-6 m depending on the start block) - fifty times inside
+    the north star.  The translation stage ALONE (reference rotations fed in) keeps the 1e-6 / 1e-9 m bounds."""
+    t = translation_tol(name, dt)
+    return max(t, 5e-6) if np.dtype(dt) == np.float32 else t
+
+
 def iteration_slack(name, dt, extra=1):
     """CG iterations may differ from the golden's by the spread the reference itself shows under 1e-15
     perturbations (g9: 101..106, g4: 20..24), plus `extra`."""

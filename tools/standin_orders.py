@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""What is sharing scipy's summation order worth?  (CPU only; calibrates the random campaign's yardstick.)
+
+The campaign (tools/random_campaign.py) counts how often the translation stage - fed the oracle's rotations - lands outside
+4 x the oracle's own movement under 1e-15 perturbations, for the product AND for a plain-f64 NumPy stand-in of the same
+recurrence (tests/numpy_backend.py).  Round 3: product 51, stand-in 37 of 2168.  The stand-in sums a row's terms with np.add.at,
+i.e. sequentially in edge order - the order scipy's CSR product uses - and so shares most of the reference's roundings; the
+product's exact sums, rounded once, cannot.  This tool runs the SAME stand-in over the same camera-mode seeds with its
+translation-stage sums formed (a) in scipy's order, (b) in reverse order, (c) exactly (extended precision, rounded once), and
+counts each against the same bound: if (b) and (c) land where the product does, the gap is the shared order, not precision.
+
+    python tools/standin_orders.py [N=3000] [out=profiles/r04_standin_orders.json] [procs=6]"""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ORDERS = ("scipy", "reversed", "exact")
+N_PERT = 8          # further "independent f64 implementations": scipy's order, right-hand side moved by one unit in the last place
+
+
+def one(seed):
+    import golden_cases as gc
+    from numpy_backend import NumpyBackend
+    from oracle import bipgo_oracle as orc
+    from test_random_parity_gpu import make_case
+    from util import SelfMovement
+    from vican_amd import frontend, synth
+    from vican_amd.geometry import SE3
+    from vican_amd.solver import Comm, TranslationSolver
+    mode, scene, flat, (wr, wt), filt, dt = make_case(seed)
+    if mode != "camera":
+        return None
+    src = synth.edges_to_dict(flat, SE3)
+    cons = synth.constraints_from_scene(scene, SE3)
+    nr, nt, ff = gc.CALLABLES[wr], gc.CALLABLES[wt], gc.CALLABLES[filt]
+    oinfo = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with SelfMovement(orc) as sm:
+            try:
+                ref = orc.bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", dt, loop=False, info=oinfo)
+            except (TypeError, np.linalg.LinAlgError):
+                return None
+    prob = frontend.flatten(src, cons, nr, nt, ff, dt)
+    if frontend.count_components(prob) > 1:
+        return None
+    Rw = {str(k): np.asarray(v.R(), dtype=np.float64) for k, v in ref.items()}
+    rc = np.stack([Rw[str(c)].T for c in prob.cam_names]).reshape(-1, 3)
+    rt = np.stack([Rw[str(s) + "_0"].T for s in prob.time_names]).reshape(-1, 9)
+    tr_ = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
+    row = dict(seed=seed, dtype=np.dtype(dt).name, weights=wt, bound=sm.bound(), cg_oracle=int(oinfo["cg_iters"]))
+    for order in ORDERS + tuple("ulp%d" % i for i in range(N_PERT)):
+        B = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=dt, deg_t=prob.deg_t,
+                         deg_c=prob.deg_c, sum_order=order if order in ORDERS else "scipy")
+        tr = TranslationSolver(B, Comm.single())
+        tr.setup(B.from_numpy(rc), B.from_numpy(rt))
+        if order not in ORDERS:
+            rng = np.random.default_rng(7000 + 97 * seed + int(order[3:]))
+            for b in (tr.b_c, tr.b_t):
+                b.numpy()[:] *= 1.0 + 2.2e-16 * rng.standard_normal(b.numpy().shape)
+        x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
+        pos = {str(c): x_c.numpy()[i] for i, c in enumerate(prob.cam_names)}
+        pos.update({str(s) + "_0": x_t.numpy()[i] for i, s in enumerate(prob.time_names)})
+        t = np.stack([pos[str(k)] for k in ref])
+        row[order + "_m"] = float(np.linalg.norm(t - tr_, axis=1).max())
+        row[order + "_cg"] = int(tr.info["cg_iters"])
+    return row
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_standin_orders.json")
+    procs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    t0 = time.time()
+    with mp.Pool(procs) as pool:
+        rows = [r for r in pool.imap_unordered(one, range(N), chunksize=8) if r is not None]
+    summary = dict(seeds=N, compared=len(rows), seconds=time.time() - t0,
+                   note="translation stage of the NumPy stand-in (tests/numpy_backend.py), the oracle's rotations fed in, against "
+                        "bound = max(1e-6 m, 4 x the oracle's self-movement under 1e-15 perturbations); sums of the stage formed in "
+                        "scipy's order / reversed / exactly (extended precision, rounded once)")
+    for order in ORDERS + tuple("ulp%d" % i for i in range(N_PERT)):
+        summary[order] = dict(over_bound=sum(1 for r in rows if r[order + "_m"] >= r["bound"]),
+                              iteration_differs_from_oracle=sum(1 for r in rows if r[order + "_cg"] != r["cg_oracle"]),
+                              max_m=max(r[order + "_m"] for r in rows))
+    counts = [summary[o]["over_bound"] for o in ORDERS + tuple("ulp%d" % i for i in range(N_PERT))]
+    summary["over_bound_of_%d_independent_f64_variants" % len(counts)] = dict(
+        counts=counts, mean=float(np.mean(counts)), std=float(np.std(counts, ddof=1)), min=int(min(counts)), max=int(max(counts)))
+    for dt in ("float32", "float64"):
+        sub = [r for r in rows if r["dtype"] == dt]
+        summary[dt] = {order: sum(1 for r in sub if r[order + "_m"] >= r["bound"]) for order in ORDERS}
+        summary[dt]["compared"] = len(sub)
+    json.dump(summary, open(out, "w"), indent=1)
+    print(json.dumps(summary, indent=1))

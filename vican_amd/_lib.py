@@ -67,7 +67,6 @@ PROTOTYPES = {
     "vican_abi_version": (C.c_int, []),
     "vican_set_gate": (C.c_int, [_vp]),
     "vican_set_barrier_abort": (C.c_int, [_vp, _i64]),
-    "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_set_launch_events": (C.c_int, [_vp, _vp]),
     "vican_lanczos_coop_ws_doubles": (_i64, [_i32]),
     "vican_lanczos_cam_coop": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
@@ -135,14 +134,19 @@ PROTOTYPES = {
     "vican_merge_edges": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
-    "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
-    "vican_lsqr_cam_v": (C.c_int, [_i32, _vp, _f64, _vp, _vp, _vp]),
     "vican_lsqr_update": (C.c_int, [_i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_step": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_nodes": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_scalars": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "vican_lsqr_update_st": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+}
+
+# include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
+TEST_PROTOTYPES = {
+    "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
+    "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
+    "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
+    "vican_lsqr_cam_v": (C.c_int, [_i32, _vp, _f64, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -167,7 +171,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     library travels with a repository snapshot), so diagnostic variants (``extra_flags``) and rebuilds after a one-file
     edit only recompile what changed; ``force`` ignores the cache."""
     out = out or LIB_PATH
-    deps = SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h")]
+    deps = SOURCES + HEADERS + [os.path.join(INCLUDE, "vican_hip.h"), os.path.join(INCLUDE, "vican_hip_test.h")]
     if not force and not extra_flags and os.path.exists(out):
         if os.path.getmtime(out) >= max(os.path.getmtime(p) for p in deps):
             return out
@@ -245,7 +249,7 @@ def load():
     if lib.vican_abi_version() != ABI_VERSION:
         raise VicanError("%s is stale: it reports ABI %d, this package needs %d - rebuild with "
                          "`python __graft_entry__.py build`" % (LIB_PATH, lib.vican_abi_version(), ABI_VERSION))
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in {**PROTOTYPES, **TEST_PROTOTYPES}.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib

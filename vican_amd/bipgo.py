@@ -234,9 +234,17 @@ def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_mod
     """Object (marker cube) calibration from a moving camera (reference bipgo.py:493-545):
     markers take the camera role, frames the timestep role, every pose is inverted, the
     numerically smallest marker id is pinned to the identity; only marker poses are returned."""
-    root, edges = frontend.invert_object_edges(src_edges)
-    out = bipartite_se3sync(edges, {root: SE3(pose=np.eye(4))}, noise_model_r, noise_model_t, edge_filter,
-                            maxiter, lsqr_solver, dtype, info=info, group=group, verbose=verbose, tight=tight)
+    t0 = time.perf_counter()
+    root, prob = frontend.flatten_object(src_edges, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge())
+    _warn_if_disconnected(prob)
+    t1 = time.perf_counter()
+    local = {} if info is None else info
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
+    local["t_flatten"] = t1 - t0
+    if verbose:
+        print("vican_amd (object mode): %d markers, %d frames, %d merged edges | flatten %.3fs pack %.3fs rot %.3fs trans %.3fs" % (
+            prob.n_cam, prob.n_time, prob.n_edges, t1 - t0, local["t_pack"], local["t_rot"], local["t_trans"]))
+    out = _pose_dict(prob, Rc, Rt, pc, pt, dtype)
     return {k: v for k, v in out.items() if "_" not in k}               # bipgo.py:543
 
 

@@ -189,11 +189,11 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         scale = fix_scale(wmax * pmax, n_add, &inv, 49);
         // p = r + beta p on both node sets
         for (int j = tid; j < n3; j += CGR_THREADS) {
-            if (!first) pcs[j] = rcs[j] + beta * pcs[j];
+            if (!first) pcs[j] = mul_add_2r(beta, pcs[j], rcs[j]);
             qc[j] = 0ull; qc[n3 + j] = 0ull;
         }
         if (!first)
-            for (int i = tid; i < ni; i += CGR_THREADS) pts[i] = rts[i] + beta * pts[i];
+            for (int i = tid; i < ni; i += CGR_THREADS) pts[i] = mul_add_2r(beta, pts[i], rts[i]);
         __syncthreads();
         RSTAMP(0);
 
@@ -312,16 +312,16 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         double sr = 0.0, mr = 0.0, mpc = 0.0;
         for (int j = tid; j < n3; j += CGR_THREADS) {
             const double p = pcs[j];
-            xcs[j] += alpha * p; mpc = fmax(mpc, fabs(p));
-            const double r = rcs[j] - alpha * qcs[j];
+            xcs[j] = mul_add_2r(alpha, p, xcs[j]); mpc = fmax(mpc, fabs(p));
+            const double r = mul_add_2r(-alpha, qcs[j], rcs[j]);
             rcs[j] = r; sr += r * r; mr = fmax(mr, fabs(r));
         }
         double mp = 0.0;
         s = 0.0; m = 0.0;
         for (int i = tid; i < ni; i += CGR_THREADS) {
             const double pv = pts[i];
-            xts[i] += alpha * pv; mp = fmax(mp, fabs(pv));
-            const double r = rts[i] - alpha * qts[i];
+            xts[i] = mul_add_2r(alpha, pv, xts[i]); mp = fmax(mp, fabs(pv));
+            const double r = mul_add_2r(-alpha, qts[i], rts[i]);
             rts[i] = r; s += r * r; m = fmax(m, fabs(r));
         }
         t = cgr_reduce6(s, sr, 0.0, m, mp, fmax(mr, 0.0), red);

@@ -116,6 +116,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Sum over the workgroup; result valid in thread 0.  `red` holds >= blockDim/64 doubles.
+// a b + c with TWO roundings (product, then sum) - scipy's CG forms its vector updates that way (p *= beta; p += r;
+// x += alpha * p; r -= alpha * q), and the loosely converged iterate is a chaotic function of such roundings (DESIGN.md section
+// 2): the recurrence's updates are spelled like scipy's instead of being left to -ffp-contract=fast
+__device__ __forceinline__ double mul_add_2r(double a, double b, double c) {
+#pragma clang fp contract(off)
+    const double t = a * b;
+    return t + c;
+}
 __device__ __forceinline__ double block_sum(double v, double* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;

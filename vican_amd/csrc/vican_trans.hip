@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
     double mc = 0.0;
     for (int i = threadIdx.x; i < 3 * n_cam; i += 256) {
         double p = p_c[i];
-        if (sh_go) { p = r_c[i] + beta * p; p_c[i] = p; }
+        if (sh_go) { p = mul_add_2r(beta, p, r_c[i]); p_c[i] = p; }
         mc = fmax(mc, fabs(p));
     }
 #pragma unroll
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
             if (i < n3) {
                 const size_t gi = (size_t)r0 * 3 + i;
                 double p = p_t[gi];
-                if (upd) p = r_t[gi] + beta * p;
+                if (upd) p = mul_add_2r(beta, p, r_t[gi]);
                 rr.p[m] = p; rr.d[m] = deg_t[r0 + i / 3];
             }
         }
@@ -611,7 +611,7 @@ extern "C" int vican_cg_sweep(const vican_graph_t* g, const double* w, const dou
 __global__ void cg_update_pt_kernel(long long n, const double* __restrict__ r_t, double* __restrict__ p_t, const vican_cg_state_t* __restrict__ st) {
     if (st->done || st->first) return;
     const double beta = st->beta;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p_t[i] = r_t[i] + beta * p_t[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p_t[i] = mul_add_2r(beta, p_t[i], r_t[i]);
 }
 extern "C" int vican_cg_update_pt(int32_t n_time, const double* r_t, double* p_t, const vican_cg_state_t* st, void* stream) {
     if (n_time < 0 || !r_t || !p_t || !st) return set_err(VICAN_ERR_ARG, "vican_cg_update_pt: bad argument");
@@ -712,8 +712,8 @@ __global__ __launch_bounds__(256) void cg_cam_step_kernel(int n_cam, const doubl
     for (int i = threadIdx.x; i < n; i += 256) {
         const double p = p_c[i];
         const double q = deg_c[i / 3] * p - qc_sum[i];
-        x_c[i] += alpha * p;
-        const double r = r_c[i] - alpha * q;
+        x_c[i] = mul_add_2r(alpha, p, x_c[i]);
+        const double r = mul_add_2r(-alpha, q, r_c[i]);
         r_c[i] = r;
         rr += r * r; m = fmax(m, fabs(r));
     }
@@ -745,9 +745,9 @@ __global__ __launch_bounds__(256) void cg_time_step_kernel(long long n, const do
     double rr = 0.0, m = 0.0, mp = 0.0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double pv = p_t[i];
-        x_t[i] += alpha * pv;
+        x_t[i] = mul_add_2r(alpha, pv, x_t[i]);
         mp = fmax(mp, fabs(pv));
-        const double r = r_t[i] - alpha * q_t[i];
+        const double r = mul_add_2r(-alpha, q_t[i], r_t[i]);
         r_t[i] = r;
         rr += r * r; m = fmax(m, fabs(r));
     }
@@ -802,9 +802,9 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
 #pragma unroll 4
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const double pv = p_t[i];
-        x_t[i] += alpha * pv;
+        x_t[i] = mul_add_2r(alpha, pv, x_t[i]);
         mp = fmax(mp, fabs(pv));
-        const double r = r_t[i] - alpha * q_t[i];
+        const double r = mul_add_2r(-alpha, q_t[i], r_t[i]);
         r_t[i] = r;
         rr += r * r; m = fmax(m, fabs(r));
     }
@@ -822,8 +822,8 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     for (int i = threadIdx.x; i < nc; i += 256) {
         const double p = p_c[i];
         const double q = deg_c[i / 3] * p - qc_sum[i];
-        x_c[i] += alpha * p;
-        const double r = r_c[i] - alpha * q;
+        x_c[i] = mul_add_2r(alpha, p, x_c[i]);
+        const double r = mul_add_2r(-alpha, q, r_c[i]);
         r_c[i] = r;
         rc2 += r * r; mc = fmax(mc, fabs(r));
     }
@@ -946,10 +946,10 @@ __global__ __launch_bounds__(256) void cg1_step_kernel(int n_cam, long long n, i
 #pragma unroll 4
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         double p = r_t[i], q = s_t[i];
-        if (k) { p += beta * p_t[i]; q += beta * q_t[i]; }
+        if (k) { p = mul_add_2r(beta, p_t[i], p); q = mul_add_2r(beta, q_t[i], q); }
         p_t[i] = p; q_t[i] = q;
-        x_t[i] += alpha * p;
-        const double r = r_t[i] - alpha * q;
+        x_t[i] = mul_add_2r(alpha, p, x_t[i]);
+        const double r = mul_add_2r(-alpha, q, r_t[i]);
         r_t[i] = r;
         rr += r * r; m = fmax(m, fabs(r));
     }
@@ -967,10 +967,10 @@ __global__ __launch_bounds__(256) void cg1_step_kernel(int n_cam, long long n, i
         const double rv = r_c[i];
         const double s = deg_c[i / 3] * rv - msg[i];
         double p = rv, q = s;
-        if (k) { p += beta * p_c[i]; q += beta * q_c[i]; }
+        if (k) { p = mul_add_2r(beta, p_c[i], p); q = mul_add_2r(beta, q_c[i], q); }
         p_c[i] = p; q_c[i] = q;
-        x_c[i] += alpha * p;
-        const double r = rv - alpha * q;
+        x_c[i] = mul_add_2r(alpha, p, x_c[i]);
+        const double r = mul_add_2r(-alpha, q, rv);
         r_c_new[i] = r;               // (never in place: the other blocks derive gamma and delta from r_c, some of them later than this)
         mc = fmax(mc, fabs(r));
     }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             // ONE row in the chunk (dense rows: every lane's slots belong to it): no LDS staging, no row accumulators, no fold -
             // lanes 0..2 hold p / r / deg of the row's three components, the row sum sum_c w p_c is a wave reduction of the
             // lanes' partial sums (DPP, fixed order: deterministic; plain f64 like scipy's row sum), camera side as below
-            const double pn = upd ? rv.r[0] + beta * rv.p[0] : rv.p[0];
+            const double pn = upd ? mul_add_2r(beta, rv.p[0], rv.r[0]) : rv.p[0];
             if (upd && lane < 3) p_t[(size_t)r0 * 3 + lane] = pn;
             const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
             CSTAMP(2);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         for (int t = 0; t < TRIPS; ++t) {
             const int i = lane + 64 * t;
             if (i < n3) {
-                const double p = upd ? rv.r[t] + beta * rv.p[t] : rv.p[t];
+                const double p = upd ? mul_add_2r(beta, rv.p[t], rv.r[t]) : rv.p[t];
                 pts[i] = p; dps[i] = rv.d[t] * p;
                 if (upd) p_t[(size_t)r0 * 3 + i] = p;
             }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         load_rowvals(rvf, k_fill);
         load_edges(fill, k_fill);
         __builtin_amdgcn_sched_barrier(0);
-        const double pn = upd ? rv.r + beta * rv.p : rv.p;
+        const double pn = upd ? mul_add_2r(beta, rv.p, rv.r) : rv.p;
         if (upd && lane < 3) p_t[(size_t)k * 3 + lane] = pn;
         const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
         uint32_t cam[EPL];

@@ -87,6 +87,22 @@ def _packed_keys(a):
     return buf.view(">u8").ravel().astype(np.uint64)
 
 
+def _ascii_keys(ids):
+    """Packed keys (see _packed_keys) straight from a list / array of ids: ONE C-level conversion to fixed 9-byte strings -
+    np.asarray of a list of 80 000 Python strings alone took 8 ms, this takes 3.  None if an id is longer than 8 bytes, not
+    ASCII, or the input is not one-dimensional (the caller then takes the general path)."""
+    try:
+        b = np.array(ids, dtype="S9")
+    except (UnicodeEncodeError, ValueError, TypeError):
+        return None
+    if b.ndim != 1 or not len(b):
+        return None
+    raw = b.view(np.uint8).reshape(len(b), 9)
+    if raw[:, 8].any():
+        return None
+    return np.ascontiguousarray(raw[:, :8]).view(">u8").ravel().astype(np.uint64)
+
+
 def _key_names(uk):
     """The strings of packed keys, without a Python loop: the big-endian bytes of a key ARE its characters ('S8' drops the padding)."""
     return uk.astype(">u8").view("S8").astype("U8")
@@ -98,10 +114,12 @@ def sorted_codes(ids, prefix="", with_keys=False):
     ids of at most 8 characters are packed into big-endian 64-bit integers, whose numeric order IS their string order, and
     sorted as integers.  A common prefix does not change the order of the strings, only their spelling.  Anything else falls
     back to ``np.unique``.  with_keys: also return the packed keys of the unique strings (None on the fallback path)."""
-    a = np.asarray(ids)
-    if a.dtype.kind != "U":
-        a = a.astype(str)
-    keys = _packed_keys(a)
+    keys = _ascii_keys(ids) if not (isinstance(ids, np.ndarray) and ids.dtype.kind not in "US") else None
+    if keys is None:
+        a = np.asarray(ids)
+        if a.dtype.kind != "U":
+            a = a.astype(str)
+        keys = _packed_keys(a)
     if keys is not None:
         uk, inv = np.unique(keys, return_inverse=True)
         names = _key_names(uk)
@@ -310,9 +328,104 @@ def bnorm2(prob: Problem, Rc: np.ndarray, Rt: np.ndarray) -> float:
     return float(np.sum((prob.src_kt[:, None] * be) ** 2))
 
 
+class _InvertedEdge(dict):
+    """Value dict of a re-keyed object-mode edge as the reference builds it (bipgo.py:526-531): ``corners``, ``reprojected_err``
+    and ``im_filename`` of the source edge and ``pose`` = the INVERTED pose.  The inverse is formed only if a callable asks for
+    it (the notebook's callables look at corners and reprojection error, main.ipynb:75-77): the solver's own use of the
+    inverted poses is batched (flatten_object)."""
+    __slots__ = ("_src_pose",)
+
+    def __missing__(self, key):
+        if key != "pose":
+            raise KeyError(key)
+        p = self._src_pose.inv()
+        dict.__setitem__(self, "pose", p)
+        return p
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return key == "pose" or dict.__contains__(self, key)
+
+    def _whole(self):
+        self["pose"]
+        return self
+
+    def keys(self):
+        return dict.keys(self._whole())
+
+    def values(self):
+        return dict.values(self._whole())
+
+    def items(self):
+        return dict.items(self._whole())
+
+    def __iter__(self):
+        return dict.__iter__(self._whole())
+
+    def __len__(self):
+        return dict.__len__(self._whole())
+
+
+def inverted_poses(Rs, ts):
+    """The rotations / translations of ``pose.inv()`` for a list of poses (reference geometry.py:235-243, as
+    vican_amd.geometry.SE3.inv), all at once and to the bit: the inverse is assembled in a float32 4x4 -
+    R' = float32(R^T), t' = float32((-R^T) t) with the product formed in the dtype of R and t - and handed on as float32
+    views.  np.matmul over the stack takes the same per-item path as the 3x3 @ 3 product of a single pose
+    (checked bit for bit, float64 and float32 inputs).  Returns float64 arrays ([n,3,3], [n,3]), or None when the inputs are
+    not uniformly typed 3x3 / 3 arrays (the caller then inverts pose by pose)."""
+    import operator
+    try:
+        dt = operator.attrgetter("dtype")
+        if len(set(map(dt, Rs))) != 1 or len(set(map(dt, ts))) != 1:
+            return None
+        R, t = np.array(Rs), np.array(ts)                          # (ragged shapes raise)
+    except (AttributeError, ValueError, TypeError):
+        return None
+    if R.shape[1:] != (3, 3) or t.shape[1:] != (3,) or R.dtype.kind != "f" or t.dtype.kind != "f":
+        return None
+    Rt = np.swapaxes(R, 1, 2)
+    ti = np.matmul(-Rt, t[:, :, None])[:, :, 0]
+    return Rt.astype(np.float32).astype(np.float64), ti.astype(np.float32).astype(np.float64)
+
+
+def flatten_object(src_edges, noise_model_r, noise_model_t, edge_filter, dtype=np.float32, merge=None):
+    """Front-end of ``object_bipartite_se3sync`` (bipgo.py:523-541) in ONE pass over the edge dict: markers take the camera
+    role, every pose is inverted, the numerically smallest marker id is the root and its constraint the identity.  Same
+    callables on the same value dicts (`_InvertedEdge`), same float32 rounding of the inverted poses - but the inversion is
+    one batched NumPy expression instead of a Python call and a dict copy per edge (28.7 of the 31.6 ms of a cube_calib-sized
+    call, profiles/r03_api_time.txt).  Returns (root, Problem)."""
+    from .geometry import SE3
+    rows, seen = [], set()
+    add, see, new = rows.append, seen.add, _InvertedEdge
+    for key, val in src_edges.items():                             # the only per-edge Python loop
+        ts, mid = key[1].split("_")
+        see(mid)
+        pose = val["pose"]
+        e = new(corners=val["corners"], reprojected_err=val["reprojected_err"], im_filename=val["im_filename"])
+        e._src_pose = pose
+        if edge_filter(e):
+            add((mid, ts, pose, noise_model_r(e), noise_model_t(e)))
+    root = str(min(map(int, seen)))                                 # bipgo.py:524 (numeric min over ALL source edges)
+    if not rows:
+        raise ValueError("no edge passes edge_filter")
+    cams, times, poses, kr, kt = zip(*rows)
+    Rs, ts_ = [p.R() for p in poses], [p.t() for p in poses]
+    inv = inverted_poses(Rs, ts_)
+    if inv is None:                                                 # mixed dtypes / foreign pose types: pose by pose
+        inv_p = [p.inv() for p in poses]
+        inv = _stack_f64([p.R() for p in inv_p], (3, 3)), _stack_f64([p.t() for p in inv_p], (3,))
+    return root, flatten_arrays(cams, times, np.full(len(cams), root), inv[0], inv[1], kr, kt, {root: SE3(pose=np.eye(4))}, dtype, merge)
+
+
 def invert_object_edges(src_edges):
     """Re-key a moving-camera / static-object edge dict so that markers play the
-    camera role (bipgo.py:523-531): (marker, "<t>_<root>") -> inverted pose."""
+    camera role (bipgo.py:523-531): (marker, "<t>_<root>") -> inverted pose.  The reference-shaped form (a Python call and
+    a dict copy per edge); the drop-in call uses flatten_object, which is checked against this one to the bit."""
     root = str(min(int(k[1].split("_")[1]) for k in src_edges.keys()))           # numeric min
     edges = {}
     for k, v in src_edges.items():

@@ -84,7 +84,7 @@ class Comm:
 
 class RotationSolver:
     def __init__(self, K, comm=None, m_max=32, eig_tol=1e-10, floor_tol=1e-7, min_steps=4, check_every=2, warm_min_steps=2,
-                 max_restarts=20, seed=1234, n_nodes=None):
+                 max_restarts=20, seed=1234, n_nodes=None, prop_sweeps=None):
         self.K, self.comm = K, comm or Comm()
         self.C = K.C
         self.N = K.C if n_nodes is None else n_nodes          # nodes of the eigenproblem (cameras; C+T for the general solver)
@@ -102,6 +102,16 @@ class RotationSolver:
         if self.small_graph:
             self.min_steps, self.warm_min_steps, self.check_every = max(min_steps, 8), max(warm_min_steps, 4), max(check_every, 4)
         self.max_restarts, self.seed = max_restarts, seed
+        # start block of the FIRST eigen-solve: rotations propagated from the gauge camera through the power graph
+        # (_propagated_start) instead of a random block; 0 = the random block of rounds 1-3
+        # sweeps: as many as it takes the propagation to reach (nearly) every camera - one where a camera shares timesteps
+        # with several times C others (dense captures), three on sparse co-visibility graphs
+        if prop_sweeps is None and "VICAN_PROP_SWEEPS" in os.environ:
+            prop_sweeps = int(os.environ["VICAN_PROP_SWEEPS"])
+        # (chosen in init() from the graph's GLOBAL edge and row counts, which ride with the degree message of sharded runs:
+        #  every rank must run the same number of sweeps - each carries an all-reduce)
+        self.prop_sweeps = None if prop_sweeps is None else int(prop_sweeps)
+        self.start_is_warm = False
         n, m = self.n, self.m_max
         self.ld = n
         self.V = K.empty((3 * (m + 1)) * n)         # column-major basis
@@ -127,7 +137,8 @@ class RotationSolver:
         self.Xp = K.empty(n, 3)
         self.rc = K.empty(n, 3)                     # r_c of the reference (node<-world), stacked
         self.lamC = K.empty(self.N, 9)
-        self.cam_deg = K.empty(self.N)
+        self._deg_msg = K.zeros(self.N + 2)          # [weighted degrees | edges | rows of this rank]: ONE set-up all-reduce
+        self.cam_deg = self._deg_msg[: self.N]
         self.lamT = K.empty(max(K.T, 1), 9)
         self.Rt = K.empty(max(K.T, 1), 9)
         self.zraw = K.empty(n, 3)                   # P_new rc from the fused dual update (see _tail)
@@ -289,13 +300,51 @@ class RotationSolver:
     def init(self):
         K = self.K
         K.init_duals(self.lamT, self.cam_deg)
-        self.comm.allreduce(self.cam_deg)
+        first = self.x0 is None
+        if first:
+            self._deg_msg[self.N] = float(getattr(getattr(K, "g", None), "n_edges", 0) or 0)
+            self._deg_msg[self.N + 1] = float(K.T)
+        self.comm.allreduce(self._deg_msg if first else self.cam_deg)
         K.scaled_identity(self.cam_deg, self.lamC)
-        if self.x0 is None:                                     # graph constants: once per solver object
-            lscale = float(self.cam_deg.max())                  # one-off host read: |L| <~ 2 max deg
+        if first:                                               # graph constants: once per solver object
+            h = self._deg_msg.cpu().numpy()                     # one-off host read
+            lscale = float(h[: self.N].max())                   # |L| <~ 2 max deg
             self.pivot_floor = (1e-12 * lscale) ** 2
-            g = torch.Generator(device="cpu"); g.manual_seed(self.seed)
-            self.x0 = torch.randn(self.n, 3, generator=g, dtype=torch.float64).to(self.X.device)
+            if self.prop_sweeps is None:
+                # as many sweeps as it takes the propagation to reach (nearly) every camera: one where a camera shares
+                # timesteps with several times C others (dense captures), three on sparse co-visibility graphs
+                n_e, T_ = float(h[self.N]), max(float(h[self.N + 1]), 1.0)
+                self.prop_sweeps = 3
+                if n_e > 0:
+                    hops1 = (n_e / max(self.C, 1)) * max(n_e / T_ - 1.0, 0.0) / max(self.C, 1)     # expected co-visible cameras / C
+                    self.prop_sweeps = 1 if hops1 >= 4.0 else (2 if hops1 >= 0.5 else 3)
+            if self.prop_sweeps > 0 and self.N == self.C:
+                self._x_seed = K.zeros(self.n, 3)
+                self._x_seed[:3] = torch.eye(3, dtype=torch.float64, device=self._x_seed.device)
+                self.x0 = K.empty(self.n, 3)
+            else:
+                g = torch.Generator(device="cpu"); g.manual_seed(self.seed)
+                self.x0 = torch.randn(self.n, 3, generator=g, dtype=torch.float64).to(self.X.device)
+        if self.prop_sweeps > 0 and self.N == self.C:
+            self._propagated_start()                            # (part of every solve: three sweeps, not a cached constant)
+
+    def _propagated_start(self):
+        """Start block of the first eigen-solve (the reference's ARPACK call starts from a random vector, bipgo.py:288; the
+        answer does not depend on the start, the number of operator applications does).  In the noise-free case the three
+        wanted eigenvectors ARE the stacked camera rotations, P x = Lambda_C x, so rotations propagated from the gauge camera
+        through the power graph - x <- polar(P x) per camera, starting from the identity at camera 0 and zero elsewhere: sweep
+        k reaches the cameras k co-visibility hops away - are a start as good as the measurement noise, i.e. as good as the
+        warm starts of the later iterations.  Three sweeps instead of 6-7 Lanczos steps (CPU prototype on the goldens: first
+        eigen-solve 12 -> 5 steps on small_room-sized scenes, 16 -> 10 on g3; final rotations unchanged to 1e-13 rad).
+        Cameras not reached keep the identity: a worse start for them, never a wrong answer."""
+        K, x = self.K, self.x0
+        x.copy_(self._x_seed)
+        for _ in range(self.prop_sweeps):
+            K.block_op(self.lamT, x, self.z)
+            self.comm.allreduce(self.z)
+            K.polar_dual(self.z, x, None, 0)                    # (nearest rotation per camera, det fix: geometry.py:175-191)
+            self.stats["sweeps"] += 1
+        self.start_is_warm = True
 
     def _tail(self, fuse=False):
         """Everything of a primal-dual iteration after the eigen-solve (enqueued under the Ritz gate).
@@ -315,7 +364,7 @@ class RotationSolver:
     def iterate(self, first, it=None, last=True):
         fuse = self.fuse_dual_op and not last
         self.z_ready = self.z_ready and not first
-        self.spectral(self.x0 if first else self.rc, warm=not first, it=it, tail=lambda: self._tail(fuse))
+        self.spectral(self.x0 if first else self.rc, warm=(not first) or self.start_is_warm, it=it, tail=lambda: self._tail(fuse))
         self.z_ready = fuse
         self.stats["sweeps"] += 2
 
