@@ -72,13 +72,16 @@ __device__ __forceinline__ uint2 stream_load(const uint2* p) {
 // wave sweep 184 -> 175 us, block sweep 195 -> 178 us.  Cache-resident graphs (large_shop: 2.4 MB) keep plain loads -
 // their blocks ARE re-read from L2 / Infinity Cache by the next sweep.  Both branches issue the same ten loads, so the
 // compiler's vmcnt bookkeeping stays exact.
-template <typename S, int EPL>
+// NT = 0 / 1: the choice is made at COMPILE time (wave_sweep_kernel): behind a run-time branch the compiler's vmcnt bookkeeping
+// collapses at the join - the wave sweep waited with vmcnt(0), i.e. for its whole prefetch, in front of phase 2 (round-4 ISA;
+// with the branch resolved it waits with vmcnt(10)).  NT = -1: run-time (block sweep: one barrier-synchronised wait per chunk).
+template <typename S, int EPL, int NT = -1>
 __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int tid) {
     typedef typename Vec<S>::type V;
     const S* blk = (const S*)g.blk;
     const size_t pbase = (size_t)k * 9 * g.slots + (size_t)tid * EPL;
     const uint32_t* ip = g.idx + (size_t)k * g.slots + (size_t)tid * EPL;
-    if (g.stream_nt) {
+    if (NT < 0 ? g.stream_nt != 0 : NT != 0) {
 #pragma unroll
         for (int p = 0; p < 9; ++p) c.m[p] = stream_load((const V*)(blk + pbase + (size_t)p * g.slots));
         if (EPL == 4) { const uint4 t = stream_load((const uint4*)ip); c.id[0] = t.x; c.id[1] = t.y; c.id[2] = t.z; c.id[3] = t.w; }

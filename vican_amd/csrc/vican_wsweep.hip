@@ -52,7 +52,15 @@ extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32
 // 12-wavefront instantiation is therefore built with FB = false: such a row raises the word sched[4] instead, and the
 // launcher enqueues the 8-wavefront FB = true instantiation right behind it, gated on that word - it reruns the whole
 // sweep (same outputs) only when a row needed it; dual_svd_kernel clears the word.
-template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true>
+// ONE: every chunk of the graph holds exactly ONE row (n_chunk == n_time: dense rows, e.g. 250 cameras per timestep).  The
+// row's sums then need no accumulators at all: the lanes' partial sums are reduced over the wavefront by three shared DPP
+// butterflies (wave_total3: nine f64 sums, fixed order, deterministic), the row's 3x3 product / polar factor is formed by every
+// lane for its column and handed to phase 3 through v_readlane (wave-uniform operands), and what is left in LDS is the x gather
+// and the z atomics: per chunk 72 LDS wave-instructions instead of ~100, no phase-2 LDS round trip (stamps of the general
+// kernel on the stress graph: phases 1 + 2 = 4.0 k of 9.4 k cycles per chunk and wavefront; counters: 44 % of the LDS-active
+// cycles were bank-conflict cycles, most of them the same-address pairs of the striped row accumulators).
+// NT: non-temporal loads of the edge stream, chosen at compile time (load_chunk).
+template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true, bool ONE = false, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
                                                              const double* __restrict__ lamT_inv,
                                                              const double* __restrict__ x, u64* __restrict__ zpart,
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     }
     const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8], fx9 = (MODE == 3) ? fx[9] : 0.0;
     __builtin_amdgcn_sched_barrier(0);
-    load_chunk<S, EPL>(ra, g, kc < kmax ? kc : kmax, lane);
+    load_chunk<S, EPL, NT ? 1 : 0>(ra, g, kc < kmax ? kc : kmax, lane);
     __builtin_amdgcn_sched_barrier(0);
     double xm2 = 0.0;
 #pragma unroll
@@ -187,7 +195,9 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         }
     }
     if (HAS_Z) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
-    for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
+    if (!ONE) for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
+    int vzero = 0;                                             // opaque per-lane zero: keeps wave-uniform addresses on VECTOR loads
+    if (ONE) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     __syncthreads();
     if (kc != NONE) {
         if (wave == 0 && len0 <= NW) (void)resolve(0);         // (a short first range: ticket 0 is the one that fetches the next)
@@ -234,7 +244,12 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         // dual-block rows for phase 2, one (row, block row) item = 24 contiguous bytes per lane: the chunk's rows are
         // consecutive, so these loads are fully coalesced.  Issued BEFORE the prefetch (in-order retirement again).
         double L[TRIPS][3];
-        if (MODE == 0) {
+        double L1[9];                                          // ONE: the row's whole dual block in every lane
+        if (MODE == 0 && ONE) {
+            const double* Lp = lamT_inv + (size_t)r0 * 9 + vzero;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) L1[q] = Lp[q];
+        } else if (MODE == 0) {
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
                 int j = lane + 64 * t;
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_chunk<S, EPL>(nxt, g, kp, lane);
+        load_chunk<S, EPL, NT ? 1 : 0>(nxt, g, kp, lane);
 
 #if defined(VICAN_WABLATE) && VICAN_WABLATE == 1      /* loads only: streaming rate of this access pattern */
         {
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         uint32_t cam[EPL], row[EPL];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) { cam[j] = cam_of(cur.id[j]); row[j] = row_of(cur.id[j]); }
+        double ycol[3] = {0, 0, 0};                            // ONE: column min(lane & 3, 2) of the row's 3x3 sum Z_t
         {
             S acc[9], xc[9], xn[9];
 #pragma unroll
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #pragma unroll
                     for (int q = 0; q < 9; ++q) xn[q] = xs[q * CP + cam[j + 1]];
                 }
-                const bool cont = j > 0 && row[j] == row[j - 1];
+                const bool cont = ONE ? j > 0 : (j > 0 && row[j] == row[j - 1]);
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                                             vget<S>(cur.m[6 + a], j), xc[6 + b]);
                         acc[a * 3 + b] = cont ? acc[a * 3 + b] + c : c;
                     }
-                const bool last = (j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j];
+                const bool last = !ONE && ((j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j]);
                 if (last) {
                     u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
 #if defined(VICAN_WABLATE) && (VICAN_WABLATE == 4 || VICAN_WABLATE == 5)    /* no phase-1 atomics */
@@ -303,6 +319,12 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                     for (int q = 0; q < 9; ++q) xc[q] = LEAN ? xs[q * CP + cam[j + 1]] : xn[q];
                 }
             }
+            if (ONE) {
+                // the lane's slots all belong to the chunk's one row (padding blocks are zero): nine wave sums in f64, three
+                // streams per butterfly - lane l ends up with column min(l & 3, 2) of the row's 3x3 sum
+#pragma unroll
+                for (int a = 0; a < 3; ++a) ycol[a] = wave_total3((double)acc[a * 3 + 0], (double)acc[a * 3 + 1], (double)acc[a * 3 + 2], lane);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         WSTAMP(2);                      // phase 1
@@ -310,6 +332,47 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         return vnext;
 #endif
 
+        // ---- phase 2
+        S w1[9];                                               // ONE: the phase-3 operand, wave-uniform
+        if constexpr (ONE) {
+            const int m = (lane & 3) < 2 ? (lane & 3) : 2;     // the column this lane holds
+            if (MODE != 0 && lane < 3) {                       // Z_t for dual_svd_kernel
+#pragma unroll
+                for (int a = 0; a < 3; ++a) lamT_out[(size_t)r0 * 9 + a * 3 + lane] = ycol[a];
+            }
+            double wcol[3];
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) wcol[i] = dot3<double>(L1[i * 3 + 0], ycol[0], L1[i * 3 + 1], ycol[1], L1[i * 3 + 2], ycol[2]);
+            } else if (MODE == 3) {
+                // every lane forms the polar factor of the whole Z_t (nine wave-uniform doubles through v_readlane)
+                double Zt[9], R[9];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; ++b3) Zt[a * 3 + b3] = lane_bcast(ycol[a], b3);
+                if (FB) {
+                    polar_newton3(Zt, R);
+                } else if (!polar_newton_core(Zt, R)) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) R[q] = 0.0;
+                    sched[VICAN_SCHED_REDO] = 1u;               // the gated FB instantiation redoes this sweep
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) wcol[i] = m == 0 ? R[i * 3] : (m == 1 ? R[i * 3 + 1] : R[i * 3 + 2]);
+            }
+            if (HAS_Z) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const S ws = pre_scale<S>(wcol[i], z_scale);
+#pragma unroll
+                    for (int b3 = 0; b3 < 3; ++b3) {
+                        if (sizeof(S) == 4) w1[i * 3 + b3] = (S)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)ws), b3));
+                        else w1[i * 3 + b3] = (S)lane_bcast((double)ws, b3);
+                    }
+                }
+            }
+        } else {
         // ---- phase 2 (this wavefront's rows only; LDS operations of a wavefront execute in order)
 #if defined(VICAN_WABLATE) && VICAN_WABLATE == 6      /* no fold, no y round trip through LDS (timing only: wrong results) */
         if (MODE == 0) {
@@ -361,6 +424,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                 for (int q = 0; q < 9; ++q) wv[r * 9 + q] = pre_scale<S>(R[q], z_scale);
             }
         }
+        }
         __builtin_amdgcn_wave_barrier();
         WSTAMP(3);                      // phase 2
 
@@ -371,7 +435,10 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const uint32_t rowj = LEAN ? row_of(cur.id[j]) : row[j], camj = LEAN ? cam_of(cur.id[j]) : cam[j];
-                if (rowj != prow) {
+                if (ONE) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) w[q] = w1[q];
+                } else if (rowj != prow) {
                     prow = rowj;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) w[q] = wv[rowj * 9 + q];
@@ -446,11 +513,11 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 }
 
 static thread_local const int32_t* w_gate_override = nullptr;     // the redo launch of MODE 3 runs under its own gate
-template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true>
-static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB, bool ONE, bool NT>
+static int launch_wsweep5(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
     const size_t lds = (size_t)vican_wsweep_lds_bytes(g->n_cam, g->max_rows, g->storage, g->n_copy, NW);
-    auto kern = wave_sweep_kernel<S, NW, MODE, CP, TRIPS, FB>;
+    auto kern = wave_sweep_kernel<S, NW, MODE, CP, TRIPS, FB, ONE, NT>;
     static size_t configured = 0;       // per instantiation
     if (lds > configured) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -461,9 +528,20 @@ static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const 
                        zpart, lamT_out, fx);
     return 0;
 }
+template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true, bool ONE = false>
+static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
+                          double* fx, hipStream_t st) {
+    // (streams larger than the caches exist only on graphs planned for >= 8 wavefronts: no NT instantiation at 4)
+    if (NW >= 8 && g->stream_nt) return launch_wsweep5<S, NW, MODE, CP, TRIPS, FB, ONE, (NW >= 8)>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    return launch_wsweep5<S, NW, MODE, CP, TRIPS, FB, ONE, false>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+}
 template <typename S, int NW, int MODE, int CP, bool FB>
 static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
+    // one row per chunk everywhere (n_chunk == n_time): the accumulator-free instantiation (VICAN_SWEEP_ONE_ROW=0: A/B)
+    static const int one_row_ok = getenv("VICAN_SWEEP_ONE_ROW") ? atoi(getenv("VICAN_SWEEP_ONE_ROW")) : 1;
+    if (NW >= 8 && NW <= 12 && one_row_ok && g->n_chunk == g->n_time)
+        return launch_wsweep4<S, NW, MODE, CP, 1, FB, true>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (MODE != 0 || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (3 * g->max_rows <= 128) return launch_wsweep4<S, NW, MODE, CP, 2, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     return launch_wsweep4<S, NW, MODE, CP, 3, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);

@@ -37,7 +37,11 @@ struct CgWRegs { double w[EPL]; uint32_t id[EPL]; };
 // nine planes (hi and lo words of the three sums, the three components of p_c) are reached with IMMEDIATE offsets from one
 // address register per edge: the kernel is bound by VALU issue (310 instructions per wavefront and chunk before, of which ~35
 // were plane address arithmetic and ~100 the three separate wave reductions of the one-row path - wave_total3).
-template <int NW, int EPL, int TRIPS, int CP>
+// NT: the edge stream is read with non-temporal loads (graphs whose streams exceed the caches, vican_graph_t.stream_nt) - a
+// COMPILE-TIME choice: with a run-time branch around the two forms of the loads the compiler's vmcnt bookkeeping collapses at
+// the join (s_waitcnt vmcnt(0..2) where 5-11 younger loads may stay in flight: every prefetch landed before its chunk's
+// predecessor was processed - found in round 4 in the ISA of all wave-layout kernels; round 3 had introduced the branch).
+template <int NW, int EPL, int TRIPS, int CP, bool NT>
 __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, const double* __restrict__ w,
                                                             const double* __restrict__ deg_t, const double* __restrict__ p_c,
                                                             const double* __restrict__ r_t, double* __restrict__ p_t,
@@ -83,13 +87,13 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
         if (EPL == 4) {
             uint4 t; double2 a, b;
             const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
-            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            if (NT) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
             else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
             e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
             uint2 t; double2 a;
-            if (g.stream_nt) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
+            if (NT) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
             else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
             e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
         }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 // immediate offsets, and prefetches TWO chunks ahead (three register sets of 12 + 6 VGPRs; the wait for a chunk's data was
 // 950 of 3700 cycles per chunk with one).  Same arithmetic and summation structure as the one-row path of cg_wsweep_kernel
 // (exact double-word camera sums; the row sum a fixed-order f64 wave reduction).
-template <int NW, int EPL, int CP>
+template <int NW, int EPL, int CP, bool NT>
 __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, const double* __restrict__ w,
                                                              const double* __restrict__ deg_t, const double* __restrict__ p_c,
                                                              const double* __restrict__ r_t, double* __restrict__ p_t,
@@ -367,13 +371,13 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         if (EPL == 4) {
             uint4 t; double2 a, b;
             const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
-            if (g.stream_nt) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            if (NT) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
             else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
             e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
             uint2 t; double2 a;
-            if (g.stream_nt) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
+            if (NT) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
             else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
             e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
         }
@@ -472,7 +476,7 @@ static inline int64_t wrhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_
     return 120LL * n_cam + (int64_t)n_waves * per_wave + 256;
 }
 
-template <int NW, int EPL, int TRIPS>
+template <int NW, int EPL, int TRIPS, bool NT>
 __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, const double* __restrict__ u, const double* __restrict__ v,
                                                              const double* __restrict__ rc, const double* __restrict__ rt,
                                                              double* __restrict__ rhs_t, u64* __restrict__ rhs_c_part, double scale,
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
     auto load_edges = [&](RhsWRegs<EPL>& e, int k) {
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
-        const bool nt = g.stream_nt != 0;
+        constexpr bool nt = NT;
         if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
         else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
 #pragma unroll
@@ -630,13 +634,14 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
     if (trips > 9) return set_err(VICAN_ERR_CAPACITY, "vican_trans_rhs: more than 64 rows per chunk");
     // the grid of the rotation layout has one workgroup per 12 / 8 / 4 wavefronts' worth of chunks; this kernel has nw
     hipStream_t s = (hipStream_t)stream;
-#define WRHS_LAUNCH(NW_, E_, T_)                                                                                          \
+#define WRHS_LAUNCH_(NW_, E_, T_, NT_)                                                                                    \
     do {                                                                                                                  \
-        auto kern = trans_wrhs_kernel<NW_, E_, T_>;                                                                       \
+        auto kern = trans_wrhs_kernel<NW_, E_, T_, NT_>;                                                                  \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, u, v, rc, rt, rhs_t, (u64*)rhs_c_part, scale, inv, lob); \
     } while (0)
+#define WRHS_LAUNCH(NW_, E_, T_) do { if (g->stream_nt) WRHS_LAUNCH_(NW_, E_, T_, true); else WRHS_LAUNCH_(NW_, E_, T_, false); } while (0)
 #define WRHS_PICK(NW_)                                                                                                    \
     do {                                                                                                                  \
         if (epl == 4) { if (trips <= 1) WRHS_LAUNCH(NW_, 4, 1); else if (trips <= 3) WRHS_LAUNCH(NW_, 4, 3); else WRHS_LAUNCH(NW_, 4, 9); } \
@@ -645,6 +650,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
     if (nw == 12) WRHS_PICK(12); else if (nw == 8) WRHS_PICK(8); else WRHS_PICK(4);
 #undef WRHS_PICK
 #undef WRHS_LAUNCH
+#undef WRHS_LAUNCH_
     LAUNCH_CHECK("vican_trans_rhs");
     return VICAN_OK;
 }
@@ -718,7 +724,7 @@ static inline int64_t lsqr_wstep_lds_bytes(int32_t n_cam, int32_t max_rows, int3
     return 72LL * n_cam + (int64_t)n_waves * per_wave + 256;
 }
 
-template <int NW, int EPL, int TRIPS>
+template <int NW, int EPL, int TRIPS, bool NT>
 __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, const double* __restrict__ sw, double* __restrict__ u,
                                                              const double* __restrict__ v_c, const double* __restrict__ v_t,
                                                              double* __restrict__ z_t, u64* __restrict__ zc_part, double* __restrict__ part,
@@ -749,13 +755,13 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
     if (tid == 0) s_ticket = c0 + 3 * NW;
     // the edge vector u~ (24 B per edge, read AND written every step): streamed past the caches when the graph's streams are
     // (a vector of more than the 256 MB Infinity Cache cannot be found there again a step later; it only evicts what could)
-    const bool nt_u = g.stream_nt != 0;
+    constexpr bool nt_u = NT;
 
     auto load_rows = [&](int k) -> int2 { k = k < kmax ? k : kmax; return *(const int2*)(g.chunk_row0 + k); };
     auto load_edges = [&](LsqrWRegs<EPL>& e, int k) {
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
-        const bool nt = g.stream_nt != 0;
+        constexpr bool nt = NT;
         if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
         else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
 #pragma unroll
@@ -929,13 +935,14 @@ extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vica
     const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64;
     if (trips > 3) return set_err(VICAN_ERR_CAPACITY, "vican_lsqr_step: more than 64 rows per chunk");
     hipStream_t s = (hipStream_t)stream;
-#define WSTEP_LAUNCH(NW_, E_, T_)                                                                                         \
+#define WSTEP_LAUNCH_(NW_, E_, T_, NT_)                                                                                   \
     do {                                                                                                                  \
-        auto kern = lsqr_wstep_kernel<NW_, E_, T_>;                                                                       \
+        auto kern = lsqr_wstep_kernel<NW_, E_, T_, NT_>;                                                                  \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, sw, u, v_c, v_t, z_t, (u64*)zc_part, part, st); \
     } while (0)
+#define WSTEP_LAUNCH(NW_, E_, T_) do { if (g->stream_nt) WSTEP_LAUNCH_(NW_, E_, T_, true); else WSTEP_LAUNCH_(NW_, E_, T_, false); } while (0)
 #define WSTEP_PICK(NW_)                                                                                                   \
     do {                                                                                                                  \
         if (epl == 4) { if (trips <= 1) WSTEP_LAUNCH(NW_, 4, 1); else if (trips == 2) WSTEP_LAUNCH(NW_, 4, 2); else WSTEP_LAUNCH(NW_, 4, 3); } \
@@ -944,6 +951,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vica
     if (nw == 8) WSTEP_PICK(8); else WSTEP_PICK(4);
 #undef WSTEP_PICK
 #undef WSTEP_LAUNCH
+#undef WSTEP_LAUNCH_
     LAUNCH_CHECK("vican_lsqr_step");
     return VICAN_OK;
 }
@@ -957,19 +965,21 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     const size_t lds = (size_t)vican_cg_wsweep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > 160 * 1024) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_cg_sweep (wave layout)");
     const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64, cp = (int)plane_stride(g->n_cam);
+    const bool nt = g->stream_nt != 0;
     hipStream_t s = (hipStream_t)stream;
     static const int one_row_ok = getenv("VICAN_CG_ONE_ROW") ? atoi(getenv("VICAN_CG_ONE_ROW")) : 1;      // (0: A/B against the general kernel)
     if (one_row_ok && g->n_chunk == g->n_time && nw >= 8) {
         // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
         const size_t lds1 = (size_t)72 * cp + 256;
         static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;
-#define CGW1_LAUNCH(NW_, E_, CP_)                                                                                         \
+#define CGW1_LAUNCH_(NW_, E_, CP_, NT_)                                                                                   \
         do {                                                                                                              \
-            auto kern = cg_wsweep1_kernel<NW_, E_, CP_>;                                                                  \
+            auto kern = cg_wsweep1_kernel<NW_, E_, CP_, NT_>;                                                             \
             static size_t conf = 0;                                                                                       \
             if (lds1 > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); conf = lds1; } \
             VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds1, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
         } while (0)
+#define CGW1_LAUNCH(NW_, E_, CP_) do { if (nt) CGW1_LAUNCH_(NW_, E_, CP_, true); else CGW1_LAUNCH_(NW_, E_, CP_, false); } while (0)
 #define CGW1_PICK(NW_)                                                                                                    \
         do {                                                                                                              \
             if (epl == 4) { if (cp == 256) CGW1_LAUNCH(NW_, 4, 256); else if (cp == 512) CGW1_LAUNCH(NW_, 4, 512); else CGW1_LAUNCH(NW_, 4, 1024); } \
@@ -978,19 +988,21 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
         if (nw1 == 16) CGW1_PICK(16); else if (nw1 == 8) CGW1_PICK(8); else CGW1_PICK(12);
 #undef CGW1_PICK
 #undef CGW1_LAUNCH
+#undef CGW1_LAUNCH_
         LAUNCH_CHECK("vican_cg_sweep");
         return VICAN_OK;
     }
-#define CGW_LAUNCH_(NW_, E_, T_, CP_)                                                                                     \
+#define CGW_LAUNCH_(NW_, E_, T_, CP_, NT_)                                                                                \
     do {                                                                                                                  \
-        auto kern = cg_wsweep_kernel<NW_, E_, T_, CP_>;                                                                   \
+        auto kern = cg_wsweep_kernel<NW_, E_, T_, CP_, NT_>;                                                              \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
         VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
     } while (0)
 #define CGW_LAUNCH(NW_, E_, T_)                                                                                           \
     do {                                                                                                                  \
-        if (cp == 256) CGW_LAUNCH_(NW_, E_, T_, 256); else if (cp == 512) CGW_LAUNCH_(NW_, E_, T_, 512); else CGW_LAUNCH_(NW_, E_, T_, 1024); \
+        if (nt) { if (cp == 256) CGW_LAUNCH_(NW_, E_, T_, 256, true); else if (cp == 512) CGW_LAUNCH_(NW_, E_, T_, 512, true); else CGW_LAUNCH_(NW_, E_, T_, 1024, true); } \
+        else    { if (cp == 256) CGW_LAUNCH_(NW_, E_, T_, 256, false); else if (cp == 512) CGW_LAUNCH_(NW_, E_, T_, 512, false); else CGW_LAUNCH_(NW_, E_, T_, 1024, false); } \
     } while (0)
 #define CGW_PICK(NW_)                                                                                                     \
     do {                                                                                                                  \
