@@ -286,7 +286,6 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
     g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"],
                    block_threads=args.block_threads, n_copy=args.n_copy)
     E_local = g.n_edges
-    g._csr_t = None                                     # (no LSQR here: let the CSR-order inputs go)
     del gr
     torch.cuda.empty_cache()
 

@@ -86,7 +86,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 12            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 13            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -610,6 +610,43 @@ int vican_lsqr_scalars(int32_t n_cam, const double* acc, const double* part2, in
 int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* part, int32_t last, vican_lsqr_state_t* st,
                          void* stream);
 
+
+/* ---- the four-call boundary ----------------------------------------------------------------------------
+ * For a maintainer who wants the numerics of the reference's two stages behind ONE handle: everything above composed by host
+ * code inside the library (csrc/vican_facade.hip) with the plain schedule - chunked layout planned as vican_amd/device.py does,
+ * block Lanczos with a convergence check (vican_ritz + one blocking 128-byte read) every few steps, the fused dual update, CG in
+ * bursts with the state polled in between.  Single rank, C <= 1024, CG only (lsqr_solver="direct", sharded and camera-tiled
+ * runs: the granular entry points, as vican_amd/solver.py drives them).  The library owns the plan's device memory; inputs and
+ * outputs are the caller's device buffers; every call synchronises `stream` before it returns.
+ *
+ * vican_plan_create  replaces bipgo.py:244-276 (COO triplets -> CSR, degrees, power-graph constants): the merged timestep-major
+ *     CSR problem (row_ptr [T+1], col [E] ascending inside a row, blk [E][9] and a [E] in the storage type; optionally the
+ *     translation arrays w [E], u [E][3], v [E][3] in f64 and the diagonal of the reference's J^T J, deg_t [T] / deg_c [C],
+ *     as scipy forms it - NULL: row / camera sums of w) -> chunked layout + graph constants + solver workspace.
+ * vican_solve_rot     replaces the primal-dual loop bipgo.py:279-348: maxiter iterations of {3 smallest eigenvectors of
+ *     Lambda_C - P, gauge fix, projections, dual updates}; rc_out [3C][3] = the stacked node<-world camera rotations (the
+ *     reference's r_c), Rt_out [T][9] the timestep rotations r_t; the reference returns their transposes (bipgo.py:346,348).
+ * vican_solve_trans   replaces bipgo.py:445-478: J^T b for these rotations and scipy's CG (x0 = 0, stop when |r| < rtol |b|,
+ *     at most maxiter iterations; <= 0: scipy's default 10 n) -> x_c [C][3], x_t [T][3]; VICAN_ERR_LAUNCH if it does not converge
+ *     (the reference asserts, bipgo.py:478).
+ * info (may be NULL): counters of the stage just run.                                                                        */
+typedef struct vican_plan vican_plan_t;
+typedef struct vican_solve_info {
+    int32_t iterations, sweeps, lanczos_steps, restarts;   /* rotation stage */
+    double  evals[5];                                       /* last iteration: the five smallest Ritz values (cf. eigs k=5) */
+    double  eig_resid;
+    int32_t cg_iters, cg_converged;                         /* translation stage */
+    double  cg_relres;
+} vican_solve_info_t;
+int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges, int32_t storage, const int32_t* row_ptr,
+                      const int32_t* col, const void* blk, const void* a, const double* w, const double* u, const double* v,
+                      const double* deg_t, const double* deg_c, void* stream, vican_plan_t** plan_out);
+int vican_plan_describe(const vican_plan_t* plan, vican_graph_t* g_out);   /* the layout that was planned (sizes; device pointers) */
+int vican_solve_rot(vican_plan_t* plan, int32_t maxiter, double eig_tol, double* rc_out, double* Rt_out,
+                    vican_solve_info_t* info, void* stream);
+int vican_solve_trans(vican_plan_t* plan, const double* rc, const double* Rt, double rtol, int64_t maxiter, double* x_c,
+                      double* x_t, vican_solve_info_t* info, void* stream);
+int vican_plan_destroy(vican_plan_t* plan);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,85 @@
+"""The four-call boundary of SURVEY.md 8(b) (include/vican_hip.h: vican_plan_create / vican_solve_rot / vican_solve_trans /
+vican_plan_destroy, csrc/vican_facade.hip) driven through ``ctypes`` alone - no vican_amd.solver, no vican_amd.device: what a
+maintainer of the reference would bind.  Inputs: the merged CSR problem of a golden case (host front-end), uploaded with torch
+as the allocator; outputs against the REAL reference's poses (tests/golden) with the tolerances of the drop-in tests."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from util import e2e_translation_tol, expected, iteration_slack, load_golden, rebuild_inputs
+from vican_amd import _lib, frontend
+from vican_amd.geometry import geodesic
+
+pytestmark = pytest.mark.gpu
+
+
+def solve_through_the_facade(prob, dt, maxiter=gc.MAXITER):
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tdt = torch.float32 if dt == "float32" else torch.float64
+    up = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(dev, d).contiguous()
+    row_ptr, col = up(prob.row_ptr, torch.int32), up(prob.col, torch.int32)
+    blk, a = up(prob.blk, tdt), up(prob.a, tdt)
+    w, u, v = up(prob.w, torch.float64), up(prob.u, torch.float64), up(prob.v, torch.float64)
+    deg_t, deg_c = up(prob.deg_t, torch.float64), up(prob.deg_c, torch.float64)
+    Cn, T, E = prob.n_cam, prob.n_time, prob.n_edges
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    plan = C.c_void_p()
+    rc = lib.vican_plan_create(Cn, T, E, _lib.STORE_F32 if dt == "float32" else _lib.STORE_F64, p(row_ptr), p(col), p(blk), p(a), p(w), p(u), p(v),
+                               p(deg_t), p(deg_c), stream, C.byref(plan))
+    assert rc == 0, lib.vican_last_error()
+    try:
+        g = _lib.Graph()
+        assert lib.vican_plan_describe(plan, C.byref(g)) == 0
+        assert g.n_cam == Cn and g.n_time == T and g.n_chunk >= 1 and g.n_wg >= 1
+        rcs, Rt = torch.empty(3 * Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 9, dtype=torch.float64, device=dev)
+        x_c, x_t = torch.empty(Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 3, dtype=torch.float64, device=dev)
+        info = _lib.SolveInfo()
+        rc = lib.vican_solve_rot(plan, maxiter, 1e-10, p(rcs), p(Rt), C.byref(info), stream)
+        assert rc == 0, lib.vican_last_error()
+        assert info.iterations == maxiter and info.lanczos_steps >= maxiter
+        rc = lib.vican_solve_trans(plan, p(rcs), p(Rt), 1e-5, 0, p(x_c), p(x_t), C.byref(info), stream)
+        assert rc == 0, lib.vican_last_error()
+        assert info.cg_converged == 1
+    finally:
+        assert lib.vican_plan_destroy(plan) == 0
+    Rc = np.swapaxes(rcs.cpu().numpy().reshape(Cn, 3, 3), 1, 2)          # world<-node, as the reference returns them (bipgo.py:346)
+    Rtt = np.swapaxes(Rt.cpu().numpy().reshape(T, 3, 3), 1, 2)
+    return Rc, Rtt, x_c.cpu().numpy(), x_t.cpu().numpy(), info, g
+
+
+@pytest.mark.parametrize("name,dt", [("g2_small", "float64"), ("g2_small", "float32"), ("g3_medium", "float64"), ("g3_medium", "float32"),
+                                     ("g5_strings", "float64")])
+def test_four_calls_reproduce_the_reference(name, dt):
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "conjugate_gradient", dt)
+    prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
+    Rc, Rt, pc, pt, info, graph = solve_through_the_facade(prob, dt)
+    rot, pos = {}, {}
+    for i, c in enumerate(prob.cam_names):
+        rot[str(c)], pos[str(c)] = Rc[i], pc[i]
+    for i, s in enumerate(prob.time_names):
+        rot[str(s) + "_0"], pos[str(s) + "_0"] = Rt[i], pt[i]
+    keys = [str(k) for k in exp["keys"]]
+    R = np.stack([rot[k] for k in keys]); t = np.stack([pos[k] for k in keys])
+    r_err, t_err = float(geodesic(R, exp["R"]).max()), float(np.linalg.norm(t - exp["t"], axis=1).max())
+    print("%s %s through the four calls: rot %.2e rad, trans %.2e m, %d Lanczos steps, %d sweeps, cg %d vs %d, layout %s" % (
+        name, dt, r_err, t_err, info.lanczos_steps, info.sweeps, info.cg_iters, int(exp["cg_iters"]), "wave" if graph.layout == 1 else "block"))
+    assert r_err < (5e-6 if dt == "float32" else 1e-7), r_err
+    assert t_err < e2e_translation_tol(name, dt), t_err
+    assert abs(info.cg_iters - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    evr = np.sort(exp["evals"], axis=1)[-1, :3]
+    assert np.abs(np.sort(np.array(info.evals[:3])) - evr).max() < (1e-4 if dt == "float32" else 1e-7) * np.abs(exp["evals"]).max()
+
+
+def test_bad_arguments_are_refused():
+    lib = _lib.load()
+    plan = C.c_void_p()
+    assert lib.vican_plan_create(0, 1, 1, 0, None, None, None, None, None, None, None, None, None, None, C.byref(plan)) == _lib.ERR_ARG
+    assert lib.vican_solve_rot(None, 4, 1e-10, None, None, None, None) == _lib.ERR_ARG
+    assert lib.vican_plan_destroy(None) == 0

@@ -45,7 +45,7 @@ def make_backends(C, T, deg_lo, deg_hi, seed, dt, block_threads=None, n_wg=None,
         kw = dict(layout="wave", wg_waves=int(block_threads[4:]) if len(block_threads) > 4 else None)
     g = LocalGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev),
                    torch.from_numpy(blk).to(dev, tdt), torch.from_numpy(a).to(dev, tdt),
-                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev), n_wg=n_wg, **kw)
+                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev), n_wg=n_wg, keep_csr=True, **kw)
     return HipBackend(g), NumpyBackend(C, rp, col, blk, a, w, u, v, storage=dt), g
 
 

@@ -9,7 +9,7 @@ from vican_amd.solver import Comm, RotationSolver, TranslationSolver, LsqrTransl
 dev = torch.device("cuda:0")
 for (C, T, k) in ((340, 10000, 4), (1000, 100000, 250)):
     gr = synth.make_merged_graph_torch(C, T, k, dev, torch.float32, seed=0)
-    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+    g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"], keep_csr=True)
     K = HipBackend(g)
     rot = RotationSolver(K, Comm()); rc, Rt = rot.run(4)
     for rep in range(2):

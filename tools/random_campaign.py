@@ -32,6 +32,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "random_parity")
 os.makedirs(out, exist_ok=True)
 rows, t_start = [], time.time()
+# rotation tolerances: 1e-7 rad (float64), 1e-5 rad (float32: two eigen-solvers on float32 blocks; the oracle itself moves by
+# ~4e-7 rad between runs of its randomly started ARPACK on the worst scene of the 3000, seed 1855: 5.5e-6 / 5.6e-6 / 5.9e-6 rad)
+# - the north star's is 1e-4 rad
+ROT_TOL = {"float64": 1e-7, "float32": 1e-5}
 
 
 def stage_alone(src, cons, mode, fns, dt, ref):
@@ -114,7 +118,7 @@ for seed in range(N):
                 if ref is not None:
                     rot_try = float(geodesic(np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res]),
                                              np.stack([np.asarray(ref[k].R(), dtype=np.float64) for k in ref])).max())
-                    if rot_try >= (1e-7 if dt == np.float64 else 5e-6):
+                    if rot_try >= ROT_TOL[np.dtype(dt).name]:
                         retry_why = "rotations %.2e rad from the product" % rot_try
                 if retry_why is None or attempt == 2:
                     if retry_why is not None and ref is None:
@@ -141,7 +145,7 @@ for seed in range(N):
                            cg_numpy=np_cg, cg_oracle=oinfo.get("cg_iters"), cg_oracle_min=int(sm.iters.min()), cg_oracle_max=int(sm.iters.max()),
                            cg_oracle_trials=";".join(str(int(i)) for i in sm.iters[1:]),
                            self_move_trials=";".join("%.2e" % m for m in sm.self_move))
-                if rot >= (1e-7 if dt == np.float64 else 5e-6):
+                if rot >= ROT_TOL[np.dtype(dt).name]:
                     row["outcome"] = "ROTATION MISMATCH"
                 elif err >= bound_e2e or (stage_err is not None and stage_err >= bound):
                     row["outcome"] = "TRANSLATION MISMATCH"

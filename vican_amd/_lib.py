@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so")      # VICAN_LIB: diagnostic builds (tools/)
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
-           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip")]
+           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip"),
+           os.path.join(CSRC, "vican_facade.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
 FX_DOUBLES = 20
@@ -26,7 +27,16 @@ GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
 INCLUDE = os.path.join(ROOT, "include")
 # VICAN_ABI_VERSION of include/vican_hip.h - the one place the number lives; load() rejects a library built from other sources
-ABI_VERSION = int(re.search(r"#define\s+VICAN_ABI_VERSION\s+(\d+)", open(os.path.join(INCLUDE, "vican_hip.h")).read()).group(1))
+def _header_abi_version():
+    """None when the package is deployed without the repository's include/ directory: load() then trusts the library's own
+    vican_abi_version() (a stale library cannot be told from a current one there, but importing the package must not fail)."""
+    try:
+        return int(re.search(r"#define\s+VICAN_ABI_VERSION\s+(\d+)", open(os.path.join(INCLUDE, "vican_hip.h")).read()).group(1))
+    except (OSError, AttributeError):
+        return None
+
+
+ABI_VERSION = _header_abi_version()
 
 ERR_ARG, ERR_LAUNCH, ERR_CAPACITY = -1, -2, -3          # VICAN_ERR_*
 STORE_F32, STORE_F64 = 0, 1
@@ -139,7 +149,20 @@ PROTOTYPES = {
     "vican_lsqr_nodes": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_scalars": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "vican_lsqr_update_st": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    # the four-call boundary (csrc/vican_facade.hip)
+    "vican_plan_create": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "vican_plan_describe": (C.c_int, [_vp, _G]),
+    "vican_solve_rot": (C.c_int, [_vp, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "vican_solve_trans": (C.c_int, [_vp, _vp, _vp, _f64, _i64, _vp, _vp, _vp, _vp]),
+    "vican_plan_destroy": (C.c_int, [_vp]),
 }
+
+
+class SolveInfo(C.Structure):
+    """Mirror of ``vican_solve_info_t``."""
+    _fields_ = [("iterations", C.c_int32), ("sweeps", C.c_int32), ("lanczos_steps", C.c_int32), ("restarts", C.c_int32),
+                ("evals", C.c_double * 5), ("eig_resid", C.c_double), ("cg_iters", C.c_int32), ("cg_converged", C.c_int32),
+                ("cg_relres", C.c_double)]
 
 # include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
 TEST_PROTOTYPES = {
@@ -246,6 +269,9 @@ def load():
             "or vican_amd._lib.build_library(); there is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.vican_abi_version.restype = C.c_int
+    global ABI_VERSION
+    if ABI_VERSION is None:
+        ABI_VERSION = int(lib.vican_abi_version())
     if lib.vican_abi_version() != ABI_VERSION:
         raise VicanError("%s is stale: it reports ABI %d, this package needs %d - rebuild with "
                          "`python __graft_entry__.py build`" % (LIB_PATH, lib.vican_abi_version(), ABI_VERSION))

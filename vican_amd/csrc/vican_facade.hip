@@ -1,0 +1,409 @@
+// vican_facade.hip - the four-call boundary of SURVEY.md 8(b): vican_plan_create / vican_solve_rot / vican_solve_trans /
+// vican_plan_destroy.  What a maintainer of the reference binds when he wants the numerics of
+// large_bipartite_so3sync (bipgo.py:145-350) and of the normal-equation CG (bipgo.py:445-478) behind ONE handle and has
+// no use for the ~70 granular entry points the Python driver (vican_amd/solver.py, device.py) composes.
+//
+// Everything here is HOST code on top of those entry points - the same kernels, the same fixed-point scales, the same
+// stopping rules - with the plain schedule: layout planning as device.py's _Layout (wave layout where every row fits a
+// 64-lane chunk, else block layout), block Lanczos with a convergence check (device Ritz step, one blocking 128-byte read) every
+// few steps, launch-sequence camera-side step, the fused dual update, CG iterations in bursts of eight with the state polled
+// in between.  No speculation, no cooperative kernels, no HIP graphs, single rank, C <= 1024: the Python driver remains the
+// fast path (and the only sharded / tiled / LSQR one); this one is the small stable surface.  The library owns the plan's
+// device memory (one arena); inputs and outputs are the caller's.
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <cstdarg>
+#include <cstdio>
+#include "vican_sweep_common.h"
+
+namespace {
+
+int ferr(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int ferr(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_vican_err, sizeof(g_vican_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr double X_BOUND = 1.7320508075688772;          // |x_c|_F of every sweep input (device.py: X_BOUND)
+constexpr size_t STREAM_NT_BYTES = (size_t)192 << 20;   // device.py: STREAM_NT_BYTES
+constexpr int M_MAX = 32;                               // VICAN_RITZ_MAX_STEPS
+
+struct Arena {
+    unsigned char* base = nullptr;
+    size_t size = 0, used = 0;
+    template <typename T> T* take(size_t n) {
+        used = (used + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + used) : nullptr;
+        used += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct vican_plan {
+    int C = 0, T = 0, storage = 0, epl = 4;
+    long long E = 0;
+    vican_graph_t g{};
+    int rows_per_wg_max = 1, rows_per_wg_sweep = 1;
+    double n_add = 1, n_add_cg = 1, wmax = 1, gmax = 1, lscale = 1;
+    bool have_t = false;
+    int prop_sweeps = 3;
+    Arena ar;
+    // layout arrays
+    int32_t* idx = nullptr; int32_t* chunk_row0 = nullptr; void* blk = nullptr; void* a = nullptr;
+    double *w = nullptr, *u = nullptr, *v = nullptr;
+    // graph constants
+    double *row_sum_a = nullptr, *cam_sum_a = nullptr, *rnorm = nullptr, *fx = nullptr, *row_sum_w = nullptr, *cam_sum_w = nullptr;
+    // solver workspace (names as in vican_amd/solver.py)
+    double *zpart = nullptr, *V = nullptr, *R = nullptr, *H = nullptr, *G = nullptr, *beta0 = nullptr, *HB = nullptr, *Yd = nullptr,
+           *status = nullptr, *xrow = nullptr, *z = nullptr, *X = nullptr, *Xp = nullptr, *x0 = nullptr, *rc = nullptr, *lamC = nullptr,
+           *cam_deg = nullptr, *lamT = nullptr, *Rt = nullptr, *zraw = nullptr;
+    int32_t* gate = nullptr; int32_t* coop_sync = nullptr;
+    int hw = 0, hb_stride = 0, ld = 0;
+    // translation workspace
+    double *b_c = nullptr, *b_t = nullptr, *r_c = nullptr, *p_c = nullptr, *r_t = nullptr, *p_t = nullptr, *q_t = nullptr, *qcpq = nullptr,
+           *pq_part = nullptr, *rr_part = nullptr, *ws = nullptr;
+    vican_cg_state_t* st = nullptr;
+    double* status_host = nullptr;      // pinned
+};
+
+namespace {
+
+__global__ void facade_maxima_kernel(long long n, int storage, const void* a, const double* w, const double* u, const double* v,
+                                     double* out /* [3]: max|a|, max w, max(|u|+|v|) */) {
+    double ma = 0, mw = 0, mg = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        ma = fmax(ma, fabs(storage == VICAN_STORE_F32 ? (double)((const float*)a)[i] : ((const double*)a)[i]));
+        if (w) {
+            mw = fmax(mw, w[i]);
+            const double nu = sqrt(u[3 * i] * u[3 * i] + u[3 * i + 1] * u[3 * i + 1] + u[3 * i + 2] * u[3 * i + 2]);
+            const double nv = sqrt(v[3 * i] * v[3 * i] + v[3 * i + 1] * v[3 * i + 1] + v[3 * i + 2] * v[3 * i + 2]);
+            mg = fmax(mg, nu + nv);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ma = fmax(ma, __shfl_xor(ma, o, 64)); mw = fmax(mw, __shfl_xor(mw, o, 64)); mg = fmax(mg, __shfl_xor(mg, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomic_max_pos(out, ma); atomic_max_pos(out + 1, mw); atomic_max_pos(out + 2, mg); }
+}
+
+__global__ void facade_seed_kernel(int n, double* x) {         // identity at camera 0, zero elsewhere ([n][3] row-major)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n) x[i] = (i < 9 && i / 3 == i % 3) ? 1.0 : 0.0;
+}
+
+int n_cu() {
+    int dev = 0; hipGetDevice(&dev);
+    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+}
+
+// device.py _Layout: sizes of the chunked layout for this graph
+int plan_layout(vican_plan* P, const std::vector<int32_t>& rp, std::vector<int32_t>& chunk_row0) {
+    const int C = P->C, T = P->T, storage = P->storage, epl = P->epl, ncu = n_cu();
+    const long long E = P->E;
+    const long long lim = vican_lds_limit_bytes();
+    int deg_max = 0;
+    for (int t = 0; t < T; ++t) deg_max = std::max(deg_max, rp[t + 1] - rp[t]);
+    const double deg_avg = std::max(1.0, T ? (double)E / T : 1.0);
+    vican_graph_t& g = P->g;
+    g.n_cam = C; g.n_time = T; g.storage = storage;
+    const bool wave = deg_max <= 64 * epl && C <= 1024 && E > 0;
+    int slots, max_rows, n_copy, wg_waves = 0, block_threads;
+    if (wave) {
+        slots = 64 * epl;
+        int rows_target = std::max(1, std::min(64, (int)std::ceil(1.25 * slots / deg_avg) + 1));
+        n_copy = 1;
+        while (n_copy < 8 && n_copy * epl < deg_avg) n_copy *= 2;
+        wg_waves = 12;
+        if (E < 12LL * slots * ncu) wg_waves = E >= 8LL * slots * ncu ? 8 : 4;
+        auto fits = [&](int rows, int nc, int nw) { return vican_wsweep_lds_bytes(C, rows, storage, nc, nw) <= lim; };
+        while (!fits(rows_target, n_copy, wg_waves) && n_copy > 1) n_copy /= 2;
+        while (!fits(rows_target, n_copy, wg_waves) && wg_waves > 4) wg_waves -= 4;
+        while (!fits(rows_target, n_copy, wg_waves) && rows_target > 1) --rows_target;
+        if (!fits(rows_target, n_copy, wg_waves)) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: camera tables (C=%d) do not fit in LDS", C);
+        max_rows = rows_target; block_threads = 64 * wg_waves;
+    } else {
+        block_threads = E >= 768LL * epl * ncu ? 768 : 256;
+        if (deg_max > 256 * epl) block_threads = 768;
+        if (deg_max > 768 * epl) block_threads = 1024;
+        slots = block_threads * epl;
+        if (deg_max > slots) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: a timestep row has %d edges, a chunk holds %d", deg_max, slots);
+        const int rows_target = std::min(65535, (int)std::ceil(1.25 * slots / deg_avg) + 1);
+        n_copy = 8;
+        while (n_copy > 1 && vican_max_rows_for(C, storage, n_copy) < rows_target) n_copy /= 2;
+        max_rows = vican_max_rows_for(C, storage, n_copy);
+        if (max_rows < 1) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: camera tables (C=%d) do not fit in LDS", C);
+        max_rows = std::min(max_rows, std::max(rows_target, 1));
+    }
+    chunk_row0.assign((size_t)T + 2, 0);
+    const int nchunk = vican_plan_chunks(T, rp.data(), slots, max_rows, chunk_row0.data(), T + 2);
+    if (nchunk < 0) return nchunk;
+    chunk_row0.resize((size_t)nchunk + 1);
+    int rows_max = 1;
+    for (int k = 0; k < nchunk; ++k) rows_max = std::max(rows_max, chunk_row0[k + 1] - chunk_row0[k]);
+    g.n_chunk = nchunk; g.slots = slots; g.max_rows = rows_max; g.block_threads = block_threads; g.n_copy = n_copy;
+    g.layout = wave ? VICAN_LAYOUT_WAVE : VICAN_LAYOUT_BLOCK; g.wg_waves = wg_waves;
+    const long long lds = wave ? vican_wsweep_lds_bytes(C, rows_max, storage, n_copy, wg_waves) : vican_sweep_lds_bytes(C, rows_max, storage, n_copy);
+    const int per_wg = wave ? wg_waves : 1;
+    const int occ = (int)std::max(1LL, std::min(lim / std::max(lds, 1LL), (long long)(2048 / block_threads)));
+    g.n_wg = std::max(1, std::min((nchunk + per_wg - 1) / per_wg, ncu * occ));
+    int rpw = 1;
+    for (int wg = 0; wg < g.n_wg && nchunk; ++wg) {
+        const long long k0 = (long long)wg * nchunk / g.n_wg, k1 = (long long)(wg + 1) * nchunk / g.n_wg;
+        rpw = std::max(rpw, chunk_row0[k1] - chunk_row0[k0]);
+    }
+    P->rows_per_wg_max = rpw;
+    const int per = nchunk ? (nchunk + g.n_wg - 1) / g.n_wg : 1;
+    if (wave) {
+        g.wg_chunk_cap = ((13 * per + 10 * wg_waves - 1) / (10 * wg_waves) + 3) * wg_waves;
+        P->rows_per_wg_sweep = std::max(std::min((long long)T, (long long)g.wg_chunk_cap * rows_max), 1LL);
+    } else {
+        g.wg_chunk_cap = per + std::max(2, (per + 7) / 8);
+        P->rows_per_wg_sweep = (int)std::max<long long>(std::max<long long>(rpw, std::min((long long)T, (long long)g.wg_chunk_cap * rows_max)), 1);
+    }
+    g.slot_order = deg_avg < 48 * epl ? 1 : 0;
+    const size_t nslot = (size_t)std::max(1, nchunk) * slots;
+    g.stream_nt = nslot * (9 * (storage == VICAN_STORE_F32 ? 4 : 8) + 4) > STREAM_NT_BYTES ? 1 : 0;
+    return VICAN_OK;
+}
+
+size_t carve(vican_plan* P, size_t n_row0) {
+    Arena& A = P->ar;
+    A.used = 0;
+    const int C = P->C, T1 = std::max(P->T, 1), n = 3 * C;
+    const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, s = P->storage == VICAN_STORE_F32 ? 4 : 8;
+    P->idx = A.take<int32_t>(nslot); P->chunk_row0 = A.take<int32_t>(n_row0);
+    P->blk = A.take<unsigned char>(9 * nslot * s); P->a = A.take<unsigned char>(nslot * s);
+    if (P->have_t) { P->w = A.take<double>(nslot); P->u = A.take<double>(3 * nslot); P->v = A.take<double>(3 * nslot); }
+    P->row_sum_a = A.take<double>(T1); P->cam_sum_a = A.take<double>(C); P->rnorm = A.take<double>(T1); P->fx = A.take<double>(20);
+    if (P->have_t) { P->row_sum_w = A.take<double>(T1); P->cam_sum_w = A.take<double>(C); }
+    P->zpart = A.take<double>((size_t)std::max(P->g.n_wg, 1) * 9 * C);
+    const int m = std::max(1, std::min(M_MAX, n / 3));
+    P->ld = n; P->hw = 3 * (m + 1) * 3; P->hb_stride = P->hw + 9;
+    P->V = A.take<double>((size_t)3 * (m + 1) * n); P->R = A.take<double>(3 * (size_t)n); P->H = A.take<double>(3 * (m + 1) * 3);
+    P->G = A.take<double>(9); P->beta0 = A.take<double>(9); P->HB = A.take<double>((size_t)m * P->hb_stride);
+    P->Yd = A.take<double>((size_t)3 * (m + 1) * 3); P->status = A.take<double>(16); P->gate = A.take<int32_t>(4); P->coop_sync = A.take<int32_t>(4);
+    P->xrow = A.take<double>(3 * (size_t)n); P->z = A.take<double>(3 * (size_t)n); P->X = A.take<double>(3 * (size_t)n);
+    P->Xp = A.take<double>(3 * (size_t)n); P->x0 = A.take<double>(3 * (size_t)n); P->rc = A.take<double>(3 * (size_t)n);
+    P->lamC = A.take<double>(9 * (size_t)C); P->cam_deg = A.take<double>(C); P->lamT = A.take<double>(9 * (size_t)T1);
+    P->Rt = A.take<double>(9 * (size_t)T1); P->zraw = A.take<double>(3 * (size_t)n);
+    if (P->have_t) {
+        P->b_c = A.take<double>(3 * (size_t)C); P->b_t = A.take<double>(3 * (size_t)T1); P->r_c = A.take<double>(3 * (size_t)C);
+        P->p_c = A.take<double>(3 * (size_t)C); P->r_t = A.take<double>(3 * (size_t)T1); P->p_t = A.take<double>(3 * (size_t)T1);
+        P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
+        P->pq_part = A.take<double>(std::max(P->g.n_wg, 1)); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
+        P->st = (vican_cg_state_t*)A.take<double>(19);
+    }
+    return A.used + 256;
+}
+
+#define CK(call) do { const int rc_ = (call); if (rc_ < 0) return rc_; } while (0)
+#define HIPCK(call, what) do { if ((call) != hipSuccess) return ferr(VICAN_ERR_LAUNCH, "%s: %s failed", what, #call); } while (0)
+
+int fx_finish(vican_plan* P, void* stream) { return vican_fx_finish(P->fx, X_BOUND, (double)P->rows_per_wg_sweep + 1.0, P->storage, stream); }
+
+}  // namespace
+
+extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges, int32_t storage, const int32_t* row_ptr,
+                                 const int32_t* col, const void* blk, const void* a, const double* w, const double* u,
+                                 const double* v, const double* deg_t, const double* deg_c, void* stream, vican_plan_t** plan_out) {
+    if (!plan_out) return ferr(VICAN_ERR_ARG, "vican_plan_create: plan_out is NULL");
+    *plan_out = nullptr;
+    if (n_cam <= 0 || n_time <= 0 || n_edges <= 0 || !row_ptr || !col || !blk || !a || (storage != VICAN_STORE_F32 && storage != VICAN_STORE_F64) ||
+        ((w || u || v) && !(w && u && v)))
+        return ferr(VICAN_ERR_ARG, "vican_plan_create: bad argument");
+    if (n_cam > 1024) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: more than 1024 cameras need the camera-tiled host driver (vican_amd.device.TiledBackend)");
+    hipStream_t s = (hipStream_t)stream;
+    vican_plan* P = new vican_plan();
+    P->C = n_cam; P->T = n_time; P->E = n_edges; P->storage = storage; P->epl = storage == VICAN_STORE_F32 ? 4 : 2; P->have_t = w != nullptr;
+    std::vector<int32_t> rp((size_t)n_time + 1), c0;
+    auto fail = [&](int rc) { vican_plan_destroy(P); return rc; };
+    if (hipMemcpyAsync(rp.data(), row_ptr, rp.size() * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: cannot read row_ptr"));
+    if (rp[0] != 0 || rp[n_time] != n_edges) return fail(ferr(VICAN_ERR_ARG, "vican_plan_create: row_ptr does not span n_edges"));
+    int rc = plan_layout(P, rp, c0);
+    if (rc < 0) return fail(rc);
+    const size_t bytes = carve(P, c0.size());
+    if (hipMalloc((void**)&P->ar.base, bytes) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc of %zu bytes failed", bytes));
+    P->ar.size = bytes;
+    carve(P, c0.size());
+    if (hipHostMalloc((void**)&P->status_host, 64 * sizeof(double)) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipHostMalloc failed"));
+    if (hipMemsetAsync(P->ar.base, 0, bytes, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: memset failed"));
+    if (hipMemcpyAsync(P->chunk_row0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed"));
+    P->g.blk = P->blk; P->g.idx = (const uint32_t*)P->idx; P->g.chunk_row0 = P->chunk_row0;
+    P->n_add = (double)std::max(P->rows_per_wg_max, P->g.slots) + 1.0; P->n_add_cg = P->n_add;
+    // pack: CSR order -> chunked slot order (one scratch array of slot indices)
+    int32_t* perm = nullptr;
+    const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots;
+    if (hipMalloc((void**)&perm, nslot * 4) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc failed"));
+    double* mx = P->ws ? P->ws : P->G;           // three doubles of scratch (zeroed by the memset)
+    rc = vican_pack_edges(&P->g, row_ptr, col, blk, a, w, u, v, P->a, P->w, P->u, P->v, perm, stream);
+    if (rc >= 0) {
+        hipLaunchKernelGGL(facade_maxima_kernel, dim3(256), dim3(256), 0, s, (long long)n_edges, storage, a, w, u, v, mx);
+        double h[3] = {1, 1, 1};
+        if (hipMemcpyAsync(h, mx, 24, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: maxima read failed");
+        if (rc >= 0) {
+            hipMemsetAsync(mx, 0, 24, s);
+            if (P->have_t) { P->wmax = h[1]; P->gmax = h[2]; }
+            void* cam_ws = P->zpart;             // C 64-bit words of scratch
+            rc = vican_edge_sums(&P->g, P->a, storage == VICAN_STORE_F64, h[0] > 0 ? h[0] : 1.0, P->row_sum_a, P->cam_sum_a, cam_ws, stream);
+            if (rc >= 0) rc = vican_block_norms(&P->g, P->rnorm, P->fx, stream);
+            if (rc >= 0 && P->have_t) {
+                rc = vican_edge_sums(&P->g, P->w, 1, P->wmax, P->row_sum_w, P->cam_sum_w, cam_ws, stream);
+                if (rc >= 0 && deg_t) hipMemcpyAsync(P->row_sum_w, deg_t, (size_t)n_time * 8, hipMemcpyDeviceToDevice, s);
+                if (rc >= 0 && deg_c) hipMemcpyAsync(P->cam_sum_w, deg_c, (size_t)n_cam * 8, hipMemcpyDeviceToDevice, s);
+            }
+        }
+    }
+    // |L| <~ 2 max camera degree: sizes the pivot floor of the Cholesky-QR (solver.py: RotationSolver.init)
+    std::vector<double> cs((size_t)n_cam);
+    if (rc >= 0 && (hipMemcpyAsync(cs.data(), P->cam_sum_a, cs.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+        rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: degree read failed");
+    hipFree(perm);
+    if (rc < 0) return fail(rc);
+    P->lscale = *std::max_element(cs.begin(), cs.end());
+    // propagation sweeps of the start block (solver.py: as many as it takes to reach nearly every camera)
+    const double hops1 = ((double)n_edges / n_cam) * std::max((double)n_edges / n_time - 1.0, 0.0) / n_cam;
+    P->prop_sweeps = hops1 >= 4.0 ? 1 : (hops1 >= 0.5 ? 2 : 3);
+    *plan_out = P;
+    return VICAN_OK;
+}
+
+extern "C" int vican_plan_destroy(vican_plan_t* P) {
+    if (!P) return VICAN_OK;
+    if (P->ar.base) hipFree(P->ar.base);
+    if (P->status_host) hipHostFree(P->status_host);
+    delete P;
+    return VICAN_OK;
+}
+
+extern "C" int vican_plan_describe(const vican_plan_t* P, vican_graph_t* g_out) {
+    if (!P || !g_out) return ferr(VICAN_ERR_ARG, "vican_plan_describe: bad argument");
+    *g_out = P->g;
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// rotation stage: reference large_bipartite_so3sync, bipgo.py:279-348 (schedule of vican_amd/solver.py RotationSolver, plain form)
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol, double* rc_out, double* Rt_out,
+                               vican_solve_info_t* info, void* stream) {
+    if (!P || maxiter < 1 || !(eig_tol > 0)) return ferr(VICAN_ERR_ARG, "vican_solve_rot: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = P->C, T = P->T, n = 3 * C, ld = P->ld, m_max = std::max(1, std::min(M_MAX, n / 3));
+    const vican_graph_t* g = &P->g;
+    vican_set_gate(nullptr);
+    const bool small = P->E < 2000000;
+    const int min_steps = small ? 8 : 4, warm_min = small ? 4 : 2, check_every = small ? 4 : 2, max_restarts = 20;
+    const double floor_tol = P->storage == VICAN_STORE_F64 ? 1e-13 : 1e-7, pivot_floor = (1e-12 * P->lscale) * (1e-12 * P->lscale);
+    vican_solve_info_t inf{};
+    // duals, Lambda_C = (weighted camera degree) I  (bipgo.py:271-276)
+    CK(vican_init_duals(T, P->row_sum_a, P->rnorm, P->lamT, P->fx, stream));
+    CK(fx_finish(P, stream));
+    HIPCK(hipMemcpyAsync(P->cam_deg, P->cam_sum_a, (size_t)C * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
+    CK(vican_scaled_identity(C, P->cam_deg, P->lamC, stream));
+    // start block: rotations propagated from the gauge camera through the power graph (solver.py: _propagated_start)
+    hipLaunchKernelGGL(facade_seed_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, n, P->x0);
+    for (int k = 0; k < P->prop_sweeps; ++k) {
+        CK(vican_block_op_z(g, P->lamT, P->x0, P->zpart, P->fx, P->z, stream));
+        CK(vican_polar_dual(C, P->z, P->x0, nullptr, 0, stream));
+        ++inf.sweeps;
+    }
+    bool z_ready = false;
+    for (int it = 0; it < maxiter; ++it) {
+        const int relax = std::max(0, (maxiter - 2) - it);
+        const double tol = std::min(std::max(eig_tol * std::pow(100.0, relax), eig_tol), 1e-4);
+        const bool last = it == maxiter - 1;
+        const double* start = it == 0 ? P->x0 : P->rc;
+        bool conv = false;
+        int steps = 0;
+        double* st = P->status_host;
+        for (int restart = 0; restart <= max_restarts && !conv; ++restart) {
+            const bool have_z = restart == 0 && z_ready;
+            CK(vican_lanczos_seed(n, start, P->V, ld, P->beta0, P->xrow, have_z ? P->zraw : nullptr, have_z ? P->z : nullptr, P->coop_sync, stream));
+            z_ready = false;
+            steps = 0;
+            int next_check = std::min(restart == 0 ? warm_min : min_steps, m_max), prev_steps = 0;
+            bool first = true;
+            for (;;) {
+                const int j = steps;
+                if (!(j == 0 && have_z)) { CK(vican_block_op_z(g, P->lamT, P->xrow, P->zpart, P->fx, P->z, stream)); ++inf.sweeps; }
+                CK(vican_lanczos_cam_step(C, P->lamC, P->V, ld, j, P->z, P->R, P->H, P->G, P->HB + (size_t)j * P->hb_stride,
+                                          P->HB + (size_t)j * P->hb_stride + P->hw, P->xrow, pivot_floor, nullptr, 0, stream));
+                ++steps; ++inf.lanczos_steps;
+                if (steps < next_check && steps < m_max) continue;
+                const int flags = (first ? 1 : 0) | (steps >= m_max ? 2 : 0);
+                CK(vican_ritz(P->HB, P->hb_stride, P->hw, steps, flags, tol, floor_tol, -1.0, steps - prev_steps <= 1 ? 0.5 : 0.25, P->Yd,
+                              P->status, P->gate, stream));
+                first = false; prev_steps = steps;
+                HIPCK(hipMemcpyAsync(st, P->status, 16 * 8, hipMemcpyDeviceToHost, s), "vican_solve_rot");
+                HIPCK(hipStreamSynchronize(s), "vican_solve_rot");
+                conv = st[3] != 0.0;
+                if (st[2] != 0.0) break;                       // stop (converged, noise floor, step budget or exhausted Krylov space)
+                const bool near_floor = floor_tol > 1e-12 && st[0] <= floor_tol;
+                next_check = std::min(steps + ((steps < 8 && !small) || near_floor ? 1 : check_every), m_max);
+            }
+            CK(vican_tall_combine(n, P->V, ld, 3 * steps, P->Yd, P->X, stream));
+            if (!conv) { start = P->X; ++inf.restarts; HIPCK(hipMemcpyAsync(P->Xp, P->X, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot"); start = P->Xp; }
+        }
+        for (int q = 0; q < 3; ++q) inf.evals[q] = st[7 + q];
+        inf.evals[3] = st[15]; inf.evals[4] = st[13];
+        inf.eig_resid = st[0];
+        // X = V3 V3[0:3]^-1, per-camera projection, Y = P X, camera duals, timestep duals (bipgo.py:295-334)
+        CK(vican_gauge_project(C, P->X, P->Xp, stream));
+        CK(vican_block_op_z(g, P->lamT, P->Xp, P->zpart, P->fx, P->z, stream));
+        CK(vican_polar_dual(C, P->z, P->rc, P->lamC, 1, stream));
+        if (!last) { CK(vican_dual_update_op(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, P->zpart, P->zraw, stream)); z_ready = true; }
+        else CK(vican_dual_update(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, stream));
+        CK(fx_finish(P, stream));
+        inf.sweeps += 2;
+        ++inf.iterations;
+    }
+    if (rc_out) HIPCK(hipMemcpyAsync(rc_out, P->rc, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
+    if (Rt_out) HIPCK(hipMemcpyAsync(Rt_out, P->Rt, (size_t)9 * T * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
+    HIPCK(hipStreamSynchronize(s), "vican_solve_rot");
+    if (info) *info = inf;
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// translation stage: J^T b and scipy's CG on the normal equations (bipgo.py:445-478)
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double* Rt, double rtol, int64_t maxiter, double* x_c,
+                                 double* x_t, vican_solve_info_t* info, void* stream) {
+    if (!P || !rc || !Rt || !x_c || !x_t || !(rtol >= 0)) return ferr(VICAN_ERR_ARG, "vican_solve_trans: bad argument");
+    if (!P->have_t) return ferr(VICAN_ERR_ARG, "vican_solve_trans: the plan was created without translation arrays (w, u, v)");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = P->C, T = P->T;
+    if (maxiter <= 0) maxiter = 10LL * 3 * (C + T);              // scipy's default
+    vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
+    CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
+    CK(vican_cg_init(C, T, P->b_c, P->b_t, x_c, x_t, P->r_c, P->r_t, P->p_c, P->p_t, P->st, P->ws, P->wmax, stream));
+    int n_part = 0;
+    long long launched = 0;
+    vican_cg_state_t h{};
+    int burst = 8;
+    for (;;) {
+        for (int i = 0; i < burst && launched <= maxiter; ++i, ++launched) {
+            CK(vican_cg_iter_local(&P->g, P->w, P->row_sum_w, P->r_c, P->p_c, P->r_t, P->p_t, P->q_t, P->zpart, P->pq_part, P->qcpq, rtol,
+                                   P->rr_part, n_part, P->n_add_cg, P->st, stream));
+            n_part = vican_cg_iter_finish(C, T, P->cam_sum_w, P->qcpq, P->p_c, x_c, P->r_c, P->p_t, P->q_t, x_t, P->r_t, P->rr_part, 1536, P->st, stream);
+            if (n_part < 0) return n_part;
+        }
+        HIPCK(hipMemcpyAsync(P->status_host + 16, P->st, sizeof(vican_cg_state_t), hipMemcpyDeviceToHost, s), "vican_solve_trans");
+        HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
+        std::memcpy(&h, P->status_host + 16, sizeof(h));
+        if (h.done || launched > maxiter) break;
+        burst = std::min(2 * burst, 64);
+    }
+    inf.cg_iters = h.iter; inf.cg_converged = h.done == 1;
+    inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;
+    if (info) *info = inf;
+    if (h.done != 1) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans: CG did not converge in %lld iterations (scipy exit_code != 0, bipgo.py:478)", (long long)maxiter);
+    return VICAN_OK;
+}

@@ -38,7 +38,7 @@ _ABORT = None
 
 
 _NP_OF = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
-_STAGE = {"buf": None, "event": None}
+_STAGE = {"buf": None, "event": None, "lock": __import__("threading").Lock()}       # one staging buffer per process: serialised
 
 
 def upload(dev, items):
@@ -47,6 +47,11 @@ def upload(dev, items):
     Why not ``torch.from_numpy(a).to(dev)`` per array: a pageable host-to-device copy of ~1 MB now and then takes 70-100 ms
     on this platform (about one cold drop-in call in three: tools/dbg/upload2.py), a copy from page-locked memory never; the
     staging buffer is allocated once per process and reused (an event guards it against the copy still in flight)."""
+    with _STAGE["lock"]:
+        return _upload_locked(dev, items)
+
+
+def _upload_locked(dev, items):
     offs, total = [], 0
     arrs = []
     for a, dt in items:
@@ -80,6 +85,11 @@ def upload(dev, items):
 def download(tensors):
     """Device tensors -> NumPy arrays through the page-locked staging buffer of ``upload`` (one synchronisation for all of
     them; copies into pageable memory show the same occasional 10-25 ms stalls as pageable uploads)."""
+    with _STAGE["lock"]:
+        return _download_locked(tensors)
+
+
+def _download_locked(tensors):
     ts = [t.contiguous() for t in tensors]
     offs, total = [], 0
     for t in ts:
@@ -105,15 +115,21 @@ def download(tensors):
 _STATUS_POOL = {}          # (device, doubles) -> free (pinned buffer, copy-done event, ready event, side stream) slots, see post_status
 
 
+_ABORT_TLS = __import__("threading").local()
+
+
 def barrier_abort_word(timeout_us=None):
-    """The process-wide abort word (a pinned int32 tensor); registers it with the library on first use.
-    timeout_us: spin limit of every grid barrier (default VICAN_BARRIER_TIMEOUT_US or 2 s)."""
+    """The process-wide abort word (a pinned int32 tensor).  The library keeps the registration PER HOST THREAD
+    (vican_set_barrier_abort: thread_local, like the gate and the launch timer), so every thread that builds or uses a
+    backend registers the word once - a backend used on a second thread would otherwise launch its cooperative kernels
+    with unbounded spins.  timeout_us: spin limit of every grid barrier (default VICAN_BARRIER_TIMEOUT_US or 2 s)."""
     global _ABORT
-    if _ABORT is None or timeout_us is not None:
-        if _ABORT is None:
-            _ABORT = torch.zeros(4, dtype=torch.int32).pin_memory()
-        us = int(timeout_us if timeout_us is not None else os.environ.get("VICAN_BARRIER_TIMEOUT_US", 0))
+    if _ABORT is None:
+        _ABORT = torch.zeros(4, dtype=torch.int32).pin_memory()
+    if timeout_us is not None or not getattr(_ABORT_TLS, "registered", False):
+        us = int(timeout_us if timeout_us is not None else getattr(_ABORT_TLS, "us", os.environ.get("VICAN_BARRIER_TIMEOUT_US", 0)))
         _lib.check(_lib.load().vican_set_barrier_abort(C.c_void_p(_ABORT.data_ptr()), us), "vican_set_barrier_abort")
+        _ABORT_TLS.registered, _ABORT_TLS.us = True, us
     return _ABORT
 
 
@@ -275,7 +291,7 @@ class LocalGraph:
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None, row_ptr_host=None):
+                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None, row_ptr_host=None, keep_csr=None):
         import os
         lib = _lib.load()
         if not torch.cuda.is_available():
@@ -358,8 +374,12 @@ class LocalGraph:
                                         _ptr(u) if have_t else None, _ptr(v) if have_t else None, _ptr(self.a),
                                         _ptr(self.w) if have_t else None, _ptr(self.u) if have_t else None,
                                         _ptr(self.v) if have_t else None, _ptr(perm_ws), st), "vican_pack_edges")
-        # (kept for lsqr_layout(): CSR-order inputs of the translation arrays - references, no copies)
-        self._csr_t = (row_ptr, col, w, u, v) if (have_t and rot.kind == "wave") else None
+        # The legacy host-scalar LSQR path (cross-checks only: HipBackend.lsqr_host_scalars) needs a second, block layout of the
+        # translation arrays, packed from the CSR-order inputs on first use.  They are retained - references, ~60 B per edge of
+        # HBM, and through views the caller's whole upload - ONLY when asked for (keep_csr=True / VICAN_KEEP_CSR=1): the
+        # device-resident LSQR and everything else run on the packed arrays, and "inputs may be freed by the caller" holds.
+        keep = keep_csr if keep_csr is not None else os.environ.get("VICAN_KEEP_CSR") == "1"
+        self._csr_t = (row_ptr, col, w, u, v) if (keep and have_t and rot.kind == "wave") else None
         self._lsqr_layout = None
         gref_t = gref
         # graph constants
@@ -402,6 +422,8 @@ class LocalGraph:
             return self.rot, self.desc, self.w, self.u, self.v
         if self._lsqr_layout is None:
             lib = _lib.load()
+            if self._csr_t is None:
+                raise _lib.VicanError("the host-scalar LSQR path needs the CSR-order inputs: build the LocalGraph with keep_csr=True")
             row_ptr, col, w, u, v = self._csr_t
             bl = self._mk_block()
             desc = bl.describe(self.n_cam, self._storage, None)

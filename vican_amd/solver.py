@@ -60,6 +60,26 @@ class Comm:
             self.n_allreduce += 1
         return t
 
+    def any_flag(self, flag, device=None):
+        """Logical OR of a host flag over the ranks (one tiny MAX all-reduce; device tensor for RCCL groups)."""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device if self._device_collectives() else None)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        return bool(t.item() > 0)
+
+    def _device_collectives(self):
+        """True if the group runs collectives on device tensors (RCCL) - decided from the group's backend CONFIGURATION
+        ("nccl", or "cpu:gloo,cuda:nccl" of a default multi-backend group), not from the single name get_backend() reports."""
+        if getattr(self, "_dev_coll", None) is None:
+            name = str(torch.distributed.get_backend(self.group))
+            try:
+                cfg = str(torch.distributed.get_backend_config(self.group))
+            except Exception:                                   # noqa: BLE001  (older torch)
+                cfg = name
+            self._dev_coll = "nccl" in name or "cuda:nccl" in cfg or cfg.strip() == "nccl"
+        return self._dev_coll
+
     def gather_rows(self, loc, n_local, bounds):
         """Concatenate per-rank row blocks (rank r owns rows bounds[r] .. bounds[r + 1]) into the full [T, width] array
         on every rank: ONE all-gather of equally sized (padded) blocks - each rank sends only its own rows."""
@@ -71,7 +91,7 @@ class Comm:
         send[:n_local] = loc[:n_local]
         # the path is chosen by the backend's NAME, never by catching an error (a failing RCCL collective must surface):
         # RCCL gathers device tensors in place; gloo has no all-gather for device tensors, so its blocks travel through host memory
-        if torch.distributed.get_backend(self.group) == "nccl" or not loc.is_cuda:
+        if self._device_collectives() or not loc.is_cuda:
             recv = torch.empty(self.world * nmax, width, dtype=loc.dtype, device=loc.device)
             torch.distributed.all_gather_into_tensor(recv, send, group=self.group)
         else:
@@ -703,7 +723,14 @@ def with_cooperative_fallback(K, comm, fn):
         if not aborted():
             raise
         out = None
-    if aborted():
+    flag = bool(aborted())
+    if comm is not None and comm.world > 1:
+        # every rank must take the same branch: the rank whose barrier timed out would raise while its peers return and block
+        # in the next collective - the abort flag is all-reduced (MAX) so that all of them raise together
+        any_flag = getattr(comm, "any_flag", None)
+        if any_flag is not None:
+            flag = any_flag(flag, getattr(K, "dev", None))
+    if flag:
         if comm is not None and comm.world > 1:
             raise RuntimeError("a grid barrier of a cooperative kernel timed out on rank %d (device shared with another resident "
                                "kernel?); set VICAN_COOP=0 to run sharded solves without cooperative kernels" % comm.rank)
