@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=4)
     ap.add_argument("--no-large-shop", action="store_true", help="skip the large_shop wall-clock measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-capture measurement (detail.sparse) of the default run")
+    ap.add_argument("--no-wide", action="store_true", help="skip the camera-tiled measurement (detail.wide: 4000 cameras) of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
     ap.add_argument("--n-copy", type=int, default=None)
@@ -209,6 +210,56 @@ def large_shop_wall_clock(args, dev, tdt, comm):
             res["cpu_baseline"] = cpu_baselines(Cl, cl, Tl2, args.maxiter)
         except Exception as exc:
             res["cpu_baseline"] = {"value": None, "error": repr(exc)}
+    return res
+
+
+def wide_operator(args, dev, tdt, comm):
+    """More cameras than the LDS-resident sweeps hold (C = 4000 > 1024): the camera-TILED path (device.TiledBackend: a rows pass
+    over all tiles, the per-row combination, a camera pass per tile - every block read TWICE per operator application, block
+    layout, no fused dual update).  Reported so that the regime has a number: full solves and the operator application alone,
+    against the same algorithmic bytes an untiled sweep would move (E(9s+4) + 4(T+1) + 72T + 144C)."""
+    from vican_amd import synth
+    from vican_amd.device import make_backend
+    from vican_amd.solver import RotationSolver, TranslationSolver
+    Cw, Tw, cw = 4000, 50000, 250
+    gr = synth.make_merged_graph_torch(Cw, Tw, cw, dev, tdt, seed=0)
+    E = int(gr["col"].numel())
+    g, K = make_backend(Cw, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+    del gr
+    torch.cuda.empty_cache()
+    rot, tr = RotationSolver(K, comm), TranslationSolver(K, comm)
+
+    def solve():
+        rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+        rc, Rt = rot.run(args.maxiter)
+        tr.setup(rc, Rt)
+        tr.solve(3 * (Cw + Tw))
+        K.synchronize()
+    solve()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        solve()
+    ms = (time.perf_counter() - t0) / 2 * 1e3
+    x, z = rot.X, rot.z
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+    for a, b in ev:
+        a.record()
+        K.block_op(rot.lamT, x, z)
+        b.record()
+    torch.cuda.synchronize()
+    op_ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
+    s_ = 4 if args.dtype == "f32" else 8
+    bytes_op = E * (9 * s_ + 4) + 4 * (Tw + 1) + 72 * Tw + 144 * Cw
+    res = {"workload": "wide: %d cameras x %d timesteps x %d cams/timestep, %d merged edges, camera-tiled (%d tiles of <= 1024 cameras)" % (
+               Cw, Tw, cw, E, len(g.tiles)),
+           "ms_per_solve": ms, "value_edges_per_s": E * args.maxiter / (ms * 1e-3), "sweeps_per_step": rot.stats["sweeps"],
+           "lanczos_steps": rot.stats["lanczos_steps"], "cg_iters": tr.info.get("cg_iters"),
+           "operator_ms": op_ms, "operator_bytes_algorithmic": bytes_op,
+           "operator_frac": bytes_op / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "note": "operator = all launches of one application z = P x (event pair around them); every block is read twice"}
+    del K, g, rot, tr
+    torch.cuda.empty_cache()
     return res
 
 
@@ -561,6 +612,11 @@ def main():
                                        "max_rows": ms["detail"]["max_rows"], "n_copy": ms["detail"]["n_copy"], "steps": 3, "warmup": 1}
         except Exception as exc:
             out["detail"]["sparse"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and args.workload == "stress" and not args.no_wide:
+        try:
+            out["detail"]["wide"] = wide_operator(args, dev, tdt, comm)
+        except Exception as exc:
+            out["detail"]["wide"] = {"error": repr(exc)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Ts = args.cpu_sample_timesteps or {"stress": 300, "sparse": 20000}.get(args.workload, 10000)
         try:

@@ -86,7 +86,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 13            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 14            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -610,6 +610,23 @@ int vican_lsqr_scalars(int32_t n_cam, const double* acc, const double* part2, in
 int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* part, int32_t last, vican_lsqr_state_t* st,
                          void* stream);
 
+
+/* ---- collectives of the sharded solve (vican_comm_*) --------------------------------------------------------
+ * Timestep rows are sharded over ranks, every camera-side quantity is replicated; what crosses ranks are f64 sum-all-reduces of
+ * camera-side partials (the reference has no distributed code: this is the counterpart of bipgo.py:300,318 / :477 when the rows
+ * of R~ live on several GPUs).  A communicator held by the library: RCCL loaded at run time (dlopen librccl.so.1; no link-time
+ * dependency), ncclAllReduce enqueued on the caller's stream in stream order - no host synchronisation, no Python hop.
+ *   vican_comm_unique_id   128 bytes (ncclUniqueId) written by ONE rank, handed to the others by any means
+ *   vican_comm_create      collective over the group: every rank calls it with the same id (ncclCommInitRank)
+ *   vican_comm_allreduce_sum   buf[0:n] (device, f64) <- sum over ranks, in place; world == 1: nothing is enqueued
+ *   vican_block_op_z_comm  vican_block_op_z followed by the all-reduce of z [3C][3] behind one host call (comm NULL: single rank) */
+typedef struct vican_comm vican_comm_t;
+int vican_comm_unique_id(void* id_out /* 128 bytes, host */);
+int vican_comm_create(int32_t rank, int32_t world, const void* unique_id, vican_comm_t** comm_out);
+int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream);
+int vican_comm_destroy(vican_comm_t* comm);
+int vican_block_op_z_comm(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx, double* z,
+                          vican_comm_t* comm, void* stream);
 
 /* ---- the four-call boundary ----------------------------------------------------------------------------
  * For a maintainer who wants the numerics of the reference's two stages behind ONE handle: everything above composed by host

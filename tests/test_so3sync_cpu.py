@@ -7,7 +7,7 @@ import pytest
 import golden_cases as gc
 from numpy_backend import NumpyBackend
 from oracle import bipgo_oracle as orc
-from util import load_golden, rebuild_inputs
+from util import load_golden, oracle_attempts, rebuild_inputs
 from vican_amd import frontend
 from vican_amd.solver import Comm, GeneralRotationSolver
 
@@ -30,14 +30,19 @@ def golden(name, dt):
 def test_oracle_matches_reference(name, dt):
     src, cons, nr, ff = inputs(name)
     keys, R, evals = golden(name, dt)
-    info = {}
-    res = orc.bipartite_so3sync(src, cons, nr, ff, gc.MAXITER, np.dtype(dt).type, info=info)
-    assert list(res.keys()) == keys                                   # node naming + dict order (bipgo.py:135-141)
-    err = max(np.abs(res[k] - R[i]).max() for i, k in enumerate(keys))
-    # g3: the iteration is chaotic there (~100 negative eigenvalues, interior eigenvectors) - still reproduced in
-    # float64 because the restatement makes the same LAPACK/ARPACK calls on the same data
-    assert err < (1e-7 if dt == "float64" else 2e-6), err
-    assert np.abs(np.sort(info["evals"], 1) - np.sort(evals, 1)).max() < (1e-9 if dt == "float64" else 1e-4)
+    def run():
+        info = {}
+        return orc.bipartite_so3sync(src, cons, nr, ff, gc.MAXITER, np.dtype(dt).type, info=info), info
+
+    def check(out):
+        res, info = out
+        assert list(res.keys()) == keys                               # node naming + dict order (bipgo.py:135-141)
+        err = max(np.abs(res[k] - R[i]).max() for i, k in enumerate(keys))
+        # g3: the iteration is chaotic there (~100 negative eigenvalues, interior eigenvectors) - still reproduced in
+        # float64 because the restatement makes the same LAPACK/ARPACK calls on the same data
+        assert err < (1e-7 if dt == "float64" else 2e-6), err
+        assert np.abs(np.sort(info["evals"], 1) - np.sort(evals, 1)).max() < (1e-9 if dt == "float64" else 1e-4)
+    oracle_attempts(run, check)        # (ARPACK's start vector depends on the process history: util.oracle_attempts)
 
 
 def run_numpy(name, dt, maxiter=gc.MAXITER):

@@ -91,6 +91,24 @@ def e2e_translation_tol(name, dt):
     return max(t, 5e-6) if np.dtype(dt) == np.float32 else t
 
 
+def oracle_attempts(run, check, n=4):
+    """Run ``run()`` (an oracle call) and ``check(result)`` (assertions) up to n times; the last failure propagates.
+    The oracle makes the reference's own ``eigs(k=5, sigma=-1e-6)`` call, and ARPACK draws its start vector from an INTERNAL
+    generator whose state depends on every eigs call made earlier in the process - i.e. on the order of the test suite.  About
+    one start in a few hundred goes astray on the small / chaotic cases ("No shifts could be applied", or an answer 1.5e-7
+    instead of 1e-8 from the golden run's); the next call (another start) is fine.  tools/random_campaign.py treats the oracle
+    the same way (`oracle_retry`).  The PRODUCT is deterministic and is never retried."""
+    last = None
+    for _ in range(n):
+        try:
+            res = run()
+            check(res)
+            return res
+        except (AssertionError, ArithmeticError, RuntimeError) as exc:      # (ArpackError derives from RuntimeError)
+            last = exc
+    raise last
+
+
 def iteration_slack(name, dt, extra=1):
     """CG iterations may differ from the golden's by the spread the reference itself shows under 1e-15
     perturbations (g9: 101..106, g4: 20..24), plus `extra`."""

@@ -33,12 +33,15 @@ if f:
     out.append("kernel stats: profiles/%s_kernel_stats.csv (rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline)" % tag)
 
 # 2. counters per dispatch of the dominant kernel
-def counters(sub):
+SWEEP0 = r"(block|wave)_sweep_kernel<\w+, \d+, 0[,>]"
+
+
+def counters(sub, pat=SWEEP0):
     f = first(sub + "/**/*counter_collection.csv")
     acc = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            if re.search(r"(block|wave)_sweep_kernel<\w+, \d+, 0[,>]", r["Kernel_Name"]):
+            if re.search(pat, r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
@@ -52,6 +55,28 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # half of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE is exact.
     traffic = dict(fetch_bytes=2.0 * pm["FETCH_SIZE"] * 1024, write_bytes=pm["WRITE_SIZE"] * 1024)
     traffic["hbm_bytes"] = traffic["fetch_bytes"] + traffic["write_bytes"]
+# 2b. counters of the other heavy edge kernels of the same runs (CG product, right-hand side, fused dual-update sweep)
+for label, pat, bytes_key in (("cg", r"cg_wsweep1?_kernel<", "cg_sweep"), ("rhs", r"trans_wrhs_kernel<", "trans_rhs"),
+                              ("dual_update_op", r"wave_sweep_kernel<\w+, \d+, 3[,>]", "dual_update_op_sweep")):
+    kp = {}
+    for sub in ("fetch", "write", "sq1", "sq2"):
+        c, n = counters(sub, pat)
+        kp.update(c)
+    if kp:
+        tr = None
+        if "FETCH_SIZE" in kp and "WRITE_SIZE" in kp:
+            tr = dict(fetch_bytes=2.0 * kp["FETCH_SIZE"] * 1024, write_bytes=kp["WRITE_SIZE"] * 1024)
+            tr["hbm_bytes"] = tr["fetch_bytes"] + tr["write_bytes"]
+        algo = None
+        try:
+            bl = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
+            algo = json.loads(bl[-1])["detail"]["kernels"][bytes_key]
+        except Exception:
+            pass
+        json.dump(dict(tag=tag, kernel_pattern=pat, counters_mean_per_dispatch=kp, traffic=tr, bench_detail=algo,
+                       note="means over ALL dispatches of the kernel in the bench command, cancelled speculative launches (a few microseconds) included"),
+                  open("profiles/%s_%s_counters.json" % (tag, label), "w"), indent=1)
+        out.append("%s counters: profiles/%s_%s_counters.json" % (label, tag, label))
 bench = None
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
@@ -60,8 +85,8 @@ if os.path.exists(bj):
         bench = json.loads(lines[-1])
         json.dump(bench, open("profiles/%s_bench.json" % tag, "w"), indent=1)
 tl = []
-for name, title in (("timeline_stress.txt", "stress workload (bench.py default), second-to-last solve of a rocprofv3 --kernel-trace run"),
-                    ("timeline_large_shop.txt", "large_shop workload (340 cameras x 10000 timesteps x 4 cams/timestep), second-to-last solve")):
+for name, title in (("timeline_stress.txt", "stress workload (bench.py default), a warm timed solve of a rocprofv3 --kernel-trace run"),
+                    ("timeline_large_shop.txt", "large_shop workload (340 cameras x 10000 timesteps x 4 cams/timestep), a warm timed solve")):
     fn = os.path.join(src, name)
     if os.path.exists(fn):
         tl.append("# %s  (tools/timeline.py)\n%s" % (title, open(fn).read()))

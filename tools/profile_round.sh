@@ -7,18 +7,18 @@ TAG=${1:-r01}
 O=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse --no-wide"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/bench_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq1 -- $B --steps 1 --warmup 0 > $O/bench_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 0 > $O/bench_sq2.log 2>&1
 cd $GRAFT_REPO_ROOT && python bench.py > $O/bench.json 2> $O/bench.err
-# busy/idle timelines of one solve per workload (second-to-last solve of each trace: not the one carrying HIP events)
-python tools/timeline.py $O/stats 2 > $O/timeline_stress.txt 2>&1
+# busy/idle timelines of one WARM timed solve per workload
+python tools/timeline.py $O/stats 4 > $O/timeline_stress.txt 2>&1      # (the last two solves of a run are the cold and the instrumented one: bench.py)
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse --steps 2 --warmup 1 > $O/bench_trace_ls.log 2>&1
-cd $GRAFT_REPO_ROOT && python tools/timeline.py $O/trace_ls 2 > $O/timeline_large_shop.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --workload large_shop --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_trace_ls.log 2>&1
+cd $GRAFT_REPO_ROOT && python tools/timeline.py $O/trace_ls 4 > $O/timeline_large_shop.txt 2>&1
 rm -rf $O/trace_ls $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv
 # the sparse capture (100 cameras x 2 M timesteps x 8 cameras per timestep): kernel stats + HBM traffic counters of its operator sweep
 cd /tmp

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so") 
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
            os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip"),
-           os.path.join(CSRC, "vican_facade.hip")]
+           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
 FX_DOUBLES = 20
@@ -149,6 +149,12 @@ PROTOTYPES = {
     "vican_lsqr_nodes": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_scalars": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "vican_lsqr_update_st": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    # collectives behind the C ABI (csrc/vican_comm.hip: RCCL through dlopen)
+    "vican_comm_unique_id": (C.c_int, [_vp]),
+    "vican_comm_create": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "vican_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vican_comm_destroy": (C.c_int, [_vp]),
+    "vican_block_op_z_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # the four-call boundary (csrc/vican_facade.hip)
     "vican_plan_create": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "vican_plan_describe": (C.c_int, [_vp, _G]),

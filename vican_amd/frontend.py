@@ -114,12 +114,20 @@ def sorted_codes(ids, prefix="", with_keys=False):
     ids of at most 8 characters are packed into big-endian 64-bit integers, whose numeric order IS their string order, and
     sorted as integers.  A common prefix does not change the order of the strings, only their spelling.  Anything else falls
     back to ``np.unique``.  with_keys: also return the packed keys of the unique strings (None on the fallback path)."""
-    keys = _ascii_keys(ids) if not (isinstance(ids, np.ndarray) and ids.dtype.kind not in "US") else None
-    if keys is None:
-        a = np.asarray(ids)
-        if a.dtype.kind != "U":
-            a = a.astype(str)
+    # (a NumPy unicode array: its UCS-4 code points ARE the input of _packed_keys - no conversion; a Python list / tuple of
+    #  strings: one C-level conversion to fixed-width bytes, _ascii_keys; anything else, or ids those refuse: np.asarray)
+    a = keys = None
+    if isinstance(ids, np.ndarray) and ids.dtype.kind == "U" and ids.ndim == 1:
+        a = ids
         keys = _packed_keys(a)
+    elif not isinstance(ids, np.ndarray):
+        keys = _ascii_keys(ids)
+    if keys is None:
+        if a is None:
+            a = np.asarray(ids)
+            if a.dtype.kind != "U":
+                a = a.astype(str)
+            keys = _packed_keys(a)
     if keys is not None:
         uk, inv = np.unique(keys, return_inverse=True)
         names = _key_names(uk)

@@ -38,7 +38,7 @@ from ._lib import CG_F, CG_I, CG_STATE_DOUBLES, LSQR_F, LSQR_I, LSQR_STATE_DOUBL
 class Comm:
     """Sum-all-reduce over ranks; identity for a single rank."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, native=None):
         self.group = group
         self.world = 1
         self.rank = 0
@@ -46,17 +46,55 @@ class Comm:
             self.world = torch.distributed.get_world_size(group)
             self.rank = torch.distributed.get_rank(group)
         self.n_allreduce = 0
+        # native=True / VICAN_NATIVE_COMM=1: the all-reduces go through an RCCL communicator held by the C library
+        # (include/vican_hip.h: vican_comm_*; enqueued from C on the launch stream) instead of torch.distributed.  Off by
+        # default: torch's "nccl" backend IS RCCL and is the path every test exercises; the native one has run on one GPU only.
+        self._native = None
+        if native is None:
+            native = os.environ.get("VICAN_NATIVE_COMM") == "1"
+        if native and self.world > 1 and self._device_collectives():
+            self._native = self._create_native()
+
+    def _create_native(self):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        ids = [None]
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.vican_comm_unique_id(buf), "vican_comm_unique_id")
+            ids = [buf.raw]
+        src = torch.distributed.get_global_rank(self.group, 0) if self.group is not None else 0
+        torch.distributed.broadcast_object_list(ids, src=src, group=self.group)
+        h = ctypes.c_void_p()
+        _lib.check(lib.vican_comm_create(self.rank, self.world, ctypes.create_string_buffer(ids[0], 128), ctypes.byref(h)), "vican_comm_create")
+        self._native_lib = lib
+        return h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_native", None) is not None:
+                self._native_lib.vican_comm_destroy(self._native)
+                self._native = None
+        except Exception:                                       # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @classmethod
     def single(cls):
         """A one-rank communicator even inside an initialised process group (replicated computations)."""
         c = cls.__new__(cls)
-        c.group, c.world, c.rank, c.n_allreduce = None, 1, 0, 0
+        c.group, c.world, c.rank, c.n_allreduce, c._native = None, 1, 0, 0, None
         return c
 
     def allreduce(self, t):
         if self.world > 1:
-            torch.distributed.all_reduce(t, group=self.group)
+            if self._native is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous():
+                import ctypes
+                from . import _lib
+                _lib.check(self._native_lib.vican_comm_allreduce_sum(self._native, ctypes.c_void_p(t.data_ptr()), t.numel(),
+                                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vican_comm_allreduce_sum")
+            else:
+                torch.distributed.all_reduce(t, group=self.group)
             self.n_allreduce += 1
         return t
 
