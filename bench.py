@@ -221,7 +221,7 @@ def wide_operator(args, dev, tdt, comm):
     from vican_amd import synth
     from vican_amd.device import make_backend
     from vican_amd.solver import RotationSolver, TranslationSolver
-    Cw, Tw, cw = 4000, 50000, 250
+    Cw, Tw, cw = 4000, 100000, 250
     gr = synth.make_merged_graph_torch(Cw, Tw, cw, dev, tdt, seed=0)
     E = int(gr["col"].numel())
     g, K = make_backend(Cw, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])

@@ -36,13 +36,33 @@ if f:
 SWEEP0 = r"(block|wave)_sweep_kernel<\w+, \d+, 0[,>]"
 
 
+CANCELLED = {}                                                  # (sub, pattern) -> (executed, cancelled) dispatch counts
+
+
 def counters(sub, pat=SWEEP0):
+    """Mean counter values per EXECUTED dispatch.  A speculative launch whose gate flag is already set returns at its first
+    instruction (a few microseconds, no traffic); under the profiler's serialised dispatch that happens more often than in
+    the timed run, and averaging those zeros in is what made the r03 sparse figure read 11% under the algorithmic bytes.
+    They are recognised by duration (< 0.2 of the kernel's median) and left out; the counts are kept in CANCELLED."""
     f = first(sub + "/**/*counter_collection.csv")
-    acc = collections.defaultdict(list)
+    rows = []
     if f:
         for r in csv.DictReader(open(f)):
             if re.search(pat, r["Kernel_Name"]):
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                rows.append((r["Counter_Name"], float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
+    by_kernel = collections.defaultdict(list)
+    for r in rows:
+        by_kernel[r[3]].append(r[2])
+    top = max((sorted(v)[len(v) // 2] for v in by_kernel.values()), default=0)   # (an instantiation whose dispatches are ALL cancelled has a tiny median)
+    med = {k: top for k in by_kernel}
+    acc, dropped = collections.defaultdict(list), collections.Counter()
+    for name, val, dur, kern in rows:
+        if dur < 0.2 * med[kern]:
+            dropped[name] += 1
+        else:
+            acc[name].append(val)
+    if rows:
+        CANCELLED[(sub, pat)] = (max((len(v) for v in acc.values()), default=0), max(dropped.values(), default=0))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 pm = {}
@@ -74,7 +94,8 @@ for label, pat, bytes_key in (("cg", r"cg_wsweep1?_kernel<", "cg_sweep"), ("rhs"
         except Exception:
             pass
         json.dump(dict(tag=tag, kernel_pattern=pat, counters_mean_per_dispatch=kp, traffic=tr, bench_detail=algo,
-                       note="means over ALL dispatches of the kernel in the bench command, cancelled speculative launches (a few microseconds) included"),
+                       note="means over the EXECUTED dispatches of the kernel in the bench command; cancelled speculative launches (a few microseconds, no traffic) are left out",
+                       dispatches={s_: dict(zip(("executed", "cancelled"), CANCELLED[(s_, pat)])) for s_ in ("fetch", "write", "sq1", "sq2") if (s_, pat) in CANCELLED}),
                   open("profiles/%s_%s_counters.json" % (tag, label), "w"), indent=1)
         out.append("%s counters: profiles/%s_%s_counters.json" % (label, tag, label))
 bench = None
@@ -120,11 +141,16 @@ if fs:
         st["hbm_bytes"] = st["fetch_bytes"] + st["write_bytes"]
     json.dump(dict(tag=tag, workload=sb["config"]["workload"] if sb else "sparse", counters_mean_per_dispatch=spm, traffic=st,
                    bytes_per_launch_algorithmic=sb["roofline"]["bytes_per_launch"] if sb else None,
-                   kernel=sb["roofline"]["kernel"] if sb else None), open("profiles/%s_sparse_counters.json" % tag, "w"), indent=1)
+                   kernel=sb["roofline"]["kernel"] if sb else None,
+                   dispatches={s_: dict(zip(("executed", "cancelled"), CANCELLED[(s_, SWEEP0)])) for s_ in ("sparse_fetch", "sparse_write") if (s_, SWEEP0) in CANCELLED},
+                   note="means over the EXECUTED dispatches; cancelled speculative launches (a few microseconds, no traffic) are left out"),
+              open("profiles/%s_sparse_counters.json" % tag, "w"), indent=1)
     out.append("sparse capture: profiles/%s_sparse_kernel_stats.csv, _sparse_counters.json, _sparse_bench.json" % tag)
 
 summary = dict(tag=tag, kernel=(bench["roofline"]["kernel"] if bench else "sweep kernel MODE 0 (vican_block_op)"), counters_mean_per_dispatch=pm, traffic=traffic,
                workload=bench["config"]["workload"] if bench else None,
-               bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None)
+               bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None,
+               dispatches={s_: dict(zip(("executed", "cancelled"), CANCELLED[(s_, SWEEP0)])) for s_ in ("fetch", "write", "sq1", "sq2") if (s_, SWEEP0) in CANCELLED},
+               note="means over the EXECUTED dispatches; cancelled speculative launches (a few microseconds, no traffic) are left out")
 json.dump(summary, open("profiles/%s_sweep_counters.json" % tag, "w"), indent=1)
 print("\n".join(out)); print(json.dumps(summary, indent=1)[:1500])
