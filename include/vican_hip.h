@@ -86,7 +86,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 14            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 15            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -220,6 +220,14 @@ int vican_block_op_z(const vican_graph_t* g, const double* lamT_inv, const doubl
 int vican_bip_scales(double* fx, double x_bound, double n_add, int32_t storage, void* stream);
 int vican_bip_apply(const vican_graph_t* g, const double* x_cam, const double* x_time, void* zpart,
                     double* fx, double* z_cam, double* y_time, void* stream);
+
+/* Camera-tiled operator, one tile in the wave layout (graphs with more cameras than one LDS table holds; the reference
+ * has no camera limit, bipgo.py:225-232).  rows: y_time[t] = sum_{c in tile} M_ct^T x_cam[c] ([T][9], every row written);
+ * cams: z_cam[c] = sum_t M_ct w_time[t] for the tile's cameras ([C_tile][9]), w_time = Lambda_t^-1 (sum of all tiles'
+ * y_time) formed by the caller (vican_sum_apply3), |w_time[t]|_F within the bound fx was finished for (vican_duals_bound
+ * over ALL tiles' row norms + vican_fx_finish).  Both stream the tile's blocks once.  Block-layout tiles: vican_bip_apply. */
+int vican_tile_rows(const vican_graph_t* g, const double* x_cam, double* y_time, double* fx, void* stream);
+int vican_tile_cams(const vican_graph_t* g, const double* w_time, void* zpart, double* fx, double* z_cam, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,

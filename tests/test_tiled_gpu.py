@@ -14,6 +14,14 @@ from util import expected, load_golden, pose_errors, rebuild_inputs, translation
 from vican_amd.solver import Comm, solve_on_backend                         # noqa: E402
 
 
+@pytest.fixture(params=["wave", "block"], autouse=True)
+def tile_layout(request, monkeypatch):
+    """Every test of this file runs with the tiles in the wave layout (vican_tile_rows / vican_tile_cams, the wave CG product in
+    partial mode) and in the block layout (vican_bip_apply twice, the block CG product)."""
+    monkeypatch.setenv("VICAN_TILE_LAYOUT", request.param)
+    return request.param
+
+
 def _tiled(C, rp, col, blk, a, w, u, v, dt, tile):
     from vican_amd.device import TiledBackend, TiledGraph
     dev = torch.device("cuda:0")
@@ -21,6 +29,8 @@ def _tiled(C, rp, col, blk, a, w, u, v, dt, tile):
     g = TiledGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(blk).to(dev, tdt),
                    torch.from_numpy(a).to(dev, tdt), torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev),
                    tile=tile)
+    import os
+    assert all(t.layout == os.environ["VICAN_TILE_LAYOUT"] for t in g.tiles)
     return g, TiledBackend(g)
 
 
@@ -122,3 +132,30 @@ def test_tiled_translation_stage_has_no_camera_limit(C, T, tile):
         assert th.info["converged"] and abs(th.info["cg_iters"] - tn.info["cg_iters"]) <= 2
         scale = max(np.abs(xn[0]).max(), 1.0)
         assert np.abs(xh[0] - xn[0]).max() < tol * scale and np.abs(xh[1][:T] - xn[1][:T]).max() < tol * scale
+
+
+def test_tile_layout_default_is_wave_with_block_fallback(monkeypatch):
+    """Without VICAN_TILE_LAYOUT a tile takes the wave layout if its rows fit a 64-lane chunk (128 f64 edges) and the block
+    layout otherwise - here 400 cameras in tiles of 256, 200-300 cameras per timestep: the first tile's rows have ~128-190
+    edges (block), the second tile's ~70-110 (wave); the mixed operator against the NumPy restatement."""
+    from vican_amd.device import TiledBackend, TiledGraph
+    monkeypatch.delenv("VICAN_TILE_LAYOUT")
+    C, T, tile = 400, 60, 256
+    rp, col, blk, a, w, u, v = random_graph(C, T, 200, 300, 4, False)
+    dev = torch.device("cuda:0")
+    g = TiledGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(blk).to(dev), torch.from_numpy(a).to(dev),
+                   torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev), tile=tile)
+    assert [t.layout for t in g.tiles] == ["block", "wave"]
+    K = TiledBackend(g)
+    N = NumpyBackend(C, rp, col, blk, a, w, u, v, storage=np.float64)
+    rng = np.random.default_rng(1)
+    x = np.linalg.qr(rng.standard_normal((3 * C, 3)))[0]
+    lh, ch, ln, cn = K.empty(T, 9), K.empty(C), N.empty(T, 9), N.empty(C)
+    K.init_duals(lh, ch); N.init_duals(ln, cn)
+    rc = np.linalg.qr(rng.standard_normal((C, 3, 3)))[0].reshape(3 * C, 3)
+    Rh, Rn = K.empty(T, 9), N.empty(T, 9)
+    K.dual_update(K.from_numpy(rc), Rh, lh); N.dual_update(N.from_numpy(rc), Rn, ln)
+    assert np.abs(Rh.cpu().numpy() - Rn.numpy()).max() < 1e-9
+    zh, zn = K.empty(3 * C, 3), N.empty(3 * C, 3)
+    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)
+    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-9 * np.abs(zn.numpy()).max()

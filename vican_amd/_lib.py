@@ -117,6 +117,8 @@ PROTOTYPES = {
     "vican_sum_apply3": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_tile_rows": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_tile_cams": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vican_cg1_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
@@ -214,7 +216,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     sweep = SOURCES[0]
     jobs = [(sweep, ["-DVICAN_SWEEP_SPLIT", "-DVICAN_SWEEP_PART=%d" % m]) for m in range(4)]
     jobs += [(sweep, ["-DVICAN_SWEEP_SPLIT"])]
-    jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT", "-DVICAN_WSWEEP_PART=%d" % m]) for m in (0, 1, 3)]
+    jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT", "-DVICAN_WSWEEP_PART=%d" % m]) for m in (0, 1, 3, 4)]
     jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT"])]
     jobs += [(src, []) for src in SOURCES[1:]]
     import tempfile

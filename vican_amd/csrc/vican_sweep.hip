@@ -1148,6 +1148,32 @@ extern "C" int vican_bip_apply(const vican_graph_t* g, const double* x_cam, cons
     return vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 3, fx + 7, z_cam, stream);
 }
 
+// ---- camera-tiled operator (more cameras than one LDS table holds), one tile in the WAVE layout -----------------------------
+// z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) needs the row sums over ALL cameras before any camera's output: per tile a rows
+// pass (sweep MODE 1: y_time = the tile's share of Z_t), the caller sums the tiles' shares and applies Lambda_t^-1
+// (vican_sum_apply3), then a camera pass per tile (sweep MODE 4: z_cam = sum_t M_ct w_t).  Both passes stream the tile's
+// blocks through the wave-layout kernel (the round-3 path ran the two-sided block-layout sweep, MODE 2, twice with a zero
+// operand on one side each time).  fx: the tile's scales for the CURRENT duals, bounds taken over all tiles' rows
+// (vican_duals_bound with the global row norms + vican_fx_finish).
+extern "C" int vican_tile_rows(const vican_graph_t* g, const double* x_cam, double* y_time, double* fx, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_tile_rows")) return rc;
+    if (g->layout != VICAN_LAYOUT_WAVE) return set_err(VICAN_ERR_ARG, "vican_tile_rows: wave layout only (block-layout tiles: vican_bip_apply)");
+    if (!x_cam || !y_time || !fx) return set_err(VICAN_ERR_ARG, "vican_tile_rows: null pointer");
+    if (g->n_chunk == 0) return set_err(VICAN_ERR_ARG, "vican_tile_rows: graph without edges");
+    if (int rc = sweep_any<1>(g, nullptr, x_cam, nullptr, nullptr, y_time, nullptr, fx, stream)) return rc;
+    LAUNCH_CHECK("vican_tile_rows");
+    return VICAN_OK;
+}
+extern "C" int vican_tile_cams(const vican_graph_t* g, const double* w_time, void* zpart, double* fx, double* z_cam, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_tile_cams")) return rc;
+    if (g->layout != VICAN_LAYOUT_WAVE) return set_err(VICAN_ERR_ARG, "vican_tile_cams: wave layout only (block-layout tiles: vican_bip_apply)");
+    if (!w_time || !zpart || !fx || !z_cam) return set_err(VICAN_ERR_ARG, "vican_tile_cams: null pointer");
+    if (g->n_chunk == 0) return set_err(VICAN_ERR_ARG, "vican_tile_cams: graph without edges");
+    if (int rc = vican_wsweep(4, g, w_time, nullptr, (u64*)zpart, nullptr, fx, stream)) return rc;
+    LAUNCH_CHECK("vican_tile_cams");
+    return vican_slab_reduce_fx(zpart, g->n_wg, g->n_cam, 9, 1.0, fx + 3, fx + 7, z_cam, stream);
+}
+
 __global__ void set_double_kernel(double* p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 // Fixed-point scales for vican_bip_apply: the phase-3 operand is x_time itself (|x_t|_F <= x_bound), i.e. omega = 1.
 extern "C" int vican_bip_scales(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(BLOCK) void cg_sweep_kernel(vican_graph_t g, const 
 extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,
                                                                      void* qc_part, double* pq_part, const vican_cg_state_t* st,
-                                                                     void* stream);       // vican_wtrans.hip
+                                                                     void* stream, int partial);       // vican_wtrans.hip
 static int cg_sweep_launch(const vican_graph_t* g, const double* w, const double* deg_t, const double* p_c,
                            const double* r_t, double* p_t, double* q_t, void* qc_part, double* pq_part,
                            const vican_cg_state_t* st, void* stream, const int partial) {
@@ -572,8 +572,7 @@ static int cg_sweep_launch(const vican_graph_t* g, const double* w, const double
     if (!w || !deg_t || !p_c || !r_t || !p_t || !q_t || !qc_part || !pq_part || !st)
         return set_err(VICAN_ERR_ARG, "vican_cg_sweep: null pointer");
     if (g->layout == VICAN_LAYOUT_WAVE) {
-        if (partial) return set_err(VICAN_ERR_ARG, "vican_cg_sweep_partial: camera tiles are block layouts");
-        return vican_cg_wsweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream);
+        return vican_cg_wsweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream, partial);
     }
     const size_t lds = (size_t)cg_lds_bytes(g->n_cam, g->max_rows, g->n_copy);
     const int epl = g->slots / g->block_threads;

@@ -46,6 +46,9 @@ extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32
 // MODE 0: zpart[wg] = sum M (lamT_inv (sum M^T x))          operator P x
 // MODE 1: lamT_out[t] = Z_t = sum_c M_ct^T x_c               dual update (SVDs in dual_svd_kernel)
 // MODE 3: MODE 1 and zpart[wg] = sum M polar(Z_t)            dual update fused with the next operator application
+// MODE 4: zpart[wg] = sum M w_t, w_t GIVEN (lamT_inv = [T][9])  camera half of the operator on a camera tile (more cameras than one
+//         LDS table holds: rows pass = MODE 1 per tile, w_t = Lambda_t^-1 (sum of the tiles' Z_t), then this) - no x table,
+//         no phase 1; |w_t|_F <= omega * x_bound, the bound fx[2] was sized for
 // FB (MODE 3): rows whose Newton polar iteration does not apply (ill-conditioned Z_t) take the SVD inside the kernel.
 // That path is a function call, and a call site makes the register allocator spill in the streaming loop at 12
 // wavefronts (168 VGPRs: 89 spilled, 774 us against 181 us for MODE 0; without the call 164 VGPRs, no spills).  The
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int EPL = Vec<S>::N, BLOCK = NW * 64;
-    constexpr bool HAS_Z = (MODE == 0 || MODE == 3);
+    constexpr bool HAS_Z = (MODE == 0 || MODE == 3 || MODE == 4);
     // TRIPS: (row, dual-block row) items per lane in phase 2 = ceil(3 max_rows / 64), 1..3 (max_rows <= 64)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double s_xm[16];
@@ -163,13 +166,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     int2 va = load_rows(kc), vb;              // (chunk_row0 has n_chunk + 1 entries; 8-byte loads may be unaligned: fine)
 
     // ---- prologue (as block_sweep_kernel): measure max_c |x_c|_F, stage x as planes, zero the accumulators
-    constexpr int XC = (CP + BLOCK - 1) / BLOCK;
+    constexpr int XC = MODE == 4 ? 1 : (CP + BLOCK - 1) / BLOCK;
     double xv[XC][9];
 #pragma unroll
     for (int m = 0; m < XC; ++m) {
         const int c = tid + m * BLOCK;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) xv[m][i] = c < C ? x[(size_t)c * 9 + i] : 0.0;
+        for (int i = 0; i < 9; ++i) xv[m][i] = (MODE != 4 && c < C) ? x[(size_t)c * 9 + i] : 0.0;
     }
     const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8], fx9 = (MODE == 3) ? fx[9] : 0.0;
     __builtin_amdgcn_sched_barrier(0);
@@ -189,13 +192,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #pragma unroll
     for (int m = 0; m < XC; ++m) {
         const int c = tid + m * BLOCK;
-        if (c < C) {
+        if (MODE != 4 && c < C) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) xs[i * CP + c] = pre_scale<S>(xv[m][i], 1.0);
         }
     }
     if (HAS_Z) for (int i = tid; i < nx; i += BLOCK) zs[i] = 0ull;
-    if (!ONE) for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
+    if (!ONE && MODE != 4) for (int i = lane; i < 9 * RW * ncopy; i += 64) ys[i] = 0ull;
     int vzero = 0;                                             // opaque per-lane zero: keeps wave-uniform addresses on VECTOR loads
     if (ONE) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     __syncthreads();
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     int shift = 0;
     if (xm2 > 0.0) { const double r2 = fx8 * fx8 / xm2; shift = r2 >= 1.0 ? (ilogb(r2) >> 1) : 0; }
     shift = shift < 0 ? 0 : (shift > 40 ? 40 : shift);
-    if (MODE == 3) shift = 0;                                  // phase-3 operand = polar factors, |.|_F = x_bound
+    if (MODE == 3 || MODE == 4) shift = 0;                     // phase-3 operand = polar factors, |.|_F = x_bound / the given rows
     const double up = ldexp(1.0, shift);
     // (wave-uniform doubles that live through the whole loop: into scalar registers)
     auto uni = [](double v) -> double {
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     };
     const double y_scale = uni(fx0 * up), y_inv = uni(fx1 / up), z_scale = uni((MODE == 3) ? fx9 : fx2 * up);
-    if (MODE == 0 && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
+    if ((MODE == 0 || MODE == 4) && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;   // omega bound: raised by dual_svd_kernel
 
 #ifdef VICAN_WSTAMP
@@ -245,10 +248,18 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         // consecutive, so these loads are fully coalesced.  Issued BEFORE the prefetch (in-order retirement again).
         double L[TRIPS][3];
         double L1[9];                                          // ONE: the row's whole dual block in every lane
-        if (MODE == 0 && ONE) {
+        double W4[MODE == 4 ? 3 * TRIPS : 1];                  // MODE 4: the given phase-3 operand of the chunk's rows, 9 nrows doubles
+        if ((MODE == 0 || MODE == 4) && ONE) {
             const double* Lp = lamT_inv + (size_t)r0 * 9 + vzero;
 #pragma unroll
             for (int q = 0; q < 9; ++q) L1[q] = Lp[q];
+        } else if (MODE == 4) {
+#pragma unroll
+            for (int t = 0; t < 3 * TRIPS; ++t) {
+                int j = lane + 64 * t;
+                j = j < nrows * 9 ? j : 0;                  // (lanes without an item re-read item 0)
+                W4[t] = lamT_inv[(size_t)r0 * 9 + j];
+            }
         } else if (MODE == 0) {
 #pragma unroll
             for (int t = 0; t < TRIPS; ++t) {
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #pragma unroll
         for (int j = 0; j < EPL; ++j) { cam[j] = cam_of(cur.id[j]); row[j] = row_of(cur.id[j]); }
         double ycol[3] = {0, 0, 0};                            // ONE: column min(lane & 3, 2) of the row's 3x3 sum Z_t
-        {
+        if constexpr (MODE != 4) {
             S acc[9], xc[9], xn[9];
 #pragma unroll
             for (int q = 0; q < 9; ++q) xc[q] = xs[q * CP + cam[0]];
@@ -336,11 +347,11 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         S w1[9];                                               // ONE: the phase-3 operand, wave-uniform
         if constexpr (ONE) {
             const int m = (lane & 3) < 2 ? (lane & 3) : 2;     // the column this lane holds
-            if (MODE != 0 && lane < 3) {                       // Z_t for dual_svd_kernel
+            if ((MODE == 1 || MODE == 3) && lane < 3) {        // Z_t for dual_svd_kernel
 #pragma unroll
                 for (int a = 0; a < 3; ++a) lamT_out[(size_t)r0 * 9 + a * 3 + lane] = ycol[a];
             }
-            double wcol[3];
+            double wcol[3] = {0, 0, 0};
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) wcol[i] = dot3<double>(L1[i * 3 + 0], ycol[0], L1[i * 3 + 1], ycol[1], L1[i * 3 + 2], ycol[2]);
@@ -361,7 +372,10 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
 #pragma unroll
                 for (int i = 0; i < 3; ++i) wcol[i] = m == 0 ? R[i * 3] : (m == 1 ? R[i * 3 + 1] : R[i * 3 + 2]);
             }
-            if (HAS_Z) {
+            if (MODE == 4) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) w1[q] = pre_scale<S>(L1[q], z_scale);      // (wave-uniform already)
+            } else if (HAS_Z) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const S ws = pre_scale<S>(wcol[i], z_scale);
@@ -387,6 +401,13 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             }
         }
 #else
+        if (MODE == 4) {
+#pragma unroll
+            for (int t = 0; t < 3 * TRIPS; ++t) {
+                const int j = lane + 64 * t;
+                if (j < nrows * 9) wv[j] = pre_scale<S>(W4[t], z_scale);
+            }
+        } else
         for (int i = lane; i < nrows * 9; i += 64) {
             const int oo = i % 9;
             long long s = 0;
@@ -542,7 +563,8 @@ static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const 
     static const int one_row_ok = getenv("VICAN_SWEEP_ONE_ROW") ? atoi(getenv("VICAN_SWEEP_ONE_ROW")) : 1;
     if (NW >= 8 && NW <= 12 && one_row_ok && g->n_chunk == g->n_time)
         return launch_wsweep4<S, NW, MODE, CP, 1, FB, true>(g, lamT_inv, x, zpart, lamT_out, fx, st);
-    if (MODE != 0 || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    // TRIPS = ceil(3 max_rows / 64) row items per lane: dual-block rows (MODE 0) / thirds of the given row operands (MODE 4)
+    if ((MODE != 0 && MODE != 4) || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (3 * g->max_rows <= 128) return launch_wsweep4<S, NW, MODE, CP, 2, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     return launch_wsweep4<S, NW, MODE, CP, 3, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
 }
@@ -566,7 +588,7 @@ static int launch_wsweep1(const vican_graph_t* g, const double* lamT_inv, const 
         w_gate_override = nullptr;
         return rc;
     }
-    if (g->wg_waves == 16 && MODE == 0) return launch_wsweep2<S, 16, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
+    if (g->wg_waves == 16 && (MODE == 0 || MODE == 4)) return launch_wsweep2<S, 16, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (g->wg_waves >= 12 && MODE != 3) return launch_wsweep2<S, 12, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     if (g->wg_waves >= 8) return launch_wsweep2<S, 8, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     return launch_wsweep2<S, 4, MODE>(g, lamT_inv, x, zpart, lamT_out, fx, st);
@@ -594,6 +616,7 @@ extern "C" {
 __attribute__((visibility("hidden"))) int vican_wsweep_part_0(WSWEEP_PART_ARGS);
 __attribute__((visibility("hidden"))) int vican_wsweep_part_1(WSWEEP_PART_ARGS);
 __attribute__((visibility("hidden"))) int vican_wsweep_part_3(WSWEEP_PART_ARGS);
+__attribute__((visibility("hidden"))) int vican_wsweep_part_4(WSWEEP_PART_ARGS);
 }
 #endif
 // entry used by vican_sweep.hip's dispatcher for graphs in the wave layout
@@ -602,10 +625,12 @@ extern "C" __attribute__((visibility("hidden"))) int vican_wsweep(int mode, WSWE
     if (mode == 0) return vican_wsweep_part_0(g, lamT_inv, x, zpart, lamT_out, fx, stream);
     if (mode == 1) return vican_wsweep_part_1(g, lamT_inv, x, zpart, lamT_out, fx, stream);
     if (mode == 3) return vican_wsweep_part_3(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 4) return vican_wsweep_part_4(g, lamT_inv, x, zpart, lamT_out, fx, stream);
 #else
     if (mode == 0) return dispatch_wsweep<0>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
     if (mode == 1) return dispatch_wsweep<1>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
     if (mode == 3) return dispatch_wsweep<3>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
+    if (mode == 4) return dispatch_wsweep<4>(g, lamT_inv, x, zpart, lamT_out, fx, stream);
 #endif
     return set_err(VICAN_ERR_ARG, "%s: this sweep mode needs the block layout", "vican wave sweep");
 }

@@ -46,7 +46,11 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
                                                             const double* __restrict__ deg_t, const double* __restrict__ p_c,
                                                             const double* __restrict__ r_t, double* __restrict__ p_t,
                                                             double* __restrict__ q_t, u64* __restrict__ qc_part,
-                                                            double* __restrict__ pq_part, const vican_cg_state_t* __restrict__ st) {
+                                                            double* __restrict__ pq_part, const vican_cg_state_t* __restrict__ st,
+                                                            const int partial) {
+    // partial != 0 (camera tiles, vican_cg_sweep_partial - as in cg_sweep_kernel, vican_trans.hip): g holds the edges of ONE camera
+    // tile; p_t is read as it is (already updated; r_t / deg_t are not used: any readable pointers), q_t receives the tile's
+    // row sums sum_{c in tile} w p_c alone, no p.q partial; the camera sums of the tile's cameras are complete either way
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red[16];
     __shared__ int s_ticket;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     double* pts = (double*)(qt + (size_t)2 * RW * 3 * ncopy);  // [RW * 3] p of the chunk's rows
     double* dps = pts + RW * 3;                                // [RW * 3] deg * p
     const uint32_t pad_cam = (uint32_t)((lane & 31) < C ? (lane & 31) : 0);
-    const bool upd = !st->first;
+    const bool upd = !st->first && !partial;
     const double beta = st->beta, scale = st->qscale, inv = st->qinv;
     const int lob = st->lo_bits;
     const double lo_scale = ldexp(1.0, lob);
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             }
             const double srow = wave_total3(acc[0], acc[1], acc[2], lane);     // lanes 0, 1, 2: the row sums of the three components
             if (lane < 3) {
-                const double qv = rv.d[0] * pn - srow;
+                const double qv = partial ? srow : rv.d[0] * pn - srow;
                 q_t[(size_t)r0 * 3 + lane] = qv;
                 pq += pn * qv;
             }
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
             sum = stripe_sum(sum, ncopy); slo = stripe_sum(slo, ncopy);
             if (live && (a & cmask) == 0) {
                 const int i = a / ncopy;
-                const double qv = dps[i] - fix2_value((long long)sum, (long long)slo, lob, inv);
+                const double sv = fix2_value((long long)sum, (long long)slo, lob, inv);
+                const double qv = partial ? sv : dps[i] - sv;
                 q_t[(size_t)r0 * 3 + i] = qv;
                 pq += pts[i] * qv;
             }
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
     for (int pl = 0; pl < 6; ++pl)                             // the slab keeps planes of stride C ([2][3][C]: cg_fold_kernel)
         for (int i = tid; i < C; i += NW * 64) qc_part[((size_t)blockIdx.x * 6 + pl) * C + i] = qc[pl * CP + i];
     const double t = block_sum(pq, red);
-    if (tid == 0) pq_part[blockIdx.x] = t;
+    if (tid == 0 && !partial) pq_part[blockIdx.x] = t;
 #ifdef VICAN_CGWSTAMP
     if (lane == 0 && cgw_stamp_buf) {
         double* o = cgw_stamp_buf + ((size_t)blockIdx.x * NW + wave) * 10;
@@ -960,7 +965,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vica
 extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican_graph_t* g, const double* w, const double* deg_t,
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,
                                                                      void* qc_part, double* pq_part, const vican_cg_state_t* st,
-                                                                     void* stream) {
+                                                                     void* stream, int partial) {
     const int nw = g->wg_waves >= 12 ? 12 : (g->wg_waves >= 8 ? 8 : 4);
     const size_t lds = (size_t)vican_cg_wsweep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > 160 * 1024) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_cg_sweep (wave layout)");
@@ -968,7 +973,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     const bool nt = g->stream_nt != 0;
     hipStream_t s = (hipStream_t)stream;
     static const int one_row_ok = getenv("VICAN_CG_ONE_ROW") ? atoi(getenv("VICAN_CG_ONE_ROW")) : 1;      // (0: A/B against the general kernel)
-    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8) {
+    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8 && !partial) {
         // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
         const size_t lds1 = (size_t)72 * cp + 256;
         static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;
@@ -997,7 +1002,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
         auto kern = cg_wsweep_kernel<NW_, E_, T_, CP_, NT_>;                                                              \
         static size_t conf = 0;                                                                                           \
         if (lds > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); conf = lds; } \
-        VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
+        VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st, partial); \
     } while (0)
 #define CGW_LAUNCH(NW_, E_, T_)                                                                                           \
     do {                                                                                                                  \

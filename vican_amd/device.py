@@ -993,9 +993,10 @@ TILE_CAMS = 1024
 
 
 class TiledGraph:
-    """The edge set cut by camera range into tiles of at most `tile` cameras, each a block-layout ``LocalGraph`` over ALL
-    timestep rows (camera indices local to the tile); the translation CG runs tile by tile as well, so there is no limit
-    on the number of cameras (the reference has none, bipgo.py:225-232).
+    """The edge set cut by camera range into tiles of at most `tile` cameras, each a ``LocalGraph`` over ALL timestep rows
+    (camera indices local to the tile) in the layout the planner picks for it - the wave layout wherever the tile's rows fit
+    a 64-lane chunk (VICAN_TILE_LAYOUT=block|wave forces one); the translation CG runs tile by tile as well, so there is no
+    limit on the number of cameras (the reference has none, bipgo.py:225-232).
 
     The reference has no camera limit (bipgo.py:225-232); the fused sweeps keep the camera tables in LDS, which caps
     them at 1024 cameras.  Beyond that the operator z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) is evaluated tile by
@@ -1022,8 +1023,18 @@ class TiledGraph:
             rp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
             rp[1:] = torch.cumsum(torch.bincount(rows[sel], minlength=T), 0)
             pick = lambda x: None if x is None else x[sel].contiguous()
-            self.tiles.append(LocalGraph(c1 - c0, rp.to(torch.int32), (col[sel] - c0).to(torch.int32), blk[sel].contiguous(), a[sel].contiguous(),
-                                         pick(w), pick(u), pick(v), layout="block"))
+            # wave layout wherever the tile's rows fit a 64-lane chunk, whatever it pads (measured on 4000 cameras x 250 per
+            # timestep: 15 % padding, and still 52 + 53 us per tile for the rows and camera passes against 2 x 78 us for the
+            # block layout's two-sided sweep)
+            args = (c1 - c0, rp.to(torch.int32), (col[sel] - c0).to(torch.int32), blk[sel].contiguous(), a[sel].contiguous(), pick(w), pick(u), pick(v))
+            want = os.environ.get("VICAN_TILE_LAYOUT") or None
+            try:
+                t = LocalGraph(*args, layout=want or "wave")
+            except _lib.VicanError:
+                if want == "wave":
+                    raise
+                t = LocalGraph(*args, layout="block")
+            self.tiles.append(t)
         # global graph constants
         self.row_sum_a = torch.stack([t.row_sum_a for t in self.tiles]).sum(0)
         self.rnorm = torch.stack([t.rnorm for t in self.tiles]).sum(0)
@@ -1046,8 +1057,10 @@ class TiledGraph:
 
 
 class TiledBackend(HipBackend):
-    """``HipBackend`` interface on a ``TiledGraph``: the edge sweeps run tile by tile through the one-pass bipartite
-    operator (sweep MODE 2: y_t = sum_c M_ct^T x_c and z_c = sum_t M_ct x_t in one pass over a tile's blocks), the
+    """``HipBackend`` interface on a ``TiledGraph``: the edge sweeps run tile by tile - a rows pass (y_t = the tile's share
+    of sum_c M_ct^T x_c) and a camera pass (z_c = sum_t M_ct w_t for the tile's cameras) per tile: wave-layout tiles through
+    vican_tile_rows / vican_tile_cams (sweep MODEs 1 and 4 of the wave kernel), block-layout tiles through the one-pass
+    bipartite operator (sweep MODE 2 with a zero operand on the unused side); the
     per-row partials of the tiles are summed in tile order by ``vican_sum_apply3``; everything camera-sided (Lanczos
     step, Ritz, gauge, polar) is the launch-sequence path of the untiled backend, which has no camera limit; the CG
     product and the LSQR steps run tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows; vican_lsqr_step per tile):
@@ -1097,8 +1110,11 @@ class TiledBackend(HipBackend):
         half runs on a zero operand and is discarded)."""
         for k, K in enumerate(self.tiles):
             r0, r1 = self._tile_rows(k)
-            self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.zero_rows), _ptr(K.zpart), _ptr(K.g.fx),
-                                              _ptr(self.scratch_c[k]), _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
+            if K.layout == "wave":
+                self._ck(self.lib.vican_tile_rows(K._gref, _ptr(x[r0:r1]), _ptr(self.ypart[k]), _ptr(K.g.fx), _stream()), "vican_tile_rows")
+            else:
+                self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.zero_rows), _ptr(K.zpart), _ptr(K.g.fx),
+                                                  _ptr(self.scratch_c[k]), _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
 
     # -- rotation stage ---------------------------------------------------------------------------------------
     def init_duals(self, lamT_inv, cam_deg):
@@ -1117,8 +1133,12 @@ class TiledBackend(HipBackend):
         self._sum_apply(lamT_inv, self.ypart, len(self.tiles), self.wrow)
         for k, K in enumerate(self.tiles):
             r0, r1 = self._tile_rows(k)
-            self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.wrow), _ptr(K.zpart), _ptr(K.g.fx), _ptr(z_out[r0:r1]),
-                                              _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
+            if K.layout == "wave":
+                self._ck(self.lib.vican_tile_cams(K._gref, _ptr(self.wrow), _ptr(K.zpart), _ptr(K.g.fx), _ptr(z_out[r0:r1]), _stream()),
+                         "vican_tile_cams")
+            else:
+                self._ck(self.lib.vican_bip_apply(K._gref, _ptr(x[r0:r1]), _ptr(self.wrow), _ptr(K.zpart), _ptr(K.g.fx), _ptr(z_out[r0:r1]),
+                                                  _ptr(self.ypart[k]), _stream()), "vican_bip_apply")
 
     def dual_update(self, rc, Rt, lamT_inv):
         """Z_t = sum_c M_ct^T R_c over all tiles, then R_t, Lambda_t^-1 = U S^-1 U^T per row (bipgo.py:318-332)."""
