@@ -159,3 +159,41 @@ def test_tile_layout_default_is_wave_with_block_fallback(monkeypatch):
     zh, zn = K.empty(3 * C, 3), N.empty(3 * C, 3)
     K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)
     assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-9 * np.abs(zn.numpy()).max()
+
+
+def test_tiled_dense_rows_take_the_one_row_kernels(tile_layout):
+    """Tiles whose rows fill a chunk on their own (600 cameras in tiles of 300, 360-440 cameras per timestep, f32 blocks: ~200
+    edges per tile row, one row per 256-slot chunk, 12 wavefronts): the accumulator-free one-row instantiations of the rows
+    pass (MODE 1) and the camera pass (MODE 4), and the general CG product in partial mode (the one-row CG kernel has none)."""
+    from vican_amd.solver import TranslationSolver
+    C, T, tile = 600, 4000, 300
+    rp, col, blk, a, w, u, v = random_graph(C, T, 360, 440, 6, False)
+    g, K = _tiled(C, rp, col, blk, a, w, u, v, np.float32, tile)
+    if tile_layout == "wave":
+        assert all(t.n_chunk == t.n_time and t.wg_waves == 12 for t in g.tiles)
+    N = NumpyBackend(C, rp, col, blk, a, w, u, v, storage=np.float32)
+    rng = np.random.default_rng(1)
+    x = np.linalg.qr(rng.standard_normal((3 * C, 3)))[0]
+    lh, ch, ln, cn = K.empty(T, 9), K.empty(C), N.empty(T, 9), N.empty(C)
+    K.init_duals(lh, ch); N.init_duals(ln, cn)
+    zh, zn = K.empty(3 * C, 3), N.empty(3 * C, 3)
+    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)                # scaled-identity duals
+    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 2e-5 * np.abs(zn.numpy()).max()
+    rc = np.linalg.qr(rng.standard_normal((C, 3, 3)))[0].reshape(3 * C, 3)
+    Rh, Rn = K.empty(T, 9), N.empty(T, 9)
+    K.dual_update(K.from_numpy(rc), Rh, lh); N.dual_update(N.from_numpy(rc), Rn, ln)
+    assert np.abs(Rh.cpu().numpy() - Rn.numpy()).max() < 2e-5
+    # (sums of ~400 random rotations: some Z_t are nearly singular and U S^-1 U^T amplifies the float32 rounding of the blocks -
+    #  the operator is compared on the SAME full 3x3 duals, the restatement's)
+    lh = K.from_numpy(ln.numpy())
+    K.set_duals(lh)
+    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)
+    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 2e-5 * np.abs(zn.numpy()).max()
+    rt = np.linalg.qr(rng.standard_normal((T, 3, 3)))[0].reshape(T, 9)
+    th, tn = TranslationSolver(K, Comm.single(), rtol=1e-9), TranslationSolver(N, Comm.single(), rtol=1e-9)
+    th.setup(K.from_numpy(rc), K.from_numpy(rt)); tn.setup(N.from_numpy(rc), N.from_numpy(rt))
+    xh = [x_.cpu().numpy().copy() for x_ in th.solve(3 * (C + T))]
+    xn = [x_.numpy().copy() for x_ in tn.solve(3 * (C + T))]
+    assert th.info["converged"] and abs(th.info["cg_iters"] - tn.info["cg_iters"]) <= 2
+    scale = max(np.abs(xn[0]).max(), 1.0)
+    assert np.abs(xh[0] - xn[0]).max() < 1e-6 * scale and np.abs(xh[1][:T] - xn[1][:T]).max() < 1e-6 * scale
