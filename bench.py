@@ -214,9 +214,9 @@ def large_shop_wall_clock(args, dev, tdt, comm):
 
 
 def wide_operator(args, dev, tdt, comm):
-    """More cameras than the LDS-resident sweeps hold (C = 4000 > 1024): the camera-TILED path (device.TiledBackend: a rows pass
-    over all tiles, the per-row combination, a camera pass per tile - every block read TWICE per operator application, wave-layout
-    tiles where the rows allow, no fused dual update).  Reported so that the regime has a number: full solves and the operator application alone,
+    """More cameras than the LDS-resident sweeps hold (C = 4000 > 1024): the camera-TILED path (device.TiledBackend: tiles of <= 1024
+    cameras in the wave layout with a shared chunking, the operator as one launch that reads every block once - vican_tiled_op -
+    where the grid is co-resident, else a rows pass and a camera pass per tile; no fused dual update).  Reported so that the regime has a number: full solves and the operator application alone,
     against the same algorithmic bytes an untiled sweep would move (E(9s+4) + 4(T+1) + 72T + 144C)."""
     from vican_amd import synth
     from vican_amd.device import make_backend
@@ -257,7 +257,10 @@ def wide_operator(args, dev, tdt, comm):
            "lanczos_steps": rot.stats["lanczos_steps"], "cg_iters": tr.info.get("cg_iters"),
            "operator_ms": op_ms, "operator_bytes_algorithmic": bytes_op,
            "operator_frac": bytes_op / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "tile_layouts": [t.layout for t in g.tiles],
-           "note": "operator = all launches of one application z = P x (event pair around them); every block is read twice"}
+           "fused_single_launch": getattr(K, "_fused", None) is not None,
+           "padded_slots_over_edges": g.padded_slots() / max(E, 1),
+           "note": "operator = all launches of one application z = P x (event pair around them); fused_single_launch: the tiles share "
+                   "their chunking and vican_tiled_op reads every block once (else a rows pass and a camera pass per tile)"}
     del K, g, rot, tr
     torch.cuda.empty_cache()
     return res

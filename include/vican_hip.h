@@ -86,7 +86,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 15            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 16            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -228,6 +228,30 @@ int vican_bip_apply(const vican_graph_t* g, const double* x_cam, const double* x
  * over ALL tiles' row norms + vican_fx_finish).  Both stream the tile's blocks once.  Block-layout tiles: vican_bip_apply. */
 int vican_tile_rows(const vican_graph_t* g, const double* x_cam, double* y_time, double* fx, void* stream);
 int vican_tile_cams(const vican_graph_t* g, const double* w_time, void* zpart, double* fx, double* z_cam, void* stream);
+
+/* The tiled operator in ONE launch that reads every block once (csrc/vican_tsweep.hip).  Needs tiles that share their
+ * chunking: vican_plan_chunks_multi plans it (chunk k = the same timestep rows in every tile; a row joins the open chunk
+ * while every tile's edges still fit `slots`), each tile is then packed with that chunk_row0.  A workgroup is bound to a
+ * tile; the wavefront that owns chunk k publishes its tile's share of the chunk's row sums, keeps the blocks in registers,
+ * and an iteration later reads all tiles' shares, applies Lambda_t^-1 and forms the camera sums.  ypart[2]: the tile's
+ * share buffers [T][9] of alternate launches (parity 0, 1, 0, ...), both filled by vican_tiled_op_sentinel before the first
+ * launch and after an aborted one.  The grid (n_tile * n_wg_tile workgroups of 512 threads) must be co-resident
+ * (VICAN_ERR_CAPACITY otherwise: use vican_tile_rows / vican_tile_cams); spins are bounded (vican_set_barrier_abort).
+ * Afterwards z_cam of tile k = vican_slab_reduce_fx(zpart_k, n_wg_tile, C_k, 9, 1.0, fx_k + 3, fx_k + 7, ...).          */
+typedef struct {
+    vican_graph_t g;          /* the tile: wave layout, chunking shared with the other tiles */
+    const double* x;          /* [C_tile][9]  the tile's slice of the operand */
+    void* zpart;              /* >= n_wg_tile slabs [9][C_tile] of 64-bit words */
+    double* fx;               /* the tile's scales (vican_duals_bound over ALL tiles' row norms + vican_fx_finish with
+                                 n_add >= rows one workgroup of the fused launch handles) */
+    double* ypart[2];         /* [T][9] each */
+} vican_tile_t;
+int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const* row_ptrs_host, int32_t slots,
+                            int32_t max_rows, int32_t* chunk_row0_out, int32_t cap);
+int64_t vican_tiled_op_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy);
+int vican_tiled_op_sentinel(double* ypart, int64_t n_doubles, void* stream);
+int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
+                   const double* lamT_inv, int32_t parity, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,

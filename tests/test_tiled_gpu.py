@@ -14,11 +14,17 @@ from util import expected, load_golden, pose_errors, rebuild_inputs, translation
 from vican_amd.solver import Comm, solve_on_backend                         # noqa: E402
 
 
-@pytest.fixture(params=["wave", "block"], autouse=True)
+@pytest.fixture(params=["fused", "wave", "block"], autouse=True)
 def tile_layout(request, monkeypatch):
-    """Every test of this file runs with the tiles in the wave layout (vican_tile_rows / vican_tile_cams, the wave CG product in
-    partial mode) and in the block layout (vican_bip_apply twice, the block CG product)."""
-    monkeypatch.setenv("VICAN_TILE_LAYOUT", request.param)
+    """Every test of this file runs three ways: "fused" = the default (wave-layout tiles with a SHARED chunking, the operator as
+    one launch that reads every block once: vican_tiled_op), "wave" = wave-layout tiles with their own chunkings (a rows pass and
+    a camera pass per tile: vican_tile_rows / vican_tile_cams, the wave CG product in partial mode), "block" = block-layout tiles
+    (vican_bip_apply twice, the block CG product)."""
+    if request.param == "fused":
+        monkeypatch.setenv("VICAN_TILE_LAYOUT", "wave")
+    else:
+        monkeypatch.setenv("VICAN_TILE_LAYOUT", request.param)
+        monkeypatch.setenv("VICAN_TILE_SHARED", "0")
     return request.param
 
 
@@ -31,7 +37,11 @@ def _tiled(C, rp, col, blk, a, w, u, v, dt, tile):
                    tile=tile)
     import os
     assert all(t.layout == os.environ["VICAN_TILE_LAYOUT"] for t in g.tiles)
-    return g, TiledBackend(g)
+    K = TiledBackend(g)
+    shared = os.environ.get("VICAN_TILE_SHARED", "1") != "0"
+    assert (g.shared_chunks is not None) == shared and (K._fused is not None) == shared, K.coop_failures
+    K._expect_fused = shared
+    return g, K
 
 
 @pytest.mark.parametrize("C,T,tile", [(1500, 400, 1024), (90, 300, 32)])
@@ -53,8 +63,10 @@ def test_tiled_operator_and_dual_update_match_numpy(C, T, tile):
     K.dual_update(K.from_numpy(rc), Rh, lh); N.dual_update(N.from_numpy(rc), Rn, ln)
     assert np.abs(Rh.cpu().numpy() - Rn.numpy()).max() < 1e-9
     assert np.abs(lh.cpu().numpy() - ln.numpy()).max() <= 1e-9 * np.abs(ln.numpy()).max()
-    K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)        # with the new (full 3x3) duals
-    assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-9 * np.abs(zn.numpy()).max()
+    for _ in range(3):                                                               # with the new (full 3x3) duals; alternating share buffers
+        K.block_op(lh, K.from_numpy(x), zh); N.block_op(ln, N.from_numpy(x), zn)
+        assert np.abs(zh.cpu().numpy() - zn.numpy()).max() <= 1e-9 * np.abs(zn.numpy()).max()
+    assert (K._fused is not None) == K._expect_fused, K.coop_failures             # the fused launch was not refused
 
 
 def test_full_solve_with_1500_cameras_matches_numpy():
@@ -169,7 +181,7 @@ def test_tiled_dense_rows_take_the_one_row_kernels(tile_layout):
     C, T, tile = 600, 4000, 300
     rp, col, blk, a, w, u, v = random_graph(C, T, 360, 440, 6, False)
     g, K = _tiled(C, rp, col, blk, a, w, u, v, np.float32, tile)
-    if tile_layout == "wave":
+    if tile_layout in ("wave", "fused"):
         assert all(t.n_chunk == t.n_time and t.wg_waves == 12 for t in g.tiles)
     N = NumpyBackend(C, rp, col, blk, a, w, u, v, storage=np.float32)
     rng = np.random.default_rng(1)

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so") 
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
            os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip"),
-           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip")]
+           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
 FX_DOUBLES = 20
@@ -53,6 +53,11 @@ class Graph(C.Structure):
         ("stream_nt", C.c_int32), ("slot_order", C.c_int32),
         ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
     ]
+
+
+class Tile(C.Structure):
+    """Mirror of ``vican_tile_t`` (vican_tiled_op)."""
+    _fields_ = [("g", Graph), ("x", C.c_void_p), ("zpart", C.c_void_p), ("fx", C.c_void_p), ("ypart", C.c_void_p * 2)]
 
 
 # doubles first (17), then 4 int32: 152 bytes == 19 doubles
@@ -118,6 +123,10 @@ PROTOTYPES = {
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_tile_rows": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_plan_chunks_multi": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
+    "vican_tiled_op_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "vican_tiled_op_sentinel": (C.c_int, [_vp, C.c_int64, _vp]),
+    "vican_tiled_op": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "vican_tile_cams": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

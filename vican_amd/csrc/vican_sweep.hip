@@ -98,6 +98,31 @@ extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slot
     return nc;
 }
 
+// The same for camera tiles that must SHARE their chunking (vican_tiled_op): chunk k covers the same timestep rows in every
+// tile; a row joins the open chunk while every tile's edges of the chunk still fit its slots.  rps: n_tile row-pointer arrays.
+extern "C" int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const* rps, int32_t slots, int32_t max_rows,
+                                       int32_t* out, int32_t cap) {
+    if (n_time < 0 || n_tile <= 0 || !rps || slots <= 0 || max_rows <= 0 || max_rows > 65535)
+        return set_err(VICAN_ERR_ARG, "vican_plan_chunks_multi: bad argument");
+    for (int k = 0; k < n_tile; ++k) if (!rps[k]) return set_err(VICAN_ERR_ARG, "vican_plan_chunks_multi: null row pointer array");
+    int32_t nc = 0, r = 0;
+    while (r < n_time) {
+        if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks_multi: output too small"); out[nc] = r; }
+        int32_t r1 = r;
+        while (r1 < n_time && (r1 - r) < max_rows) {
+            bool fits = true;
+            for (int k = 0; k < n_tile && fits; ++k) fits = (rps[k][r1 + 1] - rps[k][r]) <= slots;
+            if (!fits) break;
+            ++r1;
+        }
+        if (r1 == r) return set_err(VICAN_ERR_CAPACITY, "vican_plan_chunks_multi: a timestep row has more edges than a chunk holds");
+        r = r1;
+        ++nc;
+    }
+    if (out) { if (nc >= cap) return set_err(VICAN_ERR_ARG, "vican_plan_chunks_multi: output too small"); out[nc] = n_time; }
+    return nc;
+}
+
 // (dynamic LDS a kernel may ask for: the 160 KB of a CU minus room for the kernels' few static __shared__ words - a graph that
 //  fitted the 160 KB exactly, C = 1024 in f64 with two accumulator copies, failed at hipFuncSetAttribute)
 extern "C" int64_t vican_lds_limit_bytes(void) { return 160 * 1024 - 1024; }

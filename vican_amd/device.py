@@ -37,7 +37,7 @@ def n_cu():
 _ABORT = None
 
 
-_NP_OF = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64}
+_NP_OF = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8}
 _STAGE = {"buf": None, "event": None, "lock": __import__("threading").Lock()}       # one staging buffer per process: serialised
 
 
@@ -154,44 +154,52 @@ def _stream():
     return h
 
 
+def _wave_params(lib, n_cam, deg_avg, n_edges, storage, n_copy=None, wg_waves=None):
+    """(slots, rows_target, n_copy, wg_waves) of a wave layout: what the LDS of a compute unit allows for this graph."""
+    epl = 4 if storage == _lib.STORE_F32 else 2
+    lim = int(lib.vican_lds_limit_bytes())
+    # one wavefront per chunk (vican_wsweep.hip): 64 lanes x EPL slots, whole rows, <= 64 rows per chunk
+    slots = 64 * epl
+    rows_target = max(1, min(64, int(math.ceil(1.25 * slots / deg_avg)) + 1))
+    if n_copy is None:        # lanes of a wavefront that share a row = deg / EPL
+        n_copy = 1        # (measured on the stress graph, 62 lanes per row: 8 copies 187 us, 16 copies 195 us - the fold grows)
+        while n_copy < 8 and n_copy * epl < deg_avg:
+            n_copy *= 2
+    if wg_waves is None:
+        wg_waves = 12
+        if n_edges < 12 * slots * n_cu():          # small graphs: fewer wavefronts per workgroup, more workgroups
+            wg_waves = 8 if n_edges >= 8 * slots * n_cu() else 4
+    fits = lambda rows, nc, nw: int(lib.vican_wsweep_lds_bytes(n_cam, rows, storage, nc, nw)) <= lim
+    while not fits(rows_target, n_copy, wg_waves) and n_copy > 1:
+        n_copy //= 2
+    if not fits(rows_target, n_copy, wg_waves):
+        # before giving up wavefronts (occupancy): a row limit without the 25 % margin, if the chunks still fill their
+        # slots with it (ragged rows of 2-8 edges: 62 rows instead of 64 keep 12 wavefronts resident instead of 8;
+        # worth 1.5 % there - that sweep is bound by the LDS work per row, not by occupancy: tools/ragged_time.py)
+        r = rows_target
+        while r > 1 and not fits(r, n_copy, wg_waves):
+            r -= 1
+        if fits(r, n_copy, wg_waves) and r * deg_avg >= 1.05 * slots:
+            rows_target = r
+    while not fits(rows_target, n_copy, wg_waves) and wg_waves > 4:
+        wg_waves -= 4
+    while not fits(rows_target, n_copy, wg_waves) and rows_target > 1:
+        rows_target -= 1
+    if not fits(rows_target, n_copy, wg_waves):
+        raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % n_cam)
+    return slots, rows_target, n_copy, wg_waves
+
+
 class _Layout:
     """One chunked edge layout of a rank's rows (device arrays + the vican_graph_t view of them)."""
 
     def __init__(self, lib, kind, n_cam, n_time, rp_host, deg_max, deg_avg, n_edges, storage, dev, block_threads=None, n_wg=None,
-                 n_copy=None, wg_waves=None):
+                 n_copy=None, wg_waves=None, forced_chunks=None):
         epl = 4 if storage == _lib.STORE_F32 else 2
         self.kind, self.n_time = kind, n_time
         lim = int(lib.vican_lds_limit_bytes())
         if kind == "wave":
-            # one wavefront per chunk (vican_wsweep.hip): 64 lanes x EPL slots, whole rows, <= 64 rows per chunk
-            slots = 64 * epl
-            rows_target = max(1, min(64, int(math.ceil(1.25 * slots / deg_avg)) + 1))
-            if n_copy is None:        # lanes of a wavefront that share a row = deg / EPL
-                n_copy = 1        # (measured on the stress graph, 62 lanes per row: 8 copies 187 us, 16 copies 195 us - the fold grows)
-                while n_copy < 8 and n_copy * epl < deg_avg:
-                    n_copy *= 2
-            if wg_waves is None:
-                wg_waves = 12
-                if n_edges < 12 * slots * n_cu():          # small graphs: fewer wavefronts per workgroup, more workgroups
-                    wg_waves = 8 if n_edges >= 8 * slots * n_cu() else 4
-            fits = lambda rows, nc, nw: int(lib.vican_wsweep_lds_bytes(n_cam, rows, storage, nc, nw)) <= lim
-            while not fits(rows_target, n_copy, wg_waves) and n_copy > 1:
-                n_copy //= 2
-            if not fits(rows_target, n_copy, wg_waves):
-                # before giving up wavefronts (occupancy): a row limit without the 25 % margin, if the chunks still fill their
-                # slots with it (ragged rows of 2-8 edges: 62 rows instead of 64 keep 12 wavefronts resident instead of 8;
-                # worth 1.5 % there - that sweep is bound by the LDS work per row, not by occupancy: tools/ragged_time.py)
-                r = rows_target
-                while r > 1 and not fits(r, n_copy, wg_waves):
-                    r -= 1
-                if fits(r, n_copy, wg_waves) and r * deg_avg >= 1.05 * slots:
-                    rows_target = r
-            while not fits(rows_target, n_copy, wg_waves) and wg_waves > 4:
-                wg_waves -= 4
-            while not fits(rows_target, n_copy, wg_waves) and rows_target > 1:
-                rows_target -= 1
-            if not fits(rows_target, n_copy, wg_waves):
-                raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % n_cam)
+            slots, rows_target, n_copy, wg_waves = _wave_params(lib, n_cam, deg_avg, n_edges, storage, n_copy, wg_waves)
             max_rows, block_threads = rows_target, 64 * wg_waves
         else:
             wg_waves = 0
@@ -217,9 +225,18 @@ class _Layout:
                 raise _lib.VicanError("camera tables (C=%d) do not fit in LDS" % n_cam)
             max_rows = min(max_rows, max(rows_target, 1))
         cap = n_time + 2
-        c0 = np.empty(cap, dtype=np.int32)
-        nchunk = _lib.check(lib.vican_plan_chunks(n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
-                                                   C.c_void_p(c0.ctypes.data), cap), "vican_plan_chunks")
+        if forced_chunks is not None:
+            # a chunking shared with other graphs over the same rows (camera tiles, vican_tiled_op): taken as given if it fits
+            c0 = np.ascontiguousarray(forced_chunks, dtype=np.int32)
+            nchunk = len(c0) - 1
+            rp_np = rp_host.numpy()
+            if nchunk < 1 or c0[0] != 0 or c0[-1] != n_time or (np.diff(c0) < 1).any() or int(np.diff(c0).max()) > max_rows \
+                    or int((rp_np[c0[1:]] - rp_np[c0[:-1]]).max()) > slots:
+                raise _lib.VicanError("the forced chunking does not fit this layout (rows per chunk <= %d, edges <= %d)" % (max_rows, slots))
+        else:
+            c0 = np.empty(cap, dtype=np.int32)
+            nchunk = _lib.check(lib.vican_plan_chunks(n_time, C.c_void_p(rp_host.data_ptr()), slots, max_rows,
+                                                       C.c_void_p(c0.ctypes.data), cap), "vican_plan_chunks")
         self.chunk_row0_host = c0[: nchunk + 1].copy()
         rows_per_chunk = np.diff(self.chunk_row0_host) if nchunk else np.zeros(0, np.int32)
         self.max_rows = int(rows_per_chunk.max()) if nchunk else 1
@@ -291,7 +308,8 @@ class LocalGraph:
     """
 
     def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, block_threads=None,
-                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None, row_ptr_host=None, keep_csr=None):
+                 n_wg=None, n_copy=None, layout=None, wg_waves=None, deg_t=None, deg_c=None, row_ptr_host=None, keep_csr=None,
+                 forced_chunks=None):
         import os
         lib = _lib.load()
         if not torch.cuda.is_available():
@@ -318,8 +336,10 @@ class LocalGraph:
         rot = None
         if layout != "block" and block_threads is None and deg_max <= 64 * epl and self.n_cam <= 1024 and self.n_edges > 0:
             try:
-                rot = mk("wave", n_wg=n_wg, n_copy=n_copy, wg_waves=wg_waves)
+                rot = mk("wave", n_wg=n_wg, n_copy=n_copy, wg_waves=wg_waves, forced_chunks=forced_chunks)
             except _lib.VicanError:
+                if forced_chunks is not None:
+                    raise
                 rot = None
             # (capture-sized graphs are latency-bound, padding costs them nothing, and only the wave layout has the resident
             #  CG kernel: ragged rows of 2-5 edges - what real captures look like - pad a 64-row chunk by 15 % and stay here)
@@ -1017,24 +1037,66 @@ class TiledGraph:
         rows = torch.repeat_interleave(torch.arange(T, device=dev), row_ptr[1:] - row_ptr[:-1])
         self.bounds = list(range(0, self.n_cam, tile)) + [self.n_cam]
         self.tiles = []
+        want = os.environ.get("VICAN_TILE_LAYOUT") or None
+        storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
+        parts = []
         for k in range(len(self.bounds) - 1):
             c0, c1 = self.bounds[k], self.bounds[k + 1]
             sel = ((col >= c0) & (col < c1)).nonzero().squeeze(1)
             rp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
             rp[1:] = torch.cumsum(torch.bincount(rows[sel], minlength=T), 0)
-            pick = lambda x: None if x is None else x[sel].contiguous()
-            # wave layout wherever the tile's rows fit a 64-lane chunk, whatever it pads (measured on 4000 cameras x 250 per
-            # timestep: 15 % padding, and still 52 + 53 us per tile for the rows and camera passes against 2 x 78 us for the
-            # block layout's two-sided sweep)
-            args = (c1 - c0, rp.to(torch.int32), (col[sel] - c0).to(torch.int32), blk[sel].contiguous(), a[sel].contiguous(), pick(w), pick(u), pick(v))
-            want = os.environ.get("VICAN_TILE_LAYOUT") or None
+            parts.append((c0, c1, sel, rp.to(torch.int32)))
+        rps_host = download([p_[3] for p_ in parts]) if T else [np.zeros(1, np.int32) for _ in parts]
+        rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
+        # A chunking SHARED by all tiles (chunk k = the same timestep rows in every tile) lets the operator run as ONE launch
+        # that reads every block once (vican_tiled_op, csrc/vican_tsweep.hip); it pads a little more than per-tile chunkings
+        # (a row joins a chunk only while EVERY tile's edges still fit).  VICAN_TILE_SHARED=0: per-tile chunkings (two passes).
+        self.shared_chunks = None
+        if want != "block" and os.environ.get("VICAN_TILE_SHARED", "1") != "0" and T > 0 and self.n_edges > 0:
             try:
-                t = LocalGraph(*args, layout=want or "wave")
+                cap_rows, slots = 64, 0
+                for (c0, c1, sel, _), rph in zip(parts, rps_host):
+                    n_e = int(rph[-1])
+                    if n_e == 0:
+                        raise _lib.VicanError("a tile without edges")
+                    slots, rows_t, n_copy_k, _ = _wave_params(lib, c1 - c0, max(1.0, n_e / T), n_e, storage)
+                    # (the fused launch runs 8 wavefronts per workgroup whatever the tile's own plan says: its LDS must fit too)
+                    while rows_t > 1 and int(lib.vican_tiled_op_lds_bytes(c1 - c0, rows_t, storage, n_copy_k)) > int(lib.vican_lds_limit_bytes()):
+                        rows_t -= 1
+                    cap_rows = min(cap_rows, rows_t)
+                ptrs = (C.c_void_p * len(parts))(*[r.ctypes.data for r in rps_host])
+                out = np.empty(T + 2, dtype=np.int32)
+                nch = _lib.check(lib.vican_plan_chunks_multi(T, len(parts), C.cast(ptrs, C.c_void_p), slots, cap_rows,
+                                                             C.c_void_p(out.ctypes.data), T + 2), "vican_plan_chunks_multi")
+                self.shared_chunks = out[: nch + 1].copy()
             except _lib.VicanError:
-                if want == "wave":
-                    raise
-                t = LocalGraph(*args, layout="block")
-            self.tiles.append(t)
+                self.shared_chunks = None
+        def build(shared):
+            tiles = []
+            for (c0, c1, sel, rp), rph in zip(parts, rps_host):
+                pick = lambda x: None if x is None else x[sel].contiguous()
+                # wave layout wherever the tile's rows fit a 64-lane chunk, whatever it pads (measured on 4000 cameras x 250 per
+                # timestep: 15 % padding, and still 52 + 53 us per tile for the rows and camera passes against 2 x 78 us for the
+                # block layout's two-sided sweep)
+                args = (c1 - c0, rp, (col[sel] - c0).to(torch.int32), blk[sel].contiguous(), a[sel].contiguous(), pick(w), pick(u), pick(v))
+                if shared is not None:
+                    t = LocalGraph(*args, layout="wave", row_ptr_host=rph, forced_chunks=shared)
+                else:
+                    try:
+                        t = LocalGraph(*args, layout=want or "wave", row_ptr_host=rph)
+                    except _lib.VicanError:
+                        if want == "wave":
+                            raise
+                        t = LocalGraph(*args, layout="block", row_ptr_host=rph)
+                tiles.append(t)
+            return tiles
+        try:
+            self.tiles = build(self.shared_chunks)
+        except _lib.VicanError:
+            if self.shared_chunks is None:
+                raise
+            self.shared_chunks = None
+            self.tiles = build(None)
         # global graph constants
         self.row_sum_a = torch.stack([t.row_sum_a for t in self.tiles]).sum(0)
         self.rnorm = torch.stack([t.rnorm for t in self.tiles]).sum(0)
@@ -1083,6 +1145,9 @@ class TiledBackend(HipBackend):
         self.wrow = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)           # phase-3 operand of the second pass
         self.zero_rows = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)
         self.scratch_c = [torch.zeros(3 * (b1 - b0), 3, dtype=torch.float64, device=self.dev) for b0, b1 in zip(graph.bounds[:-1], graph.bounds[1:])]
+        self._fused = None
+        if getattr(graph, "shared_chunks", None) is not None and os.environ.get("VICAN_TILE_FUSED", "1") != "0":
+            self._setup_fused()
         if graph.tiles[0].w is not None:
             self.n_add_cg = float(max(max(t.tl.rows_per_wg_max, t.tl.slots) for t in graph.tiles) + 1)
             self._cg_wmax = graph.wmax
@@ -1095,6 +1160,63 @@ class TiledBackend(HipBackend):
     def _tile_rows(self, k):
         b = self.g.bounds
         return 3 * b[k], 3 * b[k + 1]
+
+    # -- the operator as ONE launch that reads every block once (vican_tiled_op; tiles with a shared chunking) ----------
+    def _setup_fused(self):
+        nt, T1 = len(self.tiles), max(self.T, 1)
+        nwgt = n_cu() // nt
+        if nwgt < 1 or nt > 64:
+            return
+        tl = self.g.tiles
+        if int(self.lib.vican_tiled_op_lds_bytes(max(t.n_cam for t in tl), max(t.max_rows for t in tl), tl[0].desc.storage,
+                                                 max(t.n_copy for t in tl))) > int(self.lib.vican_lds_limit_bytes()):
+            return
+        f = _LsqrCtx()
+        f.nwgt, f.parity = nwgt, 0
+        # adds into one camera accumulator by one workgroup of the fused launch = rows it handles (<= its chunks x rows per chunk):
+        # the tiles' fixed-point scales are finished for at least that many
+        n_chunk = self.g.tiles[0].n_chunk
+        for t in self.g.tiles:
+            t.rows_per_wg_sweep = max(t.rows_per_wg_sweep, min(self.T, -(-n_chunk // nwgt) * t.max_rows))
+        f.x = torch.zeros(3 * self.C, 3, dtype=torch.float64, device=self.dev)           # the operand, at a fixed address
+        f.yp = torch.empty(2, nt, T1, 9, dtype=torch.float64, device=self.dev)           # share buffers of alternate launches
+        self._ck(self.lib.vican_tiled_op_sentinel(_ptr(f.yp), f.yp.numel(), _stream()), "vican_tiled_op_sentinel")
+        f.host = (_lib.Tile * nt)()
+        b = self.g.bounds
+        # (slabs of the fused launch: n_wg_tile per tile - a tile's own zpart is sized for ITS plan's workgroups)
+        f.zpart = [torch.empty(nwgt * 9 * K.C, dtype=torch.float64, device=self.dev) for K in self.tiles]
+        for k, K in enumerate(self.tiles):
+            e = f.host[k]
+            e.g = K.g.desc
+            e.x = f.x.data_ptr() + 8 * 9 * b[k]
+            e.zpart, e.fx = f.zpart[k].data_ptr(), K.g.fx.data_ptr()
+            e.ypart[0], e.ypart[1] = f.yp[0, k].data_ptr(), f.yp[1, k].data_ptr()
+        raw = np.frombuffer(bytes(f.host), dtype=np.uint8).copy()
+        f.dev = upload(self.dev, [(raw, torch.uint8)])[0]
+        self._fused = f
+
+    def _fused_op(self, lamT_inv, x, z_out):
+        """False: the fused launch is not available (grid not co-resident) - the caller takes the two-pass path."""
+        f = self._fused
+        f.x.copy_(x)
+        rc = self.lib.vican_tiled_op(C.cast(f.host, C.c_void_p), _ptr(f.dev), len(self.tiles), f.nwgt, _ptr(lamT_inv), f.parity, _stream())
+        if rc == _lib.ERR_CAPACITY:
+            self._fused = None
+            self.coop_failures.append("vican_tiled_op: " + self.lib.vican_last_error().decode())
+            return False
+        self._ck(rc, "vican_tiled_op")
+        f.parity ^= 1
+        for k, K in enumerate(self.tiles):
+            r0, r1 = self._tile_rows(k)
+            fxp = K.g.fx.data_ptr()
+            self._ck(self.lib.vican_slab_reduce_fx(_ptr(f.zpart[k]), f.nwgt, K.C, 9, 1.0, C.c_void_p(fxp + 8 * 3), C.c_void_p(fxp + 8 * 7),
+                                                   _ptr(z_out[r0:r1]), _stream()), "vican_slab_reduce_fx")
+        return True
+
+    def cooperative_failed(self, which):
+        """As HipBackend.cooperative_failed; the fused tiled operator spins on other workgroups too and is dropped with the rest."""
+        self._fused = None
+        super().cooperative_failed(which)
 
     def _sum_apply(self, A, B, n_b, out, width=9):
         self._ck(self.lib.vican_sum_apply3(self.T, width, _ptr(A), _ptr(B), n_b, B.stride(0), _ptr(out), _stream()), "vican_sum_apply3")
@@ -1128,7 +1250,10 @@ class TiledBackend(HipBackend):
         self._refresh_scales(lamT_inv)
 
     def block_op(self, lamT_inv, x, z_out):
-        """z_out = P x: rows pass over all tiles, w_t = Lambda_t^-1 (sum of the tiles' row partials), camera pass per tile."""
+        """z_out = P x: one fused launch where the tiles share their chunking (every block read once); else a rows pass over all
+        tiles, w_t = Lambda_t^-1 (sum of the tiles' row partials) and a camera pass per tile."""
+        if self._fused is not None and self._fused_op(lamT_inv, x, z_out):
+            return
         self._rows_T(x)
         self._sum_apply(lamT_inv, self.ypart, len(self.tiles), self.wrow)
         for k, K in enumerate(self.tiles):
