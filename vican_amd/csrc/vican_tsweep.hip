@@ -127,6 +127,7 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
 #pragma unroll
         for (int j = 0; j < EPL; ++j) { cam[j] = cam_of(cur.id[j]); row[j] = row_of(cur.id[j]); }
         S acc[9], xc[9], xn[9];
+        bool run_real = false;
 #pragma unroll
         for (int q = 0; q < 9; ++q) xc[q] = xs[q * CP + cam[0]];
 #pragma unroll
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
                                         vget<S>(cur.m[6 + a], j), xc[6 + b]);
                     acc[a * 3 + b] = cont ? acc[a * 3 + b] + c : c;
                 }
-            const bool last = (j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j];
+            // (a shared chunking pads more than a tile's own would - a quarter of the slots on the wide workload; padding slots
+            //  sit at the END of a chunk in the row-major slot order, i.e. whole lanes hold nothing else: their zero sums are not sent)
+            run_real = (cont && run_real) || cur.id[j] != VICAN_PAD_SLOT;     // (padding slots report row 0: a run may mix both)
+            const bool last = ((j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j]) && run_real;
             if (last) {
                 u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
 #pragma unroll
@@ -241,14 +245,16 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
                 for (int q = 0; q < 9; ++q) w[q] = wv[rowj * 9 + q];
             }
             u64* zc = zs + camj;
+            if (prev.id[j] != VICAN_PAD_SLOT) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const S v = dot3<S>(vget<S>(prev.m[i * 3 + 0], j), w[b], vget<S>(prev.m[i * 3 + 1], j), w[3 + b],
-                                        vget<S>(prev.m[i * 3 + 2], j), w[6 + b]);
-                    lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
-                }
+                    for (int b = 0; b < 3; ++b) {
+                        const S v = dot3<S>(vget<S>(prev.m[i * 3 + 0], j), w[b], vget<S>(prev.m[i * 3 + 1], j), w[3 + b],
+                                            vget<S>(prev.m[i * 3 + 2], j), w[6 + b]);
+                        lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
+                    }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     };
