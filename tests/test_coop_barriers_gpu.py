@@ -157,3 +157,73 @@ def test_dropin_solve_survives_a_busy_device():
     R = np.stack([out[k].R() for k in out]); Rr = np.stack([ref[k].R() for k in ref])
     t = np.stack([out[k].t() for k in out]); tr = np.stack([ref[k].t() for k in ref])
     assert float(geodesic(R, Rr).max()) < 1e-9 and float(np.linalg.norm(t - tr, axis=1).max()) < 1e-7
+
+
+def _tiled_setup():
+    from numpy_backend import NumpyBackend
+    from test_kernels_gpu import random_graph
+    from vican_amd.device import TiledBackend, TiledGraph
+    C_, T, tile = 600, 4000, 300
+    rp, col, blk, a, w, u, v = random_graph(C_, T, 40, 60, 8, False)
+    dev = torch.device("cuda:0")
+    to = lambda x: torch.from_numpy(x).to(dev)
+    g = TiledGraph(C_, to(rp), to(col), to(blk), to(a), to(w), to(u), to(v), tile=tile)
+    K = TiledBackend(g)
+    N = NumpyBackend(C_, rp, col, blk, a, w, u, v, storage=np.float64)
+    lh, ch, ln, cn = K.empty(T, 9), K.empty(C_), N.empty(T, 9), N.empty(C_)
+    K.init_duals(lh, ch); N.init_duals(ln, cn)
+    x = np.linalg.qr(np.random.default_rng(3).standard_normal((3 * C_, 3)))[0]
+    zn = N.empty(3 * C_, 3)
+    N.block_op(ln, N.from_numpy(x), zn)
+    return K, lh, K.from_numpy(x), zn.numpy()
+
+
+def test_fused_tiled_operator_waits_for_a_busy_device_and_repeats_bit_identically():
+    """vican_tiled_op (one workgroup per compute unit, wavefronts that wait for other tiles' row-sum shares) behind a filler that
+    holds most compute units for 30 ms: the resident workgroups spin on shares of workgroups that are not running yet, the
+    launch ends when the filler does - same bits as the undisturbed launch, no abort."""
+    K, lh, x, zn = _tiled_setup()
+    assert K._fused is not None
+    z0, z1 = K.empty(zn.shape[0], 3), K.empty(zn.shape[0], 3)
+    K.block_op(lh, x, z0)
+    torch.cuda.synchronize()
+    assert np.abs(z0.cpu().numpy() - zn).max() <= 1e-10 * np.abs(zn).max()
+    side = torch.cuda.Stream()
+    for free_cus in (0, 16):
+        torch.cuda.synchronize()
+        occupy(K.lib, 256 - free_cus, 30_000, side)
+        K.block_op(lh, x, z1)
+        torch.cuda.synchronize()
+        assert K._fused is not None and not K.barrier_aborted(), K.coop_failures
+        assert torch.equal(z0, z1)
+
+
+def test_fused_tiled_operator_aborts_instead_of_hanging_and_the_two_pass_path_takes_over():
+    """Spin limit 3 ms, filler 300 ms on all but ONE compute unit (the workgroups that exchange shares are neighbours in
+    dispatch order - blockIdx % n_tile is the tile -, so a few free compute units are enough for the launch to make progress
+    pair by pair): the one resident workgroup gives up waiting for the shares of its partner that cannot start, the host sees
+    the abort word, the backend drops the fused launch and the rows pass + camera pass per tile deliver the result."""
+    from vican_amd.device import barrier_abort_word
+    K, lh, x, zn = _tiled_setup()
+    assert K._fused is not None
+    z = K.empty(zn.shape[0], 3)
+    barrier_abort_word(timeout_us=3000)
+    try:
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        occupy(K.lib, 255, 300_000, side)
+        K.block_op(lh, x, z)
+        torch.cuda.current_stream().synchronize()
+        if not K.barrier_aborted():
+            pytest.skip("the fused grid found room next to the filler on this device")
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            K.cooperative_failed("test")
+        assert caught and K._fused is None and not K.barrier_aborted()
+        torch.cuda.synchronize()
+        K.block_op(lh, x, z)                                 # two passes per tile now
+        torch.cuda.synchronize()
+        assert np.abs(z.cpu().numpy() - zn).max() <= 1e-10 * np.abs(zn).max()
+    finally:
+        barrier_abort_word(timeout_us=0)
+        torch.cuda.synchronize()
