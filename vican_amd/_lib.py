@@ -51,7 +51,7 @@ class Graph(C.Structure):
         ("max_rows", C.c_int32), ("storage", C.c_int32), ("block_threads", C.c_int32), ("n_wg", C.c_int32),
         ("n_copy", C.c_int32), ("wg_chunk_cap", C.c_int32), ("layout", C.c_int32), ("wg_waves", C.c_int32),
         ("stream_nt", C.c_int32), ("slot_order", C.c_int32),
-        ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p),
+        ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p), ("idx16", C.c_void_p),
     ]
 
 
@@ -123,6 +123,7 @@ PROTOTYPES = {
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_tile_rows": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_pack_idx16": (C.c_int, [_G, _vp, _vp]),
     "vican_plan_chunks_multi": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
     "vican_tiled_op_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vican_tiled_op_sentinel": (C.c_int, [_vp, C.c_int64, _vp]),

@@ -56,7 +56,7 @@ struct vican_plan {
     int prop_sweeps = 3;
     Arena ar;
     // layout arrays
-    int32_t* idx = nullptr; int32_t* chunk_row0 = nullptr; void* blk = nullptr; void* a = nullptr;
+    int32_t* idx = nullptr; int32_t* chunk_row0 = nullptr; void* blk = nullptr; void* a = nullptr; uint16_t* idx16 = nullptr;
     double *w = nullptr, *u = nullptr, *v = nullptr;
     // graph constants
     double *row_sum_a = nullptr, *cam_sum_a = nullptr, *rnorm = nullptr, *fx = nullptr, *row_sum_w = nullptr, *cam_sum_w = nullptr;
@@ -178,6 +178,8 @@ size_t carve(vican_plan* P, size_t n_row0) {
     const int C = P->C, T1 = std::max(P->T, 1), n = 3 * C;
     const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, s = P->storage == VICAN_STORE_F32 ? 4 : 8;
     P->idx = A.take<int32_t>(nslot); P->chunk_row0 = A.take<int32_t>(n_row0);
+    // (one row per chunk: the 2-byte camera index of the one-row kernels, vican_graph_t.idx16)
+    P->idx16 = (P->g.layout == VICAN_LAYOUT_WAVE && P->g.n_chunk == P->T && P->E > 0) ? A.take<uint16_t>(nslot) : nullptr;
     P->blk = A.take<unsigned char>(9 * nslot * s); P->a = A.take<unsigned char>(nslot * s);
     if (P->have_t) { P->w = A.take<double>(nslot); P->u = A.take<double>(3 * nslot); P->v = A.take<double>(3 * nslot); }
     P->row_sum_a = A.take<double>(T1); P->cam_sum_a = A.take<double>(C); P->rnorm = A.take<double>(T1); P->fx = A.take<double>(20);
@@ -243,6 +245,10 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (hipMalloc((void**)&perm, nslot * 4) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc failed"));
     double* mx = P->ws ? P->ws : P->G;           // three doubles of scratch (zeroed by the memset)
     rc = vican_pack_edges(&P->g, row_ptr, col, blk, a, w, u, v, P->a, P->w, P->u, P->v, perm, stream);
+    if (rc >= 0 && P->idx16) {
+        rc = vican_pack_idx16(&P->g, P->idx16, stream);
+        if (rc >= 0) P->g.idx16 = P->idx16;
+    }
     if (rc >= 0) {
         hipLaunchKernelGGL(facade_maxima_kernel, dim3(256), dim3(256), 0, s, (long long)n_edges, storage, a, w, u, v, mx);
         double h[3] = {1, 1, 1};

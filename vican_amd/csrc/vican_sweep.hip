@@ -98,6 +98,24 @@ extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slot
     return nc;
 }
 
+__global__ void pack_idx16_kernel(const uint32_t* __restrict__ idx, uint16_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t v = idx[i];
+        out[i] = v == VICAN_PAD_SLOT ? (uint16_t)0xFFFF : (uint16_t)(v & 0xFFFFu);
+    }
+}
+extern "C" int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_pack_idx16")) return rc;
+    if (!out) return set_err(VICAN_ERR_ARG, "vican_pack_idx16: null pointer");
+    if (g->layout != VICAN_LAYOUT_WAVE || g->n_chunk != g->n_time)
+        return set_err(VICAN_ERR_ARG, "vican_pack_idx16: needs a wave-layout graph with one row per chunk");
+    const long long n = (long long)g->n_chunk * g->slots;
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(pack_idx16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, g->idx, out, n);
+    LAUNCH_CHECK("vican_pack_idx16");
+    return VICAN_OK;
+}
+
 // The same for camera tiles that must SHARE their chunking (vican_tiled_op): chunk k covers the same timestep rows in every
 // tile; a row joins the open chunk while every tile's edges of the chunk still fit its slots.  rps: n_tile row-pointer arrays.
 extern "C" int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const* rps, int32_t slots, int32_t max_rows,

@@ -94,6 +94,24 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
     }
 }
 
+// The chunk of a ONE-ROW graph (vican_graph_t.idx16): the nine planes as load_chunk, the cameras from the 2-byte index - 8 (4)
+// bytes per lane instead of 16 (8); ids are expanded to the 32-bit form (row field 0) so that the kernels' bodies do not change.
+template <typename S, int EPL, bool NT>
+__device__ __forceinline__ void load_chunk_one(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int lane) {
+    typedef typename Vec<S>::type V;
+    const S* blk = (const S*)g.blk;
+    const size_t pbase = (size_t)k * 9 * g.slots + (size_t)lane * EPL;
+    const uint16_t* ip = g.idx16 + (size_t)k * g.slots + (size_t)lane * EPL;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) c.m[p] = NT ? stream_load((const V*)(blk + pbase + (size_t)p * g.slots)) : *(const V*)(blk + pbase + (size_t)p * g.slots);
+    uint32_t lo, hi = 0;
+    if (EPL == 4) { const uint2 t = NT ? stream_load((const uint2*)ip) : *(const uint2*)ip; lo = t.x; hi = t.y; }
+    else          { lo = NT ? __builtin_nontemporal_load((const uint32_t*)ip) : *(const uint32_t*)ip; }
+    const uint32_t h[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) c.id[j] = h[j] == 0xFFFFu ? VICAN_PAD_SLOT : h[j];
+}
+
 template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);
 template <> __device__ __forceinline__ float pre_scale<float>(double v, double) { return (float)v; }
 template <> __device__ __forceinline__ double pre_scale<double>(double v, double) { return v; }

@@ -374,17 +374,22 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
         if (EPL == 4) {
-            uint4 t; double2 a, b;
+            uint2 t2; double2 a, b;
             const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
-            if (NT) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
-            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
-            e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
+            // (2-byte camera indices of one-row graphs, vican_graph_t.idx16: 8 instead of 16 bytes per lane)
+            if (NT) { t2 = stream_load((const uint2*)(g.idx16 + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            else { t2 = *(const uint2*)(g.idx16 + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
+            const uint32_t h[4] = {t2.x & 0xFFFFu, t2.x >> 16, t2.y & 0xFFFFu, t2.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e.id[j] = h[j] == 0xFFFFu ? VICAN_PAD_SLOT : h[j];
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
-            uint2 t; double2 a;
-            if (NT) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
-            else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
-            e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
+            uint32_t t1; double2 a;
+            if (NT) { t1 = __builtin_nontemporal_load((const uint32_t*)(g.idx16 + s)); a = stream_load((const double2*)(w + s)); }
+            else { t1 = *(const uint32_t*)(g.idx16 + s); a = *(const double2*)(w + s); }
+            const uint32_t h0 = t1 & 0xFFFFu, h1 = t1 >> 16;
+            e.id[0] = h0 == 0xFFFFu ? VICAN_PAD_SLOT : h0; e.id[1] = h1 == 0xFFFFu ? VICAN_PAD_SLOT : h1;
+            e.w[0] = a.x; e.w[1] = a.y;
         }
     };
     auto load_rowvals = [&](RowVals& rv, int k) {
@@ -973,7 +978,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     const bool nt = g->stream_nt != 0;
     hipStream_t s = (hipStream_t)stream;
     static const int one_row_ok = getenv("VICAN_CG_ONE_ROW") ? atoi(getenv("VICAN_CG_ONE_ROW")) : 1;      // (0: A/B against the general kernel)
-    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8 && !partial) {
+    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8 && !partial && g->idx16) {
         // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
         const size_t lds1 = (size_t)72 * cp + 256;
         static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;

@@ -398,6 +398,12 @@ class LocalGraph:
         # translation arrays, packed from the CSR-order inputs on first use.  They are retained - references, ~60 B per edge of
         # HBM, and through views the caller's whole upload - ONLY when asked for (keep_csr=True / VICAN_KEEP_CSR=1): the
         # device-resident LSQR and everything else run on the packed arrays, and "inputs may be freed by the caller" holds.
+        # one row per chunk everywhere (dense rows): the 2-byte camera index the one-row kernels read (vican_graph_t.idx16)
+        self.idx16 = None
+        if rot.kind == "wave" and rot.n_chunk == self.n_time and self.n_edges > 0 and os.environ.get("VICAN_IDX16", "1") != "0":
+            self.idx16 = torch.empty(rot.nslot, dtype=torch.int16, device=dev)
+            _lib.check(lib.vican_pack_idx16(gref, _ptr(self.idx16), st), "vican_pack_idx16")
+            self.desc.idx16 = self.idx16.data_ptr()
         keep = keep_csr if keep_csr is not None else os.environ.get("VICAN_KEEP_CSR") == "1"
         self._csr_t = (row_ptr, col, w, u, v) if (keep and have_t and rot.kind == "wave") else None
         self._lsqr_layout = None
