@@ -539,6 +539,10 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
         "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
+                     # achieved / frac are on the ALGORITHMIC bytes of SURVEY.md 8(d), E(9s + 4) + ...; wave-layout graphs carry a 2-byte
+                     # index (vican_graph_t.idx16), so the sweep streams 2 bytes per edge less than that figure
+                     "index_bytes_per_edge": 2 if g.layout == "wave" else 4,
+                     "bytes_streamed_per_launch": int(op_bytes - (2 * E_local if g.layout == "wave" else 0)),
                      "avg_launch_ms": float(kern_ms.mean()) if len(kern_ms) else None,
                      "padded_slots_over_edges": g.padded_slots() / max(E_local, 1)},
         "detail": {"rot_loop_ms_per_step": t_rot * 1e3, "cg_ms_per_step": t_tr * 1e3,     # split of the last (instrumented) step

@@ -83,14 +83,16 @@ typedef struct vican_graph {
     const void*     blk;      /* [n_chunk][9][slots] */
     const uint32_t* idx;      /* [n_chunk][slots]    */
     const int32_t*  chunk_row0; /* [n_chunk+1] first row of each chunk */
-    const uint16_t* idx16;    /* optional (NULL: none).  Wave-layout graphs whose chunks hold ONE row each (n_chunk == n_time: dense
-                                 rows): [n_chunk][slots] the camera index alone, 0xFFFF = padding (vican_pack_idx16).  The row field of
-                                 idx is zero everywhere on such a graph, and the one-row kernels (operator sweep, dual-update sweeps,
-                                 CG product) read these 2 bytes per edge instead of the 4 of idx */
+    const uint16_t* idx16;    /* wave layout: [n_chunk][slots]  camera | (row - chunk_row0) << 10,  0xFFFF = padding (vican_pack_idx16) -
+                                 a wave-layout chunk has <= 1024 cameras and <= 64 rows, so idx fits 16 bits; the edge sweeps of the
+                                 wave layout (vican_block_op(_z), vican_dual_update(_op), vican_tile_rows / _cams, vican_tiled_op, the
+                                 one-row CG product) stream these 2 bytes per edge instead of the 4 of idx and REQUIRE the array.
+                                 (C = 1024 with 64 rows in a chunk would make camera 1023 of row 63 look like padding: such graphs
+                                 are planned with <= 63 rows per chunk.)  NULL in the block layout */
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 17            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 18            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -257,7 +259,7 @@ int vican_tiled_op_sentinel(double* ypart, int64_t n_doubles, void* stream);
 int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
                    const double* lamT_inv, int32_t parity, void* stream);
 
-/* idx16 of a packed one-row wave-layout graph (see vican_graph_t.idx16): out [n_chunk][slots], then set g->idx16 = out. */
+/* idx16 of a packed wave-layout graph (see vican_graph_t.idx16): out [n_chunk][slots], then set g->idx16 = out. */
 int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,

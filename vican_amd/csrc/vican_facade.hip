@@ -116,7 +116,7 @@ int plan_layout(vican_plan* P, const std::vector<int32_t>& rp, std::vector<int32
     int slots, max_rows, n_copy, wg_waves = 0, block_threads;
     if (wave) {
         slots = 64 * epl;
-        int rows_target = std::max(1, std::min(64, (int)std::ceil(1.25 * slots / deg_avg) + 1));
+        int rows_target = std::max(1, std::min(C >= 1024 ? 63 : 64, (int)std::ceil(1.25 * slots / deg_avg) + 1));   // (2-byte index: vican_graph_t.idx16)
         n_copy = 1;
         while (n_copy < 8 && n_copy * epl < deg_avg) n_copy *= 2;
         wg_waves = 12;
@@ -178,8 +178,8 @@ size_t carve(vican_plan* P, size_t n_row0) {
     const int C = P->C, T1 = std::max(P->T, 1), n = 3 * C;
     const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, s = P->storage == VICAN_STORE_F32 ? 4 : 8;
     P->idx = A.take<int32_t>(nslot); P->chunk_row0 = A.take<int32_t>(n_row0);
-    // (one row per chunk: the 2-byte camera index of the one-row kernels, vican_graph_t.idx16)
-    P->idx16 = (P->g.layout == VICAN_LAYOUT_WAVE && P->g.n_chunk == P->T && P->E > 0) ? A.take<uint16_t>(nslot) : nullptr;
+    // (wave layout: the 2-byte index the edge sweeps stream, vican_graph_t.idx16)
+    P->idx16 = P->g.layout == VICAN_LAYOUT_WAVE ? A.take<uint16_t>(nslot) : nullptr;
     P->blk = A.take<unsigned char>(9 * nslot * s); P->a = A.take<unsigned char>(nslot * s);
     if (P->have_t) { P->w = A.take<double>(nslot); P->u = A.take<double>(3 * nslot); P->v = A.take<double>(3 * nslot); }
     P->row_sum_a = A.take<double>(T1); P->cam_sum_a = A.take<double>(C); P->rnorm = A.take<double>(T1); P->fx = A.take<double>(20);

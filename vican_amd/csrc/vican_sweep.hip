@@ -101,14 +101,14 @@ extern "C" int vican_plan_chunks(int32_t n_time, const int32_t* rp, int32_t slot
 __global__ void pack_idx16_kernel(const uint32_t* __restrict__ idx, uint16_t* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const uint32_t v = idx[i];
-        out[i] = v == VICAN_PAD_SLOT ? (uint16_t)0xFFFF : (uint16_t)(v & 0xFFFFu);
+        out[i] = v == VICAN_PAD_SLOT ? (uint16_t)0xFFFF : (uint16_t)((v & 0x3FFu) | ((v >> 16) << 10));
     }
 }
 extern "C" int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* stream) {
     if (int rc = vican_check_graph(g, "vican_pack_idx16")) return rc;
     if (!out) return set_err(VICAN_ERR_ARG, "vican_pack_idx16: null pointer");
-    if (g->layout != VICAN_LAYOUT_WAVE || g->n_chunk != g->n_time)
-        return set_err(VICAN_ERR_ARG, "vican_pack_idx16: needs a wave-layout graph with one row per chunk");
+    if (g->layout != VICAN_LAYOUT_WAVE || (g->n_cam == 1024 && g->max_rows == 64))
+        return set_err(VICAN_ERR_ARG, "vican_pack_idx16: needs a wave-layout graph (with <= 63 rows per chunk if it has 1024 cameras)");
     const long long n = (long long)g->n_chunk * g->slots;
     if (n == 0) return VICAN_OK;
     hipLaunchKernelGGL(pack_idx16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, g->idx, out, n);

@@ -94,10 +94,11 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
     }
 }
 
-// The chunk of a ONE-ROW graph (vican_graph_t.idx16): the nine planes as load_chunk, the cameras from the 2-byte index - 8 (4)
-// bytes per lane instead of 16 (8); ids are expanded to the 32-bit form (row field 0) so that the kernels' bodies do not change.
+// A wave-layout chunk through the 2-byte index (vican_graph_t.idx16: camera | row << 10): the nine planes as load_chunk, 8 (4)
+// bytes of index per lane instead of 16 (8); ids are expanded to the 32-bit form of idx so that the kernels' bodies do not change.
+__device__ __forceinline__ uint32_t idx16_expand(uint32_t h) { return h == 0xFFFFu ? VICAN_PAD_SLOT : ((h & 0x3FFu) | ((h >> 10) << 16)); }
 template <typename S, int EPL, bool NT>
-__device__ __forceinline__ void load_chunk_one(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int lane) {
+__device__ __forceinline__ void load_chunk16(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int lane) {
     typedef typename Vec<S>::type V;
     const S* blk = (const S*)g.blk;
     const size_t pbase = (size_t)k * 9 * g.slots + (size_t)lane * EPL;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void load_chunk_one(ChunkRegs<S, EPL>& c, const vican
     else          { lo = NT ? __builtin_nontemporal_load((const uint32_t*)ip) : *(const uint32_t*)ip; }
     const uint32_t h[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) c.id[j] = h[j] == 0xFFFFu ? VICAN_PAD_SLOT : h[j];
+    for (int j = 0; j < EPL; ++j) c.id[j] = idx16_expand(h[j]);
 }
 
 template <typename S> __device__ __forceinline__ S pre_scale(double v, double scale);

@@ -33,35 +33,36 @@
 #define TS_G __attribute__((address_space(1)))
 __device__ __forceinline__ void ts_st(TS_G double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ts_ld(TS_G const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// load_chunk (vican_sweep_common.h) on address-space-1 pointers
+// load_chunk16 (vican_sweep_common.h) on address-space-1 pointers
 template <typename S, int EPL, bool NT>
-__device__ __forceinline__ void ts_load_chunk(ChunkRegs<S, EPL>& c, TS_G const S* blk, TS_G const uint32_t* idx, const int slots, const int k, const int lane) {
-    typedef typename Vec<S>::type V;
+__device__ __forceinline__ void ts_load_chunk(ChunkRegs<S, EPL>& c, TS_G const S* blk, TS_G const uint16_t* idx16, const int slots, const int k, const int lane) {
     const size_t pbase = (size_t)k * 9 * slots + (size_t)lane * EPL;
-    TS_G const uint32_t* ip = idx + (size_t)k * slots + (size_t)lane * EPL;
+    TS_G const uint16_t* ip = idx16 + (size_t)k * slots + (size_t)lane * EPL;
+    uint32_t lo, hi = 0;
     if constexpr (sizeof(S) == 4) {
         typedef float v4f __attribute__((ext_vector_type(4)));
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
             TS_G const v4f* q = (TS_G const v4f*)(blk + pbase + (size_t)p * slots);
             const v4f t = NT ? __builtin_nontemporal_load(q) : *q;
             c.m[p] = make_float4(t.x, t.y, t.z, t.w);
         }
-        const v4u t = NT ? __builtin_nontemporal_load((TS_G const v4u*)ip) : *(TS_G const v4u*)ip;
-        c.id[0] = t.x; c.id[1] = t.y; c.id[2] = t.z; c.id[3] = t.w;
+        const v2u t = NT ? __builtin_nontemporal_load((TS_G const v2u*)ip) : *(TS_G const v2u*)ip;
+        lo = t.x; hi = t.y;
     } else {
         typedef double v2d __attribute__((ext_vector_type(2)));
-        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
             TS_G const v2d* q = (TS_G const v2d*)(blk + pbase + (size_t)p * slots);
             const v2d t = NT ? __builtin_nontemporal_load(q) : *q;
             c.m[p] = make_double2(t.x, t.y);
         }
-        const v2u t = NT ? __builtin_nontemporal_load((TS_G const v2u*)ip) : *(TS_G const v2u*)ip;
-        c.id[0] = t.x; c.id[1] = t.y;
+        lo = NT ? __builtin_nontemporal_load((TS_G const uint32_t*)ip) : *(TS_G const uint32_t*)ip;
     }
+    const uint32_t h[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) c.id[j] = idx16_expand(h[j]);
 }
 
 extern "C" int64_t vican_tiled_op_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
     const vican_tile_t* Tp = tiles + tile;
     const vican_graph_t g = Tp->g;
     TS_G const S* const g_blk = (TS_G const S*)g.blk;
-    TS_G const uint32_t* const g_idx = (TS_G const uint32_t*)g.idx;
+    TS_G const uint16_t* const g_idx = (TS_G const uint16_t*)g.idx16;
     TS_G const int32_t* const g_row0 = (TS_G const int32_t*)g.chunk_row0;
     TS_G const double* const x = (TS_G const double*)Tp->x;
     TS_G double* const yp_pub = (TS_G double*)Tp->ypart[parity];       // [T][9] this tile's shares, this launch
@@ -335,7 +336,7 @@ extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t
     for (int k = 0; k < n_tile; ++k) {
         const vican_tile_t& t = tiles_host[k];
         if (int rc = vican_check_graph(&t.g, "vican_tiled_op")) return rc;
-        if (t.g.layout != VICAN_LAYOUT_WAVE || !t.g.blk || !t.x || !t.zpart || !t.fx || !t.ypart[0] || !t.ypart[1])
+        if (t.g.layout != VICAN_LAYOUT_WAVE || !t.g.blk || !t.g.idx16 || !t.x || !t.zpart || !t.fx || !t.ypart[0] || !t.ypart[1])
             return set_err(VICAN_ERR_ARG, "vican_tiled_op: tiles must be wave layouts with all buffers set");
         if (t.g.n_chunk != g0.n_chunk || t.g.slots != g0.slots || t.g.storage != g0.storage || t.g.n_time != g0.n_time ||
             t.g.stream_nt != g0.stream_nt || t.g.n_chunk == 0)

@@ -62,8 +62,8 @@ extern "C" int64_t vican_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, int32
 // and the z atomics: per chunk 72 LDS wave-instructions instead of ~100, no phase-2 LDS round trip (stamps of the general
 // kernel on the stress graph: phases 1 + 2 = 4.0 k of 9.4 k cycles per chunk and wavefront; counters: 44 % of the LDS-active
 // cycles were bank-conflict cycles, most of them the same-address pairs of the striped row accumulators).
-// The one-row instantiations read the 2-byte camera index of such graphs (vican_graph_t.idx16, load_chunk_one): 38 instead of 40
-// bytes per edge in f32 - they are only launched on graphs that carry it.
+// The edge stream is read through the 2-byte index of the wave layout (vican_graph_t.idx16, load_chunk16): 38 instead of 40 bytes
+// per edge in f32 (operator sweep on the stress graph 167.8 -> 155.9 us on the same box).
 // NT: non-temporal loads of the edge stream, chosen at compile time (load_chunk).
 template <typename S, int NW, int MODE, int CP, int TRIPS, bool FB = true, bool ONE = false, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __restrict__ gate, vican_graph_t g,
@@ -178,8 +178,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     }
     const double fx0 = fx[0], fx1 = fx[1], fx2 = fx[2], fx8 = fx[8], fx9 = (MODE == 3) ? fx[9] : 0.0;
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ONE) load_chunk_one<S, EPL, NT>(ra, g, kc < kmax ? kc : kmax, lane);
-    else load_chunk<S, EPL, NT ? 1 : 0>(ra, g, kc < kmax ? kc : kmax, lane);
+    load_chunk16<S, EPL, NT>(ra, g, kc < kmax ? kc : kmax, lane);
     __builtin_amdgcn_sched_barrier(0);
     double xm2 = 0.0;
 #pragma unroll
@@ -273,8 +272,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ONE) load_chunk_one<S, EPL, NT>(nxt, g, kp, lane);
-        else load_chunk<S, EPL, NT ? 1 : 0>(nxt, g, kp, lane);
+        load_chunk16<S, EPL, NT>(nxt, g, kp, lane);
 
 #if defined(VICAN_WABLATE) && VICAN_WABLATE == 1      /* loads only: streaming rate of this access pattern */
         {
@@ -565,7 +563,7 @@ static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const 
                           double* fx, hipStream_t st) {
     // one row per chunk everywhere (n_chunk == n_time): the accumulator-free instantiation (VICAN_SWEEP_ONE_ROW=0: A/B)
     static const int one_row_ok = getenv("VICAN_SWEEP_ONE_ROW") ? atoi(getenv("VICAN_SWEEP_ONE_ROW")) : 1;
-    if (NW >= 8 && NW <= 12 && one_row_ok && g->n_chunk == g->n_time && g->idx16)
+    if (NW >= 8 && NW <= 12 && one_row_ok && g->n_chunk == g->n_time)
         return launch_wsweep4<S, NW, MODE, CP, 1, FB, true>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     // TRIPS = ceil(3 max_rows / 64) row items per lane: dual-block rows (MODE 0) / thirds of the given row operands (MODE 4)
     if ((MODE != 0 && MODE != 4) || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);
@@ -625,6 +623,7 @@ __attribute__((visibility("hidden"))) int vican_wsweep_part_4(WSWEEP_PART_ARGS);
 #endif
 // entry used by vican_sweep.hip's dispatcher for graphs in the wave layout
 extern "C" __attribute__((visibility("hidden"))) int vican_wsweep(int mode, WSWEEP_PART_ARGS) {
+    if (!g->idx16) return set_err(VICAN_ERR_ARG, "%s: the wave layout needs vican_graph_t.idx16 (vican_pack_idx16)", "vican wave sweep");
 #if defined(VICAN_WSWEEP_SPLIT)
     if (mode == 0) return vican_wsweep_part_0(g, lamT_inv, x, zpart, lamT_out, fx, stream);
     if (mode == 1) return vican_wsweep_part_1(g, lamT_inv, x, zpart, lamT_out, fx, stream);

@@ -160,7 +160,8 @@ def _wave_params(lib, n_cam, deg_avg, n_edges, storage, n_copy=None, wg_waves=No
     lim = int(lib.vican_lds_limit_bytes())
     # one wavefront per chunk (vican_wsweep.hip): 64 lanes x EPL slots, whole rows, <= 64 rows per chunk
     slots = 64 * epl
-    rows_target = max(1, min(64, int(math.ceil(1.25 * slots / deg_avg)) + 1))
+    # (<= 64 rows per chunk; 63 with 1024 cameras: camera 1023 of row 63 would read as the padding word of the 2-byte index)
+    rows_target = max(1, min(63 if n_cam >= 1024 else 64, int(math.ceil(1.25 * slots / deg_avg)) + 1))
     if n_copy is None:        # lanes of a wavefront that share a row = deg / EPL
         n_copy = 1        # (measured on the stress graph, 62 lanes per row: 8 copies 187 us, 16 copies 195 us - the fold grows)
         while n_copy < 8 and n_copy * epl < deg_avg:
@@ -398,9 +399,9 @@ class LocalGraph:
         # translation arrays, packed from the CSR-order inputs on first use.  They are retained - references, ~60 B per edge of
         # HBM, and through views the caller's whole upload - ONLY when asked for (keep_csr=True / VICAN_KEEP_CSR=1): the
         # device-resident LSQR and everything else run on the packed arrays, and "inputs may be freed by the caller" holds.
-        # one row per chunk everywhere (dense rows): the 2-byte camera index the one-row kernels read (vican_graph_t.idx16)
+        # wave layout: the 2-byte index the edge sweeps stream (vican_graph_t.idx16: camera | row << 10)
         self.idx16 = None
-        if rot.kind == "wave" and rot.n_chunk == self.n_time and self.n_edges > 0 and os.environ.get("VICAN_IDX16", "1") != "0":
+        if rot.kind == "wave":
             self.idx16 = torch.empty(rot.nslot, dtype=torch.int16, device=dev)
             _lib.check(lib.vican_pack_idx16(gref, _ptr(self.idx16), st), "vican_pack_idx16")
             self.desc.idx16 = self.idx16.data_ptr()
