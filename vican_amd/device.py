@@ -1205,6 +1205,8 @@ class TiledBackend(HipBackend):
     def _fused_op(self, lamT_inv, x, z_out):
         """False: the fused launch is not available (grid not co-resident) - the caller takes the two-pass path."""
         f = self._fused
+        if torch.cuda.is_current_stream_capturing():
+            return False                # (the share buffer's parity is a launch ARGUMENT: a replayed graph would reuse one buffer)
         f.x.copy_(x)
         rc = self.lib.vican_tiled_op(C.cast(f.host, C.c_void_p), _ptr(f.dev), len(self.tiles), f.nwgt, _ptr(lamT_inv), f.parity, _stream())
         if rc == _lib.ERR_CAPACITY:
