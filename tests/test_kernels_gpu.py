@@ -64,6 +64,8 @@ CONFIGS = [  # C, T, deg_lo, deg_hi, block_threads, n_wg, empty_rows
     (300, 900, 60, 128, "wave12", 9, False),
     (1000, 200, 100, 128, "wave12", None, False),
     (100, 4000, 2, 9, "wave12", 5, False),
+    # 1024 cameras, short rows: 63 rows per chunk (camera 1023 of a row 63 would read as the padding word of the 2-byte index)
+    (1024, 700, 1, 4, "wave4", None, False),
 ]
 
 
