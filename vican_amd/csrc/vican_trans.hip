@@ -772,8 +772,9 @@ extern "C" int vican_cg_time_step(int32_t n_time, const double* p_t, const doubl
 }
 
 // cg_cam_step + cg_time_step in ONE launch: every block derives alpha itself (the camera-side dot product is
-// 3C elements: cheaper to recompute per block than to wait for another kernel), block 0 also updates the camera
-// vectors and the state.  Same thread mappings and summation orders as the two separate kernels => same bits.
+// 3C elements: cheaper to recompute per block than to wait for another kernel); the LAST block (an extra one: the time side is
+// strided over gridDim.x - 1 blocks) updates the camera vectors and their part of the state - as block 0's epilogue it
+// stretched the launch by its 3-4 us.  Same thread mappings and summation orders as the two separate kernels => same bits.
 __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, const double* __restrict__ deg_c,
                                                       const double* __restrict__ qc_sum, const double* __restrict__ pq_time,
                                                       const double* __restrict__ p_c, double* x_c, double* r_c,
@@ -797,9 +798,11 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     }
     __syncthreads();
     const double alpha = sh_alpha;
+    const int nb = (int)gridDim.x - 1;                     // blocks of the time side
+    if ((int)blockIdx.x < nb) {
     double rr = 0.0, m = 0.0, mp = 0.0;
 #pragma unroll 4
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
         const double pv = p_t[i];
         x_t[i] = mul_add_2r(alpha, pv, x_t[i]);
         mp = fmax(mp, fabs(pv));
@@ -815,8 +818,8 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     __syncthreads();
     if (threadIdx.x == 0) { rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
                             rr_part[2 * CG_PARTS + blockIdx.x] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7])); }
-    if (blockIdx.x != 0) return;
-    __syncthreads();
+    return;
+    }
     double rc2 = 0.0, mc = 0.0;
     for (int i = threadIdx.x; i < nc; i += 256) {
         const double p = p_c[i];
@@ -1086,7 +1089,7 @@ extern "C" int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double*
         return set_err(VICAN_ERR_ARG, "vican_cg_iter_finish: bad argument");
     const long long n = 3LL * n_time;
     int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
-    hipLaunchKernelGGL(cg_step_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n_cam, n, deg_c, qcpq, qcpq + 3 * n_cam,
+    hipLaunchKernelGGL(cg_step_kernel, dim3(nb + 1), dim3(256), 0, (hipStream_t)stream, n_cam, n, deg_c, qcpq, qcpq + 3 * n_cam,
                        p_c, x_c, r_c, p_t, q_t, x_t, r_t, rr_part, st);
     LAUNCH_CHECK("vican_cg_iter_finish");
     return nb;
