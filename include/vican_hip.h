@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 18            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 19            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -514,6 +514,20 @@ int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
  * (pq_part = NULL: the camera part only):  the message a sharded run all-reduces per CG iteration.          */
 int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                   const vican_cg_state_t* st, void* stream);
+/* The CG Laplacian product of a camera-tiled graph in ONE launch (csrc/vican_tcg.hip; per tile: vican_cg_sweep_partial): tile k's
+ * sweep writes its share of the row sums into acc_t and the double-word slabs of its own cameras into qc_part (n_wg_tile slabs
+ * of 6 C_tile words; fold with vican_cg_fold(pq_part = NULL)); p_t already updated (vican_cg_update_pt), rows combined by
+ * vican_cg_combine_rows.  2..4 wave-layout tiles of one launch shape (12 wavefronts per workgroup), VICAN_ERR_CAPACITY otherwise. */
+typedef struct {
+    vican_graph_t g;
+    const double* w;          /* the tile's weights in its slot order */
+    const double* p_c;        /* [C_tile][3] the tile's slice of the camera vector */
+    double* acc_t;            /* [T][3] receives sum_{c in tile} w p_c */
+    void* qc_part;            /* n_wg_tile slabs of 6 C_tile 64-bit words */
+} vican_cg_tile_t;
+int vican_cg_sweep_tiles(const vican_cg_tile_t* tiles, int32_t n_tile, int32_t n_wg_tile, const double* p_t,
+                         const vican_cg_state_t* st, void* stream);
+
 /* Camera-tiled graphs (more cameras than one LDS table holds; the reference has no camera limit, bipgo.py:225-232): the
  * product q = A p one camera tile at a time.  vican_cg_update_pt: p_t <- r_t + beta p_t (skipped on the first iteration) -
  * what vican_cg_sweep does while it loads its rows.  vican_cg_sweep_partial (g = ONE tile's block-layout graph, w its

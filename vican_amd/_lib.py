@@ -19,9 +19,9 @@ LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so") 
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
            os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip"),
-           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip")]
+           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip"), os.path.join(CSRC, "vican_tcg.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
-HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), WSWEEP]
+HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), os.path.join(CSRC, "vican_cgw_impl.h"), WSWEEP]
 FX_DOUBLES = 20
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
@@ -58,6 +58,11 @@ class Graph(C.Structure):
 class Tile(C.Structure):
     """Mirror of ``vican_tile_t`` (vican_tiled_op)."""
     _fields_ = [("g", Graph), ("x", C.c_void_p), ("zpart", C.c_void_p), ("fx", C.c_void_p), ("ypart", C.c_void_p * 2)]
+
+
+class CgTile(C.Structure):
+    """Mirror of ``vican_cg_tile_t`` (vican_cg_sweep_tiles)."""
+    _fields_ = [("g", Graph), ("w", C.c_void_p), ("p_c", C.c_void_p), ("acc_t", C.c_void_p), ("qc_part", C.c_void_p)]
 
 
 # doubles first (17), then 4 int32: 152 bytes == 19 doubles
@@ -123,6 +128,7 @@ PROTOTYPES = {
     "vican_bip_scales": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
     "vican_bip_apply": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_tile_rows": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
+    "vican_cg_sweep_tiles": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "vican_pack_idx16": (C.c_int, [_G, _vp, _vp]),
     "vican_plan_chunks_multi": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
     "vican_tiled_op_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

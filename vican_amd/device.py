@@ -1163,6 +1163,19 @@ class TiledBackend(HipBackend):
             self.pq_part = torch.empty(1024, dtype=torch.float64, device=self.dev)
             self.acc_t = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)   # per-tile row sums of the CG product
             self.rhs_part = torch.zeros(nt, T1, 3, dtype=torch.float64, device=self.dev)
+            # the tiles' CG products in ONE launch (vican_cg_sweep_tiles: 2..4 wave-layout tiles of one launch shape; the
+            # launcher refuses anything else and the per-tile launches take over)
+            self._tcg = None
+            if 2 <= nt <= 4 and all(K.layout == "wave" for K in self.tiles) and os.environ.get("VICAN_TILE_CG_FUSED", "1") != "0":
+                t = _LsqrCtx()
+                t.nwgt = max(1, n_cu() // nt)
+                t.host = (_lib.CgTile * nt)()
+                t.parts = [torch.empty(t.nwgt * 6 * K.C, dtype=torch.float64, device=self.dev) for K in self.tiles]
+                for k, K in enumerate(self.tiles):
+                    t.host[k].g = K.g.desc
+                    t.host[k].acc_t, t.host[k].qc_part = self.acc_t[k].data_ptr(), t.parts[k].data_ptr()
+                    self.n_add_cg = max(self.n_add_cg, float(-(-K.g.n_chunk // t.nwgt) * K.g.max_rows + 1))
+                self._tcg = t
 
     def _tile_rows(self, k):
         b = self.g.bounds
@@ -1302,7 +1315,19 @@ class TiledBackend(HipBackend):
         self._ck(self.lib.vican_cg_begin(self.C, _ptr(r_c), _ptr(p_c), float(rtol), _ptr(self.rr_part), int(n_rr_part), self.n_add_cg,
                                          _ptr(st), _stream()), "vican_cg_begin")
         self._ck(self.lib.vican_cg_update_pt(self.T, _ptr(r_t), _ptr(p_t), _ptr(st), _stream()), "vican_cg_update_pt")
-        for k, K in enumerate(self.tiles):
+        t = self._tcg
+        if t is not None:
+            for k in range(len(self.tiles)):
+                t.host[k].w, t.host[k].p_c = self._cg_w[k].data_ptr(), p_c.data_ptr() + 8 * 3 * b[k]
+            rc = self.lib.vican_cg_sweep_tiles(C.cast(t.host, C.c_void_p), len(self.tiles), t.nwgt, _ptr(p_t), _ptr(st), _stream())
+            if rc == _lib.ERR_CAPACITY:
+                self._tcg = t = None                         # (launch shapes differ / small graphs: per-tile launches)
+            else:
+                self._ck(rc, "vican_cg_sweep_tiles")
+                for k, K in enumerate(self.tiles):
+                    self._ck(self.lib.vican_cg_fold(_ptr(t.parts[k]), t.nwgt, K.C, None, C.c_void_p(qcpq.data_ptr() + 8 * 3 * b[k]), _ptr(st),
+                                                    _stream()), "vican_cg_fold")
+        for k, K in enumerate(self.tiles if t is None else ()):
             part = K.zpart[: K.tl.n_wg * 6 * K.C]
             self._ck(self.lib.vican_cg_sweep_partial(K._gref_t, _ptr(self._cg_w[k]), _ptr(p_c[b[k]: b[k + 1]]), _ptr(p_t), _ptr(self.acc_t[k]),
                                                      _ptr(part), _ptr(st), _stream()), "vican_cg_sweep_partial")
