@@ -75,6 +75,33 @@ def test_plan_chunks_edge_cases(lib):
     assert lib.vican_plan_chunks(3, None, 64, 8, None, 0) == -1
 
 
+def test_plan_chunks_multi_is_one_chunking_that_fits_every_tile(lib):
+    """vican_plan_chunks_multi (the shared chunking of camera tiles, vican_tiled_op): whole rows, every tile's edges of a chunk
+    within `slots`, greedy (the next row would not have fitted in some tile), one tile = vican_plan_chunks."""
+    rng = np.random.default_rng(1)
+    T, n_tile, slots, max_rows = 800, 3, 64, 9
+    rps = [np.concatenate([[0], np.cumsum(rng.integers(0, 30, T))]).astype(np.int32) for _ in range(n_tile)]
+    ptrs = (C.c_void_p * n_tile)(*[r.ctypes.data for r in rps])
+    out = np.empty(T + 2, dtype=np.int32)
+    n = lib.vican_plan_chunks_multi(T, n_tile, C.cast(ptrs, C.c_void_p), slots, max_rows, C.c_void_p(out.ctypes.data), len(out))
+    assert n > 0
+    c0 = out[: n + 1]
+    assert c0[0] == 0 and c0[-1] == T and np.all(np.diff(c0) > 0) and np.diff(c0).max() <= max_rows
+    for k in range(n):
+        assert all(r[c0[k + 1]] - r[c0[k]] <= slots for r in rps)
+        if c0[k + 1] < T and c0[k + 1] - c0[k] < max_rows:
+            assert any(r[c0[k + 1] + 1] - r[c0[k]] > slots for r in rps)
+    one = (C.c_void_p * 1)(rps[0].ctypes.data)
+    out1 = np.empty(T + 2, dtype=np.int32)
+    n1 = lib.vican_plan_chunks_multi(T, 1, C.cast(one, C.c_void_p), slots, max_rows, C.c_void_p(out1.ctypes.data), len(out1))
+    n2, c2 = plan(lib, rps[0], slots, max_rows)
+    assert n1 == n2 and list(out1[: n1 + 1]) == list(c2)
+    big = np.array([0, 100], dtype=np.int32)                       # a row that does not fit one of the tiles
+    small = np.array([0, 3], dtype=np.int32)
+    two = (C.c_void_p * 2)(small.ctypes.data, big.ctypes.data)
+    assert lib.vican_plan_chunks_multi(1, 2, C.cast(two, C.c_void_p), 64, 8, C.c_void_p(out.ctypes.data), len(out)) == -3
+
+
 def test_lds_budget(lib):
     for storage in (_lib.STORE_F32, _lib.STORE_F64):
         for c in (3, 24, 340, 1000):

@@ -756,3 +756,19 @@ def test_lanczos_step_folding_the_slabs_itself(cfg, dt):
         outs.append([t.clone() for t in (Hcol, beta, xo, V)])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg", [c for c in CONFIGS if isinstance(c[4], str)])
+def test_wave_layout_carries_its_index_in_two_bytes(cfg):
+    """vican_graph_t.idx16 (vican_pack_idx16): camera | row << 10 of every slot of a wave-layout graph, 0xFFFF for padding -
+    the word the rotation sweeps stream instead of the 4-byte idx."""
+    C_, T, lo, hi, bt, n_wg, empty = cfg
+    H, N, g = make_backends(C_, T, lo, hi, 13, np.float32, bt, n_wg, empty)
+    assert g.layout == "wave" and g.idx16 is not None and g.desc.idx16 == g.idx16.data_ptr()
+    idx = g.idx.cpu().numpy().view(np.uint32)
+    i16 = g.idx16.cpu().numpy().view(np.uint16)
+    pad = idx == 0xFFFFFFFF
+    assert np.array_equal(i16[pad], np.full(int(pad.sum()), 0xFFFF, dtype=np.uint16))
+    cam, row = idx[~pad] & 0xFFFF, idx[~pad] >> 16
+    assert cam.max() < 1024 and row.max() < 64 and not np.any((cam == 1023) & (row == 63))
+    assert np.array_equal(i16[~pad], (cam | (row << 10)).astype(np.uint16))
