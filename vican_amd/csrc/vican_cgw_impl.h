@@ -69,17 +69,17 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
         if (EPL == 4) {
-            uint4 t; double2 a, b;
+            double2 a, b;
             const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
-            if (NT) { t = stream_load((const uint4*)(g.idx + s)); a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
-            else { t = *(const uint4*)(g.idx + s); a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
-            e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w;
+            load_idx16<EPL, NT>(e.id, g.idx16 + s);                                // (2-byte index of the wave layout)
+            if (NT) { a = stream_load((const double2*)wk); b = stream_load((const double2*)(wk + 128)); }
+            else { a = *(const double2*)wk; b = *(const double2*)(wk + 128); }
             e.w[0] = a.x; e.w[1] = a.y; e.w[2] = b.x; e.w[3] = b.y;
         } else {
-            uint2 t; double2 a;
-            if (NT) { t = stream_load((const uint2*)(g.idx + s)); a = stream_load((const double2*)(w + s)); }
-            else { t = *(const uint2*)(g.idx + s); a = *(const double2*)(w + s); }
-            e.id[0] = t.x; e.id[1] = t.y; e.w[0] = a.x; e.w[1] = a.y;
+            double2 a;
+            load_idx16<EPL, NT>(e.id, g.idx16 + s);
+            if (NT) a = stream_load((const double2*)(w + s)); else a = *(const double2*)(w + s);
+            e.w[0] = a.x; e.w[1] = a.y;
         }
     };
     // row values of a chunk: lane + 64 t < 3 nrows holds (p_t, r_t, deg_t) of one (row, component) item

@@ -97,6 +97,16 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<S, EPL>& c, const vican_gra
 // A wave-layout chunk through the 2-byte index (vican_graph_t.idx16: camera | row << 10): the nine planes as load_chunk, 8 (4)
 // bytes of index per lane instead of 16 (8); ids are expanded to the 32-bit form of idx so that the kernels' bodies do not change.
 __device__ __forceinline__ uint32_t idx16_expand(uint32_t h) { return h == 0xFFFFu ? VICAN_PAD_SLOT : ((h & 0x3FFu) | ((h >> 10) << 16)); }
+// the EPL ids of a lane from the 2-byte index, expanded to the 32-bit form (ip: the lane's first slot)
+template <int EPL, bool NT>
+__device__ __forceinline__ void load_idx16(uint32_t (&id)[EPL], const uint16_t* ip) {
+    uint32_t lo, hi = 0;
+    if (EPL == 4) { const uint2 t = NT ? stream_load((const uint2*)ip) : *(const uint2*)ip; lo = t.x; hi = t.y; }
+    else          { lo = NT ? __builtin_nontemporal_load((const uint32_t*)ip) : *(const uint32_t*)ip; }
+    const uint32_t h[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) id[j] = idx16_expand(h[j]);
+}
 template <typename S, int EPL, bool NT>
 __device__ __forceinline__ void load_chunk16(ChunkRegs<S, EPL>& c, const vican_graph_t& g, int k, int lane) {
     typedef typename Vec<S>::type V;

@@ -230,8 +230,7 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
         constexpr bool nt = NT;
-        if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
-        else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+        load_idx16<EPL, NT>(e.id, g.idx16 + s);                                    // (2-byte index of the wave layout)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             // EPL 4: permuted storage (slot_pos8): slots (4l+j, 4l+j+1) at doubles [64 j + 2 l, +2) - dense 16-byte loads
@@ -348,6 +347,7 @@ __global__ __launch_bounds__(NW * 64) void trans_wrhs_kernel(vican_graph_t g, co
 extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vican_graph_t* g, const double* u, const double* v, const double* rc,
                                                                       const double* rt, double* rhs_t, void* rhs_c_part, double scale,
                                                                       double inv, int lob, void* stream) {
+    if (!g->idx16) return set_err(VICAN_ERR_ARG, "%s: the wave layout needs vican_graph_t.idx16 (vican_pack_idx16)", "vican_trans_wrhs");
     const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
     // (measured: 8 wavefronts beat 12 even where 12 fit the register budget: stress 240 vs 253 us, sparse 207 vs 302 us)
     int nw = g->wg_waves >= 8 ? 8 : 4;
@@ -486,8 +486,7 @@ __global__ __launch_bounds__(NW * 64) void lsqr_wstep_kernel(vican_graph_t g, co
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
         constexpr bool nt = NT;
-        if (EPL == 4) { const uint4 t = nt ? stream_load((const uint4*)(g.idx + s)) : *(const uint4*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; e.id[2] = t.z; e.id[3] = t.w; }
-        else          { const uint2 t = nt ? stream_load((const uint2*)(g.idx + s)) : *(const uint2*)(g.idx + s); e.id[0] = t.x; e.id[1] = t.y; }
+        load_idx16<EPL, NT>(e.id, g.idx16 + s);                                    // (2-byte index of the wave layout)
 #pragma unroll
         for (int j = 0; j < EPL; j += 2) {
             const double* a = sw + (size_t)k * g.slots + wpos8<EPL>(lane, j);
@@ -652,6 +651,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_winit(const vica
 extern "C" __attribute__((visibility("hidden"))) int vican_lsqr_wstep(const vican_graph_t* g, const double* sw, double* u, const double* v_c,
                                                                       const double* v_t, double* z_t, void* zc_part, double* part,
                                                                       const vican_lsqr_state_t* st, void* stream) {
+    if (!g->idx16) return set_err(VICAN_ERR_ARG, "%s: the wave layout needs vican_graph_t.idx16 (vican_pack_idx16)", "vican_lsqr_wstep");
     int nw = g->wg_waves >= 8 ? 8 : 4;
     while (nw > 4 && lsqr_wstep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw -= 4;
     const size_t lds = (size_t)lsqr_wstep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
@@ -685,6 +685,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
                                                                      const double* p_c, const double* r_t, double* p_t, double* q_t,
                                                                      void* qc_part, double* pq_part, const vican_cg_state_t* st,
                                                                      void* stream, int partial) {
+    if (!g->idx16) return set_err(VICAN_ERR_ARG, "%s: the wave layout needs vican_graph_t.idx16 (vican_pack_idx16)", "vican_cg_wsweep");
     const int nw = g->wg_waves >= 12 ? 12 : (g->wg_waves >= 8 ? 8 : 4);
     const size_t lds = (size_t)vican_cg_wsweep_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > 160 * 1024) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_cg_sweep (wave layout)");
