@@ -344,10 +344,15 @@ class LocalGraph:
                 rot = None
             # (capture-sized graphs are latency-bound, padding costs them nothing, and only the wave layout has the resident
             #  CG kernel: ragged rows of 2-5 edges - what real captures look like - pad a 64-row chunk by 15 % and stay here)
-            if rot is not None and layout is None and self.n_edges >= 2_000_000 and rot.nslot > 1.06 * max(self.n_edges, 1) + 64 * epl * 8:
-                # rows pack badly into 64-lane chunks (very short rows: a chunk holds at most 64 of them; rows of ~200 edges: one
+            if rot is not None and layout is None and self.n_edges >= 2_000_000 and rot.nslot > 1.40 * max(self.n_edges, 1) + 64 * epl * 8:
+                # rows pack badly into 64-lane chunks (very short rows: a chunk holds at most 64 of them; rows of ~150 edges: one
                 # per chunk): the block layout is taken where it pads LESS - with rows of 1-4 edges its chunks are limited by
-                # their row count too and it pads more (measured: 2.07x against 1.6x)
+                # their row count too and it pads more (measured: 2.07x against 1.6x).  Padding up to 1.4 slots per edge stays
+                # in the wave layout: measured whole solves on 25 M edges of 1000 cameras (ms, wave / block) - 30 edges per row
+                # (1.07 slots per edge in the wave layout) 6.39 / 7.26, 60 (1.07) 5.50 / 6.55, 100 (1.28) 5.79 / 6.42, 120 (1.07)
+                # 5.18 / 6.40, 200 (1.28, one row per chunk) 4.92 / 5.27; only at 150 (1.71) the block layout wins, 5.74 / 6.28 -
+                # the sweeps run alike per slot, the translation kernels of the wave layout are the faster ones (round 4; the
+                # rule was 1.06 before and sent all of these to the block layout)
                 alt = mk("block", block_threads=block_threads, n_wg=n_wg, n_copy=n_copy)
                 if alt.nslot < rot.nslot:
                     rot = alt
