@@ -674,14 +674,13 @@ int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* par
  *   vican_comm_unique_id   128 bytes (ncclUniqueId) written by ONE rank, handed to the others by any means
  *   vican_comm_create      collective over the group: every rank calls it with the same id (ncclCommInitRank)
  *   vican_comm_allreduce_sum   buf[0:n] (device, f64) <- sum over ranks, in place; world == 1: nothing is enqueued
- *   vican_block_op_z_comm  vican_block_op_z followed by the all-reduce of z [3C][3] behind one host call (comm NULL: single rank) */
+ * (the composite "sweep + fold + all-reduce behind one host call", vican_block_op_z_comm, has no caller yet and lives in
+ *  include/vican_hip_test.h until it has one) */
 typedef struct vican_comm vican_comm_t;
 int vican_comm_unique_id(void* id_out /* 128 bytes, host */);
 int vican_comm_create(int32_t rank, int32_t world, const void* unique_id, vican_comm_t** comm_out);
 int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream);
 int vican_comm_destroy(vican_comm_t* comm);
-int vican_block_op_z_comm(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx, double* z,
-                          vican_comm_t* comm, void* stream);
 
 /* ---- the four-call boundary ----------------------------------------------------------------------------
  * For a maintainer who wants the numerics of the reference's two stages behind ONE handle: everything above composed by host

@@ -44,6 +44,51 @@ def test_struct_sizes():
     assert _lib.CG_STATE_DOUBLES * 8 == 17 * 8 + 4 * 4
 
 
+def header_struct(name, header="vican_hip.h"):
+    """[(field, C type string)] of `typedef struct ... { ... } <name>;` in the header, comments stripped, in order."""
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef\s+struct\s*\w*\s*\{([^}]*)\}\s*%s\s*;" % re.escape(name), txt, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"(.*?[\s\*])(\w+(?:\s*,\s*\w+)*)$", decl)
+        ctype, names = m.group(1).strip(), [n.strip() for n in m.group(2).split(",")]
+        out += [(n, ctype) for n in names]
+    return out
+
+
+def test_graph_struct_in_the_header_the_ctypes_mirror_and_the_documented_stub_agree():
+    """vican_graph_t three times: the header (the truth), vican_amd/_lib.Graph, and the `class Graph` a maintainer copies out
+    of INTEGRATION.md - rounds 3 and 4 each shipped that stub one field short (a caller's struct 8 bytes smaller than the one
+    the library reads).  The stub's class statement is EXECUTED here and compared field by field."""
+    fields = header_struct("vican_graph_t")
+    kind = lambda ctype: C.c_void_p if "*" in ctype else {"int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double}[ctype.replace("const ", "")]
+    want = [(n, kind(t)) for n, t in fields]
+    assert [(n, t) for n, t in _lib.Graph._fields_] == want
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    src = [b for b in blocks if "class Graph(C.Structure)" in b]
+    assert len(src) == 1
+    stmt = re.search(r"(class Graph\(C\.Structure\):.*?)\n(?=\S)", src[0], flags=re.S).group(1)
+    ns = {"C": C}
+    exec(stmt, ns)                                             # noqa: S102  (our own documentation)
+    stub = ns["Graph"]
+    assert [(n, t) for n, t in stub._fields_] == want, "INTEGRATION.md's Graph stub drifted from include/vican_hip.h"
+    assert C.sizeof(stub) == C.sizeof(_lib.Graph)
+    # every entry point the document names exists in one of the two headers; every argtypes list it shows has the bound arity
+    named = set(re.findall(r"\bvican_[a-z0-9_]+\b", md))
+    known = set(header_symbols()) | set(header_symbols("vican_hip_test.h"))
+    types = {"vican_graph_t", "vican_lsqr_state_t", "vican_amd", "vican_hip", "vican_facade", "vican_plan_t", "vican_solve_info_t", "vican_comm_t", "vican_cg_state_t"}
+    patterns = {n for n in named if n.endswith("_")}          # prefixes like vican_comm_ in prose
+    unknown = {n for n in named - known - types - patterns if not any(k.startswith(n) for k in known)}
+    assert not unknown, "INTEGRATION.md names entry points the headers do not declare: %s" % sorted(unknown)
+    for name, args in re.findall(r"lib\.(vican_\w+)\.argtypes = \[(.*?)\]", md, flags=re.S):
+        assert len([a for a in args.split(",") if a.strip()]) == len(_lib.PROTOTYPES[name][1]), name
+
+
 def plan(lib, rp, slots, max_rows):
     rp = np.asarray(rp, dtype=np.int32)
     out = np.empty(len(rp) + 1, dtype=np.int32)

@@ -76,10 +76,11 @@ def test_bench_launches_its_own_ranks(workload, scaling, gpus):
     if scaling == "strong":
         assert out["detail"]["rows_rank0"] == 10000 // gpus
         # collectives per solve: one all-reduce per operator application (propagated start + Lanczos steps + the tails'
-        # sweeps), ONE message per CG iteration, one set-up message - and nothing that grows with the number of ranks
+        # sweeps), TWO messages per CG iteration (scipy's recurrence, the default of sharded runs: [q_c | p.q] and r.r) + the
+        # r.r of the start, one set-up message - and nothing that grows with the number of ranks
         d = out["detail"]
-        expect = d["sweeps_per_step"] + d["cg_iters"] + 1
-        assert expect - 2 <= d["n_allreduce_per_solve"] <= expect + 8, (d["n_allreduce_per_solve"], expect)
+        expect = d["sweeps_per_step"] + 2 * d["cg_iters"] + 2
+        assert expect - 2 <= d["n_allreduce_per_solve"] <= expect + 10, (d["n_allreduce_per_solve"], expect)
     else:
         assert out["detail"]["rows_rank0"] == 4000
 

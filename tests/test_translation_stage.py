@@ -39,7 +39,8 @@ def reference_rotations(prob, exp):
 
 class LoneShardComm(Comm):
     """A "sharded" run whose other ranks hold no rows: world = 2 as far as the solver's choice of path goes, every all-reduce
-    is the identity.  Drives the sharded code (ONE message per CG iteration: vican_cg1_iter_local / _finish) in one process."""
+    is the identity.  Drives the sharded code in one process: by default scipy's recurrence with two messages per CG iteration
+    (vican_cg_iter_local / _finish + vican_cg_end), with one_message=True the Chronopoulos-Gear arrangement (vican_cg1_*)."""
 
     def __init__(self):
         self.group, self.world, self.rank, self.n_allreduce = None, 2, 0, 0
@@ -49,9 +50,11 @@ class LoneShardComm(Comm):
         return t
 
 
-def run_stage(K, prob, exp, comm=None):
+def run_stage(K, prob, exp, comm=None, one_message=None):
     rc, rt = reference_rotations(prob, exp)
     tr = TranslationSolver(K, comm or Comm.single())
+    if one_message is not None:
+        tr.one_message = bool(one_message)
     tr.setup(K.from_numpy(rc), K.from_numpy(rt))
     x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
     pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
@@ -78,11 +81,29 @@ def test_one_message_cg_numpy_backend(name, dt):
     exp = expected(g, "conjugate_gradient", dt)
     K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type, deg_t=prob.deg_t, deg_c=prob.deg_c)
     comm = LoneShardComm()
-    dist, info = run_stage(K, prob, exp, comm)
+    dist, info = run_stage(K, prob, exp, comm, one_message=True)
     assert info.get("one_message")
     assert dist < stage_tol(name, dt), dist
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
     assert comm.n_allreduce <= 1 + info["cg_iters"] + 1 + 64            # bursts: overshoot bounded
+
+
+@pytest.mark.parametrize("name,dt", CASES)
+def test_sharded_default_is_scipys_recurrence_numpy_backend(name, dt):
+    """The DEFAULT of sharded runs (the rearranged CG stays off in parity mode): scipy's own recurrence, two
+    messages per iteration ([q_c | p.q], then r.r) - the same iterates, bit for bit, as the single-rank solve of the same
+    backend, and the message count that goes with it."""
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    mk = lambda: NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type,
+                              deg_t=prob.deg_t, deg_c=prob.deg_c)
+    comm = LoneShardComm()
+    dist, info = run_stage(mk(), prob, exp, comm)
+    dist1, info1 = run_stage(mk(), prob, exp)
+    assert not info.get("one_message")
+    assert dist == dist1 and info["cg_iters"] == info1["cg_iters"]
+    # set-up message + r.r of the start + two per launched iteration (bursts overshoot by at most 64 iterations)
+    assert 2 * info["cg_iters"] <= comm.n_allreduce <= 2 + 2 * (info["cg_iters"] + 1 + 64)
 
 
 def hip_backend(prob, dt):
@@ -115,7 +136,7 @@ def test_one_message_cg_on_gpu(name, dt):
     g, case, prob = flatten_case(name, dt)
     exp = expected(g, "conjugate_gradient", dt)
     K = hip_backend(prob, dt)
-    dist, info = run_stage(K, prob, exp, LoneShardComm())
+    dist, info = run_stage(K, prob, exp, LoneShardComm(), one_message=True)
     dist2, info2 = run_stage(K, prob, exp)
     print("%s %s: one-message CG %.2e m from the reference's iterate (scipy's recurrence: %.2e), cg %d / %d vs %d" % (
         name, dt, dist, dist2, info["cg_iters"], info2["cg_iters"], int(exp["cg_iters"])))
@@ -128,7 +149,7 @@ def test_one_message_cg_on_gpu(name, dt):
 @pytest.mark.parametrize("dt", ["float32", "float64"])
 def test_one_message_cg_at_large_shop_scale(dt):
     """g9 through the one-message arrangement: inside the reference's own band and iteration window (as the test below)."""
-    dist, info, exp = large_shop_stage(dt, LoneShardComm())
+    dist, info, exp = large_shop_stage(dt, LoneShardComm(), one_message=True)
     print("g9 %s: one-message CG: %.2e m from the reference's iterate, cg %d vs %d" % (dt, dist, info["cg_iters"], int(exp["cg_iters"])))
     assert info.get("one_message")
     assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
@@ -136,7 +157,39 @@ def test_one_message_cg_at_large_shop_scale(dt):
     assert lo - 1 <= info["cg_iters"] <= hi + 1, (info["cg_iters"], lo, hi)
 
 
-def large_shop_stage(dt, comm=None):
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dt", CASES)
+def test_sharded_default_is_scipys_recurrence_on_gpu(name, dt):
+    """Sharded default on the device (launch sequence vican_cg_iter_local / _finish / vican_cg_end, two messages): inside
+    the same bounds as the single-rank solve, and the SAME iterate as the launch-sequence single-rank path (the resident
+    kernel of capture-sized graphs is bit-identical to that sequence: tests/test_coop_barriers_gpu.py)."""
+    g, case, prob = flatten_case(name, dt)
+    exp = expected(g, "conjugate_gradient", dt)
+    K = hip_backend(prob, dt)
+    comm = LoneShardComm()
+    dist, info = run_stage(K, prob, exp, comm)
+    dist1, info1 = run_stage(K, prob, exp)
+    print("%s %s: sharded default (two messages) %.3e m, single rank %.3e m, cg %d / %d vs %d, %d all-reduces" % (
+        name, dt, dist, dist1, info["cg_iters"], info1["cg_iters"], int(exp["cg_iters"]), comm.n_allreduce))
+    assert not info.get("one_message")
+    assert dist < stage_tol(name, dt), dist
+    assert info["cg_iters"] == info1["cg_iters"] and abs(dist - dist1) <= 1e-12
+    assert 2 * info["cg_iters"] <= comm.n_allreduce <= 2 + 2 * (info["cg_iters"] + 1 + 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_sharded_default_at_large_shop_scale(dt):
+    """g9 through the sharded default (scipy's recurrence, two messages): the reference's band and iteration window."""
+    dist, info, exp = large_shop_stage(dt, LoneShardComm())
+    print("g9 %s: sharded default: %.2e m from the reference's iterate, cg %d vs %d" % (dt, dist, info["cg_iters"], int(exp["cg_iters"])))
+    assert not info.get("one_message")
+    assert dist < min(translation_tol("g9_large_shop", dt), 2e-3), dist
+    lo, hi = reference_window("g9_large_shop", dt, int(exp["cg_iters"]))
+    assert lo - 1 <= info["cg_iters"] <= hi + 1, (info["cg_iters"], lo, hi)
+
+
+def large_shop_stage(dt, comm=None, one_message=None):
     from util import load_golden
     from vican_amd import frontend, synth
     from vican_amd.geometry import SE3
@@ -149,7 +202,7 @@ def large_shop_stage(dt, comm=None):
     cons = synth.constraints_from_scene(scene, SE3)
     nr, nt, ff = (gc.CALLABLES[gc.LARGE_SHOP[k]] for k in ("noise_r", "noise_t", "filt"))
     prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
-    dist, info = run_stage(hip_backend(prob, dt), prob, exp, comm)
+    dist, info = run_stage(hip_backend(prob, dt), prob, exp, comm, one_message)
     return dist, info, exp
 
 

@@ -172,7 +172,6 @@ PROTOTYPES = {
     "vican_comm_create": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "vican_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vican_comm_destroy": (C.c_int, [_vp]),
-    "vican_block_op_z_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # the four-call boundary (csrc/vican_facade.hip)
     "vican_plan_create": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "vican_plan_describe": (C.c_int, [_vp, _G]),
@@ -190,6 +189,8 @@ class SolveInfo(C.Structure):
 
 # include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
 TEST_PROTOTYPES = {
+    "vican_comm_force_enqueue": (C.c_int, [_vp, _i32]),
+    "vican_block_op_z_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),
@@ -214,7 +215,7 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     """Compile the HIP sources for gfx950 into ``vican_amd/csrc/libvican_hip.so`` (or ``out``).
 
     One hipcc per translation unit, in parallel, then a link step.  Objects are cached OUTSIDE the tree
-    (``$VICAN_BUILD_CACHE`` or ``<tmp>/vican_amd_build_cache/<sha1 of flags + source + headers>.o`` - only the linked
+    (``$VICAN_BUILD_CACHE`` or ``<tmp>/vican_amd_build_cache_<uid>/<sha1 of flags + source + headers>.o``, mode 0700 - only the linked
     library travels with a repository snapshot), so diagnostic variants (``extra_flags``) and rebuilds after a one-file
     edit only recompile what changed; ``force`` ignores the cache."""
     out = out or LIB_PATH
@@ -236,8 +237,14 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     jobs += [(WSWEEP, ["-DVICAN_WSWEEP_SPLIT"])]
     jobs += [(src, []) for src in SOURCES[1:]]
     import tempfile
-    cache = os.environ.get("VICAN_BUILD_CACHE") or os.path.join(tempfile.gettempdir(), "vican_amd_build_cache")
-    os.makedirs(cache, exist_ok=True)
+    # per-user object cache, private to its owner: the objects are linked into the library this process loads, so a
+    # directory another user could have created (or can write to) must never be trusted
+    cache = os.environ.get("VICAN_BUILD_CACHE") or os.path.join(tempfile.gettempdir(), "vican_amd_build_cache_%d" % os.getuid())
+    os.makedirs(cache, mode=0o700, exist_ok=True)
+    st_c = os.stat(cache)
+    if st_c.st_uid != os.getuid() or (st_c.st_mode & 0o022):
+        raise VicanError("build cache %s is not a private directory of uid %d (owner %d, mode %o): refusing to link objects "
+                         "from it; set VICAN_BUILD_CACHE to a directory of your own" % (cache, os.getuid(), st_c.st_uid, st_c.st_mode & 0o777))
     hdr = b"".join(open(p, "rb").read() for p in sorted(set(HEADERS) - {WSWEEP}) + [os.path.join(INCLUDE, "vican_hip.h")])
     # the compiler is part of the key: a toolchain upgrade must not reuse objects
     tool = subprocess.run([hipcc_path(), "--version"], capture_output=True).stdout

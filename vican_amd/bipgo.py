@@ -69,9 +69,9 @@ def _shard_rows(T, world, rank):
 
 
 def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=np.float32,
-                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False, cg_stop_at=None):
+                  group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False, cg_stop_at=None, comm=None):
     """Solve a flattened problem on this rank's GPU; returns host arrays
-    (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3])."""
+    (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3]).  comm: a ready solver.Comm (default: Comm(group))."""
     from .device import TILE_CAMS, download, make_backend, upload      # needs the GPU + extension
 
     if lsqr_solver not in ("conjugate_gradient", "direct"):
@@ -82,7 +82,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         raise UnboundLocalError("local variable 'r_c' referenced before assignment")
     if not torch.cuda.is_available():
         raise VicanError("no GPU visible: vican_amd has no CPU fallback")
-    comm = Comm(group)
+    comm = Comm(group) if comm is None else comm
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     T = prob.n_time

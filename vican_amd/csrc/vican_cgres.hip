@@ -178,9 +178,9 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
     for (int k = 0;; ++k) {
         rho = rr_cam + rr_time;
         if (k == 0) { bnorm2 = rho; atol2 = rtol * rtol * rho; }
+        if (k >= max_iter) break;                                                    // scipy: range(maxiter), no test behind the last update
         if (sqrt(rho) < sqrt(atol2) || rho == 0.0) { done = 1; break; }            // scipy: norm(r) < atol, before the step
         if (!(rho == rho)) { done = -2; break; }                                     // NaN input: scipy would spin to maxiter; report instead
-        if (k >= max_iter) break;
         const bool first = k == 0;
         beta = first ? 0.0 : rho / rho_prev;
         // fixed-point scale of this iteration (49 bits below a bound on max |w p|, as cg_begin_kernel): both node sets

@@ -1,7 +1,7 @@
 // vican_comm.hip - the collective of the sharded solve behind the C ABI (vican_comm_*).
 //
 // What crosses ranks on this path is small and of one kind: sum-all-reduces of camera-side partials in f64 (3C x 3 doubles per
-// operator application, ONE message of 3C + 2 doubles per CG iteration, one set-up message).  The Python
+// operator application, two messages - 3C + 1 doubles and one scalar - per CG iteration, one set-up message).  The Python
 // driver issues them through torch.distributed (its "nccl" backend IS RCCL).  These entry points let a caller without torch -
 // or one who wants the collective enqueued by the same host call that enqueues the kernel in front of it - hold an RCCL
 // communicator inside the library: the message is reduced in place by ncclAllReduce on the caller's stream, in stream order
@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include "vican_common.h"
+#include "vican_hip_test.h"
 
 namespace {
 
@@ -51,7 +52,7 @@ int rccl_err(const char* who, ncclResult_t e) {
 
 }  // namespace
 
-struct vican_comm { ncclComm_t comm; int rank, world; };
+struct vican_comm { ncclComm_t comm; int rank, world; int force_enqueue; };
 
 extern "C" int vican_comm_unique_id(void* id_out) {
     Rccl* r = rccl();
@@ -73,15 +74,31 @@ extern "C" int vican_comm_create(int32_t rank, int32_t world, const void* unique
     ncclComm_t c = nullptr;
     const ncclResult_t e = r->CommInitRank(&c, world, id, rank);          // collective: every rank of the group calls it
     if (e != ncclSuccess) return rccl_err("vican_comm_create", e);
-    *comm_out = new vican_comm{c, rank, world};
+    *comm_out = new vican_comm{c, rank, world, 0};
     return VICAN_OK;
 }
 
 extern "C" int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream) {
     if (!comm || !buf || n < 0) return set_err(VICAN_ERR_ARG, "%s: bad argument", "vican_comm_allreduce_sum");
-    if (n == 0 || comm->world == 1) return VICAN_OK;                      // (one rank: the identity, nothing enqueued)
+    if (n == 0) return VICAN_OK;
+    if (comm->world == 1) {
+        // one rank: the sum is the identity and nothing is enqueued - unless vican_comm_force_enqueue asked for the collective
+        // to run anyway (tests, timing on a 1-GPU box).  RCCL itself elides an in-place ncclSum on a one-rank communicator
+        // (no kernel, no copy), so the forced call asks for ncclAvg = sum x 1/world = x 1.0: the same bits, and RCCL's own
+        // one-rank reduce kernel on the caller's stream.
+        if (!comm->force_enqueue) return VICAN_OK;
+        const ncclResult_t e = rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclAvg, comm->comm, (hipStream_t)stream);
+        return e == ncclSuccess ? VICAN_OK : rccl_err("vican_comm_allreduce_sum", e);
+    }
     const ncclResult_t e = rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, comm->comm, (hipStream_t)stream);
     return e == ncclSuccess ? VICAN_OK : rccl_err("vican_comm_allreduce_sum", e);
+}
+
+// test / timing switch (include/vican_hip_test.h): a one-rank communicator really calls ncclAllReduce
+extern "C" int vican_comm_force_enqueue(vican_comm_t* comm, int32_t on) {
+    if (!comm) return set_err(VICAN_ERR_ARG, "%s: NULL communicator", "vican_comm_force_enqueue");
+    comm->force_enqueue = on != 0;
+    return VICAN_OK;
 }
 
 extern "C" int vican_comm_destroy(vican_comm_t* comm) {

@@ -320,8 +320,15 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
         CK(vican_polar_dual(C, P->z, P->x0, nullptr, 0, stream));
         ++inf.sweeps;
     }
-    bool z_ready = false;
+    bool z_ready = false, have5 = false;
     for (int it = 0; it < maxiter; ++it) {
+        // bipgo.py:283: the reference leaves its loop once all five returned eigenvalues are <= 1e-6 in magnitude (>= 5 near-null
+        // vectors: graphs with several components) - same exit as solver.py RotationSolver.run takes on `small5`
+        if (have5) {
+            bool all_small = true;
+            for (int q = 0; q < 5; ++q) all_small = all_small && std::isfinite(inf.evals[q]) && std::fabs(inf.evals[q]) <= 1e-6;
+            if (all_small) break;
+        }
         const int relax = std::max(0, (maxiter - 2) - it);
         const double tol = std::min(std::max(eig_tol * std::pow(100.0, relax), eig_tol), 1e-4);
         const bool last = it == maxiter - 1;
@@ -359,6 +366,7 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
         }
         for (int q = 0; q < 3; ++q) inf.evals[q] = st[7 + q];
         inf.evals[3] = st[15]; inf.evals[4] = st[13];
+        have5 = true;
         inf.eig_resid = st[0];
         // X = V3 V3[0:3]^-1, per-camera projection, Y = P X, camera duals, timestep duals (bipgo.py:295-334)
         CK(vican_gauge_project(C, P->X, P->Xp, stream));
@@ -395,7 +403,8 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     vican_cg_state_t h{};
     int burst = 8;
     for (;;) {
-        for (int i = 0; i < burst && launched <= maxiter; ++i, ++launched) {
+        // (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x; no test behind the last one)
+        for (int i = 0; i < burst && launched < maxiter; ++i, ++launched) {
             CK(vican_cg_iter_local(&P->g, P->w, P->row_sum_w, P->r_c, P->p_c, P->r_t, P->p_t, P->q_t, P->zpart, P->pq_part, P->qcpq, rtol,
                                    P->rr_part, n_part, P->n_add_cg, P->st, stream));
             n_part = vican_cg_iter_finish(C, T, P->cam_sum_w, P->qcpq, P->p_c, x_c, P->r_c, P->p_t, P->q_t, x_t, P->r_t, P->rr_part, 1536, P->st, stream);
@@ -404,10 +413,10 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
         HIPCK(hipMemcpyAsync(P->status_host + 16, P->st, sizeof(vican_cg_state_t), hipMemcpyDeviceToHost, s), "vican_solve_trans");
         HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
         std::memcpy(&h, P->status_host + 16, sizeof(h));
-        if (h.done || launched > maxiter) break;
+        if (h.done || launched >= maxiter) break;
         burst = std::min(2 * burst, 64);
     }
-    inf.cg_iters = h.iter; inf.cg_converged = h.done == 1;
+    inf.cg_iters = h.done == 1 ? h.iter : (int32_t)std::min<long long>(launched, 2147483647LL); inf.cg_converged = h.done == 1;
     inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;
     if (info) *info = inf;
     if (h.done != 1) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans: CG did not converge in %lld iterations (scipy exit_code != 0, bipgo.py:478)", (long long)maxiter);

@@ -44,8 +44,8 @@ extern "C" int vican_cg_sweep_tiles(const vican_cg_tile_t* tiles, int32_t n_tile
         const vican_cg_tile_t& s = tiles[k < n_tile ? k : 0];
         if (k < n_tile) {
             if (int rc = vican_check_graph(&s.g, "vican_cg_sweep_tiles")) return rc;
-            if (s.g.layout != VICAN_LAYOUT_WAVE || !s.w || !s.p_c || !s.acc_t || !s.qc_part || s.g.n_chunk == 0)
-                return set_err(VICAN_ERR_ARG, "vican_cg_sweep_tiles: tiles must be non-empty wave layouts with all buffers set");
+            if (s.g.layout != VICAN_LAYOUT_WAVE || !s.g.idx16 || !s.w || !s.p_c || !s.acc_t || !s.qc_part || s.g.n_chunk == 0)
+                return set_err(VICAN_ERR_ARG, "vican_cg_sweep_tiles: tiles must be non-empty wave layouts (2-byte index packed: vican_pack_idx16) with all buffers set");
             const int nwk = s.g.wg_waves >= 12 ? 12 : (s.g.wg_waves >= 8 ? 8 : 4);
             if (nwk != nw || s.g.slots != g0.slots || s.g.stream_nt != g0.stream_nt || (int)plane_stride(s.g.n_cam) != cp ||
                 (3 * s.g.max_rows + 63) / 64 != trips)

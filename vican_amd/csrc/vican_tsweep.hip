@@ -354,16 +354,15 @@ extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t
 #define TS_LAUNCH4(S_, CP_, T_, NT_)                                                                                         \
     do {                                                                                                                     \
         auto kern = tiled_sweep_kernel<S_, CP_, T_, NT_>;                                                                    \
-        static size_t conf = 0, checked = 0;                                                                                 \
+        static size_t conf = 0;                                                                                              \
         if (lds > conf) {                                                                                                    \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
                 return set_err(VICAN_ERR_LAUNCH, "vican_tiled_op: cannot raise dynamic LDS limit");                          \
             conf = lds;                                                                                                      \
         }                                                                                                                    \
-        if (lds > checked) {                                                                                                 \
-            if (int rc = vican_coresident_ok((const void*)kern, TS_NW * 64, lds, grid, "vican_tiled_op")) return rc;         \
-            checked = lds;                                                                                                   \
-        }                                                                                                                    \
+        /* co-residency on EVERY launch, as the other cooperative launchers do: it depends on the grid and the device, not */ \
+        /* only on the LDS size (the workgroups spin on each other's shares: a grid that is not resident would hang)       */ \
+        if (int rc = vican_coresident_ok((const void*)kern, TS_NW * 64, lds, grid, "vican_tiled_op")) return rc;             \
         VICAN_LAUNCH_SWEEP(kern, dim3(grid), dim3(TS_NW * 64), lds, st, tiles_dev, (int)n_tile, lamT_inv, (int)parity,        \
                            g_vican_abort_word, g_vican_sync_ticks);                                                          \
     } while (0)

@@ -1200,9 +1200,10 @@ class TiledBackend(HipBackend):
         f.nwgt, f.parity = nwgt, 0
         # adds into one camera accumulator by one workgroup of the fused launch = rows it handles (<= its chunks x rows per chunk):
         # the tiles' fixed-point scales are finished for at least that many
+        # (tiled_sweep_kernel hands chunks out per WAVEFRONT with stride nwgt * 8: a workgroup takes up to 8 * ceil(n / (8 nwgt)))
         n_chunk = self.g.tiles[0].n_chunk
         for t in self.g.tiles:
-            t.rows_per_wg_sweep = max(t.rows_per_wg_sweep, min(self.T, -(-n_chunk // nwgt) * t.max_rows))
+            t.rows_per_wg_sweep = max(t.rows_per_wg_sweep, min(self.T, 8 * -(-n_chunk // (8 * nwgt)) * t.max_rows))
         f.x = torch.zeros(3 * self.C, 3, dtype=torch.float64, device=self.dev)           # the operand, at a fixed address
         f.yp = torch.empty(2, nt, T1, 9, dtype=torch.float64, device=self.dev)           # share buffers of alternate launches
         self._ck(self.lib.vican_tiled_op_sentinel(_ptr(f.yp), f.yp.numel(), _stream()), "vican_tiled_op_sentinel")

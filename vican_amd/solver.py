@@ -38,7 +38,7 @@ from ._lib import CG_F, CG_I, CG_STATE_DOUBLES, LSQR_F, LSQR_I, LSQR_STATE_DOUBL
 class Comm:
     """Sum-all-reduce over ranks; identity for a single rank."""
 
-    def __init__(self, group=None, native=None):
+    def __init__(self, group=None, native=None, force_sharded=False):
         self.group = group
         self.world = 1
         self.rank = 0
@@ -46,14 +46,23 @@ class Comm:
             self.world = torch.distributed.get_world_size(group)
             self.rank = torch.distributed.get_rank(group)
         self.n_allreduce = 0
+        # force_sharded: take the sharded code paths (launch sequences, host-issued all-reduces, two-message CG) although this
+        # rank holds every row - how the multi-GPU schedule is exercised, timed and compared bit for bit on ONE GPU
+        self.force_sharded = bool(force_sharded)
         # native=True / VICAN_NATIVE_COMM=1: the all-reduces go through an RCCL communicator held by the C library
         # (include/vican_hip.h: vican_comm_*; enqueued from C on the launch stream) instead of torch.distributed.  Off by
-        # default: torch's "nccl" backend IS RCCL and is the path every test exercises; the native one has run on one GPU only.
+        # default: torch's "nccl" backend IS RCCL and is the path every multi-rank test exercises; the native one has run on
+        # one GPU only (one-rank communicator: tests/test_comm_gpu.py, profiles/r05_rccl_onerank.txt).
         self._native = None
         if native is None:
             native = os.environ.get("VICAN_NATIVE_COMM") == "1"
         if native and self.world > 1 and self._device_collectives():
             self._native = self._create_native()
+
+    @property
+    def sharded(self):
+        """True where the solver must take the sharded schedule (more than one rank, or forced on one)."""
+        return self.world > 1 or getattr(self, "force_sharded", False)
 
     def _create_native(self):
         import ctypes
@@ -80,20 +89,34 @@ class Comm:
             pass
 
     @classmethod
-    def single(cls):
-        """A one-rank communicator even inside an initialised process group (replicated computations)."""
+    def single(cls, force_sharded=False, native=False):
+        """A one-rank communicator even inside an initialised process group (replicated computations).
+        force_sharded: the solver takes its multi-rank schedule on it; native: the all-reduces of that schedule are REAL
+        ncclAllReduce calls on a one-rank RCCL communicator held by the C library (RCCL's one-rank kernel on the launch
+        stream: what one GPU can execute of the collective path; include/vican_hip_test.h: vican_comm_force_enqueue)."""
         c = cls.__new__(cls)
         c.group, c.world, c.rank, c.n_allreduce, c._native = None, 1, 0, 0, None
+        c.force_sharded = bool(force_sharded)
+        if native:
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.vican_comm_unique_id(buf), "vican_comm_unique_id")
+            h = ctypes.c_void_p()
+            _lib.check(lib.vican_comm_create(0, 1, buf, ctypes.byref(h)), "vican_comm_create")
+            _lib.check(lib.vican_comm_force_enqueue(h, 1), "vican_comm_force_enqueue")
+            c._native_lib, c._native = lib, h
         return c
 
     def allreduce(self, t):
-        if self.world > 1:
+        if self.sharded:
             if self._native is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous():
                 import ctypes
                 from . import _lib
                 _lib.check(self._native_lib.vican_comm_allreduce_sum(self._native, ctypes.c_void_p(t.data_ptr()), t.numel(),
                                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vican_comm_allreduce_sum")
-            else:
+            elif self.world > 1:
                 torch.distributed.all_reduce(t, group=self.group)
             self.n_allreduce += 1
         return t
@@ -211,7 +234,7 @@ class RotationSolver:
         """z = P x for the next lanczos_cam_step.  Single rank: the sweep's slabs are folded inside that step's kernel
         (returns True: z itself is not written); sharded: fold, then all-reduce the camera-side partials."""
         self.stats["sweeps"] += 1
-        if self.comm.world == 1 and self.fold_in_step and hasattr(self.K, "block_op_slabs"):
+        if not self.comm.sharded and self.fold_in_step and hasattr(self.K, "block_op_slabs"):
             self.K.block_op_slabs(self.lamT, x)
             return True
         self.K.block_op(self.lamT, x, z)
@@ -276,7 +299,7 @@ class RotationSolver:
                 # capture-sized graphs, single rank: all steps up to the next check as ONE cooperative launch (sweep and
                 # camera-side step per Lanczos step, vican_lres.hip) - bit-identical to the launch pairs below
                 j_res = 0
-                if (self.comm.world == 1 and self.small_graph and self.N == getattr(K, "C", -1) and hasattr(K, "lanczos_resident_steps")
+                if (not self.comm.sharded and self.small_graph and self.N == getattr(K, "C", -1) and hasattr(K, "lanczos_resident_steps")
                         and not (j == 0 and have_z)):
                     j_res = K.lanczos_resident_steps(min(max(next_check, j + 1), self.m_max))
                 if j_res > j:
@@ -301,7 +324,7 @@ class RotationSolver:
                     # Sharded runs speculate only where a check is expected to pass (a step count remembered from an
                     # earlier solve of this graph): the tail's all-reduces are issued by the host and cannot be gated, so
                     # every failed check would pay for two collectives on cancelled data.
-                    speculate = self.comm.world == 1 or (restart == 0 and it in self.pred_steps and steps >= self.pred_steps[it])
+                    speculate = not self.comm.sharded or (restart == 0 and it in self.pred_steps and steps >= self.pred_steps[it])
                     if speculate:
                         with K.gated(self.gate):               # speculative: runs iff the device says converged
                             K.tall_combine(n, self.V, ld, 3 * steps, self.Yd, self.X)
@@ -530,7 +553,10 @@ class TranslationSolver:
         n_edges = getattr(getattr(K, "g", None), "n_edges", None)
         self.small_graph = n_edges is not None and n_edges < 2_000_000
         self._graphs, self._n_solves, self._last_iters = {}, 0, None
-        self.one_message = os.environ.get("VICAN_CG_MESSAGES", "1") != "2"
+        # Sharded runs keep scipy's own recurrence (bipgo.py:477) - two all-reduces per iteration, [q_c | p.q] and r.r - as
+        # SURVEY.md 8(e) prescribes for parity mode.  VICAN_CG_MESSAGES=1 opts into the Chronopoulos-Gear arrangement (ONE
+        # message per iteration, other roundings: measurably further from scipy's iterates, profiles/r04_random_parity_3000_summary.json)
+        self.one_message = os.environ.get("VICAN_CG_MESSAGES", "2") == "1"
         self._cg1 = None
 
     def _state(self):
@@ -548,7 +574,7 @@ class TranslationSolver:
         """stop_at: run exactly this many iterations, whatever the residual (the state reports done = 0) - what an
         iteration-matched comparison with scipy's iterates needs (tests/test_cg_iterates.py)."""
         K, comm, st = self.K, self.comm, self.st
-        multi = comm.world > 1
+        multi = comm.sharded
         maxiter = 10 * n_unknowns_total if maxiter is None else maxiter       # scipy default
         rtol = self.rtol
         if stop_at is not None:
@@ -594,11 +620,12 @@ class TranslationSolver:
         self._n_solves += 1
         first_burst = True
         while True:
-            burst = min(self.poll_every, maxiter + 1 - it_launched)
+            # (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x, no test behind the last one)
+            burst = min(self.poll_every, maxiter - it_launched)
             if first_burst and self._last_iters is not None:
                 # the same system was solved before (time series, benchmark loop): launch exactly as many iterations
                 # as it took then, plus the one that detects convergence, before the first poll
-                burst = min(max(self._last_iters + 1, 1), 64, maxiter + 1 - it_launched)
+                burst = min(max(self._last_iters + 1, 1), 64, maxiter - it_launched)
             first_burst = False
             left = burst
             if it_launched == 0:                                  # the first iteration passes other arguments
@@ -622,11 +649,11 @@ class TranslationSolver:
                     n_part = one_iteration(n_part)
                     it_launched += 1
             s = self._state()
-            if s["done"] or it_launched > maxiter:
+            if s["done"] or it_launched >= maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
         self._last_iters = int(s["iter"]) if s["done"] == 1 else None
-        self.info = dict(cg_iters=s["iter"], converged=s["done"] == 1,
+        self.info = dict(cg_iters=s["iter"] if s["done"] else it_launched, converged=s["done"] == 1,
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
         return self.x_c, self.x_t
 
@@ -635,7 +662,7 @@ class TranslationSolver:
         """Exactly n_iter iterations of the recurrence this solver would run (resident kernel, launch sequence or the
         sharded runs' one-message arrangement), stopping test disabled (rtol = 0)."""
         K, comm, st = self.K, self.comm, self.st
-        multi = comm.world > 1
+        multi = comm.sharded
         if not multi and self.small_graph and getattr(K, "cg_resident_ok", False):
             K.cg_resident(self.deg_t, self.deg_c, self.b_c, self.b_t, self.x_c, self.x_t, 0.0, n_iter, st)
             s = self._state()
@@ -651,7 +678,7 @@ class TranslationSolver:
             try:
                 # (bursts of the polling loop overshoot: bound them to what is asked for)
                 self.poll_every, keep = n_iter, self.poll_every
-                out = self._solve_one_message(n_iter - 1)
+                out = self._solve_one_message(n_iter)
                 self.poll_every = keep
             finally:
                 self.rtol, self._last_iters = rtol, last
@@ -679,7 +706,7 @@ class TranslationSolver:
         arrangement of the same CG (include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish; scipy's recurrence
         needs two reductions per iteration because its beta depends on the r.r of the update that precedes the product).
         Same iterates in exact arithmetic, scipy's stopping test on the directly formed r.r; other roundings.
-        VICAN_CG_MESSAGES=2 keeps scipy's recurrence (two messages per iteration) on sharded runs."""
+        Opt-in (VICAN_CG_MESSAGES=1): sharded runs default to scipy's recurrence, two messages per iteration."""
         K, comm, st = self.K, self.comm, self.st
         if self._cg1 is None:
             C, T = K.C, max(K.T, 1)
@@ -689,7 +716,7 @@ class TranslationSolver:
         n_part, k, s, poll = 0, 0, None, self.poll_every
         burst = poll if self._last_iters is None else min(max(self._last_iters + 1, 1), 64)
         while True:
-            for _ in range(min(burst, maxiter + 1 - k)):
+            for _ in range(min(burst, maxiter - k)):
                 K.cg1_iter_local(self.deg_t, r_c, self.r_t, s_t, msg, st, n_part)
                 comm.allreduce(msg)
                 n_part = K.cg1_iter_finish(k, self.deg_c, msg, r_c, r_c_new, self.p_c, q_c, self.x_c, self.r_t, s_t, self.p_t, self.q_t,
@@ -697,7 +724,7 @@ class TranslationSolver:
                 r_c, r_c_new = r_c_new, r_c
                 k += 1
             s = self._state()
-            if s["done"] or k > maxiter:
+            if s["done"] or k >= maxiter:
                 break
             poll = min(poll * 2, 64)
             burst = poll
@@ -935,7 +962,7 @@ class LsqrTranslationSolver:
 
     def solve(self, rc, rt, n_unknowns_total, bnorm2_true=None, iter_lim=None):
         K, comm = self.K, self.comm
-        multi = comm.world > 1
+        multi = comm.sharded
         eps = np.finfo(np.float64).eps
         for t in (self.v_c, self.w_c, self.x_c, self.v_t, self.w_t, self.x_t):
             t.zero_()
