@@ -161,19 +161,24 @@ def test_one_message_cg_at_large_shop_scale(dt):
 @pytest.mark.parametrize("name,dt", CASES)
 def test_sharded_default_is_scipys_recurrence_on_gpu(name, dt):
     """Sharded default on the device (launch sequence vican_cg_iter_local / _finish / vican_cg_end, two messages): inside
-    the same bounds as the single-rank solve, and the SAME iterate as the launch-sequence single-rank path (the resident
-    kernel of capture-sized graphs is bit-identical to that sequence: tests/test_coop_barriers_gpu.py)."""
+    the same bounds as the single-rank solve, and bit for bit the iterate of the launch-sequence single-rank path (the
+    resident kernel that capture-sized graphs take on one rank pre-sums a lane's same-row terms differently: the same
+    recurrence, other roundings - its stopping iteration may differ by one on weighted scenes, g3 f64: 34 / 35, golden 35)."""
     g, case, prob = flatten_case(name, dt)
     exp = expected(g, "conjugate_gradient", dt)
     K = hip_backend(prob, dt)
     comm = LoneShardComm()
     dist, info = run_stage(K, prob, exp, comm)
     dist1, info1 = run_stage(K, prob, exp)
-    print("%s %s: sharded default (two messages) %.3e m, single rank %.3e m, cg %d / %d vs %d, %d all-reduces" % (
-        name, dt, dist, dist1, info["cg_iters"], info1["cg_iters"], int(exp["cg_iters"]), comm.n_allreduce))
-    assert not info.get("one_message")
+    K._cgres_ok = False                                         # single rank on the launch sequence
+    dist2, info2 = run_stage(K, prob, exp)
+    print("%s %s: sharded default (two messages) %.3e m, single rank %.3e m resident / %.3e m launch sequence, cg %d / %d / %d vs %d, "
+          "%d all-reduces" % (name, dt, dist, dist1, dist2, info["cg_iters"], info1["cg_iters"], info2["cg_iters"], int(exp["cg_iters"]),
+                              comm.n_allreduce))
+    assert not info.get("one_message") and info1.get("resident") and not info2.get("resident")
     assert dist < stage_tol(name, dt), dist
-    assert info["cg_iters"] == info1["cg_iters"] and abs(dist - dist1) <= 1e-12
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    assert info["cg_iters"] == info2["cg_iters"] and dist == dist2
     assert 2 * info["cg_iters"] <= comm.n_allreduce <= 2 + 2 * (info["cg_iters"] + 1 + 64)
 
 

@@ -30,6 +30,7 @@ from vican_amd.geometry import SE3, geodesic                # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "random_parity")
+SEED0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0       # first seed (a second, disjoint sample of scenes: 3000)
 os.makedirs(out, exist_ok=True)
 rows, t_start = [], time.time()
 # rotation tolerances: 1e-7 rad (float64), 1e-5 rad (float32: two eigen-solvers on float32 blocks; the oracle itself moves by
@@ -48,7 +49,7 @@ def stage_alone(src, cons, mode, fns, dt, ref):
     from vican_amd.solver import Comm, TranslationSolver
     nr, nt, ff = fns
     if mode == "object":          # (the object wrapper returns markers only; object scenes are f64, where end to end IS stage-accurate)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
     prob = frontend.flatten(src, cons, nr, nt, ff, dt)
     dev = torch.device("cuda", torch.cuda.current_device())
     tdt = torch.float32 if dt == np.float32 else torch.float64
@@ -60,8 +61,10 @@ def stage_alone(src, cons, mode, fns, dt, ref):
     rt = np.stack([Rw[str(s) + "_0"].T for s in prob.time_names]).reshape(-1, 9)
     tr_ = np.stack([np.asarray(ref[k].t(), dtype=np.float64) for k in ref])
 
-    def run(B, comm=None):
+    def run(B, comm=None, one_message=None):
         tr = TranslationSolver(B, comm or Comm.single())
+        if one_message is not None:
+            tr.one_message = one_message
         tr.setup(B.from_numpy(rc), B.from_numpy(rt))
         x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
         pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
@@ -72,13 +75,13 @@ def stage_alone(src, cons, mode, fns, dt, ref):
     # independent f64 implementation of the same recurrence: what IT does against the bound calibrates the bound
     from numpy_backend import NumpyBackend
     N = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=dt, deg_t=prob.deg_t, deg_c=prob.deg_c)
-    # ... and through the sharded runs' arrangement of the CG (ONE message per iteration, Chronopoulos-Gear: vican_cg1_*), one
-    # rank holding every row
+    # ... and through the sharded runs' schedule, one rank holding every row: their default (scipy's recurrence, two messages per
+    # iteration: vican_cg_iter_local / _finish / vican_cg_end) and the opt-in Chronopoulos-Gear arrangement (ONE message: vican_cg1_*)
     from test_translation_stage import LoneShardComm
-    return run(K) + run(N) + run(K, LoneShardComm())
+    return run(K) + run(N) + run(K, LoneShardComm(), True) + run(K, LoneShardComm(), False)
 
 
-for seed in range(N):
+for seed in range(SEED0, SEED0 + N):
     mode, scene, flat, (wr, wt), filt, dt = make_case(seed)
     src = synth.edges_to_dict(flat, SE3)
     nr, nt, ff = gc.CALLABLES[wr], gc.CALLABLES[wt], gc.CALLABLES[filt]
@@ -137,8 +140,8 @@ for seed in range(N):
                 # oracle's own movement under perturbations of THAT size (stage_trans_m, fed the oracle's rotations, keeps 1e-15)
                 move_rot = sm.more_trials(max(rot, 1e-15))
                 bound_e2e = max(bound, 4.0 * float(move_rot.max()))
-                stage_err, stage_cg, np_err, np_cg, om_err, om_cg = stage_alone(src, cons, mode, (nr, nt, ff), dt, ref)
-                row.update(stage_one_message_m=om_err, cg_one_message=om_cg)
+                stage_err, stage_cg, np_err, np_cg, om_err, om_cg, sd_err, sd_cg = stage_alone(src, cons, mode, (nr, nt, ff), dt, ref)
+                row.update(stage_one_message_m=om_err, cg_one_message=om_cg, stage_sharded_default_m=sd_err, cg_sharded_default=sd_cg)
                 row.update(rot_rad=rot, trans_m=err, stage_trans_m=stage_err, stage_numpy_m=np_err, self_move_max=float(sm.self_move.max()),
                            self_move_median=float(np.median(sm.self_move)), self_move_at_rot_max=float(move_rot.max()), bound_m=bound,
                            bound_e2e_m=bound_e2e, cg_stage=stage_cg,
@@ -155,7 +158,7 @@ for seed in range(N):
     if seed % 50 == 49:
         print("seed %d  %.0f s" % (seed, time.time() - t_start), flush=True)
 keys = ["seed", "mode", "dtype", "weights", "filter", "cameras", "timesteps", "source_edges", "rot_rad", "trans_m", "stage_trans_m", "stage_numpy_m",
-        "stage_one_message_m", "cg_one_message", "self_move_max", "self_move_median", "self_move_at_rot_max", "bound_m", "bound_e2e_m", "cg", "cg_stage", "cg_numpy", "cg_oracle", "cg_oracle_min", "cg_oracle_max",
+        "stage_one_message_m", "cg_one_message", "stage_sharded_default_m", "cg_sharded_default", "self_move_max", "self_move_median", "self_move_at_rot_max", "bound_m", "bound_e2e_m", "cg", "cg_stage", "cg_numpy", "cg_oracle", "cg_oracle_min", "cg_oracle_max",
         "cg_oracle_trials", "self_move_trials", "oracle_retry", "outcome"]
 with open(os.path.join(out, "random_parity.csv"), "w", newline="") as f:
     wr_ = csv.DictWriter(f, fieldnames=keys)
@@ -172,7 +175,7 @@ summary = {
                "relative, the amount by which the two rotation stages differ; stage_numpy_m / cg_numpy = the same stage through the plain-f64 "
                "NumPy stand-in (calibrates the bound); stage_one_message_m / cg_one_message = the same stage through the sharded runs' "
                "one-message arrangement of the CG (vican_cg1_iter_local / _finish, Chronopoulos-Gear) on one rank",
-    "seeds": N, "compared": len(cmp_rows),
+    "seeds": N, "first_seed": SEED0, "compared": len(cmp_rows),
     "oracle_runs_repeated": {str(r["seed"]): r["oracle_retry"] for r in rows if r.get("oracle_retry")},
     "outcomes": {o: sum(1 for r in rows if r["outcome"] == o) for o in sorted(set(r["outcome"] for r in rows))},
     "max_rot_rad_f64": max((r["rot_rad"] for r in cmp_rows if r["dtype"] == "float64"), default=None),
@@ -190,6 +193,8 @@ summary = {
     # 1e-15-perturbed run of the ORACLE ITSELF stops at another iteration than its unperturbed run
     "stage_over_bound": sum(1 for r in cmp_rows if r.get("stage_trans_m") is not None and r["stage_trans_m"] >= r["bound_m"]),
     "numpy_stand_in_over_bound": sum(1 for r in cmp_rows if r.get("stage_numpy_m") is not None and r["stage_numpy_m"] >= r["bound_m"]),
+    "sharded_default_over_bound": sum(1 for r in cmp_rows if r.get("stage_sharded_default_m") is not None and r["stage_sharded_default_m"] >= r["bound_m"]),
+    "sharded_default_iteration_differs_from_oracle": sum(1 for r in cmp_rows if r.get("cg_sharded_default") is not None and r["cg_sharded_default"] != r["cg_oracle"]),
     "one_message_over_bound": sum(1 for r in cmp_rows if r.get("stage_one_message_m") is not None and r["stage_one_message_m"] >= r["bound_m"]),
     "one_message_iteration_differs_from_oracle": sum(1 for r in cmp_rows if r.get("cg_one_message") is not None and r["cg_one_message"] != r["cg_oracle"]),
     "one_message_cg_iteration_difference_le_2_fraction": (lambda v: sum(1 for a, b in v if abs(a - b) <= 2) / max(len(v), 1))(

@@ -9,7 +9,7 @@ product's exact sums, rounded once, cannot.  This tool runs the SAME stand-in ov
 translation-stage sums formed (a) in scipy's order, (b) in reverse order, (c) exactly (extended precision, rounded once), and
 counts each against the same bound: if (b) and (c) land where the product does, the gap is the shared order, not precision.
 
-    python tools/standin_orders.py [N=3000] [out=profiles/r04_standin_orders.json] [procs=6]"""
+    python tools/standin_orders.py [N=3000] [out=profiles/r04_standin_orders.json] [procs=6] [first_seed=0]"""
 import json
 import multiprocessing as mp
 import os
@@ -80,10 +80,11 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_standin_orders.json")
     procs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     t0 = time.time()
     with mp.Pool(procs) as pool:
-        rows = [r for r in pool.imap_unordered(one, range(N), chunksize=8) if r is not None]
-    summary = dict(seeds=N, compared=len(rows), seconds=time.time() - t0,
+        rows = [r for r in pool.imap_unordered(one, range(seed0, seed0 + N), chunksize=8) if r is not None]
+    summary = dict(seeds=N, first_seed=seed0, compared=len(rows), seconds=time.time() - t0,
                    note="translation stage of the NumPy stand-in (tests/numpy_backend.py), the oracle's rotations fed in, against "
                         "bound = max(1e-6 m, 4 x the oracle's self-movement under 1e-15 perturbations); sums of the stage formed in "
                         "scipy's order / reversed / exactly (extended precision, rounded once)")
