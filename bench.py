@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=4)
     ap.add_argument("--no-large-shop", action="store_true", help="skip the large_shop wall-clock measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-capture measurement (detail.sparse) of the default run")
+    ap.add_argument("--no-facade", action="store_true", help="skip the four-call C boundary timing (detail.facade) of the default run")
     ap.add_argument("--no-wide", action="store_true", help="skip the camera-tiled measurement (detail.wide: 4000 cameras) of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
@@ -211,6 +212,55 @@ def large_shop_wall_clock(args, dev, tdt, comm):
         except Exception as exc:
             res["cpu_baseline"] = {"value": None, "error": repr(exc)}
     return res
+
+
+def facade_timing(args, dev, tdt, shapes):
+    """The four-call C boundary (include/vican_hip.h: vican_plan_create / vican_solve_rot / vican_solve_trans /
+    vican_plan_destroy; csrc/vican_facade.hip) driven through ctypes alone on the benchmark's graphs: ms per full solve
+    (rotation loop + translation CG, the plan kept) - what a maintainer who binds only those four calls gets, next to the
+    Python driver's number for the same graph."""
+    import ctypes as C
+    from vican_amd import _lib, synth
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for name, (Cn, Tn, cpt, n_solves) in shapes.items():
+        gr = synth.make_merged_graph_torch(Cn, Tn, cpt, dev, tdt, seed=0)
+        E = int(gr["col"].numel())
+        plan = C.c_void_p()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = lib.vican_plan_create(Cn, Tn, E, _lib.STORE_F32 if tdt == torch.float32 else _lib.STORE_F64, p(gr["row_ptr"]), p(gr["col"]),
+                                   p(gr["blk"]), p(gr["a"]), p(gr["w"]), p(gr["u"]), p(gr["v"]), None, None, stream, C.byref(plan))
+        torch.cuda.synchronize()
+        t_plan = time.perf_counter() - t0
+        if rc != 0:
+            out[name] = {"error": (lib.vican_last_error() or b"?").decode()}
+            continue
+        del gr
+        torch.cuda.empty_cache()
+        try:
+            rcs, Rt = torch.empty(3 * Cn, 3, dtype=torch.float64, device=dev), torch.empty(Tn, 9, dtype=torch.float64, device=dev)
+            x_c, x_t = torch.empty(Cn, 3, dtype=torch.float64, device=dev), torch.empty(Tn, 3, dtype=torch.float64, device=dev)
+            info = _lib.SolveInfo()
+
+            def solve():
+                _lib.check(lib.vican_solve_rot(plan, args.maxiter, 1e-10, p(rcs), p(Rt), C.byref(info), stream), "vican_solve_rot")
+                _lib.check(lib.vican_solve_trans(plan, p(rcs), p(Rt), 1e-5, 0, p(x_c), p(x_t), C.byref(info), stream), "vican_solve_trans")
+            solve()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_solves):
+                solve()
+            torch.cuda.synchronize()
+            out[name] = {"ms_per_solve": (time.perf_counter() - t0) / n_solves * 1e3, "plan_create_ms": t_plan * 1e3, "solves_timed": n_solves,
+                         "sweeps": int(info.sweeps), "lanczos_steps": int(info.lanczos_steps), "cg_iters": int(info.cg_iters),
+                         "cg_converged": bool(info.cg_converged), "merged_edges": E}
+        finally:
+            lib.vican_plan_destroy(plan)
+            torch.cuda.empty_cache()
+    return out
 
 
 def wide_operator(args, dev, tdt, comm):
@@ -659,6 +709,20 @@ def main():
             out["detail"]["wide"] = wide_operator(args, dev, tdt, comm)
         except Exception as exc:
             out["detail"]["wide"] = {"error": repr(exc)[:300]}
+    if rank == 0 and world == 1 and args.workload == "stress" and not args.no_facade:
+        # the four-call C boundary on the same graphs, next to the Python driver's numbers
+        try:
+            f = facade_timing(args, dev, tdt, {"stress": (C, Tn, cpt, 5), "large_shop": (340, 10000, 4, 10)})
+            if "ms_per_solve" in f.get("stress", {}):
+                f["stress"]["python_driver_ms_per_solve"] = m["ms_per_step"]
+                f["stress"]["ratio_to_python_driver"] = f["stress"]["ms_per_solve"] / m["ms_per_step"]
+            ls = out["detail"].get("large_shop_wall_clock", {})
+            if "ms_per_solve" in f.get("large_shop", {}) and "ms_per_solve" in ls:
+                f["large_shop"]["python_driver_ms_per_solve"] = ls["ms_per_solve"]
+                f["large_shop"]["ratio_to_python_driver"] = f["large_shop"]["ms_per_solve"] / ls["ms_per_solve"]
+            out["detail"]["facade"] = f
+        except Exception as exc:
+            out["detail"]["facade"] = {"error": repr(exc)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Ts = args.cpu_sample_timesteps or {"stress": 300, "sparse": 20000}.get(args.workload, 10000)
         try:

@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 19            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 20            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -570,6 +570,16 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
                          const double* p_c, double* x_c, double* r_c, const double* p_t,
                          const double* q_t, double* x_t, double* r_t, double* rr_part,
                          int32_t part_cap, vican_cg_state_t* st, void* stream);
+/* Single rank: one iteration in three launches - [vican_cg_begin when first != 0] + vican_cg_sweep + a fold whose LAST
+ * workgroup forms alpha once + a step whose last workgroup runs the next iteration's vican_cg_begin (csrc/vican_trans.hip:
+ * hand-overs by agent-scope ticket, no workgroup waits for another).  State and vectors after k calls = after k x
+ * (vican_cg_iter_local, vican_cg_iter_finish) plus the next call's vican_cg_begin, bit for bit; poll st->done as there.
+ * ticket: 256 zeroed bytes owned by the solve, 128-byte aligned (two uint32 tickets on the first cache line, two doubles of hand-over on the second);
+ * rr_part >= 1536 doubles.  scipy cg, bipgo.py:477.                                                                    */
+int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
+                        double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
+                        void* qc_part, double* pq_part, double* qcpq, double rtol, double* rr_part, int32_t part_cap,
+                        double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ticket, void* stream);
 
 /* ONE message per CG iteration for timestep-sharded solves (replaces the two reductions per iteration of the pair above;
  * scipy.sparse.linalg.cg at bipgo.py:476-478 on a sharded graph): the Chronopoulos-Gear arrangement - the product is formed

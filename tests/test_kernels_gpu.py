@@ -208,6 +208,98 @@ def test_translation_kernels_and_cg(cfg):
     assert np.abs(xc_h.sum(0) + xt_h.sum(0)).max() < 1e-8 * scale * (C + T)
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[8], CONFIGS[10], CONFIGS[11], CONFIGS[12], (1000, 3000, 250, 250, "wave12", None, False)])
+@pytest.mark.parametrize("rtol", [1e-5, 1e-9])
+def test_fused_cg_iteration(cfg, rtol, monkeypatch):
+    """vican_cg_iter_fused (sweep, a fold whose LAST workgroup forms alpha, a step whose last workgroup runs the next iteration's
+    head: three launches, hand-overs by agent-scope ticket, p_t.q_t over fixed slices) against the four-launch sequence
+    vican_cg_iter_local / vican_cg_iter_finish.
+      * the hand-overs are exercised under UNEVEN load (a filler kernel occupies part of the chip on another stream while the
+        iterations run) and the iterates must be bit-identical from run to run - a stale or early read of a hand-over word
+        would show as a different iterate;
+      * against the sequence: the same recurrence, the timestep part of p.q grouped differently (and, in the sequence, in the
+        order the sweep's tickets happened to fall): same iterates to rounding, same iteration count on these well-conditioned
+        systems, and after every iteration the state of the fused path equals the sequence's state after ITS next head;
+      * the tickets are left at zero; iteration budget as scipy's range(maxiter)."""
+    from test_coop_barriers_gpu import occupy
+    from vican_amd.solver import Comm, TranslationSolver
+    C, T, lo, hi, bt, nwg, er = cfg
+    if isinstance(bt, str) and hi > 128 and bt.startswith("wave"):
+        dtp = np.float32                                         # (rows of 250 edges fit a wave chunk only with float32 blocks)
+    else:
+        dtp = np.float64
+    H, N, g = make_backends(C, T, lo, hi, 300 + C, dtp, bt, nwg, False)
+    H._cgres_ok = False                                          # (capture-sized graphs: the launch paths, not the resident kernel)
+    rng = np.random.default_rng(3)
+    rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
+    rt = synth.random_rotations(rng, T).reshape(T, 9)
+    names = ("x_c", "x_t", "r_c", "r_t", "p_c", "p_t", "q_t")
+    side = torch.cuda.Stream()
+
+    def run_fused(n_iter, load):
+        ts = TranslationSolver(H, Comm.single(), rtol=rtol)
+        ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+        H.cg_init(ts.b_c, ts.b_t, ts.x_c, ts.x_t, ts.r_c, ts.r_t, ts.p_c, ts.p_t, ts.st)
+        torch.cuda.synchronize()
+        states = []
+        for k in range(n_iter):
+            if load and k % 2 == 0:
+                occupy(H.lib, 64 + 37 * (k % 5), 40 + 30 * (k % 3), side)      # part of the chip busy for 40-100 us
+            H.cg_iter_fused(ts.deg_t, ts.deg_c, ts.r_c, ts.p_c, ts.x_c, ts.r_t, ts.p_t, ts.q_t, ts.x_t, ts.qcpq, rtol, ts.st, first=(k == 0))
+            if k in (0, 3, n_iter - 1):
+                torch.cuda.synchronize()
+                states.append(([getattr(ts, nm).clone() for nm in names], ts._state()))
+        torch.cuda.synchronize()
+        assert int(H._cg_ticket[:2].abs().sum().item()) == 0
+        return states
+    ref = run_fused(10, False)
+    for rep in range(4):
+        got = run_fused(10, rep > 0)
+        for (va, sa), (vb, sb) in zip(ref, got):
+            for nm, a, b in zip(names, va, vb):
+                assert torch.equal(a, b), (rep, nm)
+            assert all(sa[k] == sb[k] or (sa[k] != sa[k] and sb[k] != sb[k]) for k in sa), (rep, sa, sb)
+    # against the launch sequence, iteration by iteration (its head of the NEXT iteration applied: the fused step has run it)
+    tf, tq = TranslationSolver(H, Comm.single(), rtol=rtol), TranslationSolver(H, Comm.single(), rtol=rtol)
+    for ts in (tf, tq):
+        ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+        H.cg_init(ts.b_c, ts.b_t, ts.x_c, ts.x_t, ts.r_c, ts.r_t, ts.p_c, ts.p_t, ts.st)
+    H.cg_begin(tq.r_c, tq.p_c, rtol, tq.st, 0)
+    for k in range(6):
+        H.cg_iter_fused(tf.deg_t, tf.deg_c, tf.r_c, tf.p_c, tf.x_c, tf.r_t, tf.p_t, tf.q_t, tf.x_t, tf.qcpq, rtol, tf.st, first=(k == 0))
+        H.cg_sweep(tq.deg_t, tq.p_c, tq.r_t, tq.p_t, tq.q_t, tq.qcpq, tq.st)
+        n_part = H.cg_iter_finish(tq.deg_c, tq.qcpq, tq.p_c, tq.x_c, tq.r_c, tq.p_t, tq.q_t, tq.x_t, tq.r_t, tq.st)
+        H.cg_begin(tq.r_c, tq.p_c, rtol, tq.st, n_part)
+        torch.cuda.synchronize()
+        sf, sq = tf._state(), tq._state()
+        for nm in names:
+            a, b = getattr(tf, nm), getattr(tq, nm)
+            assert float((a - b).abs().max()) <= 1e-11 * max(float(b.abs().max()), 1e-300), (k, nm)
+        assert sf["iter"] == sq["iter"] == k + 1 and sf["done"] == sq["done"] and sf["lo_bits"] == sq["lo_bits"]
+        for key in ("rho", "alpha", "beta", "pq", "rr_cam", "rr_time", "pmax", "qscale"):
+            assert abs(sf[key] - sq[key]) <= 1e-11 * abs(sq[key]), (k, key, sf[key], sq[key])
+        if sf["done"]:
+            break
+    # whole solves: the polled driver on either path
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("VICAN_CG_FUSED", fused)
+        ts = TranslationSolver(H, Comm.single(), rtol=rtol, poll_every=4)
+        ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+        x_c, x_t = ts.solve(3 * (C + T))
+        outs.append((x_c.clone(), x_t.clone(), dict(ts.info)))
+    assert outs[0][2]["converged"] and abs(outs[0][2]["cg_iters"] - outs[1][2]["cg_iters"]) <= max(1, outs[1][2]["cg_iters"] // 20)
+    if outs[0][2]["cg_iters"] == outs[1][2]["cg_iters"]:
+        scale = max(float(outs[1][1].abs().max()), 1.0)
+        assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e3 * rtol * scale and float((outs[0][1] - outs[1][1]).abs().max()) < 1e3 * rtol * scale
+    # iteration budget (scipy: range(maxiter), no test behind the last update)
+    monkeypatch.setenv("VICAN_CG_FUSED", "1")
+    ts = TranslationSolver(H, Comm.single(), rtol=1e-14)
+    ts.setup(H.from_numpy(rc), H.from_numpy(rt))
+    ts.solve(3 * (C + T), maxiter=3)
+    assert ts.info["cg_iters"] == 3 and not ts.info["converged"]
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[7], CONFIGS[8], CONFIGS[9], CONFIGS[10], CONFIGS[12], (340, 10000, 2, 6, "wave", None, False),
                                  (200, 30000, 2, 6, "wave", None, False)])
 @pytest.mark.parametrize("dt", [np.float64, np.float32])

@@ -161,9 +161,9 @@ def test_one_message_cg_at_large_shop_scale(dt):
 @pytest.mark.parametrize("name,dt", CASES)
 def test_sharded_default_is_scipys_recurrence_on_gpu(name, dt):
     """Sharded default on the device (launch sequence vican_cg_iter_local / _finish / vican_cg_end, two messages): inside
-    the same bounds as the single-rank solve, and bit for bit the iterate of the launch-sequence single-rank path (the
-    resident kernel that capture-sized graphs take on one rank pre-sums a lane's same-row terms differently: the same
-    recurrence, other roundings - its stopping iteration may differ by one on weighted scenes, g3 f64: 34 / 35, golden 35)."""
+    the same bounds as the two single-rank paths (resident kernel of capture-sized graphs; fused launch sequence) - the same
+    recurrence with differently grouped floating-point partial sums: the stopping iteration may differ by one on weighted
+    scenes (g3 f64: 34 / 35, golden 35)."""
     g, case, prob = flatten_case(name, dt)
     exp = expected(g, "conjugate_gradient", dt)
     K = hip_backend(prob, dt)
@@ -178,7 +178,9 @@ def test_sharded_default_is_scipys_recurrence_on_gpu(name, dt):
     assert not info.get("one_message") and info1.get("resident") and not info2.get("resident")
     assert dist < stage_tol(name, dt), dist
     assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
-    assert info["cg_iters"] == info2["cg_iters"] and dist == dist2
+    # (the single-rank launch path is the fused iteration since round 5 - p_t.q_t over fixed slices instead of per sweep
+    #  workgroup: the same recurrence to rounding, not to the bit)
+    assert dist2 < stage_tol(name, dt) and abs(info["cg_iters"] - info2["cg_iters"]) <= iteration_slack(name, dt) + 1
     assert 2 * info["cg_iters"] <= comm.n_allreduce <= 2 + 2 * (info["cg_iters"] + 1 + 64)
 
 

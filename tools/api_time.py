@@ -15,8 +15,12 @@ from vican_amd import synth                                     # noqa: E402
 from vican_amd.bipgo import bipartite_se3sync, object_bipartite_se3sync   # noqa: E402
 from vican_amd.geometry import SE3                              # noqa: E402
 
+from vican_amd.frontend import vectorized                      # noqa: E402
+
 oracle = "--oracle" in sys.argv
 unit, keep = (lambda e: 1.0), (lambda e: True)
+# the same callables with a column form (called once for all edges instead of once per edge: frontend.vectorized)
+vunit, vkeep = vectorized(lambda cols: 1.0)(lambda e: 1.0), vectorized(lambda cols: True)(lambda e: True)
 SHAPES = [("cube_calib (object mode)", "object", 1, 2000, 24, 4), ("small_room", "camera", 12, 2000, 6, 3), ("small_room x 5000", "camera", 12, 5000, 6, 3),
           ("large_shop", "camera", 340, 10000, 6, 4)]
 for name, mode, C, T, M, k in SHAPES:
@@ -40,6 +44,14 @@ for name, mode, C, T, M, k in SHAPES:
     line = "%-26s %6d source edges, %4d x %5d nodes, %6d merged edges: first call %7.1f ms, then %6.1f ms (front-end %.1f, pack %.2f, rotations %.2f, translations %.2f; cg %s)" % (
         name, len(src), binfo["n_cam"], binfo["n_time"], binfo["n_edges"], times[0][0] * 1e3, best * 1e3,
         (best - binfo["t_pack"] - binfo["t_rot"] - binfo["t_trans"]) * 1e3, binfo["t_pack"] * 1e3, binfo["t_rot"] * 1e3, binfo["t_trans"] * 1e3, binfo["cg_iters"])
+    if mode == "camera":
+        vt = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            bipartite_se3sync(src, cons, vunit, vunit, vkeep, 4, "conjugate_gradient", np.float32)
+            torch.cuda.synchronize()
+            vt.append(time.perf_counter() - t0)
+        line += "; callables with a column form: %.1f ms" % (min(vt[1:]) * 1e3)
     if oracle:
         from oracle import bipgo_oracle as orc
         t0 = time.perf_counter()

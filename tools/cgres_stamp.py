@@ -19,7 +19,7 @@ for _ in range(3):
     S.solve(3 * (C + T))
 torch.cuda.synchronize()
 ws = H._cgres_ws.cpu().numpy()
-o = ws[3 * C + 4 * H.cgl.n_wg + 1: 3 * C + 4 * H.cgl.n_wg + 11] / 100.0
+o = ws[9 * C + 4 * H.cgl.n_wg + 1: 9 * C + 4 * H.cgl.n_wg + 11] / 100.0
 names = ["beta,p update", "sweep", "slab store + pq", "barrier 1", "fold slice", "barrier 2", "gather + q_c + p.q", "step + reductions", "barrier 3", "gather rr"]
 print("iterations", S.info["cg_iters"], "n_wg", H.cgl.n_wg)
 for n, v in zip(names, o):

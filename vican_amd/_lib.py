@@ -137,6 +137,7 @@ PROTOTYPES = {
     "vican_tile_cams": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "vican_cg_iter_fused": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _i32, _vp, _vp, _vp]),
     "vican_cg1_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     "vican_cg1_iter_finish": (C.c_int, [_i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
                                         _vp, _vp]),

@@ -6,8 +6,8 @@
 // Everything here is HOST code on top of those entry points - the same kernels, the same fixed-point scales, the same
 // stopping rules - with the plain schedule: layout planning as device.py's _Layout (wave layout where every row fits a
 // 64-lane chunk, else block layout), block Lanczos with a convergence check (device Ritz step, one blocking 128-byte read) every
-// few steps, launch-sequence camera-side step, the fused dual update, CG iterations in bursts of eight with the state polled
-// in between.  No speculation, no cooperative kernels, no HIP graphs, single rank, C <= 1024: the Python driver remains the
+// few steps, launch-sequence camera-side step, the fused dual update, CG iterations (vican_cg_iter_fused) in bursts of eight
+// with the state polled in between.  No speculation, no cooperative kernels, no HIP graphs, single rank, C <= 1024: the Python driver remains the
 // fast path (and the only sharded / tiled / LSQR one); this one is the small stable surface.  The library owns the plan's
 // device memory (one arena); inputs and outputs are the caller's.
 #include <vector>
@@ -70,6 +70,7 @@ struct vican_plan {
     double *b_c = nullptr, *b_t = nullptr, *r_c = nullptr, *p_c = nullptr, *r_t = nullptr, *p_t = nullptr, *q_t = nullptr, *qcpq = nullptr,
            *pq_part = nullptr, *rr_part = nullptr, *ws = nullptr;
     vican_cg_state_t* st = nullptr;
+    uint32_t* cg_ticket = nullptr;
     double* status_host = nullptr;      // pinned
 };
 
@@ -200,6 +201,7 @@ size_t carve(vican_plan* P, size_t n_row0) {
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
         P->pq_part = A.take<double>(std::max(P->g.n_wg, 1)); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
         P->st = (vican_cg_state_t*)A.take<double>(19);
+        P->cg_ticket = A.take<uint32_t>(64);         // (vican_cg_iter_fused: two tickets + two hand-over doubles, zeroed with the arena)
     }
     return A.used + 256;
 }
@@ -398,24 +400,21 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
     CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
     CK(vican_cg_init(C, T, P->b_c, P->b_t, x_c, x_t, P->r_c, P->r_t, P->p_c, P->p_t, P->st, P->ws, P->wmax, stream));
-    int n_part = 0;
     long long launched = 0;
     vican_cg_state_t h{};
     int burst = 8;
     for (;;) {
         // (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x; no test behind the last one)
-        for (int i = 0; i < burst && launched < maxiter; ++i, ++launched) {
-            CK(vican_cg_iter_local(&P->g, P->w, P->row_sum_w, P->r_c, P->p_c, P->r_t, P->p_t, P->q_t, P->zpart, P->pq_part, P->qcpq, rtol,
-                                   P->rr_part, n_part, P->n_add_cg, P->st, stream));
-            n_part = vican_cg_iter_finish(C, T, P->cam_sum_w, P->qcpq, P->p_c, x_c, P->r_c, P->p_t, P->q_t, x_t, P->r_t, P->rr_part, 1536, P->st, stream);
-            if (n_part < 0) return n_part;
-        }
+        for (int i = 0; i < burst && launched < maxiter; ++i, ++launched)
+            CK(vican_cg_iter_fused(&P->g, P->w, P->row_sum_w, P->cam_sum_w, P->r_c, P->p_c, x_c, P->r_t, P->p_t, P->q_t, x_t, P->zpart,
+                                   P->pq_part, P->qcpq, rtol, P->rr_part, 1536, P->n_add_cg, launched == 0, P->st, P->cg_ticket, stream));
         HIPCK(hipMemcpyAsync(P->status_host + 16, P->st, sizeof(vican_cg_state_t), hipMemcpyDeviceToHost, s), "vican_solve_trans");
         HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
         std::memcpy(&h, P->status_host + 16, sizeof(h));
         if (h.done || launched >= maxiter) break;
         burst = std::min(2 * burst, 64);
     }
+    if (h.done == 1 && h.iter >= maxiter) h.done = 0;        // (found by the head that rides with the LAST allowed update: scipy does not test there)
     inf.cg_iters = h.done == 1 ? h.iter : (int32_t)std::min<long long>(launched, 2147483647LL); inf.cg_converged = h.done == 1;
     inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;
     if (info) *info = inf;

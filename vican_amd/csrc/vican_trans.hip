@@ -321,19 +321,81 @@ __device__ __forceinline__ void cg_close_iteration(const double* __restrict__ rr
     st->rr_time = t; st->rmax_time = m; st->pmax_time = mp; st->iter += 1; st->rho_prev = st->rho; st->first = 0;
 }
 
+// ---------------------------------------------------------------------------
+// Camera-side loops of the CG kernels: 3C (<= 3072 untiled) elements by ONE workgroup of 256 threads, thread t takes elements
+// t, t + 256, ... in that order.  Written as plain loops they ran one element per memory round trip - a store into x_c / r_c /
+// p_c may alias the next element's operands, so the compiler cannot hoist the loads, and 12 dependent L2 round trips made
+// cg_begin 9.4 us and the camera workgroup of cg_step 8 us on the stress graph.  Here the operands of CG_CAMK elements are loaded
+// into registers before the first use: same expressions, same per-thread order of the floating-point sums, same bits.
+// ---------------------------------------------------------------------------
+#define CG_CAMK 12
+template <bool HANDOVER>
+__device__ __forceinline__ double cg_ld(const double* p) {      // HANDOVER: written by ANOTHER workgroup of this launch (sc1 store)
+    if (HANDOVER) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ void cg_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// this thread's part of p_c . q_c, q_c = deg_c p_c - qc  (cg_cam_step / cg_step / cg_fold2)
+template <bool QC_HANDOVER>
+__device__ __forceinline__ double cg_cam_dot(int nc, const double* __restrict__ deg_c, const double* __restrict__ p_c, const double* qc) {
+    double s = 0.0;
+    for (int base = 0; base < nc; base += 256 * CG_CAMK) {
+        double pv[CG_CAMK], dv[CG_CAMK], qv[CG_CAMK];
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            const bool in = i < nc;
+            pv[k] = in ? p_c[i] : 0.0; dv[k] = in ? deg_c[i / 3] : 0.0; qv[k] = in ? cg_ld<QC_HANDOVER>(qc + i) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            if (i < nc) { const double q = dv[k] * pv[k] - qv[k]; s += pv[k] * q; }
+        }
+    }
+    return s;
+}
+// x_c += alpha p_c, r_c -= alpha q_c; this thread's parts of r_c . r_c and max |r_c|.  RC_HANDOVER: r_c is stored for another
+// workgroup of this launch (cg_step2: the next iteration's head runs in whichever workgroup finishes last)
+template <bool RC_HANDOVER>
+__device__ __forceinline__ void cg_cam_update(int nc, double alpha, const double* __restrict__ deg_c, const double* __restrict__ qc,
+                                              const double* __restrict__ p_c, double* x_c, double* r_c, double& rr, double& mx) {
+    for (int base = 0; base < nc; base += 256 * CG_CAMK) {
+        double pv[CG_CAMK], dv[CG_CAMK], qv[CG_CAMK], xv[CG_CAMK], rv[CG_CAMK];
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            const bool in = i < nc;
+            pv[k] = in ? p_c[i] : 0.0; dv[k] = in ? deg_c[i / 3] : 0.0; qv[k] = in ? qc[i] : 0.0; xv[k] = in ? x_c[i] : 0.0; rv[k] = in ? r_c[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            if (i < nc) {
+                const double p = pv[k];
+                const double q = dv[k] * p - qv[k];
+                x_c[i] = mul_add_2r(alpha, p, xv[k]);
+                const double r = mul_add_2r(-alpha, q, rv[k]);
+                if (RC_HANDOVER) cg_st(&r_c[i], r); else r_c[i] = r;
+                rr += r * r; mx = fmax(mx, fabs(r));
+            }
+        }
+    }
+}
+
 // top of an iteration: (optionally close the previous one), convergence test, beta, p_c update,
 // and the fixed-point scale of this iteration's sweep from the running bound on max|p|
-__global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* __restrict__ r_c, double* p_c,
-                                                       double rtol, const double* __restrict__ rr_part, int n_part,
-                                                       double n_add, vican_cg_state_t* st) {
-    __shared__ double sh_beta;
-    __shared__ int sh_go;
-    __shared__ double red[8];
-    if (st->done) return;
+// HANDOVER: the body runs in the LAST workgroup of the launch that produced rr_part, r_c and st->rr_cam (cg_step2_kernel):
+// those were stored with agent-scope (sc1) stores and are read here with agent-scope loads - a workgroup's vector L1 is never
+// refreshed by another workgroup's stores.  Same thread mapping, same summation orders, same bits as the stand-alone kernel.
+template <bool HANDOVER>
+__device__ __forceinline__ void cg_begin_body(int n_cam, const double* __restrict__ r_c, double* p_c, double rtol,
+                                              const double* __restrict__ rr_part, int n_part, double n_add, vican_cg_state_t* st,
+                                              double* red /* [8] */, double* sh_beta, int* sh_go, const double* hand = nullptr) {
     // close the previous iteration: fixed-order block reduction of the partials (sum, max |r_t|, max |p_t|)
     double ps = 0.0, pm = 0.0, pp = 0.0;
     for (int i = threadIdx.x; i < n_part; i += 256) {
-        ps += rr_part[i]; pm = fmax(pm, rr_part[CG_PARTS + i]); pp = fmax(pp, rr_part[2 * CG_PARTS + i]);
+        ps += cg_ld<HANDOVER>(rr_part + i); pm = fmax(pm, cg_ld<HANDOVER>(rr_part + CG_PARTS + i)); pp = fmax(pp, cg_ld<HANDOVER>(rr_part + 2 * CG_PARTS + i));
     }
     const double tsum = block_sum(ps, red);
 #pragma unroll
@@ -347,6 +409,9 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
             st->pmax_time = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
             st->iter += 1; st->rho_prev = st->rho; st->first = 0;
         }
+        // (HANDOVER: r_c.r_c and max |r_c| of the camera workgroup arrive in words of their own - the state's cache lines
+        //  were read with plain loads at the top of the launch and may sit, stale, in this XCD's L2)
+        if (HANDOVER) { st->rr_cam = cg_ld<true>(hand); st->rmax_cam = cg_ld<true>(hand + 1); }
         const double rho = st->rr_cam + st->rr_time;
         if (st->iter == 0 && st->first) { st->bnorm2 = rho; st->atol2 = rtol * rtol * rho; }
         st->rho = rho;
@@ -356,16 +421,30 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
         double beta = 0.0;
         if (go && !st->first) beta = rho / st->rho_prev;
         st->beta = beta;
-        sh_beta = beta; sh_go = go && !st->first;
+        *sh_beta = beta; *sh_go = go && !st->first;
     }
     __syncthreads();
     // p_c = r_c + beta p_c (p = r on the first iteration) and its exact maximum
-    const double beta = sh_beta;
+    const double beta = *sh_beta;
+    const int go = *sh_go;
     double mc = 0.0;
-    for (int i = threadIdx.x; i < 3 * n_cam; i += 256) {
-        double p = p_c[i];
-        if (sh_go) { p = mul_add_2r(beta, p, r_c[i]); p_c[i] = p; }
-        mc = fmax(mc, fabs(p));
+    for (int base = 0; base < 3 * n_cam; base += 256 * CG_CAMK) {          // (operands staged: see cg_cam_dot)
+        double pv[CG_CAMK], rv[CG_CAMK];
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            const bool in = i < 3 * n_cam;
+            pv[k] = in ? p_c[i] : 0.0; rv[k] = (in && go) ? cg_ld<HANDOVER>(r_c + i) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < CG_CAMK; ++k) {
+            const int i = base + (int)threadIdx.x + 256 * k;
+            if (i < 3 * n_cam) {
+                double p = pv[k];
+                if (go) { p = mul_add_2r(beta, p, rv[k]); p_c[i] = p; }
+                mc = fmax(mc, fabs(p));
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
@@ -388,6 +467,15 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
         st->lo_bits = fix2_lo_bits(n_add);
         st->qinv = inv;
     }
+}
+__global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* __restrict__ r_c, double* p_c,
+                                                       double rtol, const double* __restrict__ rr_part, int n_part,
+                                                       double n_add, vican_cg_state_t* st) {
+    __shared__ double sh_beta;
+    __shared__ int sh_go;
+    __shared__ double red[8];
+    if (st->done) return;
+    cg_begin_body<false>(n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, red, &sh_beta, &sh_go);
 }
 extern "C" int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, double rtol, const double* rr_part,
                               int32_t n_part, double n_add, vican_cg_state_t* st, void* stream) {
@@ -692,11 +780,7 @@ __global__ __launch_bounds__(256) void cg_cam_step_kernel(int n_cam, const doubl
     __shared__ double sh_alpha;
     if (st->done) return;
     const int n = 3 * n_cam;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double q = deg_c[i / 3] * p_c[i] - qc_sum[i];
-        s += p_c[i] * q;
-    }
+    const double s = cg_cam_dot<false>(n, deg_c, p_c, qc_sum);
     const double pqc = block_sum(s, red);
     if (threadIdx.x == 0) {
         const double pq = *pq_time + pqc;
@@ -708,14 +792,7 @@ __global__ __launch_bounds__(256) void cg_cam_step_kernel(int n_cam, const doubl
     __syncthreads();
     const double alpha = sh_alpha;
     double rr = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double p = p_c[i];
-        const double q = deg_c[i / 3] * p - qc_sum[i];
-        x_c[i] = mul_add_2r(alpha, p, x_c[i]);
-        const double r = mul_add_2r(-alpha, q, r_c[i]);
-        r_c[i] = r;
-        rr += r * r; m = fmax(m, fabs(r));
-    }
+    cg_cam_update<false>(n, alpha, deg_c, qc_sum, p_c, x_c, r_c, rr, m);
     const double t = block_sum(rr, red);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
@@ -785,11 +862,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     __shared__ double sh_alpha;
     if (st->done) return;
     const int nc = 3 * n_cam;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nc; i += 256) {
-        const double q = deg_c[i / 3] * p_c[i] - qc_sum[i];
-        s += p_c[i] * q;
-    }
+    const double s = cg_cam_dot<false>(nc, deg_c, p_c, qc_sum);
     const double pqc = block_sum(s, red);
     if (threadIdx.x == 0) {
         const double pq = *pq_time + pqc;
@@ -821,14 +894,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     return;
     }
     double rc2 = 0.0, mc = 0.0;
-    for (int i = threadIdx.x; i < nc; i += 256) {
-        const double p = p_c[i];
-        const double q = deg_c[i / 3] * p - qc_sum[i];
-        x_c[i] = mul_add_2r(alpha, p, x_c[i]);
-        const double r = mul_add_2r(-alpha, q, r_c[i]);
-        r_c[i] = r;
-        rc2 += r * r; mc = fmax(mc, fabs(r));
-    }
+    cg_cam_update<false>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);
     const double tc = block_sum(rc2, red);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
@@ -1018,6 +1084,34 @@ extern "C" int vican_cg1_iter_finish(int32_t n_cam, int32_t n_time, int32_t k, d
 // fold of one CG sweep in ONE launch: qcpq[0:3C] = sum_wg qc_part (double-word planes [2][3][C] per workgroup -> row-major
 // [C][3] doubles, rounded once) and qcpq[3C] = sum_wg pq_part (block 0).  Integer sums: exact, any order, overflow-proof
 // (fix3_add / fix3_value, vican_sweep_common.h).
+template <int COLS>          // columns per workgroup (1024 / COLS lane groups stride over the slabs): see slab_reduce_fx_kernel
+__device__ __forceinline__ void cg_fold_columns(const long long* __restrict__ part, int n_slab, long long n, int lob, long long (*sh)[1024],
+                                                long long& t, long long& b, long long& l, long long& col, bool& owner) {
+    constexpr int NG = 1024 / COLS;
+    const int e = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+    const long long i = (long long)blockIdx.x * COLS + e;
+    Fix3 a = {0, 0, 0};
+    if (i < n) {
+        // (two slabs per pass: four independent loads in flight per lane instead of two)
+        int k = grp;
+        for (; k + NG < n_slab; k += 2 * NG) {
+            const long long h0 = part[(size_t)k * 2 * n + i], l0 = part[(size_t)k * 2 * n + n + i];
+            const long long h1 = part[(size_t)(k + NG) * 2 * n + i], l1 = part[(size_t)(k + NG) * 2 * n + n + i];
+            fix3_add(a, h0, l0, lob); fix3_add(a, h1, l1, lob);
+        }
+        if (k < n_slab) fix3_add(a, part[(size_t)k * 2 * n + i], part[(size_t)k * 2 * n + n + i], lob);
+    }
+    sh[0][threadIdx.x] = a.top; sh[1][threadIdx.x] = a.bot; sh[2][threadIdx.x] = a.lo;
+    __syncthreads();
+    owner = grp == 0 && i < n;
+    col = i;
+    t = b = l = 0;
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) { t += sh[0][k * COLS + e]; b += sh[1][k * COLS + e]; l += sh[2][k * COLS + e]; }
+    }
+}
+template <int COLS>
 __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
                                                        const double* __restrict__ pq_part, double* __restrict__ qcpq,
                                                        const vican_cg_state_t* __restrict__ st) {
@@ -1025,17 +1119,9 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
     if (st->done) return;
     const long long n = 3LL * n_cam;
     const int lob = st->lo_bits;
-    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + e;
-    Fix3 a = {0, 0, 0};
-    if (i < n)
-        for (int k = grp; k < n_slab; k += 16) fix3_add(a, part[(size_t)k * 2 * n + i], part[(size_t)k * 2 * n + n + i], lob);
-    sh[0][threadIdx.x] = a.top; sh[1][threadIdx.x] = a.bot; sh[2][threadIdx.x] = a.lo;
-    __syncthreads();
-    if (grp == 0 && i < n) {
-        long long t = 0, b = 0, l = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { t += sh[0][k * 64 + e]; b += sh[1][k * 64 + e]; l += sh[2][k * 64 + e]; }
+    long long t, b, l, i; bool owner;
+    cg_fold_columns<COLS>(part, n_slab, n, lob, sh, t, b, l, i, owner);
+    if (owner) {
         const long long q = i / n_cam, cam = i % n_cam;
         qcpq[cam * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
     }
@@ -1056,14 +1142,204 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
         }
     }
 }
+static inline int cg_fold_cols(long long n, int n_slab) { return (n >= 64 * 256 || n_slab < 32) ? 64 : ((n >= 32 * 256 || n_slab < 64) ? 32 : 16); }
 
 extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                              const vican_cg_state_t* st, void* stream) {
     if (!qc_part || n_slab <= 0 || n_cam <= 0 || !qcpq || !st) return set_err(VICAN_ERR_ARG, "vican_cg_fold: bad argument");
     const long long n = 3LL * n_cam;
-    hipLaunchKernelGGL(cg_fold_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
-                       (const long long*)qc_part, n_slab, n_cam, pq_part, qcpq, st);
+#define CGF_LAUNCH(COLS_) hipLaunchKernelGGL(cg_fold_kernel<COLS_>, dim3((unsigned)((n + COLS_ - 1) / COLS_)), dim3(1024), 0, (hipStream_t)stream, \
+                                             (const long long*)qc_part, n_slab, n_cam, pq_part, qcpq, st)
+    const int cols = cg_fold_cols(n, n_slab);
+    if (cols == 64) CGF_LAUNCH(64); else if (cols == 32) CGF_LAUNCH(32); else CGF_LAUNCH(16);
+#undef CGF_LAUNCH
     LAUNCH_CHECK("vican_cg_fold");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Single-rank iteration in THREE launches instead of four (begin, sweep, fold, step): the tail of large graphs was 32 us of
+// a 102 us iteration on the stress graph - five-to-thirteen-microsecond launches and the gaps between them.
+//   sweep                      (unchanged)
+//   cg_fold2  = cg_fold + the scalar head of cg_step: the workgroup that finishes LAST (an agent-scope ticket) sums the p.q
+//               partials, forms p_c.q_c and alpha ONCE (cg_step derived them again in each of its ~300 workgroups)
+//   cg_step2  = cg_step with alpha from the state + cg_begin of the NEXT iteration by the workgroup that finishes last
+// No workgroup ever waits for another one (no spin, nothing to co-schedule): a hand-over goes to whoever draws the last
+// ticket.  What crosses workgroups inside a launch travels as agent-scope (sc1) stores, every storing wave drains its stores
+// (s_waitcnt vmcnt(0)) in front of the workgroup barrier that precedes the ticket, and the last workgroup reads with
+// agent-scope loads after its ticket has returned (MI355X guide, inter-workgroup visibility: per-XCD L2s are not coherent,
+// a CU's L1 is never refreshed).  Same thread mappings, summation orders and expressions as the four kernels => same bits
+// (tests/test_kernels_gpu.py::test_fused_cg_iteration_is_bit_identical).
+// ---------------------------------------------------------------------------
+// true in every thread of the workgroup that arrives last; the counter is left at zero for the next launch
+__device__ __forceinline__ bool cg_last_arrival(unsigned int* ticket, unsigned int n_arrive) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's hand-over stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#ifdef VICAN_CG_HAND_RELEASE                                   /* diagnostic: the portable form (agent-scope release / acquire) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == n_arrive - 1u;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef VICAN_CG_HAND_ACQUIRE
+        if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// p_t . q_t is formed HERE, over fixed slices in a fixed order, not taken from the sweep's pq_part: the sweeps hand their chunks
+// to wavefronts by ticket, so which wavefront adds which rows' p q - and with it the last bits of the workgroup's floating-
+// point partial - depends on timing (every other sum of the sweep is an exact integer sum).  4.8 MB of extra reads on the
+// stress graph; the single-rank CG is bit-reproducible from run to run.
+template <int COLS>
+__global__ __launch_bounds__(1024) void cg_fold2_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
+                                                        const double* __restrict__ p_t, const double* __restrict__ q_t, long long n_t,
+                                                        double* pq_part, double* qcpq,
+                                                        const double* __restrict__ deg_c, const double* __restrict__ p_c,
+                                                        vican_cg_state_t* st, unsigned int* ticket) {
+    __shared__ long long sh[3][1024];
+    __shared__ double red[16];
+    if (st->done) return;
+    const long long n = 3LL * n_cam;
+    const int lob = st->lo_bits;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    {
+        long long t, b, l, i; bool owner;
+        cg_fold_columns<COLS>(part, n_slab, n, lob, sh, t, b, l, i, owner);
+        if (owner) {
+            const long long q = i / n_cam, cam = i % n_cam;
+            cg_st(&qcpq[cam * 3 + q], fix3_value(t, b, l, lob, st->qinv));
+        }
+    }
+    {   // this workgroup's slice of p_t . q_t
+        double s = 0.0;
+#pragma unroll 4
+        for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n_t; i += (long long)gridDim.x * 1024) s += p_t[i] * q_t[i];
+        s = wave_sum(s);
+        if (e == 0) red[grp] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int k = 0; k < 16; ++k) t += red[k];
+            cg_st(&pq_part[blockIdx.x], t);
+        }
+        __syncthreads();
+    }
+    if (!cg_last_arrival(ticket, gridDim.x)) return;
+    // ---- the last workgroup: p.q of the timestep side (fixed order, as cg_fold), p_c.q_c and alpha (as cg_step) ----
+    double* pq = (double*)&sh[0][0];
+    double pq_time = 0.0;
+    const int n_pq = (int)gridDim.x;                             // one partial per workgroup of this launch, in workgroup order
+    for (int k0 = 0; k0 < n_pq; k0 += 1024) {
+        const int k = k0 + threadIdx.x;
+        pq[threadIdx.x] = k < n_pq ? cg_ld<true>(pq_part + k) : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = n_pq - k0 < 1024 ? n_pq - k0 : 1024;
+            for (int j = 0; j < m; ++j) pq_time += pq[j];
+        }
+        __syncthreads();
+    }
+    // (threads 0..255 in cg_step's mapping; the other waves add zeros)
+    double sdot = 0.0;
+    if (threadIdx.x < 256) sdot = cg_cam_dot<true>((int)n, deg_c, p_c, qcpq);
+    sdot = wave_sum(sdot);
+    if (threadIdx.x < 256 && e == 0) red[grp] = sdot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double pqc = 0.0;
+        for (int k = 0; k < 4; ++k) pqc += red[k];
+        const double pqt = pq_time + pqc;
+        qcpq[n] = pq_time;
+        st->pq_time = pq_time; st->pq = pqt; st->alpha = st->rho / pqt;
+    }
+}
+
+__global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, const double* __restrict__ deg_c,
+                                                       const double* __restrict__ qc_sum, double* p_c, double* x_c, double* r_c,
+                                                       const double* __restrict__ p_t, const double* __restrict__ q_t,
+                                                       double* __restrict__ x_t, double* __restrict__ r_t, double* rr_part,
+                                                       double rtol, double n_add, vican_cg_state_t* st, unsigned int* ticket,
+                                                       double* hand) {
+    __shared__ double red[8];
+    __shared__ double sh_beta;
+    __shared__ int sh_go;
+    if (st->done) return;
+    const int nc = 3 * n_cam;
+    const double alpha = st->alpha;                        // (cg_fold2 of this iteration: a launch ago)
+    const int nb = (int)gridDim.x - 1;                     // blocks of the time side
+    if ((int)blockIdx.x < nb) {
+        double rr = 0.0, m = 0.0, mp = 0.0;
+#pragma unroll 4
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)nb * 256) {
+            const double pv = p_t[i];
+            x_t[i] = mul_add_2r(alpha, pv, x_t[i]);
+            mp = fmax(mp, fabs(pv));
+            const double r = mul_add_2r(-alpha, q_t[i], r_t[i]);
+            r_t[i] = r;
+            rr += r * r; m = fmax(m, fabs(r));
+        }
+        const double t = block_sum(rr, red);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_down(m, o, 64)); mp = fmax(mp, __shfl_down(mp, o, 64)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red[4 + (threadIdx.x >> 6)] = mp; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cg_st(&rr_part[blockIdx.x], t); cg_st(&rr_part[CG_PARTS + blockIdx.x], fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
+            cg_st(&rr_part[2 * CG_PARTS + blockIdx.x], fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+        }
+    } else {
+        double rc2 = 0.0, mc = 0.0;
+        cg_cam_update<true>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);      // (r_c: read by whoever runs the head below)
+        const double tc = block_sum(rc2, red);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mc;
+        __syncthreads();
+        if (threadIdx.x == 0) { cg_st(hand, tc); cg_st(hand + 1, fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))); }
+    }
+    if (!cg_last_arrival(ticket, gridDim.x)) return;
+    // ---- the last workgroup: head of the next iteration (cg_begin with n_part = nb) ----
+    cg_begin_body<true>(n_cam, r_c, p_c, rtol, rr_part, nb, n_add, st, red, &sh_beta, &sh_go, hand);
+}
+
+// One CG iteration of a single rank: [cg_begin (first iteration only)] + sweep + cg_fold2 + cg_step2.  `first` != 0: the
+// call that follows vican_cg_init.  ticket: 256 zeroed bytes owned by this solve, 128-byte aligned - two 32-bit tickets (left at
+// zero by every launch) on the first cache line, two doubles of hand-over on the second (r_c.r_c, max |r_c|: a line that no
+// plain load ever touches).
+// The state after k calls equals the state after k x (vican_cg_iter_local, vican_cg_iter_finish) plus the vican_cg_begin
+// of the next call, bit for bit.
+extern "C" int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
+                                   double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
+                                   void* qc_part, double* pq_part, double* qcpq, double rtol, double* rr_part, int32_t part_cap,
+                                   double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ticket, void* stream) {
+    if (!g || !deg_c || !r_c || !p_c || !x_c || !r_t || !p_t || !q_t || !x_t || !qcpq || !rr_part || part_cap < 3 * CG_PARTS || !st || !ticket)
+        return set_err(VICAN_ERR_ARG, "vican_cg_iter_fused: bad argument");
+    int rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (first && (rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, 0, n_add, st, stream)) < 0) return rc;
+    if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
+    const long long nc = 3LL * g->n_cam, n = 3LL * g->n_time;
+    // partials of p_t . q_t, one per workgroup of the fold (<= 3 * 1024 / 16 = 192 untiled): the third plane of rr_part (max |p_t| per
+    // workgroup of the step) is free between the head that consumed it and the step that rewrites it
+    double* pq_part2 = rr_part + 2 * CG_PARTS;
+    if ((nc + 15) / 16 > CG_PARTS) return set_err(VICAN_ERR_CAPACITY, "vican_cg_iter_fused: more than 2730 cameras (camera-tiled graphs take the launch sequence)");
+#define CGF2_LAUNCH(COLS_) hipLaunchKernelGGL(cg_fold2_kernel<COLS_>, dim3((unsigned)((nc + COLS_ - 1) / COLS_)), dim3(1024), 0, s, (const long long*)qc_part, \
+                                              (int)g->n_wg, (int)g->n_cam, p_t, q_t, 3LL * g->n_time, pq_part2, qcpq, deg_c, p_c, st, ticket)
+    const int cols = cg_fold_cols(nc, g->n_wg);
+    if (cols == 64) CGF2_LAUNCH(64); else if (cols == 32) CGF2_LAUNCH(32); else CGF2_LAUNCH(16);
+#undef CGF2_LAUNCH
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
+    hipLaunchKernelGGL(cg_step2_kernel, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                       rr_part, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
+    LAUNCH_CHECK("vican_cg_iter_fused");
     return VICAN_OK;
 }
 

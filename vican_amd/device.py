@@ -704,6 +704,17 @@ class HipBackend:
                                                       _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
                                                       self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_iter_finish")
 
+    def cg_iter_fused(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, qcpq, rtol, st, first):
+        """One single-rank CG iteration in three launches (sweep, fold + alpha, step + the next iteration's head):
+        include/vican_hip.h vican_cg_iter_fused; same bits as cg_iter_local + cg_iter_finish."""
+        if getattr(self, "_cg_ticket", None) is None:
+            self._cg_ticket = torch.zeros(64, dtype=torch.int32, device=self.dev)     # line 0: tickets [2]; line 1: hand-over doubles [2]
+        part = self.zpart[: self.cgl.n_wg * 6 * self.C]
+        self._ck(self.lib.vican_cg_iter_fused(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(r_c), _ptr(p_c), _ptr(x_c),
+                                              _ptr(r_t), _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq),
+                                              float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg, int(bool(first)),
+                                              _ptr(st), _ptr(self._cg_ticket), _stream()), "vican_cg_iter_fused")
+
     # one message per CG iteration (sharded solves; include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)
     def cg1_iter_local(self, deg_t, r_c, r_t, s_t, msg, st, n_rr_part):
         if getattr(self, "_cg1_sw", None) is None:
@@ -1140,6 +1151,7 @@ class TiledBackend(HipBackend):
     product and the LSQR steps run tile by tile too (vican_cg_sweep_partial + vican_cg_combine_rows; vican_lsqr_step per tile):
     no limit on the number of cameras.  No fused dual update (a performance feature of the untiled sweeps)."""
     fused_dual_ok = False
+    cg_iter_fused = None           # (the tiled CG product is several launches: no fused iteration)
     cg1_iter_local = None          # sharded tiled solves keep the two-message CG (the one-message product is an untiled sweep)
 
     def __init__(self, graph: TiledGraph):

@@ -36,6 +36,81 @@ class Problem:
         return len(self.col)
 
 
+def vectorized(columns_fn):
+    """Decorator: give a per-edge callable (``edge_filter`` / ``noise_model_r`` / ``noise_model_t``: value dict -> bool / float,
+    bipgo.py:204,212,449) a COLUMN form that the front-end calls once instead of once per edge:
+
+        @vican_amd.frontend.vectorized(lambda cols: np.exp(-cols["reprojected_err"]))
+        def noise_t(edge): return math.exp(-edge["reprojected_err"])
+
+    ``columns_fn(cols)`` receives an ``EdgeColumns`` (``cols["reprojected_err"]`` [n], ``cols["corners"]`` [n,4,2],
+    ``cols["R"]`` [n,3,3] / ``cols["t"]`` [n,3] of ``pose``, any other field as an object array; gathered on first use) and
+    returns one value per edge (or a scalar).  The scalar form stays the definition - it is what the reference calls and what
+    runs when the attribute is absent; the two must agree (tests/test_frontend_cpu.py checks the shipped ones bit for bit)."""
+    def deco(fn):
+        fn.vectorized = columns_fn
+        return fn
+    return deco
+
+
+class EdgeColumns:
+    """Lazy column view of a list of edge value dicts (the argument of a ``.vectorized`` callable)."""
+    __slots__ = ("_vals", "_cache")
+
+    def __init__(self, vals, cache=None):
+        self._vals, self._cache = vals, ({} if cache is None else cache)
+
+    def __len__(self):
+        return len(self._vals)
+
+    def poses(self):
+        c = self._cache.get("pose")
+        if c is None:
+            c = self._cache["pose"] = [v["pose"] for v in self._vals]
+        return c
+
+    def __getitem__(self, name):
+        c = self._cache.get(name)
+        if c is None:
+            n = len(self._vals)
+            if name == "pose":
+                return self.poses()
+            if name == "R":
+                c = _stack_f64([p.R() for p in self.poses()], (3, 3)) if n else np.zeros((0, 3, 3))
+            elif name == "t":
+                c = _stack_f64([p.t() for p in self.poses()], (3,)) if n else np.zeros((0, 3))
+            elif name == "reprojected_err":
+                c = np.fromiter((v["reprojected_err"] for v in self._vals), dtype=np.float64, count=n)
+            elif name == "corners":
+                c = np.array([v["corners"] for v in self._vals], dtype=np.float64)
+            else:
+                c = np.empty(n, dtype=object)
+                c[:] = [v[name] for v in self._vals]
+            self._cache[name] = c
+        return c
+
+    def select(self, keep):
+        """The columns of the edges where `keep` (bool [n]) holds (already gathered columns are sliced, not re-gathered)."""
+        import itertools
+        vals = list(itertools.compress(self._vals, keep))
+        cache = {k: (list(itertools.compress(v, keep)) if isinstance(v, list) else v[keep]) for k, v in self._cache.items()}
+        return EdgeColumns(vals, cache)
+
+
+def _call_columns(fn, cols, dtype):
+    """fn.vectorized(cols) as an [n] array of `dtype` (scalars broadcast), or None when fn has no column form."""
+    vec = getattr(fn, "vectorized", None)
+    if vec is None:
+        return None
+    out = np.asarray(vec(cols), dtype=dtype)
+    if out.shape != (len(cols),):
+        out = np.broadcast_to(out, (len(cols),)).copy()
+    return out
+
+
+_CODES_CACHE = {"keys": None, "codes": None}        # the last kept key list and its index codes (time series: same keys, new values)
+
+
 def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype=np.float32, merge=None) -> Problem:
     """Filter, weight, apply marker constraints and merge multi-marker edges.  `merge`: the numeric half - None =
     merge_host (NumPy), or a callable (ix, R, t, k_r, k_t, dtype) -> Problem such as device.merge_edges.
@@ -46,29 +121,62 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     with tau_m = trans(S_m^-1 S_root) and kf = k_t rounded to ``dtype`` (the reference
     stores the incidence matrix in ``dtype`` but the measurements in float64,
     bipgo.py:434-439).
-    """
-    cams, times, marks, Rs, ts_, kr, kt = [], [], [], [], [], [], []
-    add_c, add_t, add_m, add_R, add_p, add_kr, add_kt = cams.append, times.append, marks.append, Rs.append, ts_.append, kr.append, kt.append
-    for key, val in src_edges.items():                             # the only per-edge Python loop
-        if not edge_filter(val):
-            continue
-        ts, mid = key[1].split("_")
-        add_c(key[0]); add_t(ts); add_m(mid)
-        pose = val["pose"]
-        add_R(pose.R()); add_p(pose.t())
-        add_kr(noise_model_r(val)); add_kt(noise_model_t(val))
-    if len(cams) == 0:
+
+    The user callables are the only per-edge Python left: each is evaluated once per (kept) edge in its own pass over the
+    value dicts (callables are treated as pure: the reference itself calls the filter twice) - or ONCE for all edges when it
+    carries a column form (``vectorized``).  Ids are split and indexed as arrays; the indices of a key list seen in the
+    previous call are reused (time series of captures with the same detections)."""
+    import itertools
+    keys, vals = list(src_edges.keys()), list(src_edges.values())
+    n_all = len(vals)
+    cols = EdgeColumns(vals)
+    keep = _call_columns(edge_filter, cols, bool)
+    if keep is None:
+        keep = np.array([bool(edge_filter(v)) for v in vals], dtype=bool) if n_all else np.zeros(0, dtype=bool)
+    if not keep.all():
+        keys, cols = list(itertools.compress(keys, keep)), cols.select(keep)
+    vals = cols._vals
+    n = len(vals)
+    if n == 0:
         raise ValueError("no edge passes edge_filter")
-    # (measured: seven list appends per edge beat one tuple append + zip(*rows) at 80 000 edges - 166 against 214 ms on the
-    #  build container)
-    R = _stack_f64(Rs, (3, 3))
-    t = _stack_f64(ts_, (3,))
-    return flatten_arrays(cams, times, marks, R, t, kr, kt, constraints, dtype, merge)
+    kr = _call_columns(noise_model_r, cols, np.float64)
+    if kr is None:
+        kr = np.array([noise_model_r(v) for v in vals], dtype=np.float64)
+    kt = _call_columns(noise_model_t, cols, np.float64)
+    if kt is None:
+        kt = np.array([noise_model_t(v) for v in vals], dtype=np.float64)
+    R, t = cols["R"], cols["t"]
+    cache = _CODES_CACHE
+    codes = cache["codes"] if cache["keys"] is not None and len(cache["keys"]) == n and cache["keys"] == keys else None
+    if codes is None:
+        cams = [k[0] for k in keys]
+        tm = np.array([k[1] for k in keys])
+        times = marks = None
+        if tm.dtype.kind == "U" and tm.ndim == 1:
+            parts = np.char.partition(tm, "_")
+            if (parts[:, 1] == "_").all() and not (np.char.find(parts[:, 2], "_") >= 0).any():
+                times, marks = parts[:, 0], parts[:, 2]
+        if times is None:                                          # not exactly one '_' somewhere: the reference's own unpacking (and its error)
+            tsm = [k[1].split("_") for k in keys]
+            times, marks = [a for a, _ in tsm], [b for _, b in tsm]
+        codes = index_codes(cams, times, marks)
+        cache["keys"], cache["codes"] = keys, codes
+    return (merge or merge_host)(index_edges(None, None, None, constraints, codes=codes), R, t, kr, kt, dtype)
 
 
 def _stack_f64(items, shape):
     """[n, *shape] float64 from a list of small arrays: one C-level conversion (np.stack of per-item np.asarray calls took
     six times as long for 80 000 rotations); lists of mixed shapes take the per-item path."""
+    # float64 ndarrays of the right size (what SE3 holds): their bytes joined and viewed - 9.5 against 16 ms for 80 000
+    # rotations; anything else (float32 poses, lists, other shapes) shows as a wrong total length and takes the paths below
+    size = int(np.prod(shape))
+    try:
+        if len(items) and type(items[0]) is np.ndarray and items[0].dtype == np.float64:
+            raw = b"".join([x.tobytes() for x in items])
+            if len(raw) == 8 * size * len(items) and all(type(x) is np.ndarray and x.dtype == np.float64 for x in items[:: max(1, len(items) // 64)]):
+                return np.frombuffer(raw, dtype=np.float64).reshape((len(items),) + shape).copy()
+    except (AttributeError, TypeError):
+        pass
     try:
         return np.array(items, dtype=np.float64).reshape((len(items),) + shape)
     except (ValueError, TypeError):
@@ -149,29 +257,22 @@ class EdgeIndex:
     __slots__ = ("n", "root", "cam_names", "time_names", "tnodes", "tnode_of_cam", "tnode_of_time", "ci", "ti", "mi", "CmT", "qtau")
 
 
-def index_edges(cam_ids, time_ids, marker_ids, constraints) -> EdgeIndex:
-    ix = EdgeIndex()
-    ix.n = len(cam_ids)
-    if ix.n == 0:
+class _Codes:
+    """String ids -> indices (the part of EdgeIndex that depends on the keys alone, not on the constraints or the values)."""
+    __slots__ = ("n", "mk_names", "mi", "cam_names", "ci", "time_names", "ti", "tnodes", "tnode_of_cam", "tnode_of_time")
+
+
+def index_codes(cam_ids, time_ids, marker_ids) -> _Codes:
+    cd = _Codes()
+    cd.n = len(cam_ids)
+    if cd.n == 0:
         raise ValueError("no edge passes edge_filter")
-    ix.root = str(min(list(constraints.keys())))                   # bipgo.py:196,411 (string min)
-    r_root = np.asarray(constraints[ix.root].R(), dtype=np.float64)
-    # per-marker constraint tables (KeyError for an unknown marker id, as bipgo.py:209)
-    mk_names, ix.mi = sorted_codes(marker_ids)
-    M = len(mk_names)
-    ix.CmT = np.empty((M, 3, 3)); Q = np.empty((M, 3, 3)); tau = np.empty((M, 3))
-    for i, m in enumerate(mk_names):
-        cm = constraints[str(m)]
-        r_m = np.asarray(cm.R(), dtype=np.float64)
-        ix.CmT[i] = r_m.T @ r_root                                 # bipgo.py:213
-        Q[i] = r_root.T @ r_m                                      # bipgo.py:451
-        tau[i] = np.asarray((cm.inv() @ constraints[ix.root]).t(), dtype=np.float64)   # bipgo.py:452
-    ix.qtau = np.einsum("mij,mj->mi", Q, tau)
+    cd.mk_names, cd.mi = sorted_codes(marker_ids)
     # bipgo.py:225-229 sorts 'c' + id / 't' + id: a common prefix changes the spelling, not the order
-    ix.cam_names, ix.ci, kc = sorted_codes(cam_ids, with_keys=True)
-    ix.time_names, ix.ti, kt = sorted_codes(time_ids, with_keys=True)
+    cd.cam_names, cd.ci, kc = sorted_codes(cam_ids, with_keys=True)
+    cd.time_names, cd.ti, kt = sorted_codes(time_ids, with_keys=True)
     # translation unknowns: cameras and "<t>_0" nodes in ONE string-sorted list (bipgo.py:426-430)
-    t0 = np.char.add(ix.time_names, "_0")
+    t0 = np.char.add(cd.time_names, "_0")
     if kc is not None and kt is not None:
         # on the packed keys: "<t>_0" = the key of <t> with '_' and '0' in its next two bytes (needs len(t) <= 6)
         ln = (kt.astype(">u8").view(np.uint8).reshape(-1, 8) != 0).sum(1).astype(np.uint64)
@@ -183,12 +284,35 @@ def index_edges(cam_ids, time_ids, marker_ids, constraints) -> EdgeIndex:
             if not (sk[1:] == sk[:-1]).any():                       # (a camera called "<t>_0": the general path merges them)
                 pos = np.empty(len(allk), dtype=np.int64)
                 pos[order] = np.arange(len(allk), dtype=np.int64)
-                ix.tnodes = np.concatenate([ix.cam_names, t0])[order]
-                ix.tnode_of_cam, ix.tnode_of_time = pos[: len(kc)], pos[len(kc):]
-                return ix
-    ix.tnodes = np.unique(np.concatenate([ix.cam_names, t0]))
-    ix.tnode_of_cam = np.searchsorted(ix.tnodes, ix.cam_names).astype(np.int64)
-    ix.tnode_of_time = np.searchsorted(ix.tnodes, t0).astype(np.int64)
+                cd.tnodes = np.concatenate([cd.cam_names, t0])[order]
+                cd.tnode_of_cam, cd.tnode_of_time = pos[: len(kc)], pos[len(kc):]
+                return cd
+    cd.tnodes = np.unique(np.concatenate([cd.cam_names, t0]))
+    cd.tnode_of_cam = np.searchsorted(cd.tnodes, cd.cam_names).astype(np.int64)
+    cd.tnode_of_time = np.searchsorted(cd.tnodes, t0).astype(np.int64)
+    return cd
+
+
+def index_edges(cam_ids, time_ids, marker_ids, constraints, codes=None) -> EdgeIndex:
+    """codes: the ids' indices if the caller has them already (index_codes of the same ids)."""
+    cd = codes if codes is not None else index_codes(cam_ids, time_ids, marker_ids)
+    ix = EdgeIndex()
+    ix.n = cd.n
+    ix.root = str(min(list(constraints.keys())))                   # bipgo.py:196,411 (string min)
+    r_root = np.asarray(constraints[ix.root].R(), dtype=np.float64)
+    # per-marker constraint tables (KeyError for an unknown marker id, as bipgo.py:209)
+    mk_names, ix.mi = cd.mk_names, cd.mi
+    M = len(mk_names)
+    ix.CmT = np.empty((M, 3, 3)); Q = np.empty((M, 3, 3)); tau = np.empty((M, 3))
+    for i, m in enumerate(mk_names):
+        cm = constraints[str(m)]
+        r_m = np.asarray(cm.R(), dtype=np.float64)
+        ix.CmT[i] = r_m.T @ r_root                                 # bipgo.py:213
+        Q[i] = r_root.T @ r_m                                      # bipgo.py:451
+        tau[i] = np.asarray((cm.inv() @ constraints[ix.root]).t(), dtype=np.float64)   # bipgo.py:452
+    ix.qtau = np.einsum("mij,mj->mi", Q, tau)
+    ix.cam_names, ix.ci, ix.time_names, ix.ti = cd.cam_names, cd.ci, cd.time_names, cd.ti
+    ix.tnodes, ix.tnode_of_cam, ix.tnode_of_time = cd.tnodes, cd.tnode_of_cam, cd.tnode_of_time
     return ix
 
 

@@ -597,9 +597,18 @@ class TranslationSolver:
             return self._solve_one_message(maxiter)
         if multi:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
-        n_part, it_launched, s = 0, 0, None
+        n_part, it_launched, s = None, 0, None          # (None: the first iteration)
+
+        # single rank: three launches per iteration instead of four, alpha and the next iteration's head by last-workgroup
+        # hand-overs inside them (vican_cg_iter_fused; bit-identical to the sequence below).  VICAN_CG_FUSED=0: the sequence.
+        fused = (not multi) and getattr(K, "cg_iter_fused", None) is not None and os.environ.get("VICAN_CG_FUSED", "1") != "0"
 
         def one_iteration(n_part):
+            if fused:
+                K.cg_iter_fused(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self.qcpq,
+                                self.rtol, st, first=(n_part is None))
+                return 0
+            n_part = n_part or 0
             K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
             if multi:
                 comm.allreduce(self.qcpq)
@@ -625,7 +634,8 @@ class TranslationSolver:
             if first_burst and self._last_iters is not None:
                 # the same system was solved before (time series, benchmark loop): launch exactly as many iterations
                 # as it took then, plus the one that detects convergence, before the first poll
-                burst = min(max(self._last_iters + 1, 1), 64, maxiter - it_launched)
+                # (the fused iteration detects convergence in the launch that made the last update)
+                burst = min(max(self._last_iters + (0 if fused else 1), 1), 64, maxiter - it_launched)
             first_burst = False
             left = burst
             if it_launched == 0:                                  # the first iteration passes other arguments
@@ -652,6 +662,8 @@ class TranslationSolver:
             if s["done"] or it_launched >= maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
+        if fused and s["done"] == 1 and s["iter"] >= maxiter:
+            s["done"] = 0              # (found by the head that rides with the LAST allowed update: scipy does not test there)
         self._last_iters = int(s["iter"]) if s["done"] == 1 else None
         self.info = dict(cg_iters=s["iter"] if s["done"] else it_launched, converged=s["done"] == 1,
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
