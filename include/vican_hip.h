@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 20            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 21            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -570,12 +570,14 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
                          const double* p_c, double* x_c, double* r_c, const double* p_t,
                          const double* q_t, double* x_t, double* r_t, double* rr_part,
                          int32_t part_cap, vican_cg_state_t* st, void* stream);
-/* Single rank: one iteration in three launches - [vican_cg_begin when first != 0] + vican_cg_sweep + a fold whose LAST
- * workgroup forms alpha once + a step whose last workgroup runs the next iteration's vican_cg_begin (csrc/vican_trans.hip:
- * hand-overs by agent-scope ticket, no workgroup waits for another).  State and vectors after k calls = after k x
- * (vican_cg_iter_local, vican_cg_iter_finish) plus the next call's vican_cg_begin, bit for bit; poll st->done as there.
- * ticket: 256 zeroed bytes owned by the solve, 128-byte aligned (two uint32 tickets on the first cache line, two doubles of hand-over on the second);
- * rr_part >= 1536 doubles.  scipy cg, bipgo.py:477.                                                                    */
+/* Single rank: one CG iteration behind one host call - vican_cg_begin + vican_cg_sweep + a fold that also forms p_t.q_t over
+ * fixed slices (bit-reproducible from run to run: the sweep's own partial depends on the order of its chunk tickets) + the
+ * step.  Same recurrence as (vican_cg_iter_local, vican_cg_iter_finish): iterates agree to the rounding of the differently
+ * grouped p_t.q_t; poll st->done as there.  first: bit 0 = the call that follows vican_cg_init; bit 1 = hand-over mode - the
+ * step's LAST workgroup (agent-scope ticket, no workgroup waits for another) runs the next iteration's vican_cg_begin, three
+ * launches per iteration instead of four (measured slower on large graphs: profiles/r05_cg_tail.txt; every call of a solve
+ * must use the same mode).  ticket: 1024 zeroed bytes owned by the solve, 128-byte aligned (tickets, hand-over words, p.q
+ * partials); rr_part >= 1536 doubles.  scipy cg, bipgo.py:477.                                                            */
 int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
                         double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
                         void* qc_part, double* pq_part, double* qcpq, double rtol, double* rr_part, int32_t part_cap,
@@ -727,6 +729,17 @@ int vican_solve_rot(vican_plan_t* plan, int32_t maxiter, double eig_tol, double*
                     vican_solve_info_t* info, void* stream);
 int vican_solve_trans(vican_plan_t* plan, const double* rc, const double* Rt, double rtol, int64_t maxiter, double* x_c,
                       double* x_t, vican_solve_info_t* info, void* stream);
+/* lsqr_solver="direct" (scipy.sparse.linalg.lsqr, bipgo.py:479-480) behind the same handle: the device-resident LSQR iteration
+ * (vican_lsqr_step: one fused pass over the edges per iteration, every scalar of scipy's loop on the device) with scipy's
+ * stopping tests - atol / btol / conlim / iter_lim as scipy's arguments (0 for iter_lim: 2 n).  bnorm2_true = |b|^2 of the
+ * reference's un-merged right-hand side (vican_amd.frontend.bnorm2), or <= 0 where no (camera, timestep) pair carries more than
+ * one detection (then it equals the merged system's own).  info: scipy's istop / itn / r1norm / arnorm / anorm / acond / xnorm. */
+typedef struct vican_lsqr_info {
+    int32_t itn, istop;
+    double rnorm, arnorm, anorm, acond, xnorm;
+} vican_lsqr_info_t;
+int vican_solve_trans_lsqr(vican_plan_t* plan, const double* rc, const double* Rt, double bnorm2_true, double atol, double btol,
+                           double conlim, int64_t iter_lim, double* x_c, double* x_t, vican_lsqr_info_t* info, void* stream);
 int vican_plan_destroy(vican_plan_t* plan);
 
 #ifdef __cplusplus

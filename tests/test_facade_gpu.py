@@ -83,3 +83,53 @@ def test_bad_arguments_are_refused():
     assert lib.vican_plan_create(0, 1, 1, 0, None, None, None, None, None, None, None, None, None, None, C.byref(plan)) == _lib.ERR_ARG
     assert lib.vican_solve_rot(None, 4, 1e-10, None, None, None, None) == _lib.ERR_ARG
     assert lib.vican_plan_destroy(None) == 0
+
+
+@pytest.mark.parametrize("name,dt", [("g2_small", "float64"), ("g2_small", "float32"), ("g3_medium", "float64"), ("g5_strings", "float64")])
+def test_lsqr_through_the_facade_reproduces_the_reference(name, dt):
+    """vican_solve_trans_lsqr (lsqr_solver="direct", bipgo.py:479-480) behind the plan handle, ctypes alone: translations against
+    the REAL reference's LSQR run with the tolerance of the drop-in test, scipy's istop and iteration count."""
+    g = load_golden(name)
+    exp = expected(g, "direct", dt)
+    if not exp:
+        pytest.skip("golden has no direct/%s run" % dt)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tdt = torch.float32 if dt == "float32" else torch.float64
+    up = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(dev, d).contiguous()
+    row_ptr, col = up(prob.row_ptr, torch.int32), up(prob.col, torch.int32)
+    blk, a = up(prob.blk, tdt), up(prob.a, tdt)
+    w, u, v = up(prob.w, torch.float64), up(prob.u, torch.float64), up(prob.v, torch.float64)
+    Cn, T, E = prob.n_cam, prob.n_time, prob.n_edges
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    plan = C.c_void_p()
+    assert lib.vican_plan_create(Cn, T, E, _lib.STORE_F32 if dt == "float32" else _lib.STORE_F64, p(row_ptr), p(col), p(blk), p(a), p(w), p(u), p(v),
+                                 None, None, stream, C.byref(plan)) == 0, lib.vican_last_error()
+    try:
+        rcs, Rt = torch.empty(3 * Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 9, dtype=torch.float64, device=dev)
+        x_c, x_t = torch.empty(Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 3, dtype=torch.float64, device=dev)
+        assert lib.vican_solve_rot(plan, gc.MAXITER, 1e-10, p(rcs), p(Rt), None, stream) == 0, lib.vican_last_error()
+        Rc_h = np.swapaxes(rcs.cpu().numpy().reshape(Cn, 3, 3), 1, 2)
+        Rt_h = np.swapaxes(Rt.cpu().numpy().reshape(T, 3, 3), 1, 2)
+        info = _lib.LsqrInfo()
+        rc = lib.vican_solve_trans_lsqr(plan, p(rcs), p(Rt), frontend.bnorm2(prob, Rc_h, Rt_h), 1e-6, 1e-6, 1e8, 0, p(x_c), p(x_t), C.byref(info), stream)
+        assert rc == 0, lib.vican_last_error()
+        # a second solve on the same plan (workspace reused) gives the same bits
+        x_c2, x_t2 = torch.empty_like(x_c), torch.empty_like(x_t)
+        assert lib.vican_solve_trans_lsqr(plan, p(rcs), p(Rt), frontend.bnorm2(prob, Rc_h, Rt_h), 1e-6, 1e-6, 1e8, 0, p(x_c2), p(x_t2), None, stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(x_c, x_c2) and torch.equal(x_t, x_t2)
+    finally:
+        assert lib.vican_plan_destroy(plan) == 0
+    pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
+    pos.update({str(s) + "_0": x_t.cpu().numpy()[i] for i, s in enumerate(prob.time_names)})
+    t = np.stack([pos[str(k)] for k in exp["keys"]])
+    t_err = float(np.linalg.norm(t - exp["t"], axis=1).max())
+    print("%s %s LSQR through the facade: trans %.2e m, itn %d, istop %d" % (name, dt, t_err, info.itn, info.istop))
+    assert t_err < (2e-6 if dt == "float64" else 5e-4), t_err
+    assert info.istop in (1, 2)
+    if "lsqr_iters" in exp:
+        assert abs(info.itn - int(exp["lsqr_iters"])) <= 2

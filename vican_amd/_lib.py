@@ -178,6 +178,7 @@ PROTOTYPES = {
     "vican_plan_describe": (C.c_int, [_vp, _G]),
     "vican_solve_rot": (C.c_int, [_vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_solve_trans": (C.c_int, [_vp, _vp, _vp, _f64, _i64, _vp, _vp, _vp, _vp]),
+    "vican_solve_trans_lsqr": (C.c_int, [_vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _vp, _vp, _vp, _vp]),
     "vican_plan_destroy": (C.c_int, [_vp]),
 }
 
@@ -187,6 +188,12 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("sweeps", C.c_int32), ("lanczos_steps", C.c_int32), ("restarts", C.c_int32),
                 ("evals", C.c_double * 5), ("eig_resid", C.c_double), ("cg_iters", C.c_int32), ("cg_converged", C.c_int32),
                 ("cg_relres", C.c_double)]
+
+class LsqrInfo(C.Structure):
+    """Mirror of ``vican_lsqr_info_t``."""
+    _fields_ = [("itn", C.c_int32), ("istop", C.c_int32), ("rnorm", C.c_double), ("arnorm", C.c_double), ("anorm", C.c_double),
+                ("acond", C.c_double), ("xnorm", C.c_double)]
+
 
 # include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
 TEST_PROTOTYPES = {

@@ -72,6 +72,11 @@ struct vican_plan {
     vican_cg_state_t* st = nullptr;
     uint32_t* cg_ticket = nullptr;
     double* status_host = nullptr;      // pinned
+    // LSQR workspace (lsqr_solver="direct"): its own allocation, made by the first vican_solve_trans_lsqr (24 bytes per edge slot)
+    unsigned char* lsqr_base = nullptr;
+    double *lu = nullptr, *lsw = nullptr, *lpart = nullptr, *lslab = nullptr, *lv_c = nullptr, *lw_c = nullptr, *lv_t = nullptr, *lw_t = nullptr,
+           *lz_t = nullptr, *lacc = nullptr, *lpart2 = nullptr, *lwp_c = nullptr, *lwp_t = nullptr, *ls2 = nullptr;
+    vican_lsqr_state_t* lst = nullptr;
 };
 
 namespace {
@@ -201,7 +206,7 @@ size_t carve(vican_plan* P, size_t n_row0) {
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
         P->pq_part = A.take<double>(std::max(P->g.n_wg, 1)); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
         P->st = (vican_cg_state_t*)A.take<double>(19);
-        P->cg_ticket = A.take<uint32_t>(64);         // (vican_cg_iter_fused: two tickets + two hand-over doubles, zeroed with the arena)
+        P->cg_ticket = A.take<uint32_t>(256);        // (vican_cg_iter_fused: tickets, hand-over words, p.q partials; zeroed with the arena)
     }
     return A.used + 256;
 }
@@ -236,7 +241,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (hipMalloc((void**)&P->ar.base, bytes) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc of %zu bytes failed", bytes));
     P->ar.size = bytes;
     carve(P, c0.size());
-    if (hipHostMalloc((void**)&P->status_host, 64 * sizeof(double)) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipHostMalloc failed"));
+    if (hipHostMalloc((void**)&P->status_host, 2048 * sizeof(double)) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipHostMalloc failed"));
     if (hipMemsetAsync(P->ar.base, 0, bytes, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: memset failed"));
     if (hipMemcpyAsync(P->chunk_row0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed"));
     P->g.blk = P->blk; P->g.idx = (const uint32_t*)P->idx; P->g.chunk_row0 = P->chunk_row0;
@@ -285,6 +290,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
 extern "C" int vican_plan_destroy(vican_plan_t* P) {
     if (!P) return VICAN_OK;
     if (P->ar.base) hipFree(P->ar.base);
+    if (P->lsqr_base) hipFree(P->lsqr_base);
     if (P->status_host) hipHostFree(P->status_host);
     delete P;
     return VICAN_OK;
@@ -414,10 +420,124 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
         if (h.done || launched >= maxiter) break;
         burst = std::min(2 * burst, 64);
     }
-    if (h.done == 1 && h.iter >= maxiter) h.done = 0;        // (found by the head that rides with the LAST allowed update: scipy does not test there)
     inf.cg_iters = h.done == 1 ? h.iter : (int32_t)std::min<long long>(launched, 2147483647LL); inf.cg_converged = h.done == 1;
     inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;
     if (info) *info = inf;
     if (h.done != 1) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans: CG did not converge in %lld iterations (scipy exit_code != 0, bipgo.py:478)", (long long)maxiter);
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// translation stage, lsqr_solver="direct": scipy.sparse.linalg.lsqr on the incidence system (bipgo.py:479-480) - the schedule
+// of vican_amd/solver.py LsqrTranslationSolver._solve_device on one rank: every scalar of scipy's loop in a device
+// vican_lsqr_state_t, ONE fused pass over the edges per iteration (vican_lsqr_step), the host polls `done` between bursts.
+// The iteration runs on the MERGED system J~ p = b~ (same normal equations, same iterates); bnorm2_true = |b|^2 of the
+// reference's un-merged right-hand side lets the residual norms - and with them scipy's stopping tests - be the reference's
+// (<= 0: the merged system's own |b~|^2, exact when no (camera, timestep) pair carries more than one marker).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+int lsqr_workspace(vican_plan* P) {
+    if (P->lsqr_base) return VICAN_OK;
+    const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, C = P->C, T1 = std::max(P->T, 1);
+    Arena A;
+    auto carve = [&]() {
+        A.used = 0;
+        P->lu = A.take<double>(3 * nslot); P->lsw = A.take<double>(nslot); P->lpart = A.take<double>(std::max<size_t>(P->g.n_wg, 1024));
+        P->lslab = A.take<double>((size_t)std::max(P->g.n_wg, 1) * 6 * C);
+        P->lv_c = A.take<double>(3 * C); P->lw_c = A.take<double>(3 * C); P->lv_t = A.take<double>(3 * T1); P->lw_t = A.take<double>(3 * T1);
+        P->lz_t = A.take<double>(3 * T1); P->lacc = A.take<double>(3 * C + 2); P->lpart2 = A.take<double>(1025);
+        P->lwp_c = A.take<double>(1024); P->lwp_t = A.take<double>(1024); P->ls2 = A.take<double>(4);
+        P->lst = (vican_lsqr_state_t*)A.take<double>((sizeof(vican_lsqr_state_t) + 7) / 8);
+        return A.used + 256;
+    };
+    const size_t bytes = carve();
+    if (hipMalloc((void**)&P->lsqr_base, bytes) != hipSuccess) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: hipMalloc of %zu bytes failed", bytes);
+    A.base = P->lsqr_base; A.size = bytes;
+    carve();
+    return VICAN_OK;
+}
+}  // namespace
+
+extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const double* Rt, double bnorm2_true, double atol, double btol,
+                                      double conlim, int64_t iter_lim, double* x_c, double* x_t, vican_lsqr_info_t* info, void* stream) {
+    if (!P || !rc || !Rt || !x_c || !x_t || !(atol >= 0) || !(btol >= 0)) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: bad argument");
+    if (!P->have_t) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: the plan was created without translation arrays (w, u, v)");
+    CK(lsqr_workspace(P));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = P->C, T = P->T, C3 = 3 * C;
+    if (iter_lim <= 0) iter_lim = 2LL * 3 * (C + T);              // scipy's default: 2 n
+    const double ctol = conlim > 0 ? 1.0 / conlim : 0.0;
+    const double smax = std::sqrt(P->wmax), n_add = P->n_add;
+    const int lo_bits = fix2_lo_bits(n_add);
+    vican_lsqr_info_t inf{};
+    auto zero = [&](double* p, size_t n) { return hipMemsetAsync(p, 0, n * 8, s) == hipSuccess; };
+    if (!zero(P->lv_c, C3) || !zero(P->lw_c, C3) || !zero(x_c, C3) || !zero(P->lv_t, 3 * (size_t)T) || !zero(P->lw_t, 3 * (size_t)T) ||
+        !zero(x_t, 3 * (size_t)T) || !zero(P->lz_t, 3 * (size_t)T) || !zero(P->lacc, C3 + 2) || !zero(P->lpart2, 1025) || !zero(P->ls2, 4))
+        return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: memset failed");
+    auto read = [&](const double* dev, double* host, size_t n) {
+        if (hipMemcpyAsync(P->status_host + 32, dev, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return false;
+        std::memcpy(host, P->status_host + 32, n * 8);
+        return true;
+    };
+    // u~_1 = b~ (unnormalised), beta_1 = |b~|
+    CK(vican_lsqr_init_u(&P->g, P->w, P->u, P->v, rc, Rt, P->lu, P->lsw, P->lpart, P->ls2, stream));
+    double h4[4];
+    if (!read(P->ls2, h4, 1)) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: read failed");
+    const double beta = std::sqrt(h4[0]);
+    const double c2 = bnorm2_true > 0 ? std::max(bnorm2_true - beta * beta, 0.0) : 0.0;
+    const double bnorm = std::sqrt(beta * beta + c2);
+    if (info) *info = inf;
+    if (beta == 0.0) return VICAN_OK;                              // x = 0 (scipy returns at once)
+    // first bidiagonalisation step alfa_1 v_1 = J~^T u_1: the fused pass with coef = -1 on v = 0
+    vican_lsqr_state_t st{};
+    double inv;
+    st.coef = -1.0; st.smax = smax; st.n_add = n_add; st.lo_bits = lo_bits;
+    st.qscale = fix_scale(smax * beta, n_add, &inv, 49); st.qinv = inv;
+    HIPCK(hipMemcpyAsync(P->lst, &st, sizeof(st), hipMemcpyHostToDevice, s), "vican_solve_trans_lsqr");
+    CK(vican_lsqr_step(&P->g, P->lsw, P->lu, P->lv_c, P->lv_t, P->lz_t, P->lslab, P->lpart, P->lacc, P->lst, stream));
+    int nb = vican_lsqr_nodes(C, T, P->lz_t, P->lacc, P->lv_t, P->lv_c, P->lpart2, P->lst, stream);
+    if (nb < 0) return nb;
+    std::vector<double> hp(1025);
+    if (!read(P->lpart2, hp.data(), 1025)) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: read failed");
+    double nv2 = 0.0;
+    for (int i = 0; i < nb; ++i) nv2 += hp[i];
+    const double alfa = std::sqrt(nv2 + hp[1024]);
+    if (alfa == 0.0) return VICAN_OK;
+    // v_1 = v / alfa, w_1 = v_1, x = 0
+    CK(vican_lsqr_update(C3, 1.0 / alfa, 0.0, 0.0, P->lv_c, P->lw_c, x_c, P->lpart, P->ls2 + 3, stream));
+    CK(vican_lsqr_update(3LL * T, 1.0 / alfa, 0.0, 0.0, P->lv_t, P->lw_t, x_t, P->lpart, P->ls2 + 1, stream));
+    st = vican_lsqr_state_t{};
+    st.alfa = alfa; st.beta = beta; st.rhobar = alfa; st.phibar = beta; st.cs2 = -1.0; st.c2 = c2; st.bnorm = bnorm; st.atol = atol; st.btol = btol;
+    st.ctol = ctol; st.coef = alfa / beta; st.smax = smax; st.n_add = n_add; st.lo_bits = lo_bits;
+    st.qscale = fix_scale(smax * (2.0 * smax + alfa), n_add, &inv, 49); st.qinv = inv;
+    st.iter_lim = (int32_t)std::min<long long>(iter_lim, 2147483647LL);
+    HIPCK(hipMemcpyAsync(P->lst, &st, sizeof(st), hipMemcpyHostToDevice, s), "vican_solve_trans_lsqr");
+    HIPCK(hipStreamSynchronize(s), "vican_solve_trans_lsqr");     // (st is a stack object)
+    const double* wpart_t = P->ls2 + 1; const double* wpart_c = P->ls2 + 3;
+    int n_wt = 1, n_wc = 1, burst = 8;
+    long long launched = 0;
+    vican_lsqr_state_t hst{};
+    for (;;) {
+        const long long todo = std::min<long long>(burst, std::max<long long>(iter_lim - launched, 1));
+        for (long long i = 0; i < todo; ++i, ++launched) {
+            CK(vican_lsqr_step(&P->g, P->lsw, P->lu, P->lv_c, P->lv_t, P->lz_t, P->lslab, P->lpart, P->lacc, P->lst, stream));
+            nb = vican_lsqr_nodes(C, T, P->lz_t, P->lacc, P->lv_t, P->lv_c, P->lpart2, P->lst, stream);
+            if (nb < 0) return nb;
+            CK(vican_lsqr_scalars(C, P->lacc, P->lpart2, nb, nullptr, wpart_t, n_wt, wpart_c, n_wc, nullptr, P->lst, stream));
+            n_wc = vican_lsqr_update_st(C3, P->lv_c, P->lw_c, x_c, P->lwp_c, 0, P->lst, stream);
+            if (n_wc < 0) return n_wc;
+            n_wt = vican_lsqr_update_st(3LL * T, P->lv_t, P->lw_t, x_t, P->lwp_t, 1, P->lst, stream);
+            if (n_wt < 0) return n_wt;
+            wpart_t = P->lwp_t; wpart_c = P->lwp_c;
+        }
+        HIPCK(hipMemcpyAsync(P->status_host + 32, P->lst, sizeof(hst), hipMemcpyDeviceToHost, s), "vican_solve_trans_lsqr");
+        HIPCK(hipStreamSynchronize(s), "vican_solve_trans_lsqr");
+        std::memcpy(&hst, P->status_host + 32, sizeof(hst));
+        if (hst.done || launched >= iter_lim) break;
+        burst = std::min(2 * burst, 64);
+    }
+    inf.itn = hst.itn; inf.istop = hst.istop; inf.rnorm = hst.rnorm; inf.arnorm = hst.arnorm; inf.anorm = hst.anorm; inf.acond = hst.acond;
+    inf.xnorm = hst.xnorm;
+    if (info) *info = inf;
     return VICAN_OK;
 }

@@ -902,40 +902,75 @@ __device__ __forceinline__ double ritz_readlane(double v, int lane) {   // lane:
 __device__ __forceinline__ double ritz_get(double v0, double v1, int i) { return i < 64 ? ritz_readlane(v0, i) : ritz_readlane(v1, i - 64); }
 // number of eigenvalues of the symmetric tridiagonal (d, e) below sigma (LAPACK dlaebz recurrence); element i of d and of
 // e^2 lives in lane i % 64's registers (NS slots: n <= 64 NS) and is read with v_readlane: no memory latency in the chain
-// Round 5: the DIVISION-FREE form.  The ratio recurrence q_i = d_i - sigma - e_{i-1}^2 / q_{i-1} (LAPACK dlaebz) puts a
-// reciprocal (v_rcp_f64 + a Newton step) and two dependent multiply-adds on the serial chain: 175 cycles per element measured
-// (bisection 20 us at n = 24, 11 rounds).  The characteristic polynomials themselves, p_i = (d_i - sigma) p_{i-1} -
-// e_{i-1}^2 p_{i-2} (q_i = p_i / p_{i-1}), need ONE dependent multiply-add per element; the count of eigenvalues below sigma
-// is the number of sign changes along p_0 = 1, p_1, ..., p_n (a zero counts as a change, as q_i <= pivmin does above).
-// Growth is bounded by rescaling the pair (p_i, p_{i-1}) with an exact power of two every four elements - |d - sigma| and e^2
-// are bounded by the Gershgorin radius r and r^2, so four elements multiply the pair by at most (2 r)^4 (r < 1e60 is safe
-// in double) - and a pair that underflows to (0, 0) cannot occur: p_i and p_{i-1} have no common zero and are rescaled to
-// |p| in [1/2, 1) before they can shrink.  The validation of the Ritz pairs against T itself (below) stays as the net.
+// Round 5 measured two division-free forms of this count (the characteristic polynomials p_i = (d_i - sigma) p_{i-1} -
+// e_{i-1}^2 p_{i-2} with power-of-two rescaling, sign changes counted with boolean logic or with integer operations on the
+// high words): both SLOWER than the ratio recurrence below - bisection at n = 24: 32.8 / 26.0 against 20.1 us
+// (profiles/r05_ritz_bench.txt).  The chain is not bound by the reciprocal but by the four v_readlane per element that feed it.
 template <int NS>
 __device__ __forceinline__ int ritz_sturm(const double* d, const double* e2, int n, double sigma, double pivmin) {
-    (void)pivmin;
-    double pm = 1.0, p = ritz_readlane(d[0], 0) - sigma;        // p_{i-1}, p_i
-    int cnt = p > 0.0 ? 0 : 1;
-    bool neg = !(p > 0.0);                                       // sign attributed to p_i (zero: the opposite of p_{i-1}'s)
-    if (p == 0.0) p = -1e-300;
+    double q = ritz_readlane(d[0], 0) - sigma;
+    int cnt = 0;
+    if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
     for (int i = 1; i < n; ++i) {
         const double di = NS == 1 ? ritz_readlane(d[0], i) : ritz_get(d[0], d[NS - 1], i);
         const double ei = NS == 1 ? ritz_readlane(e2[0], i - 1) : ritz_get(e2[0], e2[NS - 1], i - 1);
-        double pn = fma(di - sigma, p, -(ei * pm));
-        // sign of p_i: its own if non-zero, else the opposite of p_{i-1}'s - and an exact zero is replaced by a tiny value of
-        // that sign (the pivmin of the ratio form), so that a shift that hits an eigenvalue of a leading block behind a
-        // vanishing e (deflated T) does not zero the rest of the sequence
-        const bool nneg = pn != 0.0 ? pn < 0.0 : !neg;
-        if (pn == 0.0) pn = nneg ? -1e-300 : 1e-300;
-        cnt += nneg != neg ? 1 : 0;
-        neg = nneg;
-        pm = p; p = pn;
-        if ((i & 3) == 3) {                                     // exact power-of-two rescaling of the pair
-            const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(p), fabs(pm)));
-            p = ldexp(p, -ex); pm = ldexp(pm, -ex);
-        }
+        q = di - sigma - ei * ritz_rcp(q);
+        if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
     }
     return cnt;
+}
+
+// Householder tridiagonalisation of an n x n (n <= NM <= 32) symmetric matrix by ONE wavefront, everything in registers:
+// lane i < 32 holds row i of A, lane 32 + i row i of Q (= I on entry); the Householder vector lives one element per lane and
+// element j is read with v_readlane (j is a compile-time constant of the unrolled loops: v_j = 0 for j <= k makes every
+// sum and update run over all NM columns without predicates); element k of a lane's row - a run-time index - comes out of
+// an NM-way select.  A first single-wavefront version kept the rows in LDS and read one element per loop trip: one LDS
+// round trip per element, 51 us at n = 24 against 34 for the cooperative form (profiles/r05_ritz_bench.txt).
+// On return A (rows > k of the trailing blocks: the tridiagonal part that the caller reads) and Q are back in LDS, fd / fe hold
+// the first n - 2 diagonal / sub-diagonal entries.
+template <int NM>
+__device__ __forceinline__ void ritz_house_regs(double* A, double* V, const int ld, const int n, double* fd, double* fe, const int ln) {
+    const bool arow = ln < 32;
+    const int ri = ln & 31;
+    const bool rowlive = ri < n;
+    double* rowp = (arow ? A : V) + ri * ld;
+    double row[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) row[j] = (rowlive && j < n) ? rowp[j] : 0.0;
+    for (int k = 0; k + 2 < n; ++k) {
+        double sel = 0.0;                                        // element k of this lane's row
+#pragma unroll
+        for (int j = 0; j < NM; ++j) sel = (j == k) ? row[j] : sel;
+        const double akk = ritz_readlane(sel, k), x0 = ritz_readlane(sel, k + 1);     // A[k][k], A[k+1][k] (lanes k, k + 1 < 32)
+        const double aik = (arow && ri >= k + 2) ? sel : 0.0;   // column k below the sub-diagonal
+        const double sg = wave_allsum_dpp(aik * aik);
+        double tau = 0.0, alpha = x0, v0 = 0.0;
+        if (sg > 0.0) {                                          // (no reflection when the tail of the column is exactly zero)
+            const double mu = sqrt(x0 * x0 + sg);
+            alpha = x0 <= 0.0 ? mu : -mu;
+            v0 = x0 - alpha;
+            tau = 2.0 / (v0 * v0 + sg);
+        }
+        if (ln == 0) { fd[k] = akk; fe[k] = alpha; }
+        if (tau == 0.0) continue;                                // (uniform)
+        double vi = (arow && ri == k + 1) ? v0 : aik;           // v_i in lane i: 0 above k + 1
+        vi = __shfl(vi, ri, 64);                                 // ... and in lane 32 + i
+        const bool live = rowlive && (!arow || ri > k);
+        double acc = 0.0;                                        // p_i = tau (A v)_i (lanes < 32, rows > k), g_i = tau (Q v)_i (lanes >= 32)
+#pragma unroll
+        for (int j = 0; j < NM; ++j) acc += row[j] * ritz_readlane(vi, j);
+        acc = live ? acc * tau : 0.0;
+        const double K = 0.5 * tau * wave_allsum_dpp(arow ? acc * vi : 0.0);
+        const double wi = arow ? acc - K * vi : 0.0;             // w_i (lanes < 32)
+        const double fa = arow ? vi : acc, fb = arow ? wi : 0.0; // row -= fa w_j + fb v_j (A)  /  g_i v_j (Q: fa = g_i on v_j)
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            const double vj = ritz_readlane(vi, j), wj = ritz_readlane(wi, j);
+            row[j] -= arow ? (fa * wj + fb * vj) : (fa * vj);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NM; ++j) if (rowlive && j < n) rowp[j] = row[j];
 }
 
 __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ HB, int stride, int hw, int steps, int flags,
@@ -1005,53 +1040,15 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         double* ys = zt + 3 * N;                // [3][N] ... and of T
         const int ln = tid & 63, wv = tid >> 6, nwv = B >> 6;
         // Householder tridiagonalisation T = Q^T A Q (A overwritten, Q accumulated in V = I).
-        // n <= 32 (up to 10 Lanczos steps - every check of the capture-sized graphs): ONE wavefront does the whole reduction,
-        // lane i < 32 owning row i of A and lane 32 + i row i of Q, the Householder vector in registers (element j read with
-        // v_readlane), LDS operations of one wavefront in program order - no workgroup barrier anywhere.  The three barriers
-        // per step of the cooperative form below (16 wavefronts) were 1.5 us per step, 34 us of an 82 us check at n = 24.
-        // Same arithmetic per element (the sums over j run in the same index order; the 8-lane split of the cooperative
-        // matrix-vector products groups them differently: eigenpairs agree to rounding, both are validated against T below).
+        // n <= 32 (up to 10 Lanczos steps - every check of the capture-sized graphs): ONE wavefront does the whole reduction
+        // out of REGISTERS (ritz_house_regs): no workgroup barrier, no LDS round trip per element.  The three barriers per step
+        // of the cooperative form below (16 wavefronts) are 1.5 us per step, 34 us of an 82 us check at n = 24.
+#ifdef RITZ_NO_WAVE1
+        if (false) {
+#else
         if (n <= 32) {
-          if (wv == 0) {
-            const bool arow = ln < 32;
-            const int ri = ln & 31;                             // row of A (lanes 0..31) / of Q (lanes 32..63)
-            double* rowp = (arow ? A : V) + ri * ld;
-            for (int k = 0; k + 2 < n; ++k) {
-                const double aik = (arow && ri > k && ri < n) ? rowp[k] : 0.0;                 // column k below the diagonal
-                double sg = (ri >= k + 2) ? aik * aik : 0.0;
-                sg = wave_allsum_dpp(sg);
-                const double x0 = ritz_readlane(aik, k + 1);
-                double tau = 0.0, alpha = x0, v0 = 0.0;
-                if (sg > 0.0) {                                  // (no reflection when the tail of the column is exactly zero)
-                    const double mu = sqrt(x0 * x0 + sg);
-                    alpha = x0 <= 0.0 ? mu : -mu;
-                    v0 = x0 - alpha;
-                    tau = 2.0 / (v0 * v0 + sg);
-                }
-                if (ln == 0) { fd[k] = A[k * ld + k]; fe[k] = alpha; }
-                if (tau == 0.0) continue;                        // (uniform)
-                // v_i in lane i (and 32 + i): 0 above k + 1
-                double vi = ri == k + 1 ? v0 : (ri >= k + 2 ? aik : 0.0);
-                vi = __shfl(vi, ri, 64);                         // lanes 32.. take the value of their row's lane
-                // p = tau A v (rows > k), g = tau Q v (all rows)
-                double acc = 0.0;
-                const bool live = ri < n && (!arow || ri > k);
-                for (int j = k + 1; j < n; ++j) {
-                    const double vj = ritz_readlane(vi, j);
-                    acc += (live ? rowp[j] : 0.0) * vj;
-                }
-                acc *= tau;                                      // p_i (lanes < 32), g_i (lanes >= 32)
-                double kk = arow ? acc * vi : 0.0;               // K = tau / 2 p . v
-                kk = wave_allsum_dpp(kk);
-                const double K = 0.5 * tau * kk;
-                const double wi = arow ? acc - K * vi : 0.0;     // w_i (lanes < 32)
-                // A -= v w^T + w v^T on the trailing block, Q -= g v^T on its columns
-                for (int j = k + 1; j < n; ++j) {
-                    const double vj = ritz_readlane(vi, j), wj = ritz_readlane(wi, j);
-                    if (live) rowp[j] -= arow ? (vi * wj + wi * vj) : (acc * vj);
-                }
-            }
-          }
+#endif
+          if (wv == 0) { if (n <= 16) ritz_house_regs<16>(A, V, ld, n, fd, fe, ln); else ritz_house_regs<32>(A, V, ld, n, fd, fe, ln); }
           __syncthreads();
         } else
         for (int k = 0; k + 2 < n; ++k) {

@@ -1289,8 +1289,7 @@ extern "C" int vican_slab_reduce(const double* part, int32_t n_slab, int64_t n, 
 
 // slabs hold planes [ncomp][C]; the output is the row-major camera vector [C][ncomp].
 // 1024 threads = 64 elements x 16 slab groups (256 slabs -> 16 loads per thread in flight).
-// COLS columns per workgroup (64 / 32 / 16: 1024 / COLS groups of lanes stride over the slabs): a fold of 9000 columns in
-// 64-column workgroups kept 141 of the 256 compute units busy, 8.8 us per launch on the stress graph (14 launches per solve)
+// COLS columns per workgroup (1024 / COLS groups of lanes stride over the slabs)
 template <int COLS>
 __global__ __launch_bounds__(1024) void slab_reduce_fx_kernel(const int32_t* __restrict__ gate, const long long* __restrict__ part, int n_slab, long long n,
                                                               int ncomp, double scale, const double* __restrict__ pa,
@@ -1320,7 +1319,9 @@ extern "C" int vican_slab_reduce_fx(const void* part, int32_t n_slab, int32_t n_
     const long long n = (long long)n_cam * ncomp;
 #define SRF_LAUNCH(COLS_) hipLaunchKernelGGL(slab_reduce_fx_kernel<COLS_>, dim3((unsigned)((n + COLS_ - 1) / COLS_)), dim3(1024), 0, (hipStream_t)stream, \
                                              g_vican_gate, (const long long*)part, n_slab, n, ncomp, scale, pa, pb, out)
-    if (n >= 64 * 256 || n_slab < 32) SRF_LAUNCH(64); else if (n >= 32 * 256 || n_slab < 64) SRF_LAUNCH(32); else SRF_LAUNCH(16);
+    // (64-column workgroups always: 32-column ones measured 9.0 against 8.8 us on the stress graph's 256 slabs x 9000 columns, and the
+    //  CG fold 21.9 against 9.7 us with 16 columns - narrow pieces of slabs that lie far apart)
+    SRF_LAUNCH(64);
 #undef SRF_LAUNCH
     LAUNCH_CHECK("vican_slab_reduce_fx");
     return VICAN_OK;

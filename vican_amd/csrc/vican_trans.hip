@@ -1142,7 +1142,9 @@ __global__ __launch_bounds__(1024) void cg_fold_kernel(const long long* __restri
         }
     }
 }
-static inline int cg_fold_cols(long long n, int n_slab) { return (n >= 64 * 256 || n_slab < 32) ? 64 : ((n >= 32 * 256 || n_slab < 64) ? 32 : 16); }
+// (measured on the stress graph, 256 slabs x 3000 columns: 64-column workgroups 9.7 us, 16-column ones 21.9 us - 128-byte pieces
+//  of 256 slabs 48 KB apart; the narrower instantiations stay for tests)
+static inline int cg_fold_cols(long long n, int n_slab) { (void)n; (void)n_slab; return 64; }
 
 extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                              const vican_cg_state_t* st, void* stream) {
@@ -1158,13 +1160,16 @@ extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam,
 }
 
 // ---------------------------------------------------------------------------
-// Single-rank iteration in THREE launches instead of four (begin, sweep, fold, step): the tail of large graphs was 32 us of
-// a 102 us iteration on the stress graph - five-to-thirteen-microsecond launches and the gaps between them.
+// Single-rank iteration in THREE launches instead of four (begin, sweep, fold, step), bit-reproducible from run to run:
 //   sweep                      (unchanged)
-//   cg_fold2  = cg_fold + the scalar head of cg_step: the workgroup that finishes LAST (an agent-scope ticket) sums the p.q
-//               partials, forms p_c.q_c and alpha ONCE (cg_step derived them again in each of its ~300 workgroups)
-//   cg_step2  = cg_step with alpha from the state + cg_begin of the NEXT iteration by the workgroup that finishes last
-// No workgroup ever waits for another one (no spin, nothing to co-schedule): a hand-over goes to whoever draws the last
+//   cg_fold2  = cg_fold + partials of p_t.q_t over FIXED slices (the sweep's own partial depends on the order in which its
+//               wavefronts drew their chunk tickets: the only sum of the iteration that was not reproducible)
+//   cg_step2  = cg_step (alpha by every workgroup for itself) + cg_begin of the NEXT iteration by the workgroup that finishes last
+// Measured on the stress graph (profiles/r05_cg_tail.txt): the tail kernels are bound by their own dependent memory round
+// trips, not by launch gaps (1.3 us each) - a first version that also formed alpha once, in the fold's last workgroup, was
+// SLOWER (fold 9.7 -> 14.7 us, and nothing of the step's 10 us went away); what made the tail shorter was staging the
+// camera-side loops (cg_cam_dot / cg_cam_update: cg_begin 9.4 -> 8.2 us, cg_step 13.3 -> 10.6 us).
+// No workgroup ever waits for another one (no spin, nothing to co-schedule): the hand-over goes to whoever draws the last
 // ticket.  What crosses workgroups inside a launch travels as agent-scope (sc1) stores, every storing wave drains its stores
 // (s_waitcnt vmcnt(0)) in front of the workgroup barrier that precedes the ticket, and the last workgroup reads with
 // agent-scope loads after its ticket has returned (MI355X guide, inter-workgroup visibility: per-XCD L2s are not coherent,
@@ -1198,72 +1203,44 @@ __device__ __forceinline__ bool cg_last_arrival(unsigned int* ticket, unsigned i
 // stress graph; the single-rank CG is bit-reproducible from run to run.
 template <int COLS>
 __global__ __launch_bounds__(1024) void cg_fold2_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
-                                                        const double* __restrict__ p_t, const double* __restrict__ q_t, long long n_t,
-                                                        double* pq_part, double* qcpq,
-                                                        const double* __restrict__ deg_c, const double* __restrict__ p_c,
-                                                        vican_cg_state_t* st, unsigned int* ticket) {
+                                                        const double* __restrict__ p_t, const double* __restrict__ q_t, long long n_t, int n_pq,
+                                                        double* __restrict__ pq_part, double* __restrict__ qcpq,
+                                                        const vican_cg_state_t* __restrict__ st) {
     __shared__ long long sh[3][1024];
     __shared__ double red[16];
     if (st->done) return;
     const long long n = 3LL * n_cam;
     const int lob = st->lo_bits;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    {
+    if ((long long)blockIdx.x * COLS < n) {                    // (workgroups beyond the columns only take a slice of p_t.q_t)
         long long t, b, l, i; bool owner;
         cg_fold_columns<COLS>(part, n_slab, n, lob, sh, t, b, l, i, owner);
         if (owner) {
             const long long q = i / n_cam, cam = i % n_cam;
-            cg_st(&qcpq[cam * 3 + q], fix3_value(t, b, l, lob, st->qinv));
+            qcpq[cam * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
         }
     }
-    {   // this workgroup's slice of p_t . q_t
+    if ((int)blockIdx.x < n_pq) {   // this workgroup's slice of p_t . q_t (n_pq slices: enough workgroups for long captures of few cameras)
         double s = 0.0;
 #pragma unroll 4
-        for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n_t; i += (long long)gridDim.x * 1024) s += p_t[i] * q_t[i];
+        for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n_t; i += (long long)n_pq * 1024) s += p_t[i] * q_t[i];
         s = wave_sum(s);
         if (e == 0) red[grp] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int k = 0; k < 16; ++k) t += red[k];
-            cg_st(&pq_part[blockIdx.x], t);
+            pq_part[blockIdx.x] = t;
         }
-        __syncthreads();
-    }
-    if (!cg_last_arrival(ticket, gridDim.x)) return;
-    // ---- the last workgroup: p.q of the timestep side (fixed order, as cg_fold), p_c.q_c and alpha (as cg_step) ----
-    double* pq = (double*)&sh[0][0];
-    double pq_time = 0.0;
-    const int n_pq = (int)gridDim.x;                             // one partial per workgroup of this launch, in workgroup order
-    for (int k0 = 0; k0 < n_pq; k0 += 1024) {
-        const int k = k0 + threadIdx.x;
-        pq[threadIdx.x] = k < n_pq ? cg_ld<true>(pq_part + k) : 0.0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int m = n_pq - k0 < 1024 ? n_pq - k0 : 1024;
-            for (int j = 0; j < m; ++j) pq_time += pq[j];
-        }
-        __syncthreads();
-    }
-    // (threads 0..255 in cg_step's mapping; the other waves add zeros)
-    double sdot = 0.0;
-    if (threadIdx.x < 256) sdot = cg_cam_dot<true>((int)n, deg_c, p_c, qcpq);
-    sdot = wave_sum(sdot);
-    if (threadIdx.x < 256 && e == 0) red[grp] = sdot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double pqc = 0.0;
-        for (int k = 0; k < 4; ++k) pqc += red[k];
-        const double pqt = pq_time + pqc;
-        qcpq[n] = pq_time;
-        st->pq_time = pq_time; st->pq = pqt; st->alpha = st->rho / pqt;
     }
 }
 
+template <bool HANDOVER>
 __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, const double* __restrict__ deg_c,
                                                        const double* __restrict__ qc_sum, double* p_c, double* x_c, double* r_c,
                                                        const double* __restrict__ p_t, const double* __restrict__ q_t,
                                                        double* __restrict__ x_t, double* __restrict__ r_t, double* rr_part,
+                                                       const double* __restrict__ pq_part, int n_pq,
                                                        double rtol, double n_add, vican_cg_state_t* st, unsigned int* ticket,
                                                        double* hand) {
     __shared__ double red[8];
@@ -1271,7 +1248,27 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
     __shared__ int sh_go;
     if (st->done) return;
     const int nc = 3 * n_cam;
-    const double alpha = st->alpha;                        // (cg_fold2 of this iteration: a launch ago)
+    // alpha = rho / (p_t.q_t + p_c.q_c), by every workgroup for itself from the same numbers in the same order (as cg_step):
+    // the partials of p_t.q_t that the fold's workgroups left (fixed slices, workgroup order) and the camera part
+    __shared__ double sh_alpha;
+    {
+        double tq = 0.0;
+        for (int k = threadIdx.x; k < n_pq; k += 256) tq += pq_part[k];     // (n_pq <= 192: at most one term per thread)
+        __shared__ double pqs[256];
+        pqs[threadIdx.x] = tq;
+        const double sdot = cg_cam_dot<false>(nc, deg_c, p_c, qc_sum);
+        const double pqc = block_sum(sdot, red);           // (its barriers also publish pqs)
+        if (threadIdx.x == 0) {
+            double pq_time = 0.0;
+            const int m = n_pq < 256 ? n_pq : 256;
+            for (int k = 0; k < m; ++k) pq_time += pqs[k];
+            const double pq = pq_time + pqc;
+            sh_alpha = st->rho / pq;
+            if (blockIdx.x == 0) { st->pq_time = pq_time; st->pq = pq; st->alpha = sh_alpha; }
+        }
+        __syncthreads();
+    }
+    const double alpha = sh_alpha;
     const int nb = (int)gridDim.x - 1;                     // blocks of the time side
     if ((int)blockIdx.x < nb) {
         double rr = 0.0, m = 0.0, mp = 0.0;
@@ -1291,29 +1288,34 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
         if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; red[4 + (threadIdx.x >> 6)] = mp; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            cg_st(&rr_part[blockIdx.x], t); cg_st(&rr_part[CG_PARTS + blockIdx.x], fmax(fmax(red[0], red[1]), fmax(red[2], red[3])));
-            cg_st(&rr_part[2 * CG_PARTS + blockIdx.x], fmax(fmax(red[4], red[5]), fmax(red[6], red[7])));
+            const double rm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), pm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+            if (HANDOVER) { cg_st(&rr_part[blockIdx.x], t); cg_st(&rr_part[CG_PARTS + blockIdx.x], rm); cg_st(&rr_part[2 * CG_PARTS + blockIdx.x], pm); }
+            else { rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = rm; rr_part[2 * CG_PARTS + blockIdx.x] = pm; }
         }
     } else {
         double rc2 = 0.0, mc = 0.0;
-        cg_cam_update<true>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);      // (r_c: read by whoever runs the head below)
+        cg_cam_update<HANDOVER>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);  // (HANDOVER: r_c is read by whoever runs the head below)
         const double tc = block_sum(rc2, red);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mc;
         __syncthreads();
-        if (threadIdx.x == 0) { cg_st(hand, tc); cg_st(hand + 1, fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))); }
+        if (threadIdx.x == 0) {
+            const double rm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            if (HANDOVER) { cg_st(hand, tc); cg_st(hand + 1, rm); } else { st->rr_cam = tc; st->rmax_cam = rm; }
+        }
     }
+    if (!HANDOVER) return;                                 // (the next call's vican_cg_begin closes this iteration)
     if (!cg_last_arrival(ticket, gridDim.x)) return;
     // ---- the last workgroup: head of the next iteration (cg_begin with n_part = nb) ----
     cg_begin_body<true>(n_cam, r_c, p_c, rtol, rr_part, nb, n_add, st, red, &sh_beta, &sh_go, hand);
 }
 
 // One CG iteration of a single rank: [cg_begin (first iteration only)] + sweep + cg_fold2 + cg_step2.  `first` != 0: the
-// call that follows vican_cg_init.  ticket: 256 zeroed bytes owned by this solve, 128-byte aligned - two 32-bit tickets (left at
+// call that follows vican_cg_init.  ticket: 1024 zeroed bytes owned by this solve, 128-byte aligned - two 32-bit tickets (left at
 // zero by every launch) on the first cache line, two doubles of hand-over on the second (r_c.r_c, max |r_c|: a line that no
-// plain load ever touches).
+// plain load ever touches), from byte 256 the fold's partials of p_t.q_t.
 // The state after k calls equals the state after k x (vican_cg_iter_local, vican_cg_iter_finish) plus the vican_cg_begin
 // of the next call, bit for bit.
 extern "C" int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
@@ -1324,21 +1326,25 @@ extern "C" int vican_cg_iter_fused(const vican_graph_t* g, const double* w, cons
         return set_err(VICAN_ERR_ARG, "vican_cg_iter_fused: bad argument");
     int rc;
     hipStream_t s = (hipStream_t)stream;
-    if (first && (rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, 0, n_add, st, stream)) < 0) return rc;
-    if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
-    const long long nc = 3LL * g->n_cam, n = 3LL * g->n_time;
-    // partials of p_t . q_t, one per workgroup of the fold (<= 3 * 1024 / 16 = 192 untiled): the third plane of rr_part (max |p_t| per
-    // workgroup of the step) is free between the head that consumed it and the step that rewrites it
-    double* pq_part2 = rr_part + 2 * CG_PARTS;
-    if ((nc + 15) / 16 > CG_PARTS) return set_err(VICAN_ERR_CAPACITY, "vican_cg_iter_fused: more than 2730 cameras (camera-tiled graphs take the launch sequence)");
-#define CGF2_LAUNCH(COLS_) hipLaunchKernelGGL(cg_fold2_kernel<COLS_>, dim3((unsigned)((nc + COLS_ - 1) / COLS_)), dim3(1024), 0, s, (const long long*)qc_part, \
-                                              (int)g->n_wg, (int)g->n_cam, p_t, q_t, 3LL * g->n_time, pq_part2, qcpq, deg_c, p_c, st, ticket)
-    const int cols = cg_fold_cols(nc, g->n_wg);
-    if (cols == 64) CGF2_LAUNCH(64); else if (cols == 32) CGF2_LAUNCH(32); else CGF2_LAUNCH(16);
-#undef CGF2_LAUNCH
+    const long long n = 3LL * g->n_time, nc = 3LL * g->n_cam;
     int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
-    hipLaunchKernelGGL(cg_step2_kernel, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                       rr_part, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
+    const int handover = first & 2;
+    // the head of this iteration: its own launch - or, with hand-over, already run by the previous call's last workgroup
+    if ((first & 1) || !handover)
+        if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, (first & 1) ? 0 : nb, n_add, st, stream)) < 0) return rc;
+    if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
+    // partials of p_t . q_t, one per workgroup of the fold (<= 96: C <= 2048): doubles 32.. of the solve's ticket workspace
+    double* pq_part2 = (double*)(ticket + 64);
+    const int n_fold = (int)((nc + 63) / 64);
+    int n_pq = (int)((n + 8191) / 8192); if (n_pq < 1) n_pq = 1; if (n_pq > 96) n_pq = 96;       // slices of p_t.q_t (8 elements per thread and pass)
+    hipLaunchKernelGGL(cg_fold2_kernel<64>, dim3((unsigned)(n_fold > n_pq ? n_fold : n_pq)), dim3(1024), 0, s, (const long long*)qc_part, (int)g->n_wg,
+                       (int)g->n_cam, p_t, q_t, n, n_pq, pq_part2, qcpq, st);
+    if (handover)
+        hipLaunchKernelGGL(cg_step2_kernel<true>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
+    else
+        hipLaunchKernelGGL(cg_step2_kernel<false>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
     LAUNCH_CHECK("vican_cg_iter_fused");
     return VICAN_OK;
 }

@@ -704,15 +704,20 @@ class HipBackend:
                                                       _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
                                                       self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_iter_finish")
 
+    # VICAN_CG_HANDOVER=1: the step's last workgroup runs the next iteration's head (three launches per iteration instead of
+    # four); measured SLOWER on the stress graph (profiles/r05_cg_tail.txt) - the default keeps the head in its own launch
+    cg_handover = os.environ.get("VICAN_CG_HANDOVER") == "1"
+
     def cg_iter_fused(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, qcpq, rtol, st, first):
-        """One single-rank CG iteration in three launches (sweep, fold + alpha, step + the next iteration's head):
-        include/vican_hip.h vican_cg_iter_fused; same bits as cg_iter_local + cg_iter_finish."""
+        """One single-rank CG iteration behind one host call, bit-reproducible from run to run (p_t.q_t over fixed slices):
+        include/vican_hip.h vican_cg_iter_fused; same recurrence as cg_iter_local + cg_iter_finish."""
         if getattr(self, "_cg_ticket", None) is None:
-            self._cg_ticket = torch.zeros(64, dtype=torch.int32, device=self.dev)     # line 0: tickets [2]; line 1: hand-over doubles [2]
+            self._cg_ticket = torch.zeros(256, dtype=torch.int32, device=self.dev)    # line 0: tickets [2]; line 1: hand-over doubles [2]; byte 256..: p.q partials
         part = self.zpart[: self.cgl.n_wg * 6 * self.C]
         self._ck(self.lib.vican_cg_iter_fused(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(r_c), _ptr(p_c), _ptr(x_c),
                                               _ptr(r_t), _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq),
-                                              float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg, int(bool(first)),
+                                              float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg,
+                                              int(bool(first)) | (2 if self.cg_handover else 0),
                                               _ptr(st), _ptr(self._cg_ticket), _stream()), "vican_cg_iter_fused")
 
     # one message per CG iteration (sharded solves; include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)

@@ -599,9 +599,10 @@ class TranslationSolver:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
         n_part, it_launched, s = None, 0, None          # (None: the first iteration)
 
-        # single rank: three launches per iteration instead of four, alpha and the next iteration's head by last-workgroup
-        # hand-overs inside them (vican_cg_iter_fused; bit-identical to the sequence below).  VICAN_CG_FUSED=0: the sequence.
+        # single rank: one host call per iteration with p_t.q_t formed over fixed slices - bit-reproducible from run to run,
+        # which the sequence below is not (its p.q partial depends on the sweep's ticket order).  VICAN_CG_FUSED=0: the sequence.
         fused = (not multi) and getattr(K, "cg_iter_fused", None) is not None and os.environ.get("VICAN_CG_FUSED", "1") != "0"
+        handover = fused and bool(getattr(K, "cg_handover", False))     # (the step's last workgroup has run the next head already)
 
         def one_iteration(n_part):
             if fused:
@@ -635,7 +636,7 @@ class TranslationSolver:
                 # the same system was solved before (time series, benchmark loop): launch exactly as many iterations
                 # as it took then, plus the one that detects convergence, before the first poll
                 # (the fused iteration detects convergence in the launch that made the last update)
-                burst = min(max(self._last_iters + (0 if fused else 1), 1), 64, maxiter - it_launched)
+                burst = min(max(self._last_iters + (0 if handover else 1), 1), 64, maxiter - it_launched)
             first_burst = False
             left = burst
             if it_launched == 0:                                  # the first iteration passes other arguments
@@ -662,7 +663,7 @@ class TranslationSolver:
             if s["done"] or it_launched >= maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
-        if fused and s["done"] == 1 and s["iter"] >= maxiter:
+        if handover and s["done"] == 1 and s["iter"] >= maxiter:
             s["done"] = 0              # (found by the head that rides with the LAST allowed update: scipy does not test there)
         self._last_iters = int(s["iter"]) if s["done"] == 1 else None
         self.info = dict(cg_iters=s["iter"] if s["done"] else it_launched, converged=s["done"] == 1,
