@@ -451,6 +451,10 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
             self._bind("cg_sweep")
             return super().cg_iter_local(*a)
 
+        def cg_iter_fused(self, *a, **k):                   # (single rank: the events land on the call's sweep launch)
+            self._bind("cg_sweep")
+            return super().cg_iter_fused(*a, **k)
+
         def lsqr_step(self, *a):
             self._bind("lsqr_step")
             return super().lsqr_step(*a)
@@ -566,13 +570,13 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
     value = E_total * args.maxiter * steps / elapsed
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload
     # (profiles/<tag>_sweep_counters.json, written by tools/collect_profiles.py); null if none matches
-    traffic = None
+    traffic, traffic_source = None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")), reverse=True):
         try:
             pj = json.load(open(f))
             if pj.get("traffic") and pj.get("bytes_per_launch_algorithmic") == op_bytes:
-                traffic = pj["traffic"]["hbm_bytes"]
+                traffic, traffic_source = pj["traffic"]["hbm_bytes"], "profiles/" + os.path.basename(f)
                 break
         except Exception:
             pass
@@ -588,7 +592,7 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
                    "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
         "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
+                     "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
                      # achieved / frac are on the ALGORITHMIC bytes of SURVEY.md 8(d), E(9s + 4) + ...; wave-layout graphs carry a 2-byte
                      # index (vican_graph_t.idx16), so the sweep streams 2 bytes per edge less than that figure
                      "index_bytes_per_edge": 2 if g.layout == "wave" else 4,

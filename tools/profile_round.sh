@@ -7,7 +7,7 @@ TAG=${1:-r01}
 O=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse --no-wide"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse --no-wide --no-facade"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/bench_write.log 2>&1
@@ -17,7 +17,7 @@ cd $GRAFT_REPO_ROOT && python bench.py > $O/bench.json 2> $O/bench.err
 # busy/idle timelines of one WARM timed solve per workload
 python tools/timeline.py $O/stats 4 > $O/timeline_stress.txt 2>&1      # (the last two solves of a run are the cold and the instrumented one: bench.py)
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --workload large_shop --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_trace_ls.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_ls -- python3 $GRAFT_REPO_ROOT/bench.py --workload large_shop --no-cpu-baseline --no-facade --steps 3 --warmup 1 > $O/bench_trace_ls.log 2>&1
 cd $GRAFT_REPO_ROOT && python tools/timeline.py $O/trace_ls 4 > $O/timeline_large_shop.txt 2>&1
 rm -rf $O/trace_ls $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv
 # the sparse capture (100 cameras x 2 M timesteps x 8 cameras per timestep): kernel stats + HBM traffic counters of its operator sweep

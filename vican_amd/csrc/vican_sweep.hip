@@ -290,6 +290,64 @@ __global__ __launch_bounds__(64) void plan_slots_kernel(vican_graph_t g, const i
     }
 }
 
+// BANK-AWARE order for wave-layout chunks that hold ONE row (dense rows: the stress graph, 250 of 1000 cameras per timestep):
+// plan_slots_kernel above fills 32 camera classes of 2 x EPL slots each and drops whatever does not fit (13 % of the edges at
+// 98 % fill: a class holds 7.8 +- 2.8 cameras for 8 slots) into free slots anywhere - nearly every 16-lane group of every LDS
+// instruction then contains a stranger, and a stranger is a 2-way bank conflict: half of all LDS-array cycles of the sweeps
+// were conflict cycles (profiles/r04_cg_counters.json, r04_sweep_counters.json).  What the hardware asks for is weaker than
+// "lane = camera mod 32": a 64-bit LDS atomic is served in groups of 16 lanes and conflict-free iff the 16 cameras of a group
+// differ mod 16 (64-bit gathers: 32 lanes, mod 32).  So the chunk is seen as NC = 4 EPL cells of 16 lanes (cell k = slot
+// j = k / 4 of lanes 16 (k % 4) .. + 15) and the edges of residue r = camera mod 16 go ONE PER CELL, cells 0, 1, 2, ... at lane
+// offset r (alternating between the two mod-32 halves of the residue, so that the two cells of a 32-lane gather differ mod 32
+// while both halves last): a residue with n_r <= NC members causes no conflict at all.  The members beyond NC of an over-full
+// residue take the holes that under-full residues leave - all in the LAST cells - at most one per cell: such a cell costs one
+// extra cycle, and the extra cycles of different residues overlap.  Simulated on the stress graph's rows (tools: see
+// profiles/NOTES round 5): LDS cycles of a 64-bit atomic per chunk 27.6 -> 22.2 (ideal 16).
+// One THREAD per chunk, sequential (a row has <= 256 edges; packing is not on any timed path).
+__global__ void plan_slots_wave1_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                        int32_t* __restrict__ perm, int epl) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.n_chunk) return;
+    const int r0 = g.chunk_row0[k];
+    const int e0 = row_ptr[r0], e1 = row_ptr[r0 + 1];
+    int32_t* pm = perm + (size_t)k * g.slots;
+    for (int s = 0; s < g.slots; ++s) pm[s] = -1;
+    const int NC = 4 * epl;                                     // cells of 16 lanes
+    int nA[16], nB[16];
+    for (int r = 0; r < 16; ++r) nA[r] = nB[r] = 0;
+    for (int e = e0; e < e1; ++e) { const int c = col[e]; if (c & 16) ++nB[c & 15]; else ++nA[c & 15]; }
+    auto slot_of = [&](int cell, int off) { const int j = cell >> 2, grp = cell & 3; return (16 * grp + off) * epl + j; };
+    // free[cell]: lane offsets (= residues) without a primary entry in that cell
+    unsigned freem[16];
+    for (int c = 0; c < 16; ++c) {
+        unsigned m = 0;
+        for (int r = 0; r < 16; ++r) if (nA[r] + nB[r] <= c) m |= 1u << r;
+        freem[c] = c < NC ? m : 0u;
+    }
+    int rkA[16], rkB[16], nextc[16];
+    for (int r = 0; r < 16; ++r) { rkA[r] = rkB[r] = 0; nextc[r] = NC - 1; }
+    for (int e = e0; e < e1; ++e) {
+        const int c = col[e], r = c & 15;
+        const bool isB = (c & 16) != 0;
+        const int m = nA[r] < nB[r] ? nA[r] : nB[r];
+        const int rk = isB ? rkB[r]++ : rkA[r]++;
+        const int i = rk < m ? 2 * rk + (isB ? 1 : 0) : 2 * m + (rk - m);       // member index inside the residue
+        if (i < NC) { pm[slot_of(i, r)] = e; continue; }
+        // excess member: a hole of the highest cell this residue has not used for an excess yet
+        int cell = nextc[r];
+        while (cell >= 0 && freem[cell] == 0u) --cell;
+        if (cell < 0) {                                         // no hole left there: any hole (cells from the top)
+            cell = NC - 1;
+            while (cell >= 0 && freem[cell] == 0u) --cell;
+        } else nextc[r] = cell - 1;
+        if (cell >= 0) {
+            const int off = __ffs((int)freem[cell]) - 1;
+            freem[cell] &= ~(1u << off);
+            pm[slot_of(cell, off)] = e;
+        }
+    }
+}
+
 // ROW-MAJOR slot order (vican_graph_t.slot_order == 1): the chunk's edges in CSR order, i.e. lane l holds EPL consecutive
 // edges of (mostly) ONE row.  For graphs of short rows: with a few edges per row a (row, camera class) pair holds at most one
 // edge, so the bank-aware order above has no pure lanes at all - every lane flushes EPL row sums (9 LDS atomics each) and
@@ -360,8 +418,11 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
     dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
+    static const int wave1 = getenv("VICAN_SLOT_WAVE1") ? atoi(getenv("VICAN_SLOT_WAVE1")) : 1;     // (0: A/B against the class order)
     if (g->slot_order == 1)
         hipLaunchKernelGGL(plan_slots_rows_kernel, grid, block, 0, st, *g, row_ptr, perm_ws);
+    else if (wave1 && g->layout == VICAN_LAYOUT_WAVE && g->n_chunk == g->n_time && g->slots == 64 * epl)
+        hipLaunchKernelGGL(plan_slots_wave1_kernel, dim3((g->n_chunk + 63) / 64), dim3(64), 0, st, *g, row_ptr, col, perm_ws, epl);
     else
         hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
     const int32_t* perm = perm_ws;
