@@ -353,6 +353,42 @@ __global__ void plan_slots_wave1_kernel(vican_graph_t g, const int32_t* __restri
 // edge, so the bank-aware order above has no pure lanes at all - every lane flushes EPL row sums (9 LDS atomics each) and
 // re-reads EPL row operands per chunk - while here a lane changes row about once; the price is that the camera-side
 // gathers and atomics hit random banks.
+// ... and inside that order, WHICH of a row's slots each of its edges takes is free (a row's set of slots - hence every lane's
+// rows - stays as it is): round 5 uses the freedom against LDS bank conflicts on wave-layout chunks.  A 64-bit LDS atomic is
+// served in groups of 16 lanes and conflicts where two cameras of a group agree mod 16; in CSR order a group's 16 cameras are
+// random: 49 LDS cycles per 64-bit atomic and chunk where 16 would be ideal (simulated, rows of 4-60 edges).  One thread per
+// chunk walks the rows in order and gives each edge the first free slot of its row whose cell (slot j of a 16-lane group) does
+// not hold its residue yet: 35-42 cycles.  (Pack time only; sequential, O(row length^2) per row.)
+__global__ void plan_slots_rows_greedy_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                              int32_t* __restrict__ perm, int epl) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.n_chunk) return;
+    const int r0 = g.chunk_row0[k], r1 = g.chunk_row0[k + 1];
+    int32_t* pm = perm + (size_t)k * g.slots;
+    for (int s = 0; s < g.slots; ++s) pm[s] = -1;
+    unsigned cellmask[16];                                      // cell (j, 16-lane group) = j * 4 + group: residues present
+    for (int c = 0; c < 16; ++c) cellmask[c] = 0u;
+    int pos = 0;
+    for (int r = r0; r < r1; ++r) {
+        const int e0 = row_ptr[r], e1 = row_ptr[r + 1], deg = e1 - e0;
+        for (int e = e0; e < e1; ++e) {
+            const unsigned bit = 1u << (col[e] & 15);
+            int pick = -1, first_free = -1;
+            for (int s = pos; s < pos + deg; ++s) {
+                if (pm[s] >= 0) continue;
+                if (first_free < 0) first_free = s;
+                const int lane = s / epl, j = s - lane * epl;
+                if (!(cellmask[j * 4 + (lane >> 4)] & bit)) { pick = s; break; }
+            }
+            if (pick < 0) pick = first_free;
+            const int lane = pick / epl, j = pick - lane * epl;
+            cellmask[j * 4 + (lane >> 4)] |= bit;
+            pm[pick] = e;
+        }
+        pos += deg;
+    }
+}
+
 __global__ void plan_slots_rows_kernel(vican_graph_t g, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ perm) {
     const int k = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= g.slots) return;
@@ -419,7 +455,10 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
     hipStream_t st = (hipStream_t)stream;
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
     static const int wave1 = getenv("VICAN_SLOT_WAVE1") ? atoi(getenv("VICAN_SLOT_WAVE1")) : 1;     // (0: A/B against the class order)
-    if (g->slot_order == 1)
+    static const int rows_greedy = getenv("VICAN_SLOT_ROWS_GREEDY") ? atoi(getenv("VICAN_SLOT_ROWS_GREEDY")) : 1;     // (0: plain CSR order)
+    if (g->slot_order == 1 && rows_greedy && g->layout == VICAN_LAYOUT_WAVE && g->slots == 64 * epl)
+        hipLaunchKernelGGL(plan_slots_rows_greedy_kernel, dim3((g->n_chunk + 63) / 64), dim3(64), 0, st, *g, row_ptr, col, perm_ws, epl);
+    else if (g->slot_order == 1)
         hipLaunchKernelGGL(plan_slots_rows_kernel, grid, block, 0, st, *g, row_ptr, perm_ws);
     else if (wave1 && g->layout == VICAN_LAYOUT_WAVE && g->n_chunk == g->n_time && g->slots == 64 * epl)
         hipLaunchKernelGGL(plan_slots_wave1_kernel, dim3((g->n_chunk + 63) / 64), dim3(64), 0, st, *g, row_ptr, col, perm_ws, epl);
