@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 21            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 22            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -254,6 +254,14 @@ typedef struct {
 } vican_tile_t;
 int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const* row_ptrs_host, int32_t slots,
                             int32_t max_rows, int32_t* chunk_row0_out, int32_t cap);
+/* The same with the rows in a BETTER ORDER (host): consecutive rows pad a shared chunking badly when every row splits evenly over
+ * the tiles (a chunk takes a row only while every tile still has room: 1.33 slots per edge on 4 tiles x 62 edges per row).
+ * First-fit packing of the rows into a window of `window` open chunks; perm_out[new] = old row (rows of a chunk ascending),
+ * chunk_row0_out: boundaries in the new numbering (cap >= chunks + 1 entries); returns the number of chunks.  The caller
+ * builds the tiles from the rows in that order (the operator is a sum over rows: bipgo.py:300) and undoes it on what it returns
+ * per row.                                                                                                                  */
+int vican_plan_rows_multi(int32_t n_time, int32_t n_tile, const int32_t* const* row_ptrs_host, int32_t slots, int32_t max_rows,
+                          int32_t window, int32_t* perm_out, int32_t* chunk_row0_out, int32_t cap);
 int64_t vican_tiled_op_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy);
 int vican_tiled_op_sentinel(double* ypart, int64_t n_doubles, void* stream);
 int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,

@@ -147,6 +147,36 @@ def test_plan_chunks_multi_is_one_chunking_that_fits_every_tile(lib):
     assert lib.vican_plan_chunks_multi(1, 2, C.cast(two, C.c_void_p), 64, 8, C.c_void_p(out.ctypes.data), len(out)) == -3
 
 
+def test_plan_rows_multi_packs_rows_for_a_shared_chunking(lib):
+    """vican_plan_rows_multi (rows in a better ORDER for the shared chunking of camera tiles): a permutation, rows of a chunk
+    ascending, every tile's edges of a chunk within `slots`, at most max_rows rows - and fewer chunks than consecutive rows give
+    where every row splits evenly over the tiles (the wide benchmark's shape: 4 tiles x 62.5 +- 7 edges per row)."""
+    rng = np.random.default_rng(2)
+    T, n_tile, slots, max_rows = 3000, 4, 256, 64
+    cams = np.stack([rng.choice(4000, 250, replace=False) for _ in range(T)])
+    rps = [np.concatenate([[0], np.cumsum(((cams >= 1000 * k) & (cams < 1000 * (k + 1))).sum(1))]).astype(np.int32) for k in range(n_tile)]
+    ptrs = (C.c_void_p * n_tile)(*[r.ctypes.data for r in rps])
+    perm, c0 = np.empty(T, dtype=np.int32), np.empty(T + 2, dtype=np.int32)
+    n = lib.vican_plan_rows_multi(T, n_tile, C.cast(ptrs, C.c_void_p), slots, max_rows, 128, C.c_void_p(perm.ctypes.data), C.c_void_p(c0.ctypes.data), T + 2)
+    assert n > 0, lib.vican_last_error()
+    c0 = c0[: n + 1]
+    assert sorted(perm.tolist()) == list(range(T)) and c0[0] == 0 and c0[-1] == T and np.all(np.diff(c0) > 0) and np.diff(c0).max() <= max_rows
+    cnt = np.stack([np.diff(r) for r in rps], 1)[perm]                  # per-tile edges of the rows in the new order
+    for k in range(n):
+        assert np.all(np.diff(perm[c0[k]:c0[k + 1]]) > 0)
+        assert cnt[c0[k]:c0[k + 1]].sum(0).max() <= slots
+    out = np.empty(T + 2, dtype=np.int32)
+    n_consecutive = lib.vican_plan_chunks_multi(T, n_tile, C.cast(ptrs, C.c_void_p), slots, max_rows, C.c_void_p(out.ctypes.data), len(out))
+    assert n < 0.85 * n_consecutive, (n, n_consecutive)                 # (1.06-1.09 against 1.33 slots per edge)
+    # window 1 = consecutive rows; one tile, rows that do not fit, bad arguments
+    n1 = lib.vican_plan_rows_multi(T, n_tile, C.cast(ptrs, C.c_void_p), slots, max_rows, 1, C.c_void_p(perm.ctypes.data), C.c_void_p(out.ctypes.data), T + 2)
+    assert n1 == n_consecutive and list(perm) == list(range(T))
+    big = np.array([0, 300], dtype=np.int32)
+    one = (C.c_void_p * 1)(big.ctypes.data)
+    assert lib.vican_plan_rows_multi(1, 1, C.cast(one, C.c_void_p), 256, 8, 4, C.c_void_p(perm.ctypes.data), C.c_void_p(out.ctypes.data), 3) == -3
+    assert lib.vican_plan_rows_multi(1, 1, None, 256, 8, 4, C.c_void_p(perm.ctypes.data), C.c_void_p(out.ctypes.data), 3) == -1
+
+
 def test_lds_budget(lib):
     for storage in (_lib.STORE_F32, _lib.STORE_F64):
         for c in (3, 24, 340, 1000):

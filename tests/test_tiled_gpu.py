@@ -148,12 +148,17 @@ def test_tiled_translation_stage_has_no_camera_limit(C, T, tile):
 
 def test_tile_layout_default_is_wave_with_block_fallback(monkeypatch):
     """Without VICAN_TILE_LAYOUT a tile takes the wave layout if its rows fit a 64-lane chunk (128 f64 edges) and the block
-    layout otherwise - here 400 cameras in tiles of 256, 200-300 cameras per timestep: the first tile's rows have ~128-190
-    edges (block), the second tile's ~70-110 (wave); the mixed operator against the NumPy restatement."""
+    layout otherwise - here 400 cameras in two tiles of 200, 300-380 cameras per timestep with 60 % of the second tile's edges
+    dropped: the first tile's rows have ~150-190 edges (block), the second tile's ~50-90 (wave); the mixed operator against the
+    NumPy restatement."""
     from vican_amd.device import TiledBackend, TiledGraph
     monkeypatch.delenv("VICAN_TILE_LAYOUT")
     C, T, tile = 400, 60, 256
-    rp, col, blk, a, w, u, v = random_graph(C, T, 200, 300, 4, False)
+    rp, col, blk, a, w, u, v = random_graph(C, T, 300, 380, 4, False)
+    keep = (col < 200) | (np.random.default_rng(9).random(len(col)) < 0.4)
+    rows = np.repeat(np.arange(T), np.diff(rp))[keep]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=T))]).astype(np.int32)
+    col, blk, a, w, u, v = col[keep], blk[keep], a[keep], w[keep], u[keep], v[keep]
     dev = torch.device("cuda:0")
     g = TiledGraph(C, torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(blk).to(dev), torch.from_numpy(a).to(dev),
                    torch.from_numpy(w).to(dev), torch.from_numpy(u).to(dev), torch.from_numpy(v).to(dev), tile=tile)
@@ -209,3 +214,49 @@ def test_tiled_dense_rows_take_the_one_row_kernels(tile_layout):
     assert th.info["converged"] and abs(th.info["cg_iters"] - tn.info["cg_iters"]) <= 2
     scale = max(np.abs(xn[0]).max(), 1.0)
     assert np.abs(xh[0] - xn[0]).max() < 1e-6 * scale and np.abs(xh[1][:T] - xn[1][:T]).max() < 1e-6 * scale
+
+
+def test_rows_packed_for_the_shared_chunking_give_the_same_answers(tile_layout):
+    """TiledGraph(permute_rows=True) - the rows in the order vican_plan_rows_multi packs them for the shared chunking, what
+    device.make_backend builds - against the rows in their own order: fewer slots; the operator (a sum over rows) and the per-row
+    results after `unpermute_rows` the same up to the f32 rounding of the lanes' partial sums (which edges of a row share a lane
+    depends on the chunking), the translation stage the same iterate."""
+    if tile_layout != "fused":
+        pytest.skip("the packing serves the shared chunking")
+    from vican_amd.device import TiledBackend, TiledGraph
+    from vican_amd.solver import TranslationSolver
+    C, T, tile = 800, 1200, 200                                     # 4 tiles, rows of 62.5 +- 6 edges per tile: 4 rows of 256 slots at best, 3 consecutive ones most of the time
+    rp, col, blk, a, w, u, v = random_graph(C, T, 246, 254, 21, False)
+    dev = torch.device("cuda:0")
+    to = lambda x, d=None: torch.from_numpy(x).to(dev) if d is None else torch.from_numpy(x).to(dev, d)
+    args = (C, to(rp), to(col), to(blk, torch.float32), to(a, torch.float32), to(w), to(u), to(v))
+    g0, g1 = TiledGraph(*args, tile=tile), TiledGraph(*args, tile=tile, permute_rows=True)
+    assert g1.row_perm is not None and g0.row_perm is None
+    assert sorted(g1.row_perm.cpu().tolist()) == list(range(T))
+    assert g1.padded_slots() < 0.9 * g0.padded_slots(), (g1.padded_slots(), g0.padded_slots())
+    K0, K1 = TiledBackend(g0), TiledBackend(g1)
+    assert K0._fused is not None and K1._fused is not None
+    rng = np.random.default_rng(4)
+    x = K0.from_numpy(np.linalg.qr(rng.standard_normal((3 * C, 3)))[0])
+    l0, c0, l1, c1 = K0.empty(T, 9), K0.empty(C), K1.empty(T, 9), K1.empty(C)
+    K0.init_duals(l0, c0); K1.init_duals(l1, c1)
+    close = lambda p, q, tol=2e-6: float((p - q).abs().max()) <= tol * max(float(q.abs().max()), 1e-30)
+    assert close(g1.unpermute_rows(l1), l0, 1e-12) and close(c0, c1, 1e-12)
+    z0, z1 = K0.empty(3 * C, 3), K1.empty(3 * C, 3)
+    K0.block_op(l0, x, z0); K1.block_op(l1, x, z1)
+    assert close(z1, z0)
+    rc = K0.from_numpy(np.linalg.qr(rng.standard_normal((C, 3, 3)))[0].reshape(3 * C, 3))
+    R0, R1 = K0.empty(T, 9), K1.empty(T, 9)
+    K0.dual_update(rc, R0, l0); K1.dual_update(rc, R1, l1)
+    assert close(g1.unpermute_rows(R1), R0) and close(g1.unpermute_rows(l1), l0, 1e-4)
+    K0.block_op(l0, x, z0); K1.block_op(l1, x, z1)
+    assert close(z1, z0, 1e-4)
+    outs = []
+    for K, g in ((K0, g0), (K1, g1)):
+        ts = TranslationSolver(K, Comm.single(), rtol=1e-8)
+        ts.setup(rc, R0 if g is g0 else g1.permute_rows(R0))
+        xc, xt = ts.solve(3 * (C + T))
+        outs.append((xc.clone(), g.unpermute_rows(xt[:T]).clone() if g is g1 else xt[:T].clone(), ts.info["cg_iters"]))
+    assert abs(outs[0][2] - outs[1][2]) <= 1
+    scale = max(float(outs[0][1].abs().max()), 1.0)
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5 * scale and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-5 * scale

@@ -116,6 +116,10 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     def gather_rows(loc, width):          # one all-gather of the ranks' row blocks
         return comm.gather_rows(loc.reshape(-1, width), nloc, bounds)
 
+    # camera-tiled graphs keep their rows in an order of their own (device.TiledGraph.row_perm: packed for the shared chunking);
+    # per-row results come back in the problem's order
+    unperm = getattr(g, "unpermute_rows", None) or (lambda x: x)
+
     tm = {}
 
     def stages():
@@ -126,7 +130,7 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
         tm["t2"] = time.perf_counter()
         # (the rotations of all rows are needed before the translation stage only by the LSQR branch - |b|^2 of the un-merged
         #  system on the host; otherwise they travel with the translations in ONE all-gather at the end)
-        Rt_all = gather_rows(Rt_loc, 9) if lsqr_solver == "direct" and not tight else None
+        Rt_all = gather_rows(unperm(Rt_loc.reshape(-1, 9)[:max(nloc, 1)]), 9) if lsqr_solver == "direct" and not tight else None
         if tight:                                                            # not in the reference (module docstring)
             tr = TightTranslationSolver(K, comm)
             tr.setup(rc, Rt_loc)
@@ -151,10 +155,10 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     t2 = tm["t2"]
     t3 = time.perf_counter()
     if Rt_all is None:
-        both = gather_rows(torch.cat([Rt_loc.reshape(-1, 9)[:max(nloc, 1)], x_t.reshape(-1, 3)[:max(nloc, 1)]], 1), 12)
+        both = gather_rows(unperm(torch.cat([Rt_loc.reshape(-1, 9)[:max(nloc, 1)], x_t.reshape(-1, 3)[:max(nloc, 1)]], 1)), 12)
         Rt_all, xt_all = both[:, :9].contiguous(), both[:, 9:].contiguous()
     else:
-        xt_all = gather_rows(x_t, 3)
+        xt_all = gather_rows(unperm(x_t.reshape(-1, 3)[:max(nloc, 1)]), 3)
     Rc, Rt, xc_h, xt_h = download([rc.reshape(prob.n_cam, 3, 3).transpose(1, 2),          # bipgo.py:346
                                    Rt_all.reshape(T, 3, 3).transpose(1, 2), x_c, xt_all])  # bipgo.py:348
     if info is not None:

@@ -7,8 +7,8 @@
 // the same timestep rows in every tile: vican_plan_chunks_multi), a workgroup is bound to one tile, and the wavefront that
 // handles chunk k of its tile
 //     phase 1    forms its tile's share of the chunk's row sums and PUBLISHES it (72 B per row, write-through stores),
-//     ...        goes on with phase 1 of its NEXT chunk (the blocks of chunk k stay in registers: four register sets
-//                rotate - waiting for phase 3, in phase 1, arrived for the next phase 1, prefetch in flight),
+//     ...        goes on with phase 1 of its NEXT chunk (the blocks of chunk k stay in registers: TS_SETS register sets
+//                rotate - waiting for phase 3, in phase 1, prefetch in flight [, with four: arrived for the next phase 1]),
 //     phase 2/3  one iteration later reads the shares of ALL tiles for chunk k's rows, applies Lambda_t^-1 and runs
 //                phase 3 on the blocks it still holds.
 // Exchange without counters, fences or atomics: the shares live in two buffers used by alternate launches; a wavefront
@@ -21,7 +21,13 @@
 // co-resident (checked at launch: one workgroup per compute unit) and every spin is bounded (vican_set_barrier_abort).
 #include "vican_sweep_common.h"
 
+#ifndef TS_NW
 #define TS_NW 8
+#endif
+#ifndef TS_SETS
+#define TS_SETS 3                     /* register sets per wavefront: 3 = prefetch one iteration ahead, 4 = two (measured on the wide
+                                         benchmark: 227.5 us with 3, 234.9 us with 4 - every wavefront ends with TS_SETS - 2 clamped loads) */
+#endif
 #define TS_PRE 4                      /* tiles whose shares are requested ahead of phase 1 (more tiles: the reload loop) */
 #define TS_SENTINEL 0x7FF8C0DEFACE0001ull     /* quiet NaN, payload never produced by arithmetic */
 
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
         __builtin_amdgcn_wave_barrier();
     };
 
-    // one iteration: requests (shares and dual blocks of chunk kc - kstride, then the prefetch of chunk kc + 2 kstride into the
+    // one iteration: requests (shares and dual blocks of chunk kc - kstride, then the prefetch of chunk kc + (TS_SETS - 2) kstride into the
     // set `fre` that finished its phase 3 an iteration ago), phase 1 of chunk kc (set `cur`), phases 2 + 3 of chunk kc - kstride
     // (set `prev`).  Loads are unconditional (clamped).
     auto body = [&](const ChunkRegs<S, EPL>& cur, const int2 vcur, const ChunkRegs<S, EPL>& prev, const int2 vprev,
@@ -282,14 +288,14 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
 #pragma unroll
             for (int t = 0; t < TS_PRE; ++t) pre[t] = ts_ld((TS_G const double*)s_yp[t < n_tile ? t : 0] + (size_t)r0p * 9 + i);
         }
-        // ... then the prefetch of chunk kc + 2 kstride into the free set.  Vector-memory results return in issue order: the
+        // ... then the prefetch of chunk kc + (TS_SETS - 2) kstride into the free set.  Vector-memory results return in issue order: the
         // shares (older) can be consumed after phase 1 while this prefetch stays in flight until the NEXT iteration's shares
         // are consumed - a whole iteration and a phase of latency hidden.  (Issued after phase 2 instead, the prefetch sat in
         // front of the next iteration's share requests and had to land within a phase: 386 -> 349 us with the share requests
         // moved ahead of phase 1, -> this order.)
         __builtin_amdgcn_sched_barrier(0);
-        vfre = load_rows(kc + 2 * kstride);
-        ts_load_chunk<S, EPL, NT>(fre, g_blk, g_idx, g.slots, clampk(kc + 2 * kstride), lane);
+        vfre = load_rows(kc + (TS_SETS - 2) * kstride);
+        ts_load_chunk<S, EPL, NT>(fre, g_blk, g_idx, g.slots, clampk(kc + (TS_SETS - 2) * kstride), lane);
         __builtin_amdgcn_sched_barrier(0);
         if (kc < nchunk) {
             const int r0 = __builtin_amdgcn_readfirstlane(vcur.x);
@@ -299,6 +305,21 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
         if (have_prev && !aborted) phase3(prev);
     };
 
+#if TS_SETS == 3
+    ChunkRegs<S, EPL> A, B, Cc;
+    int kc = wgt * NW + wave;
+    int2 vA = load_rows(kc), vB = vA, vC = vA;
+    ts_load_chunk<S, EPL, NT>(A, g_blk, g_idx, g.slots, clampk(kc), lane);
+    // (iteration i: cur = set i % 3, prev = set (i - 1) % 3, free = set (i + 1) % 3)
+#pragma unroll 1
+    while (kc - kstride < nchunk && !aborted) {
+        body(A, vA, Cc, vC, B, vB, kc); kc += kstride;
+        if (!(kc - kstride < nchunk) || aborted) break;
+        body(B, vB, A, vA, Cc, vC, kc); kc += kstride;
+        if (!(kc - kstride < nchunk) || aborted) break;
+        body(Cc, vC, B, vB, A, vA, kc); kc += kstride;
+    }
+#else
     ChunkRegs<S, EPL> A, B, Cc, D;
     int kc = wgt * NW + wave;
     int2 vA = load_rows(kc), vB = load_rows(kc + kstride), vC = vA, vD = vA;
@@ -315,6 +336,7 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
         if (!(kc - kstride < nchunk) || aborted) break;
         body(D, vD, Cc, vC, B, vB, kc); kc += kstride;
     }
+#endif
     __syncthreads();
     TS_G u64* zp = (TS_G u64*)Tp->zpart + (size_t)wgt * 9 * C;         // slab layout [9][C]
 #pragma unroll

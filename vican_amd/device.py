@@ -1050,7 +1050,7 @@ class TiledGraph:
     them at 1024 cameras.  Beyond that the operator z = sum_t M_.t Lambda_t^-1 (sum_c M_ct^T x_c) is evaluated tile by
     tile (TiledBackend): every edge block is read twice per application instead of once."""
 
-    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, tile=None, deg_t=None, deg_c=None):
+    def __init__(self, n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, tile=None, deg_t=None, deg_c=None, permute_rows=False):
         import os
         lib = _lib.load()
         tile = int(tile or os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
@@ -1063,24 +1063,72 @@ class TiledGraph:
         row_ptr = row_ptr.to(dev, torch.int64)
         col = col.to(dev, torch.int64)
         rows = torch.repeat_interleave(torch.arange(T, device=dev), row_ptr[1:] - row_ptr[:-1])
+        # tiles of EQUAL width (4000 cameras: 4 x 1000, not 3 x 1024 + 928): a row's edges then split evenly over the tiles, and
+        # the shared chunking fills every tile's slots at the same pace (with 1024-wide tiles the three full ones average 64 edges
+        # per row - four rows = the 256 slots of a chunk exactly, so a fourth row fitted one chunk in two)
+        n_tiles = max(1, -(-self.n_cam // tile))
+        tile = min(tile, -(-(-(-self.n_cam // n_tiles)) // 8) * 8)
         self.bounds = list(range(0, self.n_cam, tile)) + [self.n_cam]
         self.tiles = []
         want = os.environ.get("VICAN_TILE_LAYOUT") or None
         storage = _lib.STORE_F32 if blk.dtype == torch.float32 else _lib.STORE_F64
-        parts = []
-        for k in range(len(self.bounds) - 1):
-            c0, c1 = self.bounds[k], self.bounds[k + 1]
-            sel = ((col >= c0) & (col < c1)).nonzero().squeeze(1)
-            rp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
-            rp[1:] = torch.cumsum(torch.bincount(rows[sel], minlength=T), 0)
-            parts.append((c0, c1, sel, rp.to(torch.int32)))
+        # row_perm[new] = old row (None: the rows in their own order), row_inv[old] = new: set by the packing below
+        self.row_perm = self.row_inv = None
+
+        def cut(rows_of_edges):
+            out = []
+            for k in range(len(self.bounds) - 1):
+                c0, c1 = self.bounds[k], self.bounds[k + 1]
+                sel = ((col >= c0) & (col < c1)).nonzero().squeeze(1)
+                if self.row_perm is not None:                   # edges of the tile in the NEW row order (stable: cameras stay ascending)
+                    sel = sel[torch.argsort(rows_of_edges[sel], stable=True)]
+                rp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+                rp[1:] = torch.cumsum(torch.bincount(rows_of_edges[sel], minlength=T), 0)
+                out.append((c0, c1, sel, rp.to(torch.int32)))
+            return out
+        parts = cut(rows)
         rps_host = download([p_[3] for p_ in parts]) if T else [np.zeros(1, np.int32) for _ in parts]
         rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
+        packed_chunks = None
+        if permute_rows and want != "block" and os.environ.get("VICAN_TILE_SHARED", "1") != "0" and T > 0 and self.n_edges > 0 and len(parts) > 1:
+            # Rows in a better ORDER for the shared chunking (vican_plan_rows_multi: consecutive rows pad it to 1.33 slots per edge on
+            # the wide benchmark graph, packed ones to 1.03): everything per row inside this graph and its backend lives
+            # in the new order; `unpermute_rows` / `permute_rows` translate at the boundary (bipgo.solve_problem)
+            try:
+                cap_rows, slots = 64, 0
+                for (c0, c1, sel, _), rph in zip(parts, rps_host):
+                    n_e = int(rph[-1])
+                    if n_e == 0:
+                        raise _lib.VicanError("a tile without edges")
+                    slots, rows_t, n_copy_k, _ = _wave_params(lib, c1 - c0, max(1.0, n_e / T), n_e, storage)
+                    while rows_t > 1 and int(lib.vican_tiled_op_lds_bytes(c1 - c0, rows_t, storage, n_copy_k)) > int(lib.vican_lds_limit_bytes()):
+                        rows_t -= 1
+                    cap_rows = min(cap_rows, rows_t)
+                ptrs = (C.c_void_p * len(parts))(*[r.ctypes.data for r in rps_host])
+                perm, c0s = np.empty(T, dtype=np.int32), np.empty(T + 2, dtype=np.int32)
+                nch = _lib.check(lib.vican_plan_rows_multi(T, len(parts), C.cast(ptrs, C.c_void_p), slots, cap_rows,
+                                                            int(os.environ.get("VICAN_TILE_PACK_WINDOW", 512)), C.c_void_p(perm.ctypes.data),
+                                                            C.c_void_p(c0s.ctypes.data), T + 2), "vican_plan_rows_multi")
+                inv = np.empty(T, dtype=np.int64)
+                inv[perm] = np.arange(T)
+                self.row_perm = torch.from_numpy(perm.astype(np.int64)).to(dev)
+                self.row_inv = torch.from_numpy(inv).to(dev)
+                packed_chunks = c0s[: nch + 1].copy()
+                parts = cut(self.row_inv[rows])
+                rps_host = download([p_[3] for p_ in parts])
+                rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
+                if deg_t is not None:
+                    deg_t = deg_t.to(dev)[self.row_perm]
+            except _lib.VicanError:
+                self.row_perm = self.row_inv = packed_chunks = None
+                parts = cut(rows)
+                rps_host = download([p_[3] for p_ in parts])
+                rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
         # A chunking SHARED by all tiles (chunk k = the same timestep rows in every tile) lets the operator run as ONE launch
         # that reads every block once (vican_tiled_op, csrc/vican_tsweep.hip); it pads a little more than per-tile chunkings
         # (a row joins a chunk only while EVERY tile's edges still fit).  VICAN_TILE_SHARED=0: per-tile chunkings (two passes).
-        self.shared_chunks = None
-        if want != "block" and os.environ.get("VICAN_TILE_SHARED", "1") != "0" and T > 0 and self.n_edges > 0:
+        self.shared_chunks = packed_chunks
+        if packed_chunks is None and want != "block" and os.environ.get("VICAN_TILE_SHARED", "1") != "0" and T > 0 and self.n_edges > 0:
             try:
                 cap_rows, slots = 64, 0
                 for (c0, c1, sel, _), rph in zip(parts, rps_host):
@@ -1138,6 +1186,14 @@ class TiledGraph:
                 self.cam_sum_w.copy_(deg_c.to(dev, torch.float64))
             self.wmax = max(t.wmax for t in self.tiles)
             # (the CG product runs tile by tile on the tiles' own weight arrays - TiledBackend.cg_iter_local: no camera limit)
+
+    def unpermute_rows(self, x):
+        """A per-row array of this graph (first dimension = rows in the graph's own order) in the CALLER's row order."""
+        return x if self.row_inv is None else x[self.row_inv]
+
+    def permute_rows(self, x):
+        """A per-row array in the caller's row order -> the graph's own order."""
+        return x if self.row_perm is None else x[self.row_perm]
 
     def op_bytes(self, ncols=3):
         return sum(t.op_bytes(ncols) for t in self.tiles) * 2
@@ -1469,7 +1525,8 @@ def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None
     import os
     tile = int(os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
     if n_cam > tile:
-        g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c)
+        g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c,
+                       permute_rows=os.environ.get("VICAN_TILE_PERMUTE", "1") != "0")
         return g, TiledBackend(g)
     g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v, deg_t=deg_t, deg_c=deg_c, row_ptr_host=row_ptr_host)
     return g, HipBackend(g)
