@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 22            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 23            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -190,6 +190,9 @@ int vican_edge_sums(const vican_graph_t* g, const void* val, int32_t val_is_f64,
 #define VICAN_FX_DOUBLES 20
 int vican_block_norms(const vican_graph_t* g, double* rnorm /*[T]*/, double* fx, void* stream);
 int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream);
+/* The same for the scale buffers of n <= 64 graphs over the SAME rows (camera tiles) in one launch: omega (fx[4], from
+ * vican_duals_bound on fx[0]) is copied from the first buffer to the others; fx, n_add: HOST arrays of n entries.            */
+int vican_fx_finish_multi(double* const* fx, const double* n_add, int32_t n, double x_bound, int32_t storage, void* stream);
 /* fx[4] for caller-supplied duals (instead of vican_init_duals / vican_dual_update). */
 int vican_duals_bound(int32_t n_time, const double* lamT_inv, const double* rnorm, double* fx,
                       void* stream);
@@ -266,6 +269,10 @@ int64_t vican_tiled_op_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storag
 int vican_tiled_op_sentinel(double* ypart, int64_t n_doubles, void* stream);
 int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
                    const double* lamT_inv, int32_t parity, void* stream);
+/* The same with operand and result in the caller's arrays (x, z: [3C][3] doubles; tiles = consecutive camera ranges in descriptor
+ * order, the descriptors' x fields are not read): the fused launch + ONE fold launch for all tiles.                            */
+int vican_tiled_op_z(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
+                     const double* lamT_inv, const double* x, double* z, int32_t parity, void* stream);
 
 /* idx16 of a packed wave-layout graph (see vican_graph_t.idx16): out [n_chunk][slots], then set g->idx16 = out. */
 int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* stream);
@@ -383,7 +390,7 @@ int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t
 /* The same step as ONE cooperative kernel: <= 32 workgroups (32 cameras each, all resident) that meet at
  * three device-side grid barriers instead of seven dependent launches.  ws: scratch of
  * vican_lanczos_coop_ws_doubles(n_cam) doubles; sync_ws: two 32-bit words, zero before the first call
- * (the kernel leaves them zero).  n_cam <= 1024.  Results equal vican_lanczos_cam_step up to the order
+ * (the kernel leaves them zero).  n_cam <= 8192 (256 workgroups of 32 cameras; VICAN_ERR_CAPACITY if that grid is not co-resident).  Results equal vican_lanczos_cam_step up to the order
  * of the (fixed-order, deterministic) partial sums.
  * zpart != NULL: z is taken straight from the fixed-point slabs [n_slab][9][n_cam] of the preceding
  * vican_block_op (folded per workgroup with the conversion of vican_slab_reduce_fx: pa = fx+3, pb = fx+7),

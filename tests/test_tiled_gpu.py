@@ -260,3 +260,36 @@ def test_rows_packed_for_the_shared_chunking_give_the_same_answers(tile_layout):
     assert abs(outs[0][2] - outs[1][2]) <= 1
     scale = max(float(outs[0][1].abs().max()), 1.0)
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5 * scale and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-5 * scale
+
+
+def test_tiled_op_in_pieces_equals_the_one_call(tile_layout):
+    """vican_tiled_op (operand at the descriptors' address) + vican_slab_reduce_fx per tile - the pieces a caller may still use -
+    against vican_tiled_op_z (operand and result in the caller's arrays, one fold launch): the same bits."""
+    if tile_layout != "fused":
+        pytest.skip("the fused launch only")
+    import ctypes as C
+    from vican_amd import _lib
+    from vican_amd.device import _ptr, _stream
+    Cn, T, tile = 90, 300, 32
+    rp, col, blk, a, w, u, v = random_graph(Cn, T, 3, 9, 5, False)
+    g, K = _tiled(Cn, rp, col, blk, a, w, u, v, np.float64, tile)
+    rng = np.random.default_rng(3)
+    x = K.from_numpy(np.linalg.qr(rng.standard_normal((3 * Cn, 3)))[0])
+    lam, cc = K.empty(T, 9), K.empty(Cn)
+    K.init_duals(lam, cc)
+    z1, z2 = K.empty(3 * Cn, 3), K.empty(3 * Cn, 3)
+    K.block_op(lam, x, z1)
+    f = K._fused
+    assert f is not None
+    f.x.copy_(x)
+    _lib.check(K.lib.vican_tiled_op(C.cast(f.host, C.c_void_p), _ptr(f.dev), len(K.tiles), f.nwgt, _ptr(lam), f.parity, _stream()), "vican_tiled_op")
+    f.parity ^= 1
+    for k, Kt in enumerate(K.tiles):
+        r0, r1 = K._tile_rows(k)
+        fxp = Kt.g.fx.data_ptr()
+        _lib.check(K.lib.vican_slab_reduce_fx(_ptr(f.zpart[k]), f.nwgt, Kt.C, 9, 1.0, C.c_void_p(fxp + 24), C.c_void_p(fxp + 56), _ptr(z2[r0:r1]),
+                                              _stream()), "vican_slab_reduce_fx")
+    assert torch.equal(z1, z2)
+    zt = torch.empty(3, 3 * Cn, dtype=torch.float64, device=z1.device).t()           # a result array that is not contiguous
+    K.block_op(lam, x.t().contiguous().t(), zt)
+    assert torch.equal(zt, z1)

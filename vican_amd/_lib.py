@@ -103,6 +103,7 @@ PROTOTYPES = {
     "vican_edge_sums": (C.c_int, [_G, _vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_block_norms": (C.c_int, [_G, _vp, _vp, _vp]),
     "vican_fx_finish": (C.c_int, [_vp, _f64, _f64, _i32, _vp]),
+    "vican_fx_finish_multi": (C.c_int, [_vp, _vp, _i32, _f64, _i32, _vp]),
     "vican_duals_bound": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "vican_slab_reduce_fx": (C.c_int, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_pack_edges": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -135,6 +136,7 @@ PROTOTYPES = {
     "vican_tiled_op_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vican_tiled_op_sentinel": (C.c_int, [_vp, C.c_int64, _vp]),
     "vican_tiled_op": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
+    "vican_tiled_op_z": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp]),
     "vican_tile_cams": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_iter_local": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_iter_finish": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

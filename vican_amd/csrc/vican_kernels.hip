@@ -522,6 +522,7 @@ __global__ __launch_bounds__(1024) void lanczos_cam_fused_kernel(int n_cam, cons
 // and the 3x3 Gram of R cross workgroups, summed in a fixed order => deterministic.
 // ---------------------------------------------------------------------------
 #define COOP_CAMS 32
+#define COOP_MAX_WG 256                 /* workgroups of the cooperative camera-side step: 8192 cameras */
 #define COOP_ROWS (3 * COOP_CAMS)
 // Everything that crosses workgroups (the partial sums) is written and read with device-scope atomics, which
 // go through to the memory-side coherence point by themselves; a device-scope FENCE would instead write back the
@@ -781,11 +782,11 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
                                       double* ws, double* Hcol, double* beta, double* x_out, double pivot_floor,
                                       uint32_t* sync_ws, const void* zpart, int32_t n_slab, const double* pa, const double* pb,
                                       int32_t fenced, void* stream) {
-    if (n_cam <= 0 || n_cam > 32 * COOP_CAMS || !lamC || !V || (!z && !zpart) || (zpart && n_slab <= 0) || !ws || !Hcol || !beta ||
+    if (n_cam <= 0 || n_cam > COOP_MAX_WG * COOP_CAMS || !lamC || !V || (!z && !zpart) || (zpart && n_slab <= 0) || !ws || !Hcol || !beta ||
         !x_out || !sync_ws || j < 0 ||
         3 * (j + 1) > 128 || ld < 3 * n_cam)                 // basis slice in LDS: 128 x 96 doubles = 96 KB
         return set_err(VICAN_ERR_ARG, "vican_lanczos_cam_coop: bad argument");
-    const int nwg = (n_cam + COOP_CAMS - 1) / COOP_CAMS;                    // <= 32 workgroups: always co-resident
+    const int nwg = (n_cam + COOP_CAMS - 1) / COOP_CAMS;                    // <= 256 workgroups (camera-tiled graphs: 4000 cameras = 125)
     const size_t lds = (size_t)3 * (j + 1) * COOP_ROWS * sizeof(double);
     static size_t configured = 0;
     if (lds > 32 * 1024 && lds > configured) {
@@ -793,11 +794,13 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
             return set_err(VICAN_ERR_LAUNCH, "vican_lanczos_cam_coop: cannot raise dynamic LDS limit");
         configured = 128 * COOP_ROWS * 8;
     }
-    {   // co-residency of the grid on an idle device (checked once per LDS size class; <= 32 workgroups of 256 threads)
+    {   // co-residency of the grid on an idle device: checked whenever the LDS size or the grid exceeds what passed before
         static size_t checked = 0;
-        if (lds > checked || checked == 0) {
+        static int checked_nwg = 0;
+        if (lds > checked || nwg > checked_nwg) {
             if (int rc = vican_coresident_ok((const void*)lanczos_cam_coop_kernel, 256, lds, nwg, "vican_lanczos_cam_coop")) return rc;
-            checked = lds > 0 ? lds : 1;
+            checked = lds > checked ? lds : checked;
+            checked_nwg = nwg > checked_nwg ? nwg : checked_nwg;
         }
     }
     hipLaunchKernelGGL(lanczos_cam_coop_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, ws, Hcol,

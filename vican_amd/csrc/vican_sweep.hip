@@ -743,9 +743,7 @@ extern "C" int vican_scaled_identity(int32_t n, const double* scale, double* out
 //   y contributions  |M^T x|      <= amax * xb          row totals <= rmax * xb
 //   z contributions  |M w|        <= amax * omega * xb  per-accumulator totals <= n_add * that
 // A single contribution must stay below 2^51 (magic-number conversion), a total below 2^62.
-__global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, double x_bound, double n_add, int bits, int tot) {
-    GATE_RETURN(gate);
-    if (threadIdx.x || blockIdx.x) return;
+__device__ __forceinline__ void fx_finish_one(double* fx, double x_bound, double n_add, int bits, int tot) {
     const double amax = fmax(fx[5], 1e-300), rmax = fmax(fx[6], 1e-300), om = fmax(fx[4], 1e-300);
     const double cy = amax * x_bound, ty = rmax * x_bound;
     const double cz = amax * om * x_bound, tz = cz * n_add;
@@ -761,6 +759,32 @@ __global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, d
     int e1 = min(bits - (int)ceil(log2(cz1)), tot - (int)ceil(log2(tz1)));
     e1 = max(min(e1, 100), -100);
     fx[9] = ldexp(1.0, e1); fx[11] = ldexp(1.0, -e1);
+}
+__global__ void fx_finish_kernel(const int32_t* __restrict__ gate, double* fx, double x_bound, double n_add, int bits, int tot) {
+    GATE_RETURN(gate);
+    if (threadIdx.x || blockIdx.x) return;
+    fx_finish_one(fx, x_bound, n_add, bits, tot);
+}
+// the scale buffers of several graphs over the SAME rows (camera tiles) in one launch: omega (fx[4]) is taken from the first
+struct FxList { double* fx[64]; double n_add[64]; };
+__global__ void fx_finish_multi_kernel(const int32_t* __restrict__ gate, FxList L, int n, double x_bound, int bits, int tot) {
+    GATE_RETURN(gate);
+    const int k = threadIdx.x;
+    if (blockIdx.x || k >= n) return;
+    if (k > 0) L.fx[k][4] = L.fx[0][4];
+    fx_finish_one(L.fx[k], x_bound, L.n_add[k], bits, tot);
+}
+extern "C" int vican_fx_finish_multi(double* const* fx, const double* n_add, int32_t n, double x_bound, int32_t storage, void* stream) {
+    if (!fx || !n_add || n <= 0 || n > 64 || !(x_bound > 0)) return set_err(VICAN_ERR_ARG, "vican_fx_finish_multi: bad argument");
+    FxList L;
+    for (int k = 0; k < n; ++k) {
+        if (!fx[k] || !(n_add[k] >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish_multi: bad argument");
+        L.fx[k] = fx[k]; L.n_add[k] = n_add[k];
+    }
+    const int bits = 47, tot = storage == VICAN_STORE_F32 ? 46 : 61;
+    hipLaunchKernelGGL(fx_finish_multi_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_vican_gate, L, (int)n, x_bound, bits, tot);
+    LAUNCH_CHECK("vican_fx_finish_multi");
+    return VICAN_OK;
 }
 extern "C" int vican_fx_finish(double* fx, double x_bound, double n_add, int32_t storage, void* stream) {
     if (!fx || !(x_bound > 0) || !(n_add >= 1)) return set_err(VICAN_ERR_ARG, "vican_fx_finish: bad argument");

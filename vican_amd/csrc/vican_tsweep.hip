@@ -79,8 +79,8 @@ extern "C" int64_t vican_tiled_op_lds_bytes(int32_t n_cam, int32_t max_rows, int
 
 template <typename S, int CP, int TRIPS, bool NT>
 __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_tile_t* __restrict__ tiles, const int n_tile,
-                                                                 const double* __restrict__ lamT_inv, const int parity,
-                                                                 uint32_t* abort_word, const unsigned long long spin_limit) {
+                                                                 const double* __restrict__ lamT_inv, const double* __restrict__ x_base,
+                                                                 const int parity, uint32_t* abort_word, const unsigned long long spin_limit) {
     constexpr int NW = TS_NW, EPL = Vec<S>::N, BLOCK = NW * 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ const double* s_yp[64];                        // this launch's share buffer of every tile
@@ -90,7 +90,10 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
     TS_G const S* const g_blk = (TS_G const S*)g.blk;
     TS_G const uint16_t* const g_idx = (TS_G const uint16_t*)g.idx16;
     TS_G const int32_t* const g_row0 = (TS_G const int32_t*)g.chunk_row0;
-    TS_G const double* const x = (TS_G const double*)Tp->x;
+    // the operand: the tile's slice of x_base ([3C][3], tiles = consecutive camera ranges in descriptor order), else the descriptor's
+    int cam0 = 0;
+    for (int t = 0; t < tile; ++t) cam0 += tiles[t].g.n_cam;
+    TS_G const double* const x = x_base ? (TS_G const double*)x_base + (size_t)9 * cam0 : (TS_G const double*)Tp->x;
     TS_G double* const yp_pub = (TS_G double*)Tp->ypart[parity];       // [T][9] this tile's shares, this launch
     TS_G double* const yp_clr = (TS_G double*)Tp->ypart[parity ^ 1];   // ... re-armed for the next launch
     TS_G double* const fx = (TS_G double*)Tp->fx;
@@ -349,8 +352,8 @@ __global__ __launch_bounds__(TS_NW * 64) void tiled_sweep_kernel(const vican_til
 // the tile's two share buffers [T][9], both filled with the sentinel (vican_tiled_op_sentinel) before the first launch and
 // after an aborted one).  parity: 0, 1, 0, ... on successive launches.  z_cam of tile k: slab-reduce its zpart over n_wg_tile
 // slabs afterwards (vican_slab_reduce_fx with fx + 3, fx + 7).  n_wg_tile workgroups per tile, n_tile * n_wg_tile <= CUs.
-extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
-                              const double* lamT_inv, int32_t parity, void* stream) {
+static int tiled_op_launch(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
+                           const double* lamT_inv, const double* x_base, int32_t parity, void* stream) {
     if (!tiles_host || !tiles_dev || n_tile <= 0 || n_tile > 64 || n_wg_tile <= 0 || !lamT_inv || (parity != 0 && parity != 1))
         return set_err(VICAN_ERR_ARG, "vican_tiled_op: bad argument");
     const vican_graph_t& g0 = tiles_host[0].g;
@@ -358,7 +361,7 @@ extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t
     for (int k = 0; k < n_tile; ++k) {
         const vican_tile_t& t = tiles_host[k];
         if (int rc = vican_check_graph(&t.g, "vican_tiled_op")) return rc;
-        if (t.g.layout != VICAN_LAYOUT_WAVE || !t.g.blk || !t.g.idx16 || !t.x || !t.zpart || !t.fx || !t.ypart[0] || !t.ypart[1])
+        if (t.g.layout != VICAN_LAYOUT_WAVE || !t.g.blk || !t.g.idx16 || (!t.x && !x_base) || !t.zpart || !t.fx || !t.ypart[0] || !t.ypart[1])
             return set_err(VICAN_ERR_ARG, "vican_tiled_op: tiles must be wave layouts with all buffers set");
         if (t.g.n_chunk != g0.n_chunk || t.g.slots != g0.slots || t.g.storage != g0.storage || t.g.n_time != g0.n_time ||
             t.g.stream_nt != g0.stream_nt || t.g.n_chunk == 0)
@@ -385,7 +388,7 @@ extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t
         /* co-residency on EVERY launch, as the other cooperative launchers do: it depends on the grid and the device, not */ \
         /* only on the LDS size (the workgroups spin on each other's shares: a grid that is not resident would hang)       */ \
         if (int rc = vican_coresident_ok((const void*)kern, TS_NW * 64, lds, grid, "vican_tiled_op")) return rc;             \
-        VICAN_LAUNCH_SWEEP(kern, dim3(grid), dim3(TS_NW * 64), lds, st, tiles_dev, (int)n_tile, lamT_inv, (int)parity,        \
+        VICAN_LAUNCH_SWEEP(kern, dim3(grid), dim3(TS_NW * 64), lds, st, tiles_dev, (int)n_tile, lamT_inv, x_base, (int)parity, \
                            g_vican_abort_word, g_vican_sync_ticks);                                                          \
     } while (0)
 #define TS_LAUNCH3(S_, CP_, T_) do { if (g0.stream_nt) TS_LAUNCH4(S_, CP_, T_, true); else TS_LAUNCH4(S_, CP_, T_, false); } while (0)
@@ -397,6 +400,54 @@ extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t
 #undef TS_LAUNCH3
 #undef TS_LAUNCH4
     LAUNCH_CHECK("vican_tiled_op");
+    return VICAN_OK;
+}
+extern "C" int vican_tiled_op(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
+                              const double* lamT_inv, int32_t parity, void* stream) {
+    return tiled_op_launch(tiles_host, tiles_dev, n_tile, n_wg_tile, lamT_inv, nullptr, parity, stream);
+}
+
+// The slab folds of all tiles in one launch: z[cam0_k + c][q] = scale_k * sum over the n_wg_tile slabs of tile k (exact integer
+// sums; scale_k = fx_k[3] * fx_k[7] as vican_slab_reduce_fx(zpart_k, n_wg_tile, C_k, 9, 1.0, fx_k + 3, fx_k + 7, z_k)).
+// 1024 threads = 64 columns x 16 groups striding over the slabs; blockIdx.y = tile.
+__global__ __launch_bounds__(1024) void tiled_fold_kernel(const int32_t* __restrict__ gate, const vican_tile_t* __restrict__ tiles,
+                                                          const int n_slab, double* __restrict__ z) {
+    GATE_RETURN(gate);
+    __shared__ long long sh[1024];
+    const int tile = (int)blockIdx.y;
+    const long long C = tiles[tile].g.n_cam, n = 9 * C;
+    if ((long long)blockIdx.x * 64 >= n) return;
+    int cam0 = 0;
+    for (int t = 0; t < tile; ++t) cam0 += tiles[t].g.n_cam;
+    const long long* part = (const long long*)tiles[tile].zpart;
+    const double* fx = tiles[tile].fx;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    long long s = 0;
+    if (i < n)
+        for (int k = grp; k < n_slab; k += 16) s += part[(size_t)k * n + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        long long t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k * 64 + e];
+        const long long q = i / C, cam = i % C;
+        z[(size_t)(cam0 + cam) * 9 + q] = (double)t * (fx[3] * fx[7]);
+    }
+}
+
+// The tiled operator with operand and result in the caller's arrays: z = P x for x, z [3C][3] doubles (tiles = consecutive camera
+// ranges in descriptor order; the descriptors' x fields are not read) - the fused launch and ONE fold launch for all tiles.
+extern "C" int vican_tiled_op_z(const vican_tile_t* tiles_host, const vican_tile_t* tiles_dev, int32_t n_tile, int32_t n_wg_tile,
+                                const double* lamT_inv, const double* x, double* z, int32_t parity, void* stream) {
+    if (!x || !z) return set_err(VICAN_ERR_ARG, "vican_tiled_op_z: NULL operand or result");
+    if (int rc = tiled_op_launch(tiles_host, tiles_dev, n_tile, n_wg_tile, lamT_inv, x, parity, stream)) return rc;
+    int n_cam = 0;
+    for (int k = 0; k < n_tile; ++k) n_cam = tiles_host[k].g.n_cam > n_cam ? tiles_host[k].g.n_cam : n_cam;
+    hipLaunchKernelGGL(tiled_fold_kernel, dim3((unsigned)((9LL * n_cam + 63) / 64), (unsigned)n_tile), dim3(1024), 0, (hipStream_t)stream,
+                       g_vican_gate, tiles_dev, (int)n_wg_tile, z);
+    LAUNCH_CHECK("vican_tiled_op_z");
     return VICAN_OK;
 }
 

@@ -645,13 +645,15 @@ class HipBackend:
             if self._coop_ws is None:
                 self._coop_ws = torch.zeros(int(self.lib.vican_lanczos_coop_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
                 self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
-            fxp = self.g.fx.data_ptr()
-            slabs = (_ptr(self.zpart), self.g.n_wg, C.c_void_p(fxp + 24), C.c_void_p(fxp + 56)) if from_slabs else (None, 0, None, None)
+            slabs = (None, 0, None, None)
+            if from_slabs:
+                fxp = self.g.fx.data_ptr()
+                slabs = (_ptr(self.zpart), self.g.n_wg, C.c_void_p(fxp + 24), C.c_void_p(fxp + 56))
             # fenced barriers where the sweeps leave little dirty data in L2 (few slabs): 0.4-0.8 us each there, ~10 us with
             # the stress graph's 256 slabs (which relies on the kernel's agent-scope atomics alone)
             rc = self.lib.vican_lanczos_cam_coop(self.C, _ptr(lamC), _ptr(V), ld, j, _ptr(z), _ptr(self._coop_ws), _ptr(Hcol),
                                                  _ptr(beta), _ptr(x_out), float(pivot_floor), _ptr(self._coop_sync), *slabs,
-                                                 int(self.g.n_wg <= 64), _stream())
+                                                 int(getattr(self.g, "n_wg", 1 << 30) <= 64), _stream())
             if rc != _lib.ERR_CAPACITY:
                 self._ck(rc, "vican_lanczos_cam_coop")
                 return
@@ -1220,7 +1222,11 @@ class TiledBackend(HipBackend):
         self.C, self.T = graph.n_cam, graph.n_time
         self.storage_f64 = graph.storage_dtype == torch.float64
         self.tiles = [HipBackend(t) for t in graph.tiles]
-        self.fold_in_step_ok, self.coop_cam_step, self.layout = False, False, "tiled"
+        # (the camera-side Lanczos step as one cooperative launch: 125 workgroups for 4000 cameras - against lap_apply + 3 Gram
+        #  products + 2 updates + the QR, 7 launches and ~75 us per step on the wide benchmark; the slabs of a tiled sweep are
+        #  folded by vican_tiled_op_z, so never `from_slabs`)
+        self.fold_in_step_ok, self.layout = False, "tiled"
+        self.coop_cam_step = os.environ.get("VICAN_COOP", "1") != "0" and self.C <= 8192
         self._status_host, self._coop_ws, self._coop_sync, self._gram_ws = {}, None, None, None
         self.coop_failures = []
         self.rr_part = torch.zeros(1536, dtype=torch.float64, device=self.dev)
@@ -1299,19 +1305,22 @@ class TiledBackend(HipBackend):
         f = self._fused
         if torch.cuda.is_current_stream_capturing():
             return False                # (the share buffer's parity is a launch ARGUMENT: a replayed graph would reuse one buffer)
-        f.x.copy_(x)
-        rc = self.lib.vican_tiled_op(C.cast(f.host, C.c_void_p), _ptr(f.dev), len(self.tiles), f.nwgt, _ptr(lamT_inv), f.parity, _stream())
+        # operand and result in the caller's arrays, the tiles' slab folds in one launch (vican_tiled_op_z; round 4 copied x to a
+        # fixed address and folded tile by tile: five launches more per application)
+        if not x.is_contiguous():
+            f.x.copy_(x)
+            x = f.x
+        z = z_out if z_out.is_contiguous() else torch.empty_like(f.x)
+        rc = self.lib.vican_tiled_op_z(C.cast(f.host, C.c_void_p), _ptr(f.dev), len(self.tiles), f.nwgt, _ptr(lamT_inv), _ptr(x), _ptr(z),
+                                       f.parity, _stream())
         if rc == _lib.ERR_CAPACITY:
             self._fused = None
-            self.coop_failures.append("vican_tiled_op: " + self.lib.vican_last_error().decode())
+            self.coop_failures.append("vican_tiled_op_z: " + self.lib.vican_last_error().decode())
             return False
-        self._ck(rc, "vican_tiled_op")
+        self._ck(rc, "vican_tiled_op_z")
         f.parity ^= 1
-        for k, K in enumerate(self.tiles):
-            r0, r1 = self._tile_rows(k)
-            fxp = K.g.fx.data_ptr()
-            self._ck(self.lib.vican_slab_reduce_fx(_ptr(f.zpart[k]), f.nwgt, K.C, 9, 1.0, C.c_void_p(fxp + 8 * 3), C.c_void_p(fxp + 8 * 7),
-                                                   _ptr(z_out[r0:r1]), _stream()), "vican_slab_reduce_fx")
+        if z is not z_out:
+            z_out.copy_(z)
         return True
 
     def cooperative_failed(self, which):
@@ -1324,9 +1333,13 @@ class TiledBackend(HipBackend):
 
     def _refresh_scales(self, lamT_inv):
         """omega = max_t |Lambda_t^-1|_F * rnorm[t] with the row norms of ALL tiles, into every tile's scale buffer."""
-        for K in self.tiles:
-            self._ck(self.lib.vican_duals_bound(self.T, _ptr(lamT_inv), _ptr(self.g.rnorm), _ptr(K.g.fx), _stream()), "vican_duals_bound")
-            K._fx_finish()
+        # (the bound once, into the first tile's buffer; one launch finishes all tiles' scales: 3 launches instead of 3 per tile)
+        tl = self.tiles
+        self._ck(self.lib.vican_duals_bound(self.T, _ptr(lamT_inv), _ptr(self.g.rnorm), _ptr(tl[0].g.fx), _stream()), "vican_duals_bound")
+        fxs = (C.c_void_p * len(tl))(*[K.g.fx.data_ptr() for K in tl])
+        nadd = (C.c_double * len(tl))(*[float(K.g.rows_per_wg_sweep + 1) for K in tl])
+        self._ck(self.lib.vican_fx_finish_multi(C.cast(fxs, C.c_void_p), C.cast(nadd, C.c_void_p), len(tl), X_BOUND, tl[0].g.desc.storage, _stream()),
+                 "vican_fx_finish_multi")
 
     def _rows_T(self, x):
         """ypart[k] = sum_{c in tile k} M_ct^T x_c for every tile (first pass of the one-pass operator; its camera-side
