@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 23            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 24            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -436,11 +436,14 @@ int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int32_t steps, 
  * blk [E][9] = sum k_r R~ R_m^T R_root, a [E] = sum k_r, w [E] = sum kf^2, u [E][3] = sum kf k_t t~, v [E][3] = sum kf k_t
  * qtau_m (kf = k_t rounded to the matrix dtype `storage`), and deg_c [n_cam], deg_t [n_time] = the diagonal of the reference's
  * J^T J, accumulated in the matrix dtype in source-edge order as scipy's csr_matmat does.  Every sum runs sequentially in
- * source-edge order with unfused IEEE operations: bit-identical to frontend.merge_host.  ws: vican_merge_ws_bytes bytes.  */
+ * source-edge order with unfused IEEE operations: bit-identical to frontend.merge_host.  ws: vican_merge_ws_bytes bytes.
+ * kr_f32 (NULL: none): per source edge, nonzero where the reference's `k_r * R` is a float32 product - a float32 rotation
+ * (every pose of object mode: SE3.inv(), geometry.py:239-243) weighted by a Python scalar: weight and product are rounded to
+ * float32 there, as numpy does.                                                                                            */
 int64_t vican_merge_ws_bytes(int64_t n, int32_t n_cam, int32_t n_time);
 int vican_merge_edges(int64_t n, int32_t n_cam, int32_t n_time, int32_t n_marker, int32_t storage,
                       const int32_t* cam, const int32_t* tim, const int32_t* marker, const double* R, const double* t,
-                      const double* kr, const double* kt, const double* CmT, const double* qtau, void* ws, int64_t ws_bytes,
+                      const double* kr, const uint8_t* kr_f32, const double* kt, const double* CmT, const double* qtau, void* ws, int64_t ws_bytes,
                       int32_t* n_merged, int32_t* row_ptr, int32_t* col, double* blk, double* a, double* w, double* u, double* v,
                       double* deg_c, double* deg_t, void* stream);
 

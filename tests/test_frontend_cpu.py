@@ -186,6 +186,65 @@ def test_object_front_end_one_pass_equals_the_reference_shaped_path(dtype):
         _same_problem(p1, p2)
 
 
+def _dense_blocks(C, T, cam, time, blocks):
+    D = np.zeros((C, T, 3, 3))
+    D[cam, time] = blocks
+    return D
+
+
+@pytest.mark.parametrize("weight", ["python_float", "numpy_float64", "numpy_float32", "python_int"])
+def test_object_mode_blocks_carry_numpys_float32_product(weight):
+    """Object mode weights float32 rotations (SE3.inv(), geometry.py:239-243): with a Python scalar numpy forms `k_r * R`
+    (bipgo.py:213) in float32 - weight AND product rounded - with a numpy float64 scalar in float64.  The merged blocks of the
+    product's front-end equal the pinned oracle's (which performs the reference's own expression edge by edge) TO THE BIT in every
+    case; before round 5 the product formed them in float64 always: 4e-8 relative, the 1e-9 ... 6e-8 rad of object-mode
+    float64 rotation offset in the random campaign (tools/object_offset_probe.py)."""
+    from oracle import bipgo_oracle as orc
+    src = _object_scene(n_time=40, n_marker=9, mpv=4, seed=11)
+    area = gc.CALLABLES["w_area_mild"]
+    nr = {"python_float": area, "numpy_float64": (lambda e: np.float64(area(e))), "numpy_float32": (lambda e: np.float32(area(e))),
+          "python_int": (lambda e: 1 + int(area(e) * 7) % 3)}[weight]
+    nt, ff = gc.CALLABLES["w_area_mild_t"], gc.CALLABLES["f_all"]
+    root, prob = frontend.flatten_object(src, nr, nt, ff, np.float64)
+    # the oracle's path: invert edge by edge, then the reference's per-edge expression (oracle/bipgo_oracle.py flatten_edges)
+    edges = {}
+    for k, v in src.items():
+        ts, mid = k[1].split("_")
+        edges[(mid, ts + "_" + root)] = dict(v, pose=v["pose"].inv())
+    mg = orc.merge_edges(orc.flatten_edges(edges, {root: SE3(pose=np.eye(4))}, nr, nt, ff))
+    rows = np.repeat(np.arange(prob.n_time), np.diff(prob.row_ptr))
+    mine = _dense_blocks(prob.n_cam, prob.n_time, prob.col, rows, prob.blk.reshape(-1, 3, 3))
+    ref = _dense_blocks(mg["C"], mg["T"], mg["cam"], mg["time"], mg["blocks"])
+    assert np.array_equal(mine, ref), np.abs(mine - ref).max()
+    # ... and it is a float32 product exactly when numpy says so
+    is32 = (nr(next(iter(src.values()))) * np.zeros(1, np.float32)).dtype == np.float32
+    assert is32 == (weight != "numpy_float64")
+    blk = prob.blk[prob.a > 0]
+    assert bool(np.all(blk == blk.astype(np.float32))) == is32
+
+
+def test_float32_poses_in_camera_mode_take_the_same_rule():
+    """Camera mode with poses built from a 4x4 matrix (float32 R): the weighted rotation is numpy's float32 product there too
+    (then multiplied by float64 constraint rotations in float64, as numpy promotes); float64 poses are untouched."""
+    from oracle import bipgo_oracle as orc
+    scene = synth.make_scene(n_cam=5, n_time=30, n_marker=4, seed=3)
+    flat = synth.make_camera_edges(scene, cpt=3, mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=4)
+    src = synth.edges_to_dict(flat, SE3)
+    cons = synth.constraints_from_scene(scene, SE3)
+    src32 = {k: dict(v, pose=SE3(pose=np.block([[v["pose"].R(), v["pose"].t()[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])))
+             for k, v in src.items()}
+    nr, nt, ff = gc.CALLABLES["w_area_mild"], gc.CALLABLES["w_area_mild_t"], gc.CALLABLES["f_all"]
+    for edges, tol in ((src32, 1e-13), (src, 1e-13)):
+        prob = frontend.flatten(edges, cons, nr, nt, ff, np.float64)
+        mg = orc.merge_edges(orc.flatten_edges(edges, cons, nr, nt, ff))
+        rows = np.repeat(np.arange(prob.n_time), np.diff(prob.row_ptr))
+        mine = _dense_blocks(prob.n_cam, prob.n_time, prob.col, rows, prob.blk.reshape(-1, 3, 3))
+        ref = _dense_blocks(mg["C"], mg["T"], mg["cam"], mg["time"], mg["blocks"])
+        # (the constraint products run in another order than BLAS's: 1e-16 relative; a float64 product of float32 poses would
+        #  show 6e-8)
+        assert np.abs(mine - ref).max() <= tol * np.abs(ref).max(), np.abs(mine - ref).max()
+
+
 def test_object_front_end_mixed_pose_dtypes_take_the_per_pose_path():
     src = _object_scene(n_time=12)
     keys = list(src)

@@ -30,10 +30,10 @@ def edge_arrays(src, nr, nt, ff):
     return cams, times, marks, R, t, np.asarray(kr, dtype=np.float64), np.asarray(kt, dtype=np.float64)
 
 
-def assert_same_bits(ix, R, t, kr, kt, dtype):
+def assert_same_bits(ix, R, t, kr, kt, dtype, kr_f32=None):
     from vican_amd.device import merge_edges
-    h = frontend.merge_host(ix, R, t, kr, kt, dtype)
-    d = merge_edges(ix, R, t, kr, kt, dtype)
+    h = frontend.merge_host(ix, R, t, kr, kt, dtype, kr_f32=kr_f32)
+    d = merge_edges(ix, R, t, kr, kt, dtype, kr_f32=kr_f32)
     assert d.on_device and d.n_edges == h.n_edges and d.n_cam == h.n_cam and d.n_time == h.n_time
     for f in FIELDS:
         a, b = np.asarray(getattr(h, f)), getattr(d, f).cpu().numpy()
@@ -70,6 +70,25 @@ def test_device_merge_long_segments_and_heavy_weights(seed):
     ix = frontend.index_edges(cams, times, marks, cons)
     for dt in (np.float32, np.float64):
         assert_same_bits(ix, R, t, kr, kt, dt)
+
+
+def test_device_merge_float32_products_where_flagged():
+    """kr_f32 (frontend.f32_product_mask): where set, weight and product k_r * R are rounded to float32 as numpy does for a
+    float32 rotation and a Python scalar - host and device agree to the bit, flagged and unflagged edges mixed."""
+    rng = np.random.default_rng(8)
+    scene = synth.make_scene(n_cam=6, n_time=200, n_marker=5, seed=8)
+    flat = synth.make_camera_edges(scene, cpt=3, mpv=3, sigma_r=1e-3, sigma_t=1e-3, seed=9)
+    src, cons = synth.edges_to_dict(flat, SE3), synth.constraints_from_scene(scene, SE3)
+    cams, times, marks, R, t, _, _ = edge_arrays(src, lambda e: 1.0, lambda e: 1.0, lambda e: True)
+    ix = frontend.index_edges(cams, times, marks, cons)
+    n = len(cams)
+    R = R.astype(np.float32).astype(np.float64)
+    kr, kt = rng.uniform(0.3, 3.0, n), rng.uniform(0.5, 2.0, n)
+    for mask in (np.ones(n, dtype=bool), rng.random(n) < 0.5):
+        for dt in (np.float32, np.float64):
+            h, _ = assert_same_bits(ix, R, t, kr, kt, dt, kr_f32=mask)
+        plain = frontend.merge_host(ix, R, t, kr, kt, np.float64)
+        assert not np.array_equal(h.blk, plain.blk)                 # (the flags do something)
 
 
 def test_device_merge_at_large_shop_size_and_its_cost():

@@ -163,7 +163,7 @@ PROTOTYPES = {
     "vican_lanczos_resident_ws_doubles": (_i64, [_i32]),
     "vican_lanczos_resident": (C.c_int, [_G, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_merge_ws_bytes": (_i64, [_i64, _i32, _i32]),
-    "vican_merge_edges": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+    "vican_merge_edges": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_init_u": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_lsqr_update": (C.c_int, [_i64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -52,6 +52,7 @@ template <typename W>
 __global__ void merge_segments_kernel(long long n, const int32_t* __restrict__ n_merged, const int32_t* __restrict__ start,
                                       const uint32_t* __restrict__ idx, const int32_t* __restrict__ marker,
                                       const double* __restrict__ R, const double* __restrict__ t, const double* __restrict__ kr,
+                                      const uint8_t* __restrict__ kr_f32,
                                       const double* __restrict__ kt, const double* __restrict__ CmT, const double* __restrict__ qtau,
                                       double* __restrict__ blk, double* __restrict__ a, double* __restrict__ w, double* __restrict__ u,
                                       double* __restrict__ v) {
@@ -66,6 +67,13 @@ __global__ void merge_segments_kernel(long long n, const int32_t* __restrict__ n
         double A[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) A[q] = k * R[(size_t)s * 9 + q];
+        // a float32 rotation weighted by a Python scalar: numpy forms `k_r * R` (bipgo.py:213) in float32 - weight and product
+        // rounded to float32 (object mode: SE3.inv() returns float32 rotations, geometry.py:239-243)
+        if (kr_f32 && kr_f32[s]) {
+            const float kf = (float)k;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) A[q] = (double)__fmul_rn(kf, (float)R[(size_t)s * 9 + q]);
+        }
         const double* B = CmT + (size_t)m * 9;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -142,7 +150,7 @@ extern "C" int64_t vican_merge_ws_bytes(int64_t n, int32_t n_cam, int32_t n_time
 
 extern "C" int vican_merge_edges(int64_t n, int32_t n_cam, int32_t n_time, int32_t n_marker, int32_t storage, const int32_t* cam,
                                  const int32_t* tim, const int32_t* marker, const double* R, const double* t, const double* kr,
-                                 const double* kt, const double* CmT, const double* qtau, void* ws, int64_t ws_bytes, int32_t* n_merged,
+                                 const uint8_t* kr_f32, const double* kt, const double* CmT, const double* qtau, void* ws, int64_t ws_bytes, int32_t* n_merged,
                                  int32_t* row_ptr, int32_t* col, double* blk, double* a, double* w, double* u, double* v, double* deg_c,
                                  double* deg_t, void* stream) {
     if (n <= 0 || n_cam <= 0 || n_time <= 0 || n_marker <= 0 || n > 0x7FFFFFF0LL || !cam || !tim || !marker || !R || !t || !kr || !kt ||
@@ -166,12 +174,12 @@ extern "C" int vican_merge_edges(int64_t n, int32_t n_cam, int32_t n_time, int32
     hipLaunchKernelGGL(merge_starts_kernel, dim3(nb), dim3(256), 0, s, (long long)n, (int)n_cam, (int)n_time, m.key2, m.seg, m.start, n_merged,
                        row_ptr, col);
     if (storage == VICAN_STORE_F32) {
-        hipLaunchKernelGGL(merge_segments_kernel<float>, dim3(nb), dim3(256), 0, s, (long long)n, n_merged, m.start, m.i1, marker, R, t, kr, kt,
+        hipLaunchKernelGGL(merge_segments_kernel<float>, dim3(nb), dim3(256), 0, s, (long long)n, n_merged, m.start, m.i1, marker, R, t, kr, kr_f32, kt,
                            CmT, qtau, blk, a, w, u, v);
         hipLaunchKernelGGL(merge_degree_kernel<float>, dim3((n_cam + 63) / 64), dim3(64), 0, s, (long long)n, (int)n_cam, m.kc2, m.i2, kt, deg_c);
         hipLaunchKernelGGL(merge_degree_kernel<float>, dim3((n_time + 63) / 64), dim3(64), 0, s, (long long)n, (int)n_time, m.kt2, m.i3, kt, deg_t);
     } else {
-        hipLaunchKernelGGL(merge_segments_kernel<double>, dim3(nb), dim3(256), 0, s, (long long)n, n_merged, m.start, m.i1, marker, R, t, kr, kt,
+        hipLaunchKernelGGL(merge_segments_kernel<double>, dim3(nb), dim3(256), 0, s, (long long)n, n_merged, m.start, m.i1, marker, R, t, kr, kr_f32, kt,
                            CmT, qtau, blk, a, w, u, v);
         hipLaunchKernelGGL(merge_degree_kernel<double>, dim3((n_cam + 63) / 64), dim3(64), 0, s, (long long)n, (int)n_cam, m.kc2, m.i2, kt, deg_c);
         hipLaunchKernelGGL(merge_degree_kernel<double>, dim3((n_time + 63) / 64), dim3(64), 0, s, (long long)n, (int)n_time, m.kt2, m.i3, kt, deg_t);

@@ -1491,7 +1491,7 @@ class TiledBackend(HipBackend):
     lsqr_u_step = _unsupported
 
 
-def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
+def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None, kr_f32=None):
     """frontend.merge_host ON THE DEVICE (vican_merge.hip; reference bipgo.py:203-221, 445-469): the per-edge arrays go to
     HBM once (124 B per source edge), the merged timestep-major CSR problem never leaves it.  Same bits as merge_host
     (tests/test_merge_gpu.py).  Returns a frontend.Problem whose numeric fields are device tensors (`on_device`)."""
@@ -1507,6 +1507,8 @@ def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
     cam, tim, mk, Rd, td, krd, ktd, CmT, qtau = upload(dev, [
         (ix.ci, i32), (ix.ti, i32), (ix.mi, i32), (np.asarray(R).reshape(n, 9), f64), (t_h, f64), (np.asarray(k_r).reshape(n), f64),
         (kt_h, f64), (np.asarray(ix.CmT).reshape(-1, 9), f64), (np.asarray(ix.qtau).reshape(-1, 3), f64)])
+    # (kr_f32: where numpy forms k_r * R in float32 - frontend.f32_product_mask)
+    flags = None if kr_f32 is None else upload(dev, [(np.ascontiguousarray(kr_f32, dtype=np.uint8).reshape(n), torch.uint8)])[0]
     wsb = int(lib.vican_merge_ws_bytes(n, C_, T_))
     if wsb < 0:
         raise _lib.VicanError("vican_merge_ws_bytes failed")
@@ -1516,7 +1518,7 @@ def merge_edges(ix, R, t, k_r, k_t, dtype=np.float32, device=None):
     blk, a, w, u, v, deg_c, deg_t = e(n, 9), e(n), e(n), e(n, 3), e(n, 3), e(C_), e(T_)
     storage = _lib.STORE_F32 if np.dtype(dtype) == np.float32 else _lib.STORE_F64
     _lib.check(lib.vican_merge_edges(n, C_, T_, int(CmT.shape[0]), storage, _ptr(cam), _ptr(tim), _ptr(mk), _ptr(Rd), _ptr(td), _ptr(krd),
-                                     _ptr(ktd), _ptr(CmT), _ptr(qtau), _ptr(ws), wsb, _ptr(nm), _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a),
+                                     _ptr(flags), _ptr(ktd), _ptr(CmT), _ptr(qtau), _ptr(ws), wsb, _ptr(nm), _ptr(row_ptr), _ptr(col), _ptr(blk), _ptr(a),
                                      _ptr(w), _ptr(u), _ptr(v), _ptr(deg_c), _ptr(deg_t), _stream()), "vican_merge_edges")
     E = int(nm.item())                                           # (the one synchronisation: sizes the outputs)
     p = frontend.Problem()

@@ -76,7 +76,8 @@ class EdgeColumns:
             if name == "pose":
                 return self.poses()
             if name == "R":
-                c = _stack_f64([p.R() for p in self.poses()], (3, 3)) if n else np.zeros((0, 3, 3))
+                rl = self._cache["R_list"] = [p.R() for p in self.poses()]
+                c = _stack_f64(rl, (3, 3)) if n else np.zeros((0, 3, 3))
             elif name == "t":
                 c = _stack_f64([p.t() for p in self.poses()], (3,)) if n else np.zeros((0, 3))
             elif name == "reprojected_err":
@@ -88,6 +89,13 @@ class EdgeColumns:
                 c[:] = [v[name] for v in self._vals]
             self._cache[name] = c
         return c
+
+    def raw(self, name):
+        """The list of per-edge objects a stacked column was made from ("R": the arrays pose.R() returned, with their dtypes)."""
+        if name == "R":
+            self["R"]
+            return self._cache.get("R_list")
+        return None
 
     def select(self, keep):
         """The columns of the edges where `keep` (bool [n]) holds (already gathered columns are sliced, not re-gathered)."""
@@ -139,9 +147,10 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     n = len(vals)
     if n == 0:
         raise ValueError("no edge passes edge_filter")
-    kr = _call_columns(noise_model_r, cols, np.float64)
+    kr = kr_raw = _call_columns(noise_model_r, cols, np.float64)
     if kr is None:
-        kr = np.array([noise_model_r(v) for v in vals], dtype=np.float64)
+        kr_raw = [noise_model_r(v) for v in vals]
+        kr = np.array(kr_raw, dtype=np.float64)
     kt = _call_columns(noise_model_t, cols, np.float64)
     if kt is None:
         kt = np.array([noise_model_t(v) for v in vals], dtype=np.float64)
@@ -161,7 +170,15 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
             times, marks = [a for a, _ in tsm], [b for _, b in tsm]
         codes = index_codes(cams, times, marks)
         cache["keys"], cache["codes"] = keys, codes
-    return (merge or merge_host)(index_edges(None, None, None, constraints, codes=codes), R, t, kr, kt, dtype)
+    # (float32 rotations - poses built from a 4x4 matrix: numpy weights them in float32, f32_product_mask; one dtype look-up for
+    #  the usual float64 ones)
+    kw = {}
+    R_list = cols.raw("R")
+    if R_list is not None and n and getattr(R_list[0], "dtype", None) == np.float32:
+        mask = f32_product_mask(kr_raw, R_list)
+        if mask is not None:
+            kw["kr_f32"] = mask
+    return (merge or merge_host)(index_edges(None, None, None, constraints, codes=codes), R, t, kr, kt, dtype, **kw)
 
 
 def _stack_f64(items, shape):
@@ -316,11 +333,46 @@ def index_edges(cam_ids, time_ids, marker_ids, constraints, codes=None) -> EdgeI
     return ix
 
 
-def weighted_rotations(kr, R, CmT_e):
+def f32_product_mask(weights, rotations):
+    """Per kept source edge: does numpy form the reference's `k_r * v['pose'].R()` (bipgo.py:213) in float32?  It does when the
+    rotation is a float32 array - every pose of object mode (SE3.inv() assembles a float32 4x4, geometry.py:239-243), poses
+    built from a 4x4 matrix - and the weight is a Python scalar (NEP 50: weak) or a float32 one: the weight is then rounded to
+    float32 and so is every product, 6e-8 relative - which showed as 1e-9 (median) ... 6e-8 rad between the product's float64
+    object-mode rotations and the reference's while this was formed in float64 (tools/object_offset_probe.py; camera-mode scenes
+    with float64 rotations agree to 1e-12).  The rule is asked of the installed numpy, one example per scalar type.
+    weights: what the callable returned (a list / tuple of scalars, or an array); rotations: the list of R() arrays.
+    Returns a bool array [n], or None when no product is a float32 one."""
+    n = len(weights)
+    if n == 0 or len(rotations) != n:
+        return None
+    rd = [getattr(r, "dtype", None) for r in rotations]
+    r32 = np.array([d == np.float32 for d in rd]) if any(d == np.float32 for d in rd) else None
+    if r32 is None:
+        return None
+    probe = np.zeros(1, dtype=np.float32)
+    if isinstance(weights, np.ndarray):
+        k32 = np.full(n, (weights[:1] * probe).dtype == np.float32)
+    else:
+        types = list(map(type, weights))
+        rule = {}
+        for tp in set(types):
+            try:
+                rule[tp] = (weights[types.index(tp)] * probe).dtype == np.float32
+            except Exception:
+                rule[tp] = False
+        k32 = np.full(n, next(iter(rule.values()))) if len(rule) == 1 else np.array([rule[tp] for tp in types])
+    mask = r32 & k32
+    return mask if mask.any() else None
+
+
+def weighted_rotations(kr, R, CmT_e, kr_f32=None):
     """(k_r R~_e) (R_m^T R_root) per edge with every rounding spelled out - products and sums in index order, no fused
     multiply-add, no BLAS - so that the device kernel (vican_merge.hip, same order, contraction off) reproduces it to the bit
-    on any machine: out[e,i,j] = ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j), a = k_r R."""
+    on any machine: out[e,i,j] = ((a_i0 b_0j + a_i1 b_1j) + a_i2 b_2j), a = k_r R (in float32 where `kr_f32`: f32_product_mask)."""
     A = kr[:, None, None] * R
+    if kr_f32 is not None:
+        m = np.asarray(kr_f32, dtype=bool)
+        A[m] = (kr[m].astype(np.float32)[:, None, None] * R[m].astype(np.float32)).astype(np.float64)
     out = np.empty_like(A)
     for i in range(3):
         for j in range(3):
@@ -328,7 +380,7 @@ def weighted_rotations(kr, R, CmT_e):
     return out
 
 
-def merge_host(ix: EdgeIndex, R, t, k_r, k_t, dtype=np.float32) -> Problem:
+def merge_host(ix: EdgeIndex, R, t, k_r, k_t, dtype=np.float32, kr_f32=None) -> Problem:
     """Numeric half of the front-end on the host (bipgo.py:203-221, 445-469): per kept source edge
         M_ct += k_r R~_e R_m^T R_root,   a_ct += k_r,   w_ct += kf^2,   u_ct += kf k_t t~_e,   v_ct += kf k_t (R_root^T R_m) tau_m
     summed SEQUENTIALLY in source-edge order (np.add.at: unbuffered, in index order) - the order scipy's csr_matmat uses for
@@ -358,7 +410,7 @@ def merge_host(ix: EdgeIndex, R, t, k_r, k_t, dtype=np.float32) -> Problem:
     rows = (ukey // C).astype(np.int64)
     p.row_ptr = np.zeros(T + 1, dtype=np.int32)
     np.cumsum(np.bincount(rows, minlength=T), out=p.row_ptr[1:])
-    p.blk = seg(weighted_rotations(kr, R, ix.CmT[ix.mi])).reshape(E, 9)
+    p.blk = seg(weighted_rotations(kr, R, ix.CmT[ix.mi], kr_f32)).reshape(E, 9)
     p.a = seg(kr)
     # Entries of the reference's normal matrix J^T J (bipgo.py:477) AS SCIPY FORMS THEM: csr_matmat accumulates the products
     # k k of the incidence entries in the matrix dtype, sequentially in source-edge order - for dtype=float32 that is float32
@@ -382,14 +434,15 @@ def merge_host(ix: EdgeIndex, R, t, k_r, k_t, dtype=np.float32) -> Problem:
     return p
 
 
-def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype=np.float32, merge=None) -> Problem:
+def flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype=np.float32, merge=None, kr_f32=None) -> Problem:
     """The array form of ``flatten`` (everything after the per-edge Python loop): one entry per KEPT source edge - camera
     id, timestamp and marker id (strings, as in the reference's keys ``(cam, "<t>_<marker>")``), measured rotation R
     [n,3,3] and translation t [n,3] of the marker in the camera frame, and the two weights the reference obtains from
     ``noise_model_r`` / ``noise_model_t``.  Callers that already hold their detections as arrays (or evaluate their
     weight functions vectorised) skip the edge dict and its per-edge callables altogether.  = index_edges + merge_host;
     the drop-in API on a GPU box runs index_edges on the host and the merge on the device (device.merge_edges)."""
-    return (merge or merge_host)(index_edges(cam_ids, time_ids, marker_ids, constraints), R, t, k_r, k_t, dtype)
+    kw = {} if kr_f32 is None else {"kr_f32": kr_f32}          # (f32_product_mask; array callers: float64 products)
+    return (merge or merge_host)(index_edges(cam_ids, time_ids, marker_ids, constraints), R, t, k_r, k_t, dtype, **kw)
 
 
 def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
@@ -505,6 +558,9 @@ class _InvertedEdge(dict):
         return dict.__len__(self._whole())
 
 
+_F32 = np.zeros(0, dtype=np.float32)            # stands for "a float32 rotation" in f32_product_mask
+
+
 def inverted_poses(Rs, ts):
     """The rotations / translations of ``pose.inv()`` for a list of poses (reference geometry.py:235-243, as
     vican_amd.geometry.SE3.inv), all at once and to the bit: the inverse is assembled in a float32 4x4 -
@@ -553,7 +609,10 @@ def flatten_object(src_edges, noise_model_r, noise_model_t, edge_filter, dtype=n
     if inv is None:                                                 # mixed dtypes / foreign pose types: pose by pose
         inv_p = [p.inv() for p in poses]
         inv = _stack_f64([p.R() for p in inv_p], (3, 3)), _stack_f64([p.t() for p in inv_p], (3,))
-    return root, flatten_arrays(cams, times, np.full(len(cams), root), inv[0], inv[1], kr, kt, {root: SE3(pose=np.eye(4))}, dtype, merge)
+    # (inverted poses are float32 whatever the source pose held: the weights' types decide the dtype of k_r * R)
+    mask = f32_product_mask(kr, [_F32] * len(kr))
+    return root, flatten_arrays(cams, times, np.full(len(cams), root), inv[0], inv[1], kr, kt, {root: SE3(pose=np.eye(4))}, dtype, merge,
+                                kr_f32=mask)
 
 
 def invert_object_edges(src_edges):
