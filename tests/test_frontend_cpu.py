@@ -269,3 +269,64 @@ def test_string_ids_sort_like_the_reference_on_the_fast_and_the_general_path():
         names, inv = frontend.sorted_codes(ids)
         ref_names, ref_inv = np.unique(np.asarray(ids).astype(str), return_inverse=True)
         assert np.array_equal(names, ref_names) and np.array_equal(inv, ref_inv)
+
+
+def test_c_passes_of_the_front_end_equal_the_python_path(monkeypatch):
+    """csrc/vican_fastpath.c (one C pass over the value dicts per column) against the list-comprehension path it replaces: the same
+    Problem to the bit for float64 poses, float32 poses (views of a 4x4: strided), a mixture, and foreign pose classes (methods
+    instead of attributes); values it does not recognise (dict subclasses, poses whose R() is a list) fall back silently."""
+    from vican_amd import _lib
+    _lib.build_fastpath()
+    monkeypatch.setattr(_lib, "_fastpath", False)                   # (re-probe under the current environment)
+    fp = _lib.fastpath()
+    assert fp is not None
+    scene = synth.make_scene(n_cam=5, n_time=40, n_marker=4, seed=3)
+    flat = synth.make_camera_edges(scene, cpt=3, mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=4)
+    src = synth.edges_to_dict(flat, SE3)
+    cons = synth.constraints_from_scene(scene, SE3)
+    p4 = lambda v: np.block([[v["pose"].R(), v["pose"].t()[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+
+    class Foreign:                                                   # a pose class of the caller's own: R() / t() only
+        def __init__(self, R, t):
+            self.rot, self.tr = R, t
+
+        def R(self):
+            return self.rot
+
+        def t(self):
+            return self.tr
+
+        def inv(self):
+            return SE3(R=self.rot, t=self.tr).inv()
+
+    variants = {
+        "f64": src,
+        "f32": {k: dict(v, pose=SE3(pose=p4(v))) for k, v in src.items()},
+        "mixed": {k: dict(v, pose=SE3(pose=p4(v)) if i % 3 == 0 else v["pose"]) for i, (k, v) in enumerate(src.items())},
+        "foreign": {k: dict(v, pose=Foreign(v["pose"].R(), v["pose"].t())) for k, v in src.items()},
+    }
+    area = vectorized_area = frontend.vectorized(lambda cols: 0.5 + np.abs(cols["corners"]).sum((1, 2)) / 4000.0 + 0.0 * cols["reprojected_err"])(
+        lambda e: 0.5 + float(np.abs(e["corners"]).sum()) / 4000.0)
+    nt, ff = gc.CALLABLES["w_area_mild_t"], gc.CALLABLES["f_err"]
+    for name, edges in variants.items():
+        cols = frontend.EdgeColumns(list(edges.values()))
+        assert cols._gather_poses_c(), name                         # the C pass recognises all four
+        p_c = frontend.flatten(edges, cons, area, nt, ff, np.float64)
+        monkeypatch.setenv("VICAN_FASTPATH", "0"); monkeypatch.setattr(_lib, "_fastpath", False)
+        assert _lib.fastpath() is None
+        p_py = frontend.flatten(edges, cons, area, nt, ff, np.float64)
+        monkeypatch.delenv("VICAN_FASTPATH"); monkeypatch.setattr(_lib, "_fastpath", False)
+        _same_problem(p_c, p_py)
+    # not recognised: a dict subclass, a pose whose R() is a nested list - the Python path serves, same result as arrays would give
+    class D(dict):
+        pass
+    odd = {k: D(v) for k, v in src.items()}
+    assert not frontend.EdgeColumns(list(odd.values()))._gather_poses_c()
+    _same_problem(frontend.flatten(odd, cons, area, nt, ff, np.float64), frontend.flatten(src, cons, area, nt, ff, np.float64))
+    lists = {k: dict(v, pose=Foreign(v["pose"].R().tolist(), v["pose"].t().tolist())) for k, v in src.items()}
+    assert not frontend.EdgeColumns(list(lists.values()))._gather_poses_c()
+    _same_problem(frontend.flatten(lists, cons, area, nt, ff, np.float64), frontend.flatten(src, cons, area, nt, ff, np.float64))
+    # columns of scalars / small arrays
+    cols = frontend.EdgeColumns(list(src.values()))
+    assert np.array_equal(cols["corners"], np.array([v["corners"] for v in src.values()], dtype=np.float64))
+    assert np.array_equal(cols["reprojected_err"], np.array([v["reprojected_err"] for v in src.values()], dtype=np.float64))

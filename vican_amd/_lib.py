@@ -300,6 +300,49 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, e
     return out
 
 
+FASTPATH_SRC = os.path.join(CSRC, "vican_fastpath.c")
+FASTPATH_SO = os.path.join(CSRC, "_vican_fastpath.so")
+_fastpath = False            # False: not tried yet; None: unavailable
+
+
+def build_fastpath(force: bool = False) -> str:
+    """Compile the C passes of the drop-in front-end (csrc/vican_fastpath.c: CPython + NumPy C API) with gcc, in-tree.
+    Host-side plumbing: the front-end runs without it (vican_amd.frontend falls back to NumPy / list comprehensions)."""
+    import sysconfig
+    import numpy as np
+    if not force and os.path.exists(FASTPATH_SO) and os.path.getmtime(FASTPATH_SO) >= os.path.getmtime(FASTPATH_SRC):
+        return FASTPATH_SO
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise VicanError("no C compiler for vican_fastpath.c")
+    tmp = FASTPATH_SO + ".tmp.%d" % os.getpid()
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-I" + np.get_include(), FASTPATH_SRC, "-o", tmp]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise VicanError("building vican_fastpath.c failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, FASTPATH_SO)
+    return FASTPATH_SO
+
+
+def fastpath():
+    """The `_vican_fastpath` extension module, or None (not built, built for another interpreter / NumPy, VICAN_FASTPATH=0)."""
+    global _fastpath
+    if _fastpath is False:
+        _fastpath = None
+        if os.environ.get("VICAN_FASTPATH", "1") != "0" and os.path.exists(FASTPATH_SO):
+            try:
+                import importlib.machinery
+                import importlib.util
+                loader = importlib.machinery.ExtensionFileLoader("_vican_fastpath", FASTPATH_SO)
+                spec = importlib.util.spec_from_loader("_vican_fastpath", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _fastpath = mod
+            except Exception:                 # (ImportError, an ABI mismatch of the NumPy C API ...): the Python path serves
+                _fastpath = None
+    return _fastpath
+
+
 def load():
     """Load the shared library and attach prototypes (raises if it is missing)."""
     global _lib
