@@ -17,7 +17,11 @@ torch.cuda.set_device(0)
 bad = 0
 # one-rank groups, created by EVERY rank in the same order (torch.distributed.new_group is collective)
 singles = [dist.new_group([r]) for r in range(world)]
-for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101)]):
+# (the last case again with camera TILES of 5 - the path graphs beyond 1024 cameras take: the tiles' rows are re-ordered inside
+#  each rank's graph, device.TiledGraph.row_perm, and handed back in the caller's order)
+for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101), (12, 101)]):
+    if seed == 6:
+        os.environ["VICAN_TILE_CAMS"] = "5"
     scene = synth.make_scene(n_cam=C, n_time=T, n_marker=3, seed=seed)
     flat = synth.make_camera_edges(scene, cpt=min(C, 3), mpv=2, sigma_r=1e-3, sigma_t=1e-3, seed=seed + 1)
     src = synth.edges_to_dict(flat, SE3); cons = synth.constraints_from_scene(scene, SE3)
@@ -32,8 +36,9 @@ for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101
         tr = max(float(np.abs(pc - pc1).max()), float(np.abs(pt - pt1).max()))
         ok = rot < (1e-7 if dt == np.float64 else 1e-5) and tr < (1e-6 if dt == np.float64 else 1e-3)
         bad += not ok
+        ok = ok and (seed != 6 or info.get("layout") == "tiled")
         if rank == 0:
-            print("C=%d T=%d %s: sharded vs single rot %.1e trans %.1e cg %s %s" % (C, T, np.dtype(dt).name, rot, tr, info.get("cg_iters"), "" if ok else "  <-- MISMATCH"))
+            print("C=%d T=%d %s %s: sharded vs single rot %.1e trans %.1e cg %s %s" % (C, T, np.dtype(dt).name, info.get("layout"), rot, tr, info.get("cg_iters"), "" if ok else "  <-- MISMATCH"))
 t = torch.tensor([bad]); dist.all_reduce(t)
 if rank == 0:
     print("dist probe: mismatches", int(t[0]))
