@@ -147,6 +147,45 @@ if fs:
               open("profiles/%s_sparse_counters.json" % tag, "w"), indent=1)
     out.append("sparse capture: profiles/%s_sparse_kernel_stats.csv, _sparse_counters.json, _sparse_bench.json" % tag)
 
+# 4. the camera-tiled path: kernel stats + counters of the fused launch
+fw = first("wide_stats/**/*kernel_stats.csv")
+if fw:
+    rows = list(csv.DictReader(open(fw)))
+    OURS_W = OURS + ("tiled_", "sum_apply3", "cg_tiles")
+    with open("profiles/%s_wide_kernel_stats.csv" % tag, "w") as o:
+        o.write("# bench.py --workload wide (4000 cameras x 100 000 timesteps x 250 cameras per timestep, 4 camera tiles); this project's kernels only\n")
+        w = csv.writer(o); w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for r in rows:
+            if any(k in r["Name"] for k in OURS_W):
+                w.writerow([r["Name"][:100], r["Calls"], "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (float(r["MinNs"]) / 1e3),
+                            "%.2f" % (float(r["MaxNs"]) / 1e3), "%.3f" % (float(r["TotalDurationNs"]) / 1e6)])
+    TILED = r"tiled_sweep_kernel<"
+    wpm = {}
+    for sub in ("wide_fetch", "wide_write", "wide_sq1"):
+        c, n = counters(sub, TILED)
+        wpm.update(c)
+    wb = None
+    bj3 = os.path.join(src, "bench_wide.json")
+    if os.path.exists(bj3):
+        lines = [l for l in open(bj3) if l.startswith("{")]
+        if lines:
+            wb = json.loads(lines[-1])
+            json.dump(wb, open("profiles/%s_wide.json" % tag, "w"), indent=1)
+    wt = None
+    if "FETCH_SIZE" in wpm and "WRITE_SIZE" in wpm:
+        wt = dict(fetch_bytes=2.0 * wpm["FETCH_SIZE"] * 1024, write_bytes=wpm["WRITE_SIZE"] * 1024)
+        wt["hbm_bytes"] = wt["fetch_bytes"] + wt["write_bytes"]
+    json.dump(dict(tag=tag, workload=wb["config"]["workload"] if wb else "wide", kernel="tiled_sweep_kernel (vican_tiled_op_z)",
+                   counters_mean_per_dispatch=wpm, traffic=wt,
+                   bytes_per_launch_algorithmic=wb["roofline"]["bytes_per_launch"] if wb else None,
+                   padded_slots_over_edges=wb["roofline"].get("padded_slots_over_edges") if wb else None,
+                   note="means over the dispatches of the fused tiled launch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads"),
+              open("profiles/%s_wide_counters.json" % tag, "w"), indent=1)
+    fn = os.path.join(src, "timeline_wide.txt")
+    if os.path.exists(fn) and os.path.exists("profiles/%s_timeline.txt" % tag):
+        open("profiles/%s_timeline.txt" % tag, "a").write("\n# wide workload (4000 cameras, camera tiles), a warm timed solve  (tools/timeline.py)\n" + open(fn).read())
+    out.append("wide: profiles/%s_wide_kernel_stats.csv, _wide_counters.json, _wide.json" % tag)
+
 summary = dict(tag=tag, kernel=(bench["roofline"]["kernel"] if bench else "sweep kernel MODE 0 (vican_block_op)"), counters_mean_per_dispatch=pm, traffic=traffic,
                workload=bench["config"]["workload"] if bench else None,
                bytes_per_launch_algorithmic=bench["roofline"]["bytes_per_launch"] if bench else None,

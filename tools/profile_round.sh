@@ -28,3 +28,14 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/sparse_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/sparse_write -- $BS --steps 1 --warmup 0 > $O/bench_sparse_write.log 2>&1
 cd $GRAFT_REPO_ROOT && python bench.py --workload sparse --no-cpu-baseline > $O/bench_sparse.json 2> $O/bench_sparse.err
 rm -rf $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv
+# the camera-tiled path (4000 cameras x 100 000 timesteps x 250 cameras per timestep): kernel stats, HBM traffic and SQ counters of the fused launch
+cd /tmp
+BW="python3 $GRAFT_REPO_ROOT/bench.py --workload wide --no-cpu-baseline --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/wide_stats -- $BW > $O/bench_wide_stats.log 2>&1
+cd $GRAFT_REPO_ROOT && python tools/timeline.py $O/wide_stats 2 > $O/timeline_wide.txt 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/wide_fetch -- $BW --steps 1 --warmup 0 > $O/bench_wide_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/wide_write -- $BW --steps 1 --warmup 0 > $O/bench_wide_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/wide_sq1 -- $BW --steps 1 --warmup 0 > $O/bench_wide_sq1.log 2>&1
+cd $GRAFT_REPO_ROOT && python bench.py --workload wide --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_wide.json 2> $O/bench_wide.err
+rm -rf $O/*/*/*kernel_trace.csv $O/*/*/*agent_info.csv

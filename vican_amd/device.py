@@ -1108,19 +1108,25 @@ class TiledGraph:
                     cap_rows = min(cap_rows, rows_t)
                 ptrs = (C.c_void_p * len(parts))(*[r.ctypes.data for r in rps_host])
                 perm, c0s = np.empty(T, dtype=np.int32), np.empty(T + 2, dtype=np.int32)
-                nch = _lib.check(lib.vican_plan_rows_multi(T, len(parts), C.cast(ptrs, C.c_void_p), slots, cap_rows,
-                                                            int(os.environ.get("VICAN_TILE_PACK_WINDOW", 512)), C.c_void_p(perm.ctypes.data),
-                                                            C.c_void_p(c0s.ctypes.data), T + 2), "vican_plan_rows_multi")
-                inv = np.empty(T, dtype=np.int64)
-                inv[perm] = np.arange(T)
-                self.row_perm = torch.from_numpy(perm.astype(np.int64)).to(dev)
-                self.row_inv = torch.from_numpy(inv).to(dev)
+                # the packing costs (rows x pool x tiles) comparisons on the host and pays where few rows fill a chunk (the
+                # integer effect: 3 or 4 rows); chunks of many short rows fill well in any order: a smaller pool there, none
+                # beyond 32 rows per chunk
+                rows_est = max(1.0, slots / max(1.0, max(float(r[-1]) for r in rps_host) / T))
+                window = int(os.environ.get("VICAN_TILE_PACK_WINDOW", 0)) or (512 if rows_est <= 8 else 128 if rows_est <= 32 else 1)
+                nch = _lib.check(lib.vican_plan_rows_multi(T, len(parts), C.cast(ptrs, C.c_void_p), slots, cap_rows, window,
+                                                            C.c_void_p(perm.ctypes.data), C.c_void_p(c0s.ctypes.data), T + 2),
+                                 "vican_plan_rows_multi")
                 packed_chunks = c0s[: nch + 1].copy()
-                parts = cut(self.row_inv[rows])
-                rps_host = download([p_[3] for p_ in parts])
-                rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
-                if deg_t is not None:
-                    deg_t = deg_t.to(dev)[self.row_perm]
+                if not np.array_equal(perm, np.arange(T, dtype=np.int32)):     # (else: the rows stay where they are)
+                    inv = np.empty(T, dtype=np.int64)
+                    inv[perm] = np.arange(T)
+                    self.row_perm = torch.from_numpy(perm.astype(np.int64)).to(dev)
+                    self.row_inv = torch.from_numpy(inv).to(dev)
+                    parts = cut(self.row_inv[rows])
+                    rps_host = download([p_[3] for p_ in parts])
+                    rps_host = [np.ascontiguousarray(r, dtype=np.int32) for r in rps_host]
+                    if deg_t is not None:
+                        deg_t = deg_t.to(dev)[self.row_perm]
             except _lib.VicanError:
                 self.row_perm = self.row_inv = packed_chunks = None
                 parts = cut(rows)

@@ -516,9 +516,14 @@ def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
         raise ValueError("no edge passes edge_filter")
     mk_names, mk_idx = np.unique(np.array(marks, dtype=str), return_inverse=True)
     Cm = np.stack([np.asarray(constraints[str(m)].R(), dtype=np.float64) @ r_root.T for m in mk_names])   # KeyError as bipgo.py:41
-    R = _stack_f64([p.R() for p in poses], (3, 3))
+    Rl = [p.R() for p in poses]
+    R = _stack_f64(Rl, (3, 3))
+    m32 = f32_product_mask(kr, Rl) if getattr(Rl[0], "dtype", None) == np.float32 else None      # (float32 rotations: numpy's float32 product)
     kr = np.asarray(kr, dtype=np.float64)
-    wR = (kr[:, None, None] * R) @ Cm[mk_idx]
+    A = kr[:, None, None] * R
+    if m32 is not None:
+        A[m32] = (kr[m32].astype(np.float32)[:, None, None] * R[m32].astype(np.float32)).astype(np.float64)
+    wR = A @ Cm[mk_idx]
     cam_nodes, ci = np.unique(np.char.add("c", np.array(cams, dtype=str)), return_inverse=True)           # bipgo.py:54
     time_nodes, ti = np.unique(np.char.add("t", np.array(times, dtype=str)), return_inverse=True)
     C, T = len(cam_nodes), len(time_nodes)
