@@ -67,9 +67,19 @@ def test_solver_logic_matches_reference(name, dt):
     assert np.abs(ev - evr).max() < (1e-7 if dt == "float64" else 1e-4) * np.abs(evals).max()
 
 
-def test_indefinite_regime_fails_loudly():
-    """g3 (noisy multi-marker edges): after one dual update the connection Laplacian has ~90 negative eigenvalues
-    and the reference's eigs(sigma=-1e-6) returns interior eigenvectors; the product refuses instead."""
+def test_indefinite_regime_reproduces_the_reference(monkeypatch):
+    """g3 (noisy multi-marker edges): after one dual update the connection Laplacian has ~90 negative eigenvalues and the
+    reference's eigs(sigma=-1e-6) returns INTERIOR eigenvectors - a chaotic iteration that the oracle only reproduces because it
+    makes the same calls.  The solver notices (smallest Ritz value further below zero than the fourth lies above), starts over and
+    takes every step on the dense Laplacian (GeneralRotationSolver._interior_step): the real reference's output to 1e-7, its five
+    eigenvalues per iteration to 1e-9.  Beyond INTERIOR_MAX_N unknowns it still refuses, loudly."""
+    keys, R, evals = golden("g3_medium", "float64")
+    names, r, rot = run_numpy("g3_medium", "float64")
+    assert names == keys and rot.interior and rot.stats["interior_from"] == 1
+    assert np.abs(r - R).max() < 1e-7, np.abs(r - R).max()
+    ev, evr = np.sort(np.array(rot.stats["evals"]), axis=1), np.sort(evals, axis=1)
+    assert ev.shape == evr.shape and np.abs(ev - evr).max() < 1e-9
+    monkeypatch.setattr(GeneralRotationSolver, "INTERIOR_MAX_N", 600)
     with pytest.raises(ArithmeticError, match="indefinite"):
         run_numpy("g3_medium", "float64")
 

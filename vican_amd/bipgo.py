@@ -262,10 +262,11 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
     per-node SVD, NOT det-fixed and NOT transposed (bipgo.py:126-127,135-141).  The gauge is the first node in
     np.unique order of the 'c<id>' / 't<timestamp>' names.  Single GPU.
 
-    Differences from the reference, both loud: ``maxiter=0`` raises the reference's UnboundLocalError; and an
-    ArithmeticError is raised when the dual iterate makes the connection Laplacian strongly indefinite - the
-    reference's shift-invert ``eigs(sigma=-1e-6)`` then returns INTERIOR eigenvectors (and a meaningless answer),
-    which the matrix-free eigen-solver does not reproduce."""
+    ``maxiter=0`` raises the reference's UnboundLocalError.  When the dual iterate makes the connection Laplacian strongly
+    indefinite the reference's shift-invert ``eigs(sigma=-1e-6)`` returns INTERIOR eigenvectors (noisy multi-marker graphs;
+    the answer is a chaotic function of the input there): the solver then starts over on the dense Laplacian and reproduces it
+    (``info["interior_from"]``; solver.GeneralRotationSolver._interior_step) up to 6144 unknowns, and raises an ArithmeticError
+    beyond that."""
     from .device import HipBackend, LocalGraph, upload
 
     if not torch.cuda.is_available():
@@ -298,6 +299,7 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
     if info is not None:
         info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
                     eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
+                    interior_from=rot.stats.get("interior_from"),
                     n_cam=prob.n_cam, n_time=prob.n_time, n_edges=prob.n_edges, n_src=prob.n_src,
                     t_pack=t1 - t0, t_rot=t2 - t1)
     if verbose:
