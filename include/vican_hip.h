@@ -92,7 +92,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 24            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 25            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -532,6 +532,10 @@ int vican_cg_sweep(const vican_graph_t* g, const double* w, const double* deg_t,
  * (pq_part = NULL: the camera part only):  the message a sharded run all-reduces per CG iteration.          */
 int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam, const double* pq_part, double* qcpq,
                   const vican_cg_state_t* st, void* stream);
+/* The folds of the camera tiles of one CG product (vican_cg_sweep_tiles) in one launch: qc_parts / n_cams: HOST arrays of n_tile
+ * slab pointers and camera counts (tiles = consecutive camera ranges); q_c of tile k lands at qcpq[3 (C_0 + ... + C_(k-1)) ...].    */
+int vican_cg_fold_tiles(const void* const* qc_parts, const int32_t* n_cams, int32_t n_tile, int32_t n_slab, double* qcpq,
+                        const vican_cg_state_t* st, void* stream);
 /* The CG Laplacian product of a camera-tiled graph in ONE launch (csrc/vican_tcg.hip; per tile: vican_cg_sweep_partial): tile k's
  * sweep writes its share of the row sums into acc_t and the double-word slabs of its own cameras into qc_part (n_wg_tile slabs
  * of 6 C_tile words; fold with vican_cg_fold(pq_part = NULL)); p_t already updated (vican_cg_update_pt), rows combined by

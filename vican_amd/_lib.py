@@ -149,6 +149,7 @@ PROTOTYPES = {
     "vican_cg_begin": (C.c_int, [_i32, _vp, _vp, _f64, _vp, _i32, _f64, _vp, _vp]),
     "vican_cg_sweep": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_fold": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vican_cg_fold_tiles": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vican_cg_update_pt": (C.c_int, [_i32, _vp, _vp, _vp, _vp]),
     "vican_cg_sweep_partial": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_cg_combine_rows": (C.c_int, [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

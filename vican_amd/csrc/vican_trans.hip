@@ -1159,6 +1159,41 @@ extern "C" int vican_cg_fold(const void* qc_part, int32_t n_slab, int32_t n_cam,
     return VICAN_OK;
 }
 
+// the folds of the camera tiles of one CG product (vican_cg_sweep_tiles) in ONE launch: blockIdx.y = tile, tile k's cameras at
+// qcpq[3 cam0_k ...] (consecutive camera ranges); same sums, same bits as vican_cg_fold per tile
+struct CgFoldTiles { const long long* part[64]; int n_cam[64]; int cam0[64]; };
+__global__ __launch_bounds__(1024) void cg_fold_tiles_kernel(CgFoldTiles T, int n_slab, double* __restrict__ qcpq,
+                                                             const vican_cg_state_t* __restrict__ st) {
+    __shared__ long long sh[3][1024];
+    if (st->done) return;
+    const int tile = (int)blockIdx.y, n_cam = T.n_cam[tile];
+    const long long n = 3LL * n_cam;
+    if ((long long)blockIdx.x * 64 >= n) return;
+    const int lob = st->lo_bits;
+    long long t, b, l, i; bool owner;
+    cg_fold_columns<64>(T.part[tile], n_slab, n, lob, sh, t, b, l, i, owner);
+    if (owner) {
+        const long long q = i / n_cam, cam = i % n_cam;
+        qcpq[(T.cam0[tile] + cam) * 3 + q] = fix3_value(t, b, l, lob, st->qinv);
+    }
+}
+extern "C" int vican_cg_fold_tiles(const void* const* qc_parts, const int32_t* n_cams, int32_t n_tile, int32_t n_slab, double* qcpq,
+                                   const vican_cg_state_t* st, void* stream) {
+    if (!qc_parts || !n_cams || n_tile <= 0 || n_tile > 64 || n_slab <= 0 || !qcpq || !st) return set_err(VICAN_ERR_ARG, "vican_cg_fold_tiles: bad argument");
+    CgFoldTiles T;
+    int cam0 = 0, cmax = 0;
+    for (int k = 0; k < n_tile; ++k) {
+        if (!qc_parts[k] || n_cams[k] <= 0) return set_err(VICAN_ERR_ARG, "vican_cg_fold_tiles: bad argument");
+        T.part[k] = (const long long*)qc_parts[k]; T.n_cam[k] = n_cams[k]; T.cam0[k] = cam0;
+        cam0 += n_cams[k];
+        cmax = n_cams[k] > cmax ? n_cams[k] : cmax;
+    }
+    hipLaunchKernelGGL(cg_fold_tiles_kernel, dim3((unsigned)((3LL * cmax + 63) / 64), (unsigned)n_tile), dim3(1024), 0, (hipStream_t)stream,
+                       T, (int)n_slab, qcpq, st);
+    LAUNCH_CHECK("vican_cg_fold_tiles");
+    return VICAN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Single-rank iteration in THREE launches instead of four (begin, sweep, fold, step), bit-reproducible from run to run:
 //   sweep                      (unchanged)

@@ -1422,9 +1422,11 @@ class TiledBackend(HipBackend):
                 self._tcg = t = None                         # (launch shapes differ / small graphs: per-tile launches)
             else:
                 self._ck(rc, "vican_cg_sweep_tiles")
-                for k, K in enumerate(self.tiles):
-                    self._ck(self.lib.vican_cg_fold(_ptr(t.parts[k]), t.nwgt, K.C, None, C.c_void_p(qcpq.data_ptr() + 8 * 3 * b[k]), _ptr(st),
-                                                    _stream()), "vican_cg_fold")
+                nt = len(self.tiles)
+                parts = (C.c_void_p * nt)(*[t.parts[k].data_ptr() for k in range(nt)])
+                ncams = (C.c_int32 * nt)(*[K.C for K in self.tiles])
+                self._ck(self.lib.vican_cg_fold_tiles(C.cast(parts, C.c_void_p), C.cast(ncams, C.c_void_p), nt, t.nwgt, _ptr(qcpq), _ptr(st),
+                                                      _stream()), "vican_cg_fold_tiles")        # (one launch for all tiles)
         for k, K in enumerate(self.tiles if t is None else ()):
             part = K.zpart[: K.tl.n_wg * 6 * K.C]
             self._ck(self.lib.vican_cg_sweep_partial(K._gref_t, _ptr(self._cg_w[k]), _ptr(p_c[b[k]: b[k + 1]]), _ptr(p_t), _ptr(self.acc_t[k]),
