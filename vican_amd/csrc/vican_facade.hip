@@ -65,6 +65,10 @@ struct vican_plan {
            *status = nullptr, *xrow = nullptr, *z = nullptr, *X = nullptr, *Xp = nullptr, *x0 = nullptr, *rc = nullptr, *lamC = nullptr,
            *cam_deg = nullptr, *lamT = nullptr, *Rt = nullptr, *zraw = nullptr;
     int32_t* gate = nullptr; int32_t* coop_sync = nullptr;
+    double *coop_ws = nullptr, *cgres_ws = nullptr;        // workspaces of the cooperative camera-side step / of the resident CG
+    bool coop_ok = true, cgres_ok = false;                  // (dropped for the rest of the plan's life once a launch is refused)
+    int pred_steps[64] = {0};                               // Lanczos steps that sufficed in primal-dual iteration `it` of the previous solve
+    double floor_level[64];                                 // ... and the residual level its f32 rounding floor sat at (< 0: none met)
     int hw = 0, hb_stride = 0, ld = 0;
     // translation workspace
     double *b_c = nullptr, *b_t = nullptr, *r_c = nullptr, *p_c = nullptr, *r_t = nullptr, *p_t = nullptr, *q_t = nullptr, *qcpq = nullptr,
@@ -200,7 +204,9 @@ size_t carve(vican_plan* P, size_t n_row0) {
     P->Xp = A.take<double>(3 * (size_t)n); P->x0 = A.take<double>(3 * (size_t)n); P->rc = A.take<double>(3 * (size_t)n);
     P->lamC = A.take<double>(9 * (size_t)C); P->cam_deg = A.take<double>(C); P->lamT = A.take<double>(9 * (size_t)T1);
     P->Rt = A.take<double>(9 * (size_t)T1); P->zraw = A.take<double>(3 * (size_t)n);
+    P->coop_ws = A.take<double>((size_t)vican_lanczos_coop_ws_doubles(C));
     if (P->have_t) {
+        P->cgres_ws = A.take<double>((size_t)vican_cg_resident_ws_doubles(C, std::max(P->g.n_wg, 1)));
         P->b_c = A.take<double>(3 * (size_t)C); P->b_t = A.take<double>(3 * (size_t)T1); P->r_c = A.take<double>(3 * (size_t)C);
         P->p_c = A.take<double>(3 * (size_t)C); P->r_t = A.take<double>(3 * (size_t)T1); P->p_t = A.take<double>(3 * (size_t)T1);
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
@@ -229,6 +235,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (n_cam > 1024) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: more than 1024 cameras need the camera-tiled host driver (vican_amd.device.TiledBackend)");
     hipStream_t s = (hipStream_t)stream;
     vican_plan* P = new vican_plan();
+    for (double& f : P->floor_level) f = -1.0;
     P->C = n_cam; P->T = n_time; P->E = n_edges; P->storage = storage; P->epl = storage == VICAN_STORE_F32 ? 4 : 2; P->have_t = w != nullptr;
     std::vector<int32_t> rp((size_t)n_time + 1), c0;
     auto fail = [&](int rc) { vican_plan_destroy(P); return rc; };
@@ -246,6 +253,13 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (hipMemcpyAsync(P->chunk_row0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed"));
     P->g.blk = P->blk; P->g.idx = (const uint32_t*)P->idx; P->g.chunk_row0 = P->chunk_row0;
     P->n_add = (double)std::max(P->rows_per_wg_max, P->g.slots) + 1.0; P->n_add_cg = P->n_add;
+    {   // the whole CG as one cooperative launch on capture-sized graphs (device.py HipBackend.cg_resident_ok, solver.py small_graph)
+        int dev_ = 0, ncu_ = 0;
+        hipGetDevice(&dev_); hipDeviceGetAttribute(&ncu_, hipDeviceAttributeMultiprocessorCount, dev_);
+        P->cgres_ok = P->have_t && P->g.layout == VICAN_LAYOUT_WAVE && n_edges < 2000000 && P->g.n_chunk > 0 && P->g.n_wg <= std::min(ncu_, 128) &&
+                      vican_cg_resident_lds_bytes(n_cam, P->g.max_rows, P->g.n_copy, P->rows_per_wg_max) <= vican_lds_limit_bytes();
+        P->coop_ok = n_cam <= 8192;
+    }
     // pack: CSR order -> chunked slot order (one scratch array of slot indices)
     int32_t* perm = nullptr;
     const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots;
@@ -349,25 +363,59 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
             CK(vican_lanczos_seed(n, start, P->V, ld, P->beta0, P->xrow, have_z ? P->zraw : nullptr, have_z ? P->z : nullptr, P->coop_sync, stream));
             z_ready = false;
             steps = 0;
-            int next_check = std::min(restart == 0 ? warm_min : min_steps, m_max), prev_steps = 0;
+            // (the same graph solved before - time series, repeated solves of one plan: straight to the step count that sufficed
+            //  last time instead of paying for checks known to fail; schedule only, every step is executed - solver.py pred_steps)
+            const int remembered = restart == 0 && it < 64 ? P->pred_steps[it] : 0;
+            int next_check = std::min(remembered > 0 ? remembered : (restart == 0 ? warm_min : min_steps), m_max), prev_steps = 0;
+            // residual level of the rounding floor: remembered per iteration index, else the one met by the previous iteration (a
+            // property of the f32 products, not of the iterate) - lets the FIRST check recognise a stalled residual (solver.py)
+            const double level = restart == 0 && it < 64 ? (P->floor_level[it] >= 0.0 ? P->floor_level[it] : (it > 0 ? P->floor_level[it - 1] : -1.0)) : -1.0;
+            double prev_res = -1.0;
+            int floor_at = 0;
             bool first = true;
             for (;;) {
                 const int j = steps;
-                if (!(j == 0 && have_z)) { CK(vican_block_op_z(g, P->lamT, P->xrow, P->zpart, P->fx, P->z, stream)); ++inf.sweeps; }
-                CK(vican_lanczos_cam_step(C, P->lamC, P->V, ld, j, P->z, P->R, P->H, P->G, P->HB + (size_t)j * P->hb_stride,
-                                          P->HB + (size_t)j * P->hb_stride + P->hw, P->xrow, pivot_floor, nullptr, 0, stream));
+                // camera side of the step as ONE cooperative launch (vican_lanczos_cam_coop; with few slabs it folds them itself:
+                // the sweep's result stays in fixed point) - the launch sequence (7 kernels per step) where that grid is refused
+                const bool sweep = !(j == 0 && have_z), from_slabs = sweep && P->coop_ok && g->n_wg <= 64;
+                if (sweep) {
+                    if (from_slabs) CK(vican_block_op(g, P->lamT, P->xrow, P->zpart, P->fx, stream));
+                    else CK(vican_block_op_z(g, P->lamT, P->xrow, P->zpart, P->fx, P->z, stream));
+                    ++inf.sweeps;
+                }
+                bool done_step = false;
+                if (P->coop_ok) {
+                    const int rc_ = vican_lanczos_cam_coop(C, P->lamC, P->V, ld, j, P->z, P->coop_ws, P->HB + (size_t)j * P->hb_stride,
+                                                           P->HB + (size_t)j * P->hb_stride + P->hw, P->xrow, pivot_floor, (uint32_t*)P->coop_sync,
+                                                           from_slabs ? P->zpart : nullptr, from_slabs ? g->n_wg : 0, from_slabs ? P->fx + 3 : nullptr,
+                                                           from_slabs ? P->fx + 7 : nullptr, g->n_wg <= 64 ? 1 : 0, stream);
+                    if (rc_ == VICAN_ERR_CAPACITY) {
+                        P->coop_ok = false;
+                        if (from_slabs) CK(vican_slab_reduce_fx(P->zpart, g->n_wg, C, 9, 1.0, P->fx + 3, P->fx + 7, P->z, stream));
+                    } else { CK(rc_); done_step = true; }
+                }
+                if (!done_step)
+                    CK(vican_lanczos_cam_step(C, P->lamC, P->V, ld, j, P->z, P->R, P->H, P->G, P->HB + (size_t)j * P->hb_stride,
+                                              P->HB + (size_t)j * P->hb_stride + P->hw, P->xrow, pivot_floor, nullptr, 0, stream));
                 ++steps; ++inf.lanczos_steps;
                 if (steps < next_check && steps < m_max) continue;
                 const int flags = (first ? 1 : 0) | (steps >= m_max ? 2 : 0);
-                CK(vican_ritz(P->HB, P->hb_stride, P->hw, steps, flags, tol, floor_tol, -1.0, steps - prev_steps <= 1 ? 0.5 : 0.25, P->Yd,
+                CK(vican_ritz(P->HB, P->hb_stride, P->hw, steps, flags, tol, floor_tol, level, steps - prev_steps <= 1 ? 0.5 : 0.25, P->Yd,
                               P->status, P->gate, stream));
-                first = false; prev_steps = steps;
+                first = false;
                 HIPCK(hipMemcpyAsync(st, P->status, 16 * 8, hipMemcpyDeviceToHost, s), "vican_solve_rot");
                 HIPCK(hipStreamSynchronize(s), "vican_solve_rot");
                 conv = st[3] != 0.0;
+                const bool floor_hit = st[4] != 0.0;
+                if (floor_hit && restart == 0 && it < 64) {     // where the floor was first reached (the earlier of the two checks), its level
+                    P->floor_level[it] = prev_res >= 0.0 ? std::max(st[0], prev_res) : std::max(st[0], P->floor_level[it]);
+                    floor_at = (prev_res >= 0.0 && prev_res <= 2.0 * P->floor_level[it]) ? prev_steps : steps;
+                }
+                if (conv && restart == 0 && it < 64) P->pred_steps[it] = floor_hit && floor_at > 0 ? floor_at : steps;
+                prev_res = st[0]; prev_steps = steps;
                 if (st[2] != 0.0) break;                       // stop (converged, noise floor, step budget or exhausted Krylov space)
                 const bool near_floor = floor_tol > 1e-12 && st[0] <= floor_tol;
-                next_check = std::min(steps + ((steps < 8 && !small) || near_floor ? 1 : check_every), m_max);
+                next_check = std::min(steps + ((steps < 8 && !small) || near_floor || remembered > 0 ? 1 : check_every), m_max);
             }
             CK(vican_tall_combine(n, P->V, ld, 3 * steps, P->Yd, P->X, stream));
             if (!conv) { start = P->X; ++inf.restarts; HIPCK(hipMemcpyAsync(P->Xp, P->X, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot"); start = P->Xp; }
@@ -405,9 +453,30 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     if (maxiter <= 0) maxiter = 10LL * 3 * (C + T);              // scipy's default
     vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
     CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
+    vican_cg_state_t h{};
+    if (P->cgres_ok) {
+        // capture-sized graphs: the whole solve as ONE cooperative launch (vican_cg_resident; an iteration of the launch sequence is
+        // three dependent launches of a few microseconds each there)
+        const int rc_ = vican_cg_resident(&P->g, P->w, P->row_sum_w, P->cam_sum_w, P->b_c, P->b_t, x_c, x_t, P->zpart, P->cgres_ws, rtol,
+                                          (int32_t)std::min<int64_t>(maxiter, 2147483647LL), P->n_add_cg, P->wmax, P->rows_per_wg_max, P->st, stream);
+        if (rc_ == VICAN_ERR_CAPACITY) P->cgres_ok = false;
+        else {
+            CK(rc_);
+            HIPCK(hipMemcpyAsync(P->status_host + 16, P->st, sizeof(vican_cg_state_t), hipMemcpyDeviceToHost, s), "vican_solve_trans");
+            HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
+            std::memcpy(&h, P->status_host + 16, sizeof(h));
+            if (h.done == -1) P->cgres_ok = false;          // a grid barrier was not passed in time (shared device): the launch sequence solves it
+            else {
+                inf.cg_iters = h.iter; inf.cg_converged = h.done == 1;
+                inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;
+                if (info) *info = inf;
+                if (h.done != 1) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans: CG did not converge in %lld iterations (scipy exit_code != 0, bipgo.py:478)", (long long)maxiter);
+                return VICAN_OK;
+            }
+        }
+    }
     CK(vican_cg_init(C, T, P->b_c, P->b_t, x_c, x_t, P->r_c, P->r_t, P->p_c, P->p_t, P->st, P->ws, P->wmax, stream));
     long long launched = 0;
-    vican_cg_state_t h{};
     int burst = 8;
     for (;;) {
         // (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x; no test behind the last one)
