@@ -286,6 +286,7 @@ def bipartite_so3sync(src_edges: dict, constraints: dict, noise_model: Callable,
     K = HipBackend(g)
     t1 = time.perf_counter()
     rot = GeneralRotationSolver(K, Comm.single(), eig_tol=eig_tol)
+    rot.dense_edges = (prob.row_ptr, prob.col, prob.blk)                               # (the interior regime places R~ exactly)
     r = rot.run(maxiter).reshape(prob.n_cam + prob.n_time, 3, 3).cpu().numpy()
     t2 = time.perf_counter()
     # the reference's `r` stays in the dtype of its first eigs call unless a later iteration rebuilds it in float64

@@ -555,15 +555,28 @@ class GeneralRotationSolver(RotationSolver):
         (r = V V_0^-1, bipgo.py:113), so any orthonormal basis of it reproduces the reference."""
         K, N, n = self.K, self.N, self.n
         dev = self.X.device
-        Rd = torch.zeros(n, n, dtype=torch.float64, device=dev)
-        x, z = K.empty(n, 3), K.empty(n, 3)
-        eye = torch.eye(3, dtype=torch.float64, device=dev)
-        for i in range(N):                                        # column block i of R~ (|x_i|_F = sqrt(3): inside bip_apply's bound)
-            x.zero_()
-            x[3 * i: 3 * i + 3] = eye
-            K.bip_apply(x, z)
-            Rd[:, 3 * i: 3 * i + 3] = z
-        self.stats["sweeps"] += N
+        edges = getattr(self, "dense_edges", None)
+        if edges is not None:
+            # the merged blocks as the caller holds them (host CSR: row_ptr [T+1], col [E], blk [E][9], float64): R~ placed entry by
+            # entry - exact, where the operator's fixed-point sums carry 1e-14 that this regime amplifies to 2e-7 in the answer
+            row_ptr, col, blk = (np.asarray(a) for a in edges)
+            C_, T_ = K.C, N - K.C
+            rows = np.repeat(np.arange(T_), np.diff(row_ptr))
+            Rh = np.zeros((N, 3, N, 3))
+            M = blk.reshape(-1, 3, 3).astype(np.float64)
+            Rh[col, :, C_ + rows, :] = M
+            Rh[C_ + rows, :, col, :] = np.swapaxes(M, 1, 2)
+            Rd = torch.from_numpy(Rh.reshape(n, n)).to(dev)
+        else:
+            Rd = torch.zeros(n, n, dtype=torch.float64, device=dev)
+            x, z = K.empty(n, 3), K.empty(n, 3)
+            eye = torch.eye(3, dtype=torch.float64, device=dev)
+            for i in range(N):                                    # column block i of R~ (|x_i|_F = sqrt(3): inside bip_apply's bound)
+                x.zero_()
+                x[3 * i: 3 * i + 3] = eye
+                K.bip_apply(x, z)
+                Rd[:, 3 * i: 3 * i + 3] = z
+            self.stats["sweeps"] += N
         L = -Rd
         idx = torch.arange(N, device=dev)
         L.view(N, 3, N, 3)[idx, :, idx, :] += self.lamC.view(N, 3, 3)
