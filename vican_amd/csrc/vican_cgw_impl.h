@@ -236,7 +236,11 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
 #endif
 #endif
             }
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 4      /* no row atomics (upper bound of a register-resident row side) */
+            if (false) {
+#else
             if (j == EPL - 1 || row[j] != row[j + 1]) {
+#endif
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const Fix2 f = to_fix2(ar[j][i], scale, lo_scale);
@@ -249,7 +253,12 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
         CSTAMP(3);                      // edges
         // fold this chunk's row sums (exact integer sums of the stripes), q_t, p.q: one lane per (item, stripe) word,
         // the n_copy words of an item summed across neighbouring lanes
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 4
+        if (lane < n3) { const double qv = dps[lane] - ar[EPL - 1][0]; q_t[(size_t)r0 * 3 + lane] = qv; pq += pts[lane] * qv; }
+        for (int base = 0; false && base < n3 * ncopy; base += 64) {
+#else
         for (int base = 0; base < n3 * ncopy; base += 64) {
+#endif
             const int a = base + lane;
             const bool live = a < n3 * ncopy;
             u64 sum = 0ull, slo = 0ull;

@@ -127,6 +127,12 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         load_rowvals(rvf, k_fill);
         load_edges(fill, k_fill);
         __builtin_amdgcn_sched_barrier(0);
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
+        asm volatile("" :: "v"(rv.p), "v"(rv.r), "v"(rv.d));
+        return;
+#endif
         const double pn = upd ? mul_add_2r(beta, rv.p, rv.r) : rv.p;
         if (upd && lane < 3) p_t[(size_t)k * 3 + lane] = pn;
         const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
@@ -146,7 +152,11 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const Fix2 f = to_fix2(wj[j] * prow[i], scale, lo_scale);
+#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
+                asm volatile("" :: "v"(f.hi), "v"(f.lo));
+#else
                 lds_add_fix(&qc[i * CP + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * CP + cam[j]], f.lo);
+#endif
             }
         }
         const double srow = wave_total3(acc[0], acc[1], acc[2], lane);         // lanes 0, 1, 2: the three row sums
