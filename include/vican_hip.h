@@ -89,10 +89,16 @@ typedef struct vican_graph {
                                  one-row CG product) stream these 2 bytes per edge instead of the 4 of idx and REQUIRE the array.
                                  (C = 1024 with 64 rows in a chunk would make camera 1023 of row 63 look like padding: such graphs
                                  are planned with <= 63 rows per chunk.)  NULL in the block layout */
+    const float*    w32;      /* optional (NULL: none): the translation weights of `w32_src` as float32, [n_chunk][slots] in PLAIN slot
+                                 order, for graphs whose weights are all exactly representable in float32 - every dtype=float32 problem:
+                                 the reference's J^T J is accumulated in float32 there (bipgo.py:434-477).  The one-row CG product
+                                 (wave layout, 4 edges per lane) then streams 6 instead of 10 bytes per edge, same bits */
+    const double*   w32_src;  /* the float64 weight array (slot order of the layout) w32 mirrors: used only when the caller passes THIS
+                                 array as `w` (scaled weights - vican_scale_weights - are another array and take the float64 stream) */
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 25            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 26            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the

@@ -39,7 +39,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 
 def test_struct_sizes():
-    assert C.sizeof(_lib.Graph) == 14 * 4 + 4 * 8      # 14 int32 + 4 pointers (blk, idx, chunk_row0, idx16)
+    assert C.sizeof(_lib.Graph) == 14 * 4 + 6 * 8      # 14 int32 + 6 pointers (blk, idx, chunk_row0, idx16, w32, w32_src)
     assert C.sizeof(_lib.Tile) == C.sizeof(_lib.Graph) + 5 * 8   # vican_tile_t: the graph + x, zpart, fx, ypart[2]
     assert _lib.CG_STATE_DOUBLES * 8 == 17 * 8 + 4 * 4
 

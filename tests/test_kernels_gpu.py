@@ -869,3 +869,39 @@ def test_wave_layout_carries_its_index_in_two_bytes(cfg):
     cam, row = idx[~pad] & 0xFFFF, idx[~pad] >> 16
     assert cam.max() < 1024 and row.max() < 64 and not np.any((cam == 1023) & (row == 63))
     assert np.array_equal(i16[~pad], (cam | (row << 10)).astype(np.uint16))
+
+
+def test_float32_weight_stream_of_the_one_row_cg_product_is_exact(monkeypatch):
+    """vican_graph_t.w32: one-row wave graphs whose translation weights are all float32 values (every dtype=float32 problem)
+    stream them as 4 bytes in plain slot order; the CG solve is bit-identical to the float64 stream (VICAN_CG_W32=0), scaled
+    weights (another array than the one w32 mirrors) take the float64 stream, and weights that are not float32 values get no
+    copy at all."""
+    from vican_amd.device import HipBackend, LocalGraph
+    from vican_amd.solver import Comm, TranslationSolver
+    C_, T_ = 300, 900
+    rp, col, blk, a, w, u, v = random_graph(C_, T_, 200, 256, 31, False)                 # one row per 256-slot chunk
+    w32ok = w.astype(np.float32).astype(np.float64)
+    dev = torch.device("cuda:0")
+    to = lambda x, d=None: torch.from_numpy(x).to(dev) if d is None else torch.from_numpy(x).to(dev, d)
+    rng = np.random.default_rng(5)
+    rc = np.linalg.qr(rng.standard_normal((C_, 3, 3)))[0].reshape(3 * C_, 3)
+    rt = np.linalg.qr(rng.standard_normal((T_, 3, 3)))[0].reshape(T_, 9)
+    outs = {}
+    for tag, weights, env in (("w32", w32ok, "1"), ("f64", w32ok, "0"), ("inexact", w, "1")):
+        monkeypatch.setenv("VICAN_CG_W32", env)
+        g = LocalGraph(C_, to(rp), to(col), to(blk, torch.float32), to(a, torch.float32), to(weights), to(u), to(v), layout="wave")
+        assert g.n_chunk == g.n_time and (g.w32 is not None) == (tag == "w32")
+        if g.w32 is not None:
+            assert g.desc.w32 == g.w32.data_ptr() and g.desc.w32_src == g.w.data_ptr()
+        K = HipBackend(g)
+        ts = TranslationSolver(K, Comm.single(), rtol=1e-9)
+        ts.setup(K.from_numpy(rc), K.from_numpy(rt))
+        xc, xt = ts.solve(3 * (C_ + T_))
+        outs[tag] = (xc.clone(), xt[:T_].clone(), ts.info["cg_iters"])
+        if tag == "w32":                                            # tight mode scales the weights: float64 stream, still a solve
+            from vican_amd.solver import TightTranslationSolver
+            tt = TightTranslationSolver(K, Comm.single(), rtol=1e-10)
+            tt.setup(K.from_numpy(rc), K.from_numpy(rt))
+            xc2, _ = tt.solve(3 * (C_ + T_))
+            assert tt.info["converged"] and float((xc2 - xc).abs().max()) < 1e-5 * max(float(xc.abs().max()), 1.0)
+    assert outs["w32"][2] == outs["f64"][2] and torch.equal(outs["w32"][0], outs["f64"][0]) and torch.equal(outs["w32"][1], outs["f64"][1])

@@ -52,6 +52,7 @@ class Graph(C.Structure):
         ("n_copy", C.c_int32), ("wg_chunk_cap", C.c_int32), ("layout", C.c_int32), ("wg_waves", C.c_int32),
         ("stream_nt", C.c_int32), ("slot_order", C.c_int32),
         ("blk", C.c_void_p), ("idx", C.c_void_p), ("chunk_row0", C.c_void_p), ("idx16", C.c_void_p),
+        ("w32", C.c_void_p), ("w32_src", C.c_void_p),
     ]
 
 

@@ -51,7 +51,12 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep_kernel(vican_graph_t g, con
 // immediate offsets, and prefetches TWO chunks ahead (three register sets of 12 + 6 VGPRs; the wait for a chunk's data was
 // 950 of 3700 cycles per chunk with one).  Same arithmetic and summation structure as the one-row path of cg_wsweep_kernel
 // (exact double-word camera sums; the row sum a fixed-order f64 wave reduction).
-template <int NW, int EPL, int CP, bool NT>
+// W32: the weights come as float32 (vican_graph_t.w32: exact copies, plain slot order - 16 bytes per lane instead of 32), are kept
+// as loaded in the register set and converted where they are used (a conversion at the load would wait for it)
+template <int EPL, bool W32>
+struct CgW1Regs { typename std::conditional<W32, float, double>::type w[EPL]; uint32_t id[EPL]; };
+
+template <int NW, int EPL, int CP, bool NT, bool W32>
 __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, const double* __restrict__ w,
                                                              const double* __restrict__ deg_t, const double* __restrict__ p_c,
                                                              const double* __restrict__ r_t, double* __restrict__ p_t,
@@ -84,10 +89,18 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
 
     struct RowVals { double p, r, d; };                        // lanes 0..2: component `lane` of the row's p_t, r_t; deg_t
-    auto load_edges = [&](CgWRegs<EPL>& e, int k) {
+    auto load_edges = [&](CgW1Regs<EPL, W32>& e, int k) {
         k = k < kmax ? k : kmax;
         const size_t s = (size_t)k * g.slots + (size_t)lane * EPL;
-        if (EPL == 4) {
+        if constexpr (EPL == 4 && W32) {
+            uint2 t2; float4 a;
+            if (NT) { t2 = stream_load((const uint2*)(g.idx16 + s)); a = stream_load((const float4*)(g.w32 + s)); }
+            else { t2 = *(const uint2*)(g.idx16 + s); a = *(const float4*)(g.w32 + s); }
+            const uint32_t h[4] = {t2.x & 0xFFFFu, t2.x >> 16, t2.y & 0xFFFFu, t2.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e.id[j] = h[j] == 0xFFFFu ? VICAN_PAD_SLOT : h[j];
+            e.w[0] = a.x; e.w[1] = a.y; e.w[2] = a.z; e.w[3] = a.w;
+        } else if constexpr (EPL == 4) {
             uint2 t2; double2 a, b;
             const double* wk = w + (size_t)k * g.slots + (size_t)lane * 2;        // permuted storage (slot_pos8): dense 16-byte loads
             // (2-byte camera indices of one-row graphs, vican_graph_t.idx16: 8 instead of 16 bytes per lane)
@@ -111,19 +124,28 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         const size_t gi = (size_t)k * 3 + l3;
         rv.p = p_t[gi]; rv.r = r_t[gi]; rv.d = deg_t[k + vzero];
     };
-    if (tid == 0) s_ticket = c0 + 4 * NW;
+#ifndef CGW1_SETS
+#define CGW1_SETS 3                    /* register sets: chunks in flight + 1 (4: three chunks ahead - diagnostic builds) */
+#endif
+    if (tid == 0) s_ticket = c0 + (CGW1_SETS + 1) * NW;
     __syncthreads();
 
     // chunks of the workgroup's range by LDS ticket (the first four rounds are static); a ticket is drawn three bodies before
     // its chunk is processed and read at the end of the body that drew it
     int q0 = c0 + wave, q1 = q0 + NW, q2 = q1 + NW, q3 = q2 + NW;
-    CgWRegs<EPL> ea, eb, ec;
+    CgW1Regs<EPL, W32> ea, eb, ec;
     RowVals ra, rb, rc;
     load_edges(ea, q0); load_rowvals(ra, q0);
     load_edges(eb, q1); load_rowvals(rb, q1);
+#if CGW1_SETS == 4
+    int q4 = q3 + NW;
+    CgW1Regs<EPL, W32> ed;
+    RowVals rd;
+    load_edges(ec, q2); load_rowvals(rc, q2);
+#endif
     double pq = 0.0;
 
-    auto body = [&](const CgWRegs<EPL>& cur, const RowVals& rv, CgWRegs<EPL>& fill, RowVals& rvf, const int k, const int k_fill) {
+    auto body = [&](const CgW1Regs<EPL, W32>& cur, const RowVals& rv, CgW1Regs<EPL, W32>& fill, RowVals& rvf, const int k, const int k_fill) {
         load_rowvals(rvf, k_fill);
         load_edges(fill, k_fill);
         __builtin_amdgcn_sched_barrier(0);
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         for (int j = 0; j < EPL; ++j) {
             const bool pad = cur.id[j] == VICAN_PAD_SLOT;
             cam[j] = pad ? pad_cam : (cur.id[j] & 0xFFFFu);
-            wj[j] = pad ? 0.0 : cur.w[j];
+            wj[j] = pad ? 0.0 : (double)cur.w[j];
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[i] += wj[j] * pcs[i * CP + cam[j]];
         }
@@ -171,6 +193,27 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t;
     };
+#if CGW1_SETS == 4
+#define CGW1_NEXT(t) do { q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = __builtin_amdgcn_readfirstlane(t); } while (0)
+#pragma unroll 1
+    while (q0 < c1) {
+        int t = draw();
+        body(ea, ra, ed, rd, q0, q3);
+        CGW1_NEXT(t);
+        if (q0 >= c1) break;
+        t = draw();
+        body(eb, rb, ea, ra, q0, q3);
+        CGW1_NEXT(t);
+        if (q0 >= c1) break;
+        t = draw();
+        body(ec, rc, eb, rb, q0, q3);
+        CGW1_NEXT(t);
+        if (q0 >= c1) break;
+        t = draw();
+        body(ed, rd, ec, rc, q0, q3);
+        CGW1_NEXT(t);
+    }
+#else
 #define CGW1_NEXT(t) do { q0 = q1; q1 = q2; q2 = q3; q3 = __builtin_amdgcn_readfirstlane(t); } while (0)
 #pragma unroll 1
     while (q0 < c1) {
@@ -186,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         body(ec, rc, eb, rb, q0, q2);
         CGW1_NEXT(t);
     }
+#endif
 #undef CGW1_NEXT
     __syncthreads();
     for (int pl = 0; pl < 6; ++pl)
@@ -707,9 +751,15 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
         // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
         const size_t lds1 = (size_t)72 * cp + 256;
         static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;
+        // (float32 weight stream: only for the very array w32 was made from, 4 edges per lane)
+        const bool w32 = g->w32 != nullptr && g->w32_src == w && epl == 4;
 #define CGW1_LAUNCH_(NW_, E_, CP_, NT_)                                                                                   \
         do {                                                                                                              \
-            auto kern = cg_wsweep1_kernel<NW_, E_, CP_, NT_>;                                                             \
+            if (w32 && E_ == 4) CGW1_LAUNCH__(NW_, 4, CP_, NT_, true); else CGW1_LAUNCH__(NW_, E_, CP_, NT_, false);      \
+        } while (0)
+#define CGW1_LAUNCH__(NW_, E_, CP_, NT_, W32_)                                                                            \
+        do {                                                                                                              \
+            auto kern = cg_wsweep1_kernel<NW_, E_, CP_, NT_, W32_>;                                                       \
             static size_t conf = 0;                                                                                       \
             if (lds1 > conf) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); conf = lds1; } \
             VICAN_LAUNCH_SWEEP(kern, dim3(g->n_wg), dim3(NW_ * 64), lds1, s, *g, w, deg_t, p_c, r_t, p_t, q_t, (u64*)qc_part, pq_part, st); \
@@ -724,6 +774,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
 #undef CGW1_PICK
 #undef CGW1_LAUNCH
 #undef CGW1_LAUNCH_
+#undef CGW1_LAUNCH__
         LAUNCH_CHECK("vican_cg_sweep");
         return VICAN_OK;
     }

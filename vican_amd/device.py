@@ -423,6 +423,18 @@ class LocalGraph:
             self.idx16 = torch.empty(rot.nslot, dtype=torch.int16, device=dev)
             _lib.check(lib.vican_pack_idx16(gref, _ptr(self.idx16), st), "vican_pack_idx16")
             self.desc.idx16 = self.idx16.data_ptr()
+        # float32 copy of the CG weights where every one of them is exactly a float32 (dtype=float32 problems: the reference's
+        # J^T J is accumulated in float32) - the one-row CG product then streams 6 instead of 10 bytes per edge, same bits
+        # (vican_graph_t.w32; plain slot order, the float64 array is in slot_pos8 order: [chunk][half][lane][2])
+        self.w32 = None
+        if (have_t and rot.kind == "wave" and epl == 4 and rot.n_chunk == self.n_time and rot.n_chunk > 0
+                and os.environ.get("VICAN_CG_W32", "1") != "0"):
+            wp = self.w.view(rot.n_chunk, 2, 64, 2).permute(0, 2, 1, 3).reshape(-1)
+            w32 = wp.to(torch.float32)
+            if bool((w32.to(torch.float64) == wp).all()):
+                self.w32 = w32.contiguous()
+                self.desc.w32, self.desc.w32_src = self.w32.data_ptr(), self.w.data_ptr()
+            del wp, w32
         keep = keep_csr if keep_csr is not None else os.environ.get("VICAN_KEEP_CSR") == "1"
         self._csr_t = (row_ptr, col, w, u, v) if (keep and have_t and rot.kind == "wave") else None
         self._lsqr_layout = None
