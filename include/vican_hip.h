@@ -98,7 +98,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 26            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 27            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -282,6 +282,10 @@ int vican_tiled_op_z(const vican_tile_t* tiles_host, const vican_tile_t* tiles_d
 
 /* idx16 of a packed wave-layout graph (see vican_graph_t.idx16): out [n_chunk][slots], then set g->idx16 = out. */
 int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* stream);
+/* w32 of a packed wave-layout graph with 4 edges per lane (see vican_graph_t.w32): out [n_chunk][slots] floats from the packed
+ * float64 weights w; *inexact (device word) = 1 if any weight is not a float32 value - then leave g->w32 NULL.  Else set
+ * g->w32 = out and g->w32_src = w.                                                                                          */
+int vican_pack_w32(const vican_graph_t* g, const double* w, float* out, int32_t* inexact, void* stream);
 
 /* Timestep dual/primal update (bipgo.py:318-332): per row t,
  * Z_t = sum_c M_ct^T Rc_c, SVD -> Rt[t] = U diag(1,1,det UV^T) V^T,

@@ -132,6 +132,7 @@ PROTOTYPES = {
     "vican_tile_rows": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
     "vican_cg_sweep_tiles": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "vican_pack_idx16": (C.c_int, [_G, _vp, _vp]),
+    "vican_pack_w32": (C.c_int, [_G, _vp, _vp, _vp, _vp]),
     "vican_plan_chunks_multi": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
     "vican_plan_rows_multi": (C.c_int, [C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_int32]),
     "vican_tiled_op_lds_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -66,6 +66,7 @@ struct vican_plan {
            *cam_deg = nullptr, *lamT = nullptr, *Rt = nullptr, *zraw = nullptr;
     int32_t* gate = nullptr; int32_t* coop_sync = nullptr;
     double *coop_ws = nullptr, *cgres_ws = nullptr;        // workspaces of the cooperative camera-side step / of the resident CG
+    float* w32 = nullptr; int32_t* w32_flag = nullptr;     // float32 copy of the CG weights (vican_graph_t.w32) where they are float32 values
     bool coop_ok = true, cgres_ok = false;                  // (dropped for the rest of the plan's life once a launch is refused)
     int pred_steps[64] = {0};                               // Lanczos steps that sufficed in primal-dual iteration `it` of the previous solve
     double floor_level[64];                                 // ... and the residual level its f32 rounding floor sat at (< 0: none met)
@@ -207,6 +208,7 @@ size_t carve(vican_plan* P, size_t n_row0) {
     P->coop_ws = A.take<double>((size_t)vican_lanczos_coop_ws_doubles(C));
     if (P->have_t) {
         P->cgres_ws = A.take<double>((size_t)vican_cg_resident_ws_doubles(C, std::max(P->g.n_wg, 1)));
+        P->w32 = A.take<float>(nslot); P->w32_flag = A.take<int32_t>(4);
         P->b_c = A.take<double>(3 * (size_t)C); P->b_t = A.take<double>(3 * (size_t)T1); P->r_c = A.take<double>(3 * (size_t)C);
         P->p_c = A.take<double>(3 * (size_t)C); P->r_t = A.take<double>(3 * (size_t)T1); P->p_t = A.take<double>(3 * (size_t)T1);
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
@@ -270,10 +272,16 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
         rc = vican_pack_idx16(&P->g, P->idx16, stream);
         if (rc >= 0) P->g.idx16 = P->idx16;
     }
+    // one-row wave graphs with 4 edges per lane: the CG weights as float32 where every one of them is a float32 value
+    const bool try_w32 = rc >= 0 && P->have_t && P->g.layout == VICAN_LAYOUT_WAVE && P->g.slots == 256 && P->g.n_chunk == n_time;
+    if (try_w32) rc = vican_pack_w32(&P->g, P->w, P->w32, P->w32_flag, stream);
     if (rc >= 0) {
         hipLaunchKernelGGL(facade_maxima_kernel, dim3(256), dim3(256), 0, s, (long long)n_edges, storage, a, w, u, v, mx);
         double h[3] = {1, 1, 1};
+        int32_t inexact = 1;
+        if (try_w32 && hipMemcpyAsync(&inexact, P->w32_flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess) rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: flag read failed");
         if (hipMemcpyAsync(h, mx, 24, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: maxima read failed");
+        if (rc >= 0 && try_w32 && inexact == 0) { P->g.w32 = P->w32; P->g.w32_src = P->w; }
         if (rc >= 0) {
             hipMemsetAsync(mx, 0, 24, s);
             if (P->have_t) { P->wmax = h[1]; P->gmax = h[2]; }

@@ -118,6 +118,33 @@ extern "C" int vican_pack_idx16(const vican_graph_t* g, uint16_t* out, void* str
     return VICAN_OK;
 }
 
+// vican_graph_t.w32: the translation weights of a wave-layout graph with 4 edges per lane (w: [n_chunk][256] doubles in the
+// layout's slot_pos8 order - [half][lane][2]) as float32 in PLAIN slot order ([lane][4]); *inexact (device word, zeroed here)
+// becomes 1 if any weight is not a float32 value - the copy must not be used then.
+__global__ void pack_w32_kernel(const double* __restrict__ w, float* __restrict__ out, long long n, int32_t* inexact) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long k = i >> 8;
+        const int s = (int)(i & 255), lane = s >> 2, j = s & 3;
+        const double v = w[k * 256 + (j < 2 ? lane * 2 + j : 128 + lane * 2 + (j - 2))];
+        const float f = (float)v;
+        out[i] = f;
+        bad = bad || (double)f != v;
+    }
+    if (bad) *inexact = 1;
+}
+extern "C" int vican_pack_w32(const vican_graph_t* g, const double* w, float* out, int32_t* inexact, void* stream) {
+    if (int rc = vican_check_graph(g, "vican_pack_w32")) return rc;
+    if (!w || !out || !inexact) return set_err(VICAN_ERR_ARG, "vican_pack_w32: null pointer");
+    if (g->layout != VICAN_LAYOUT_WAVE || g->slots != 256) return set_err(VICAN_ERR_ARG, "vican_pack_w32: needs a wave-layout graph with 4 edges per lane");
+    if (hipMemsetAsync(inexact, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return set_err(VICAN_ERR_LAUNCH, "vican_pack_w32: memset failed");
+    const long long n = (long long)g->n_chunk * g->slots;
+    if (n == 0) return VICAN_OK;
+    hipLaunchKernelGGL(pack_w32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, out, n, inexact);
+    LAUNCH_CHECK("vican_pack_w32");
+    return VICAN_OK;
+}
+
 // The same for camera tiles that must SHARE their chunking (vican_tiled_op): chunk k covers the same timestep rows in every
 // tile; a row joins the open chunk while every tile's edges of the chunk still fit its slots.  rps: n_tile row-pointer arrays.
 extern "C" int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const* rps, int32_t slots, int32_t max_rows,

@@ -429,12 +429,11 @@ class LocalGraph:
         self.w32 = None
         if (have_t and rot.kind == "wave" and epl == 4 and rot.n_chunk == self.n_time and rot.n_chunk > 0
                 and os.environ.get("VICAN_CG_W32", "1") != "0"):
-            wp = self.w.view(rot.n_chunk, 2, 64, 2).permute(0, 2, 1, 3).reshape(-1)
-            w32 = wp.to(torch.float32)
-            if bool((w32.to(torch.float64) == wp).all()):
-                self.w32 = w32.contiguous()
+            w32, flag = torch.empty(rot.nslot, dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.vican_pack_w32(gref, _ptr(self.w), _ptr(w32), _ptr(flag), st), "vican_pack_w32")
+            if int(flag.item()) == 0:
+                self.w32 = w32
                 self.desc.w32, self.desc.w32_src = self.w32.data_ptr(), self.w.data_ptr()
-            del wp, w32
         keep = keep_csr if keep_csr is not None else os.environ.get("VICAN_KEEP_CSR") == "1"
         self._csr_t = (row_ptr, col, w, u, v) if (keep and have_t and rot.kind == "wave") else None
         self._lsqr_layout = None
