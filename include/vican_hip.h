@@ -265,8 +265,10 @@ int vican_plan_chunks_multi(int32_t n_time, int32_t n_tile, const int32_t* const
                             int32_t max_rows, int32_t* chunk_row0_out, int32_t cap);
 /* The same with the rows in a BETTER ORDER (host): consecutive rows pad a shared chunking badly when every row splits evenly over
  * the tiles (a chunk takes a row only while every tile still has room: 1.33 slots per edge on 4 tiles x 62 edges per row).
- * First-fit packing of the rows into a window of `window` open chunks; perm_out[new] = old row (rows of a chunk ascending),
- * chunk_row0_out: boundaries in the new numbering (cap >= chunks + 1 entries); returns the number of chunks.  The caller
+ * One chunk at a time from a pool of the next `window` unassigned rows: the first of the pool opens the chunk, then the row
+ * that leaves the tiles most evenly filled while two average rows still fit, then the largest row that fits (window = 1: the
+ * consecutive chunking).  perm_out[new] = old row (rows of a chunk ascending), chunk_row0_out: boundaries in the new numbering
+ * (cap >= chunks + 1 entries); returns the number of chunks.  The caller
  * builds the tiles from the rows in that order (the operator is a sum over rows: bipgo.py:300) and undoes it on what it returns
  * per row.                                                                                                                  */
 int vican_plan_rows_multi(int32_t n_time, int32_t n_tile, const int32_t* const* row_ptrs_host, int32_t slots, int32_t max_rows,
