@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-capture measurement (detail.sparse) of the default run")
     ap.add_argument("--no-facade", action="store_true", help="skip the four-call C boundary timing (detail.facade) of the default run")
     ap.add_argument("--no-wide", action="store_true", help="skip the camera-tiled measurement (detail.wide: 4000 cameras) of the default run")
+    ap.add_argument("--no-sharded-schedule", action="store_true", help="skip the one-GPU cost of the multi-GPU schedule (detail.sharded_schedule) of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
     ap.add_argument("--n-copy", type=int, default=None)
@@ -326,6 +327,62 @@ def wide_operator(args, dev, tdt, comm):
     del K, g, rot, tr
     torch.cuda.empty_cache()
     return res
+
+
+def sharded_schedule(args, dev, tdt, shapes):
+    """What ONE GPU can measure of the multi-GPU schedule: warm full solves of the benchmark's graphs with
+    this rank holding every row, on (a) the single-rank schedule (cooperative / resident kernels), (b) the sharded schedule
+    with identity collectives, (c) the sharded schedule with every all-reduce a launch of the peer exchange (the rank's own
+    mailbox slot as its peer: the same kernel, granules, waits and gate as between GPUs, minus the links) and (d) with
+    ncclAllReduce on a one-rank RCCL communicator held by the C library.  ms per solve, collectives per solve, the ratio to (a)."""
+    from vican_amd import synth
+    from vican_amd.device import HipBackend, LocalGraph
+    from vican_amd.solver import Comm, RotationSolver, TranslationSolver
+    out = {}
+    for name, (Cn, Tn, cpt, n_solves) in shapes.items():
+        gr = synth.make_merged_graph_torch(Cn, Tn, cpt, dev, tdt, seed=0)
+        g = LocalGraph(Cn, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
+        del gr
+        torch.cuda.empty_cache()
+        res = {"merged_edges": g.n_edges}
+        for label, mk in (("single_rank", lambda: Comm.single()), ("sharded_identity", lambda: Comm.single(force_sharded=True)),
+                          ("sharded_peer_exchange", lambda: Comm.single(force_sharded=True, peer=True)),
+                          ("sharded_rccl_one_rank", lambda: Comm.single(force_sharded=True, native=True))):
+            try:
+                comm = mk()
+                K = HipBackend(g)
+                rot, tr = RotationSolver(K, comm), TranslationSolver(K, comm)
+
+                def solve():
+                    rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+                    tr.poll_every = 8
+                    rc, Rt = rot.run(args.maxiter)
+                    tr.setup(rc, Rt)
+                    tr.solve(3 * (Cn + Tn))
+                    K.synchronize()
+                for _ in range(3):
+                    solve()
+                n0 = comm.n_allreduce
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_solves):
+                    solve()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / n_solves * 1e3
+                res[label] = {"ms_per_solve": ms, "allreduces_per_solve": (comm.n_allreduce - n0) / n_solves, "cg_iters": tr.info.get("cg_iters"),
+                              "lanczos_steps": list(rot.stats["lanczos_steps"]), "speculates": bool(getattr(comm, "gateable", False))}
+                comm.check()
+                del K, rot, tr, comm
+            except Exception as exc:
+                res[label] = {"error": repr(exc)[:200]}
+        base = res.get("single_rank", {}).get("ms_per_solve")
+        for label in ("sharded_identity", "sharded_peer_exchange", "sharded_rccl_one_rank"):
+            if base and "ms_per_solve" in res.get(label, {}):
+                res[label]["ratio_to_single_rank"] = res[label]["ms_per_solve"] / base
+        out[name] = res
+        del g
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(args):
@@ -679,7 +736,7 @@ def main():
                                  "sample": "not timed for this workload (the oracle forms the 12000 x 12000 power-graph matrix explicitly); "
                                            "the default command carries the CPU baseline"},
                 "detail": w}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
         return
     if args.workload == "stress":
         C, Tn, cpt = args.cams or 1000, args.timesteps or 100000, args.cams_per_t or 250
@@ -738,6 +795,11 @@ def main():
             out["detail"]["facade"] = f
         except Exception as exc:
             out["detail"]["facade"] = {"error": repr(exc)[:300]}
+    if rank == 0 and world == 1 and args.workload == "stress" and not args.no_sharded_schedule:
+        try:
+            out["detail"]["sharded_schedule"] = sharded_schedule(args, dev, tdt, {"stress": (C, Tn, cpt, 5), "large_shop": (340, 10000, 4, 10)})
+        except Exception as exc:
+            out["detail"]["sharded_schedule"] = {"error": repr(exc)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Ts = args.cpu_sample_timesteps or {"stress": 300, "sparse": 20000}.get(args.workload, 10000)
         try:
@@ -745,7 +807,7 @@ def main():
         except Exception as exc:                                  # the baseline must never sink the line
             out["cpu_baseline"] = {"value": None, "error": repr(exc)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)     # (flushed here: a library's exit handler must not be able to lose the line)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -98,7 +98,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 27            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 28            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -715,18 +715,55 @@ int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* par
 /* ---- collectives of the sharded solve (vican_comm_*) --------------------------------------------------------
  * Timestep rows are sharded over ranks, every camera-side quantity is replicated; what crosses ranks are f64 sum-all-reduces of
  * camera-side partials (the reference has no distributed code: this is the counterpart of bipgo.py:300,318 / :477 when the rows
- * of R~ live on several GPUs).  A communicator held by the library: RCCL loaded at run time (dlopen librccl.so.1; no link-time
- * dependency), ncclAllReduce enqueued on the caller's stream in stream order - no host synchronisation, no Python hop.
+ * of R~ live on several GPUs).  A communicator held by the library, every collective enqueued on the caller's stream in stream
+ * order - no host synchronisation, no Python hop between a kernel and the collective behind it.  Two transports:
+ *   RCCL            loaded at run time (dlopen librccl.so.1; no link-time dependency): ncclAllReduce
+ *   peer exchange   ONE launch of the library's own kernel over mailboxes the ranks map into each other's address space
+ *                   (hipIpc handles; xGMI between the GPUs of a node): every rank pushes its partial into its slot of every
+ *                   mailbox as self-validating 8-byte granules {32 data bits | epoch tag} and sums the slots of its own mailbox
+ *                   in rank order - one hop, the same bits on every rank, no ordering between payload and flag relied on, bounded
+ *                   waits.  The launch honours vican_set_gate (a speculative tail that the device cancels advances nothing on
+ *                   any rank), so sharded solves speculate like single-rank ones.  Messages up to `max_doubles`; <= 8 ranks.
  *   vican_comm_unique_id   128 bytes (ncclUniqueId) written by ONE rank, handed to the others by any means
  *   vican_comm_create      collective over the group: every rank calls it with the same id (ncclCommInitRank)
- *   vican_comm_allreduce_sum   buf[0:n] (device, f64) <- sum over ranks, in place; world == 1: nothing is enqueued
- * (the composite "sweep + fold + all-reduce behind one host call", vican_block_op_z_comm, has no caller yet and lives in
- *  include/vican_hip_test.h until it has one) */
+ *   vican_comm_create_local  a communicator without RCCL (ranks sharing one GPU, which RCCL refuses; callers that do not want
+ *                          librccl loaded): its collectives exist as the peer exchange only
+ *   vican_comm_peer_export allocate this rank's mailbox (vican_comm_peer_bytes; uncached device memory) and write its 64-byte
+ *                          hipIpcMemHandle_t to handle_out; the caller gathers the handles of all ranks by any means
+ *   vican_comm_peer_attach handles [world][64] in rank order: map the other ranks' mailboxes; from here on
+ *                          vican_comm_allreduce_sum takes the exchange for n <= max_doubles (vican_comm_peer_enable(c, 0): back
+ *                          to RCCL).  world == 1: the rank's own slot is its peer - the same kernel, the same waits.
+ *   vican_comm_peer_status 0, or the number of element waits that timed out so far (host-visible word, no synchronisation):
+ *                          those messages came back as NaN; the caller disables the exchange and reports
+ *   vican_comm_allreduce_sum   buf[0:n] (device, f64) <- sum over ranks, in place; world == 1 without an attached exchange:
+ *                          nothing is enqueued
+ *   vican_block_op_z_comm  z = P x of this rank's rows summed over the ranks: vican_block_op_z + the all-reduce of z [3C][3]
+ *                          behind one host call (comm NULL: single rank)
+ *   vican_cg_iter_comm     one CG iteration of a sharded solve behind one host call: [cg_begin] sweep, fold (camera partials +
+ *                          FIXED slices of p_t.q_t) -> msg [3C + VICAN_CG_PQ_SLICES] all-reduced -> update of x, r with alpha
+ *                          from the reduced message -> rr_part [VICAN_CG_RR_SLICES] all-reduced; the next call's head closes
+ *                          the iteration.  scipy's recurrence, two messages per iteration; bit-reproducible and bit-identical
+ *                          on every rank (fixed slices, rank-ordered sums).  first != 0: the call after vican_cg_init and the
+ *                          all-reduce of the state's rr_time.  Same buffers as vican_cg_iter_fused otherwise. */
+#define VICAN_CG_PQ_SLICES 96
+#define VICAN_CG_RR_SLICES 512
 typedef struct vican_comm vican_comm_t;
 int vican_comm_unique_id(void* id_out /* 128 bytes, host */);
 int vican_comm_create(int32_t rank, int32_t world, const void* unique_id, vican_comm_t** comm_out);
+int vican_comm_create_local(int32_t rank, int32_t world, vican_comm_t** comm_out);
+int64_t vican_comm_peer_bytes(int32_t world, int64_t max_doubles);
+int vican_comm_peer_export(vican_comm_t* comm, int64_t max_doubles, void* handle_out /* 64 bytes, host */);
+int vican_comm_peer_attach(vican_comm_t* comm, const void* handles /* [world][64], host */);
+int vican_comm_peer_enable(vican_comm_t* comm, int32_t on);
+int vican_comm_peer_status(vican_comm_t* comm);
 int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream);
 int vican_comm_destroy(vican_comm_t* comm);
+int vican_block_op_z_comm(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx, double* z,
+                          vican_comm_t* comm, void* stream);
+int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
+                       double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
+                       void* qc_part, double* pq_part, double* msg, double rtol, double* rr_part, int32_t part_cap,
+                       double n_add, int32_t first, vican_cg_state_t* st, vican_comm_t* comm, void* stream);
 
 /* ---- the four-call boundary ----------------------------------------------------------------------------
  * For a maintainer who wants the numerics of the reference's two stages behind ONE handle: everything above composed by host

@@ -20,11 +20,6 @@ int vican_test_occupy(int32_t n_wg, int32_t threads, int32_t lds_bytes, int64_t 
  * that produced the message (tests/test_comm_gpu.py, tools/rccl_onerank.py).  The buffer keeps its bits.                */
 int vican_comm_force_enqueue(vican_comm_t* comm, int32_t on);
 
-/* z = P x of this rank's rows, summed over the ranks: vican_block_op_z followed by the all-reduce of z [3C][3] behind ONE host
- * call (comm NULL: single rank).  Not called by the drivers (they issue the collective themselves): test-only until it is. */
-int vican_block_op_z_comm(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx, double* z,
-                          vican_comm_t* comm, void* stream);
-
 /* ---- LSQR, two-pass form (cross-checks; reference bipgo.py:479-480) -------------------------------------------- */
 /* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
 int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,

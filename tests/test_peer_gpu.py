@@ -1,0 +1,146 @@
+"""The peer exchange (include/vican_hip.h: vican_comm_peer_*; csrc/vican_comm.hip): the all-reduce of the sharded solve as ONE
+launch of the library's own kernel over mailboxes the ranks map into each other's address space.
+
+What a 1-GPU box can execute of it: (a) one rank with its own mailbox slot as its peer - the same kernel, granules, waits,
+epoch and gate as with eight ranks; (b) TWO (and four) fresh processes sharing cuda:0 whose mailboxes are mapped through
+hipIpc handles - real cross-process exchanges, kernels of both processes spinning side by side - and full sharded solves
+over them against the real reference's golden.  The xGMI links between GPUs are the only part a node adds."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vican_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    env = dict(os.environ, VICAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_one_rank_exchange_keeps_the_bits_and_honours_the_gate():
+    from vican_amd.solver import Comm
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    comm = Comm.single(force_sharded=True, peer=True)
+    assert comm.transport == "peer" and comm.gateable
+    rng = np.random.default_rng(5)
+    gate = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    for n in (1, 3, 1024, 1025, 3 * 340 + 96, 9 * 1000, 70000, Comm.PEER_MAX_DOUBLES):
+        h = rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)
+        h[:: max(n // 7, 1)] = 0.0
+        if n > 2:
+            h[1], h[2] = -0.0, np.inf
+        x = torch.from_numpy(h).to("cuda:0")
+        y = x * 2.0                                   # a kernel in front of the exchange on the same stream
+        comm.allreduce(y)
+        z = y * 0.5                                   # ... and one behind it
+        # a launch the device cancels: nothing moves (and the epoch stays: the open launch behind it is served)
+        w = torch.full((n,), 3.25, dtype=torch.float64, device="cuda:0")
+        lib.vican_set_gate(C.c_void_p(gate.data_ptr()))
+        comm.allreduce(w)
+        lib.vican_set_gate(None)
+        comm.allreduce(w)
+        torch.cuda.synchronize()
+        assert np.array_equal(z.cpu().numpy().view(np.int64), h.view(np.int64)), n
+        assert bool((w == 3.25).all())
+    # messages larger than the mailboxes: a one-rank communicator enqueues nothing (identity)
+    big = torch.ones(Comm.PEER_MAX_DOUBLES + 1, dtype=torch.float64, device="cuda:0")
+    comm.allreduce(big)
+    torch.cuda.synchronize()
+    assert bool((big == 1.0).all())
+    assert lib.vican_comm_peer_status(comm.native_handle()) == 0
+    comm.check()
+    # argument checks of the C entry points
+    h = C.c_void_p()
+    assert lib.vican_comm_create_local(1, 1, C.byref(h)) == _lib.ERR_ARG
+    assert lib.vican_comm_create_local(0, 2, C.byref(h)) == 0
+    assert lib.vican_comm_peer_attach(h, None) == _lib.ERR_ARG          # nothing exported yet
+    assert lib.vican_comm_peer_status(h) == _lib.ERR_ARG
+    x = torch.ones(4, dtype=torch.float64, device="cuda:0")
+    assert lib.vican_comm_allreduce_sum(h, C.c_void_p(x.data_ptr()), 4, None) == _lib.ERR_ARG      # two ranks, no transport at all
+    assert lib.vican_comm_destroy(h) == 0
+    assert lib.vican_comm_peer_bytes(8, 1000) == 2 * 8 * 2 * 1000 * 8
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_sharded_schedule_over_the_peer_exchange_on_one_rank(dt):
+    """A large_shop-sized solve on the sharded schedule with every all-reduce a launch of the peer exchange
+    (Comm.single(force_sharded=True, peer=True)): bit-equal to the same schedule with identity collectives - speculative
+    tails included: the exchange is gated, a cancelled launch advances no epoch - run twice (bit-reproducible: the sharded CG
+    forms every partial over fixed slices), and equal to the plain single-rank solve within the eigen-solver's tolerance."""
+    from test_comm_gpu import _large_shop_problem
+    from vican_amd.bipgo import solve_problem
+    from vican_amd.geometry import geodesic
+    from vican_amd.solver import Comm
+    torch.cuda.set_device(0)
+    prob = _large_shop_problem(dt)
+    info_x, info_i, info_p = {}, {}, {}
+    comm = Comm.single(force_sharded=True, peer=True)
+    out_x = solve_problem(prob, 4, "conjugate_gradient", dt, info=info_x, comm=comm)
+    n_x = comm.n_allreduce
+    out_x2 = solve_problem(prob, 4, "conjugate_gradient", dt, comm=comm)
+    ident = Comm.single(force_sharded=True)
+    out_i = solve_problem(prob, 4, "conjugate_gradient", dt, info=info_i, comm=ident)
+    out_p = solve_problem(prob, 4, "conjugate_gradient", dt, info=info_p)
+    print("large_shop %s: %d peer exchanges in the solve (identity run: %d), cg %d / %d / %d, sweeps %d / %d" % (
+        np.dtype(dt).name, n_x, ident.n_allreduce, info_x["cg_iters"], info_i["cg_iters"], info_p["cg_iters"], info_x["sweeps"], info_p["sweeps"]))
+    assert n_x == ident.n_allreduce and n_x >= info_x["sweeps"] - 4 + 2 * info_x["cg_iters"]
+    for a, b, c in zip(out_x, out_i, out_x2):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert float(geodesic(out_x[0], out_p[0]).max()) < (1e-9 if dt == np.float64 else 2e-6)
+    assert float(geodesic(out_x[1], out_p[1]).max()) < (1e-9 if dt == np.float64 else 2e-6)
+    assert abs(info_x["cg_iters"] - info_p["cg_iters"]) <= 1
+    assert float(np.abs(out_x[2] - out_p[2]).max()) < (1e-7 if dt == np.float64 else 1e-3)
+    comm.check()
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_exchange_between_processes_through_ipc_mailboxes(nranks, tmp_path):
+    """tools/peer_probe.py: fresh processes sharing cuda:0, mailboxes mapped through hipIpc handles; every message size of
+    the solver, rank-ordered sums bit for bit on every rank, gated launches, bursts of 200 exchanges without host
+    synchronisation.  If this pool refuses same-device hipIpc the probe reports transport=torch and the test says so."""
+    out = str(tmp_path / "peer.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "peer_probe.py"), out]
+    res = subprocess.run(cmd, env=_env(VICAN_COMM="peer"), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    print(res.stdout[-3000:])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    rep = json.load(open(out))
+    if rep["transport"] != "peer":
+        pytest.skip("same-device hipIpc mapping refused on this box: %s" % rep["notes"])
+    assert "mismatches 0" in res.stdout and all(v["ok"] for v in rep["sizes"].values())
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_golden_over_the_peer_exchange_between_processes(nranks, tmp_path):
+    """BASELINE configs[3] over the exchange: tools/dist_g9.py with VICAN_COMM=peer - the large_shop-scale golden sharded over
+    fresh processes whose collectives are ALL launches of the exchange (no gloo call between a kernel and its all-reduce),
+    against the real reference's poses and against the single-rank solve."""
+    out = str(tmp_path / "g9.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "dist_g9.py"), out]
+    res = subprocess.run(cmd, env=_env(VICAN_COMM="peer"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(res.stdout[-3000:])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    rep = json.load(open(out))
+    if rep["float64"]["transport"] != "peer":
+        pytest.skip("same-device hipIpc mapping refused on this box")
+    assert "dist g9: mismatches 0" in res.stdout

@@ -25,6 +25,7 @@ from vican_amd import synth                                 # noqa: E402
 from vican_amd.bipgo import bipartite_se3sync               # noqa: E402
 from vican_amd.geometry import SE3, geodesic                # noqa: E402
 
+os.environ.setdefault("VICAN_SHARD_MIN_EDGES", "0")        # (40 000 merged edges: the small-graph policy would replicate the solve)
 backend = os.environ.get("VICAN_DIST_BACKEND", "nccl")
 dist.init_process_group(backend)
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -50,7 +51,8 @@ for dt in ("float64", "float32"):
                reference_window=[min(int(iters.min()), int(exp["cg_iters"])), max(int(iters.max()), int(exp["cg_iters"]))],
                rot_vs_single_rank_rad=float(geodesic(R, R1).max()), trans_vs_single_rank_m=float(np.linalg.norm(t - t1, axis=1).max()),
                rotations_bit_identical_to_single_rank=bool(np.array_equal(R, R1)), cg_iters_single_rank=int(info1["cg_iters"]),
-               tol_rot=5e-6 if dt == "float32" else 1e-7, tol_trans=min(translation_tol("g9_large_shop", dt), 2e-3))
+               tol_rot=5e-6 if dt == "float32" else 1e-7, tol_trans=min(translation_tol("g9_large_shop", dt), 2e-3),
+               transport=info.get("transport"), policy=info.get("policy"), n_allreduce=info.get("n_allreduce"))
     lo, hi = row["reference_window"]            # golden run + the nine runs of the sensitivity fixture (the reference's own spread)
     ok = rot < row["tol_rot"] and tr < row["tol_trans"] and lo - 1 <= row["cg_iters"] <= hi + 1
     row["ok"] = bool(ok)
@@ -58,9 +60,9 @@ for dt in ("float64", "float32"):
     report[dt] = row
     if rank == 0:
         print("g9 %s on %d ranks: rot %.2e rad, trans %.2e m vs the reference; cg %d (reference %d, its window %d..%d); vs single rank: "
-              "rot %.1e trans %.1e (cg %d)%s" % (dt, world, rot, tr, row["cg_iters"], row["cg_reference"], lo, hi,
+              "rot %.1e trans %.1e (cg %d); transport %s, %s all-reduces%s" % (dt, world, rot, tr, row["cg_iters"], row["cg_reference"], lo, hi,
                                                   row["rot_vs_single_rank_rad"], row["trans_vs_single_rank_m"], row["cg_iters_single_rank"],
-                                                  "" if ok else "   <-- MISMATCH"), flush=True)
+                                                  row["transport"], row["n_allreduce"], "" if ok else "   <-- MISMATCH"), flush=True)
 tb = torch.tensor([bad]); dist.all_reduce(tb)
 if rank == 0:
     print("dist g9: mismatches", int(tb[0]))

@@ -11,6 +11,7 @@ from vican_amd import frontend, synth
 from vican_amd.bipgo import solve_problem
 from vican_amd.geometry import SE3, geodesic
 
+os.environ.setdefault("VICAN_SHARD_MIN_EDGES", "0")        # (tiny graphs: the small-graph policy would replicate the solves)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)
@@ -38,7 +39,7 @@ for seed, (C, T) in enumerate([(3, 1), (2, 2), (4, 3), (5, 7), (8, 40), (12, 101
         bad += not ok
         ok = ok and (seed != 6 or info.get("layout") == "tiled")
         if rank == 0:
-            print("C=%d T=%d %s %s: sharded vs single rot %.1e trans %.1e cg %s %s" % (C, T, np.dtype(dt).name, info.get("layout"), rot, tr, info.get("cg_iters"), "" if ok else "  <-- MISMATCH"))
+            print("C=%d T=%d %s %s: sharded vs single rot %.1e trans %.1e cg %s transport %s %s" % (C, T, np.dtype(dt).name, info.get("layout"), rot, tr, info.get("cg_iters"), info.get("transport"), "" if ok else "  <-- MISMATCH"))
 t = torch.tensor([bad]); dist.all_reduce(t)
 if rank == 0:
     print("dist probe: mismatches", int(t[0]))

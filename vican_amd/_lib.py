@@ -71,6 +71,7 @@ CG_STATE_DOUBLES = 19
 CG_F = dict(rho=0, rho_prev=1, pq=2, alpha=3, beta=4, bnorm2=5, atol2=6, rr_cam=7, pq_time=8, rr_time=9,
             rmax_cam=10, rmax_time=11, pmax=12, qscale=13, qinv=14, wmax=15, pmax_time=16)
 CG_I = dict(iter=34, done=35, first=36, lo_bits=37)     # int32 index into the same buffer viewed as int32
+CG_PQ_SLICES, CG_RR_SLICES = 96, 512                   # VICAN_CG_PQ_SLICES / VICAN_CG_RR_SLICES (vican_cg_iter_comm)
 
 # vican_lsqr_state_t: 28 doubles then 8 int32 (256 bytes = 32 doubles)
 LSQR_STATE_DOUBLES = 32
@@ -177,8 +178,16 @@ PROTOTYPES = {
     # collectives behind the C ABI (csrc/vican_comm.hip: RCCL through dlopen)
     "vican_comm_unique_id": (C.c_int, [_vp]),
     "vican_comm_create": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "vican_comm_create_local": (C.c_int, [_i32, _i32, C.POINTER(_vp)]),
+    "vican_comm_peer_bytes": (_i64, [_i32, _i64]),
+    "vican_comm_peer_export": (C.c_int, [_vp, _i64, _vp]),
+    "vican_comm_peer_attach": (C.c_int, [_vp, _vp]),
+    "vican_comm_peer_enable": (C.c_int, [_vp, _i32]),
+    "vican_comm_peer_status": (C.c_int, [_vp]),
     "vican_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vican_comm_destroy": (C.c_int, [_vp]),
+    "vican_block_op_z_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vican_cg_iter_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _f64, _i32, _vp, _vp, _vp]),
     # the four-call boundary (csrc/vican_facade.hip)
     "vican_plan_create": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "vican_plan_describe": (C.c_int, [_vp, _G]),
@@ -204,7 +213,6 @@ class LsqrInfo(C.Structure):
 # include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
 TEST_PROTOTYPES = {
     "vican_comm_force_enqueue": (C.c_int, [_vp, _i32]),
-    "vican_block_op_z_comm": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),

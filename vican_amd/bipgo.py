@@ -68,6 +68,25 @@ def _shard_rows(T, world, rank):
     return (T * rank) // world, (T * (rank + 1)) // world
 
 
+# Small-graph policy of multi-rank groups.  Sharding the timestep rows over N ranks removes (1 - 1/N) of the EDGE work of a
+# solve and adds ~30-70 latency-bound collectives plus the launch-sequence schedule in place of the cooperative kernels; the
+# camera side (Lanczos steps, Ritz, per-camera SVDs: most of a capture-sized solve) is replicated either way.  Below the
+# threshold every rank solves the WHOLE graph with the single-rank schedule - no collective at all, the same bits on every
+# rank (the single-rank solve is bit-reproducible), 1.0 x the one-GPU time instead of the measured ~0.5 x.  Measured on one
+# MI355X (tools/shard_threshold.py, profiles/r06_shard_threshold.txt): the break-even of an 8-way split lies between 2 M and
+# 4 M merged edges.  VICAN_SHARD_MIN_EDGES overrides (0: always shard).
+SHARD_MIN_EDGES = 3_000_000
+
+
+def shard_policy(n_edges_total, world):
+    """'sharded' or 'replicated' for a graph of n_edges_total merged edges in a group of `world` ranks."""
+    import os
+    if world <= 1:
+        return "single"
+    lim = int(os.environ.get("VICAN_SHARD_MIN_EDGES", SHARD_MIN_EDGES))
+    return "sharded" if n_edges_total >= lim else "replicated"
+
+
 def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=np.float32,
                   group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False, cg_stop_at=None, comm=None):
     """Solve a flattened problem on this rank's GPU; returns host arrays
@@ -83,6 +102,9 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     if not torch.cuda.is_available():
         raise VicanError("no GPU visible: vican_amd has no CPU fallback")
     comm = Comm(group) if comm is None else comm
+    policy = shard_policy(prob.n_edges, comm.world)
+    if policy == "replicated" and not getattr(comm, "force_sharded", False):
+        comm = Comm.single()               # every rank solves the whole graph (small-graph policy above): no collective
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     T = prob.n_time
@@ -152,6 +174,8 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
 
     # (a cooperative kernel whose grid barrier timed out - device shared - makes the stages run again on the launch sequences)
     rot, tr, rc, Rt_all, Rt_loc, x_c, x_t = with_cooperative_fallback(K, comm, stages)
+    if hasattr(comm, "check"):
+        comm.check()                       # (a timed-out wait of the peer exchange: NaN messages - an error, never a silent result)
     t2 = tm["t2"]
     t3 = time.perf_counter()
     if Rt_all is None:
@@ -168,7 +192,8 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                     cg_iters=tr.info.get("cg_iters"), cg_relres=tr.info.get("relres"), lsqr_iters=tr.info.get("lsqr_iters"),
                     lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T,
                     n_edges=prob.n_edges, n_src=prob.n_src, n_chunk=getattr(g, "n_chunk", None), n_wg=getattr(g, "n_wg", None), layout=g.layout,
-                    t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world)
+                    t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world, policy=policy,
+                    transport=getattr(comm, "transport", None), n_allreduce=getattr(comm, "n_allreduce", None))
     return Rc, Rt, xc_h, xt_h
 
 

@@ -52,7 +52,136 @@ int rccl_err(const char* who, ncclResult_t e) {
 
 }  // namespace
 
-struct vican_comm { ncclComm_t comm; int rank, world; int force_enqueue; };
+// ---------------------------------------------------------------------------------------------------------------------------
+// Peer exchange: the all-reduce as ONE launch of the library's own kernel over mailboxes that the ranks map into each other's
+// address space (hipIpc: dmabuf handles; xGMI between the GPUs of a node).
+//
+// The messages of this path are 8 ... 72 KB of f64 (latency-bound: SURVEY.md 8(e)); a ring or tree of RCCL pays several hops
+// and a host-side enqueue of its own.  Here every rank PUSHES its partial into a slot of every rank's mailbox and then sums the
+// `world` slots of its OWN mailbox in rank order - one hop, and the same sum in the same order on every rank (bit-identical
+// results: the replicated camera side must not drift apart).  No data-then-flag ordering is relied on: the payload travels in
+// 8-byte granules {32 data bits | 32-bit tag}, each written by ONE 8-byte system-scope store (the granule RCCL's LL protocol
+// uses on the same links) and valid iff its tag is the collective's epoch.  The thread that owns element i pushes it and later
+// collects it: no workgroup waits for another workgroup of its own launch.
+//   mailbox of a rank: granule[2 parities][world sources][2 * cap]   (uncached device memory: remote writes must not meet a
+//                      stale line of the owner's L2)
+//   epoch            : a DEVICE word, advanced by the launch itself (its last workgroup) - a launch that the solver's gate
+//                      cancels on the device (speculative tails) advances nothing, on any rank; parities alternate with it, so
+//                      a source can overwrite a slot only after the owner has collected it (it needs the owner's NEXT push first)
+//   waits            : bounded (vican_set_barrier_abort's limit); a timeout raises the host-visible status word, the message
+//                      is left as NaN, and the exchange is disabled for this communicator (vican_comm_peer_status)
+// ---------------------------------------------------------------------------------------------------------------------------
+#define VICAN_PEER_MAX 8
+#define VICAN_PEER_WG 1024
+struct PeerArgs {
+    unsigned long long* mbox[VICAN_PEER_MAX];   // every rank's mailbox as mapped in THIS process ([rank] = the local one)
+    int rank, world;
+    long long cap;                              // doubles per message
+    unsigned int* state;                        // device: [0] epoch, [1] arrival ticket
+    unsigned int* status;                       // host-visible (pinned): [0] timed-out waits
+    unsigned long long limit;                   // spin bound, ticks of the 100 MHz counter
+};
+struct vican_comm {
+    ncclComm_t comm; int rank, world; int force_enqueue;
+    // peer exchange
+    void* mb_local = nullptr; int64_t mb_cap = 0; bool mb_attached = false, mb_enabled = false;
+    void* mb_opened[VICAN_PEER_MAX] = {};       // handles of the other ranks opened here (to be closed)
+    PeerArgs pa = {};
+    int device = -1;
+};
+
+namespace {
+typedef unsigned long long u64;
+__device__ __forceinline__ void granule_store(u64* p, unsigned int data, unsigned int tag) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)data, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ u64 granule_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// buf[0:n] <- sum over ranks (in place).  EPT elements per thread, all pushes before the first wait.
+template <int EPT>
+__global__ __launch_bounds__(VICAN_PEER_WG) void peer_allreduce_kernel(const int32_t* gate, PeerArgs a, double* buf, long long n) {
+    GATE_RETURN(gate);
+    __shared__ int s_last;
+    const unsigned int epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int tag = (epoch & 0x7FFFFFFFu) + 1u;
+    const long long par = epoch & 1u;
+    const long long slot = 2 * a.cap;                                    // granules per (parity, source)
+    const long long base = (long long)blockIdx.x * (VICAN_PEER_WG * EPT) + threadIdx.x;
+    // ---- push: this rank's slot in every mailbox (its own included: one code path for every source)
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long long i = base + (long long)k * VICAN_PEER_WG;
+        if (i < n) {
+            const u64 bits = (u64)__double_as_longlong(buf[i]);
+            const unsigned int lo = (unsigned int)bits, hi = (unsigned int)(bits >> 32);
+            for (int d = 0; d < a.world; ++d) {
+                const int dst = (a.rank + d) % a.world;                  // (every rank starts with itself: spreads the links)
+                u64* q = a.mbox[dst] + (par * a.world + a.rank) * slot + 2 * i;
+                granule_store(q, lo, tag);
+                granule_store(q + 1, hi, tag);
+            }
+        }
+    }
+    // ---- collect: the `world` slots of the own mailbox, summed in rank order
+    const u64* mine = a.mbox[a.rank] + par * a.world * slot;
+    bool timed_out = false;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const long long i = base + (long long)k * VICAN_PEER_WG;
+        if (i < n) {
+            u64 g0[VICAN_PEER_MAX], g1[VICAN_PEER_MAX];
+            unsigned int pending = a.world >= 32 ? 0xFFFFFFFFu : ((1u << a.world) - 1u);
+            unsigned long long t0 = 0;
+            unsigned int spins = 0;
+            while (pending && !timed_out) {
+#pragma unroll
+                for (int s = 0; s < VICAN_PEER_MAX; ++s)
+                    if (s < a.world && (pending >> s & 1u)) { g0[s] = granule_load(mine + s * slot + 2 * i); g1[s] = granule_load(mine + s * slot + 2 * i + 1); }
+#pragma unroll
+                for (int s = 0; s < VICAN_PEER_MAX; ++s)
+                    if (s < a.world && (pending >> s & 1u) && (unsigned int)(g0[s] >> 32) == tag && (unsigned int)(g1[s] >> 32) == tag) pending &= ~(1u << s);
+                if (pending) {
+                    if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > a.limit) timed_out = true;
+                }
+            }
+            double acc = __longlong_as_double(0x7FF8000000000000LL);
+            if (!timed_out) {
+                acc = __longlong_as_double((long long)(((g1[0] & 0xFFFFFFFFull) << 32) | (g0[0] & 0xFFFFFFFFull)));     // (not 0 + v_0: keeps -0)
+#pragma unroll
+                for (int s = 1; s < VICAN_PEER_MAX; ++s)
+                    if (s < a.world) acc += __longlong_as_double((long long)(((g1[s] & 0xFFFFFFFFull) << 32) | (g0[s] & 0xFFFFFFFFull)));
+            }
+            buf[i] = acc;
+        }
+    }
+    if (timed_out) __hip_atomic_fetch_add(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- the workgroup that finishes last advances the epoch (every workgroup has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1u;
+        if (s_last) {
+            __hip_atomic_store(a.state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.state, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int peer_allreduce(vican_comm* c, double* buf, int64_t n, hipStream_t st) {
+    const int64_t per_wg = VICAN_PEER_WG;
+    if (n <= 64 * per_wg) {
+        const unsigned grid = (unsigned)((n + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL(peer_allreduce_kernel<1>, dim3(grid), dim3(VICAN_PEER_WG), 0, st, g_vican_gate, c->pa, buf, (long long)n);
+    } else {
+        const unsigned grid = (unsigned)((n + 4 * per_wg - 1) / (4 * per_wg));
+        hipLaunchKernelGGL(peer_allreduce_kernel<4>, dim3(grid), dim3(VICAN_PEER_WG), 0, st, g_vican_gate, c->pa, buf, (long long)n);
+    }
+    LAUNCH_CHECK("vican_comm_allreduce_sum (peer exchange)");
+    return VICAN_OK;
+}
+}  // namespace
 
 extern "C" int vican_comm_unique_id(void* id_out) {
     Rccl* r = rccl();
@@ -78,15 +207,110 @@ extern "C" int vican_comm_create(int32_t rank, int32_t world, const void* unique
     return VICAN_OK;
 }
 
+// a communicator WITHOUT RCCL: its all-reduces exist only as the peer exchange below (vican_comm_peer_export / _attach) -
+// ranks that share one GPU (RCCL refuses those), callers that do not want librccl loaded
+extern "C" int vican_comm_create_local(int32_t rank, int32_t world, vican_comm_t** comm_out) {
+    if (!comm_out || world < 1 || world > VICAN_PEER_MAX || rank < 0 || rank >= world) return set_err(VICAN_ERR_ARG, "%s: bad argument", "vican_comm_create_local");
+    *comm_out = new vican_comm{nullptr, rank, world, 0};
+    return VICAN_OK;
+}
+
+// ---- peer exchange: set-up ----------------------------------------------------------------------------------------------
+#define PEER_HIP(call, who)                                                                                 \
+    do {                                                                                                    \
+        const hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                             \
+            snprintf(g_vican_err, sizeof(g_vican_err), "%s: %s: %s", who, #call, hipGetErrorString(e_));    \
+            (void)hipGetLastError();                                                                        \
+            return VICAN_ERR_LAUNCH;                                                                        \
+        }                                                                                                   \
+    } while (0)
+
+static void peer_release(vican_comm* c) {
+    for (int r = 0; r < VICAN_PEER_MAX; ++r)
+        if (c->mb_opened[r]) { (void)hipIpcCloseMemHandle(c->mb_opened[r]); c->mb_opened[r] = nullptr; }
+    if (c->mb_local) { (void)hipFree(c->mb_local); c->mb_local = nullptr; }
+    if (c->pa.state) { (void)hipFree(c->pa.state); c->pa.state = nullptr; }
+    if (c->pa.status) { (void)hipHostFree(c->pa.status); c->pa.status = nullptr; }
+    c->mb_attached = c->mb_enabled = false;
+}
+
+extern "C" int64_t vican_comm_peer_bytes(int32_t world, int64_t max_doubles) {
+    if (world < 1 || world > VICAN_PEER_MAX || max_doubles < 1) return 0;
+    return 2LL * world * 2LL * max_doubles * 8LL;
+}
+
+extern "C" int vican_comm_peer_export(vican_comm_t* c, int64_t max_doubles, void* handle_out) {
+    if (!c || max_doubles < 1 || !handle_out) return set_err(VICAN_ERR_ARG, "%s: bad argument", "vican_comm_peer_export");
+    if (c->world > VICAN_PEER_MAX) return set_err(VICAN_ERR_CAPACITY, "%s: more ranks than the peer exchange serves", "vican_comm_peer_export");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "vican_comm_peer_export hands out 64-byte handles");
+    peer_release(c);
+    const char* who = "vican_comm_peer_export";
+    PEER_HIP(hipGetDevice(&c->device), who);
+    const size_t bytes = (size_t)vican_comm_peer_bytes(c->world, max_doubles);
+    // uncached: a remote rank's stores must never meet a stale line of this GPU's L2 (and nothing of the mailbox is ever re-read)
+    PEER_HIP(hipExtMallocWithFlags(&c->mb_local, bytes, hipDeviceMallocUncached), who);
+    PEER_HIP(hipMemset(c->mb_local, 0, bytes), who);
+    PEER_HIP(hipMalloc((void**)&c->pa.state, 256), who);
+    PEER_HIP(hipMemset(c->pa.state, 0, 256), who);
+    PEER_HIP(hipHostMalloc((void**)&c->pa.status, 64, hipHostMallocMapped), who);
+    memset(c->pa.status, 0, 64);
+    PEER_HIP(hipDeviceSynchronize(), who);
+    c->mb_cap = max_doubles;
+    memset(handle_out, 0, 64);
+    if (c->world > 1) {
+        hipIpcMemHandle_t h;
+        PEER_HIP(hipIpcGetMemHandle(&h, c->mb_local), who);
+        memcpy(handle_out, &h, 64);
+    }
+    return VICAN_OK;
+}
+
+extern "C" int vican_comm_peer_attach(vican_comm_t* c, const void* handles) {
+    const char* who = "vican_comm_peer_attach";
+    if (!c || !c->mb_local || (c->world > 1 && !handles)) return set_err(VICAN_ERR_ARG, "%s: bad argument (vican_comm_peer_export first)", who);
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) { c->pa.mbox[r] = (unsigned long long*)c->mb_local; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + 64 * r, 64);
+        void* p = nullptr;
+        PEER_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), who);
+        c->mb_opened[r] = p;
+        c->pa.mbox[r] = (unsigned long long*)p;
+    }
+    c->pa.rank = c->rank; c->pa.world = c->world; c->pa.cap = c->mb_cap;
+    c->pa.limit = g_vican_sync_ticks ? g_vican_sync_ticks : 200000000ull;          // (2 s of the 100 MHz counter)
+    c->mb_attached = true;
+    c->mb_enabled = true;
+    return VICAN_OK;
+}
+
+extern "C" int vican_comm_peer_enable(vican_comm_t* c, int32_t on) {
+    if (!c) return set_err(VICAN_ERR_ARG, "%s: NULL communicator", "vican_comm_peer_enable");
+    if (on && !c->mb_attached) return set_err(VICAN_ERR_ARG, "%s: no mailboxes attached", "vican_comm_peer_enable");
+    c->mb_enabled = on != 0;
+    return VICAN_OK;
+}
+
+// 0: every wait so far was served; > 0: that many element waits timed out (their messages came back as NaN) - the caller
+// stops using the exchange (vican_comm_peer_enable(c, 0)) and reports; < 0: no exchange attached.  Host-visible word: no sync.
+extern "C" int vican_comm_peer_status(vican_comm_t* c) {
+    if (!c || !c->mb_attached) return VICAN_ERR_ARG;
+    return (int)*(volatile unsigned int*)c->pa.status;
+}
+
 extern "C" int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream) {
     if (!comm || !buf || n < 0) return set_err(VICAN_ERR_ARG, "%s: bad argument", "vican_comm_allreduce_sum");
     if (n == 0) return VICAN_OK;
+    if (comm->mb_enabled && n <= comm->mb_cap) return peer_allreduce(comm, buf, n, (hipStream_t)stream);
+    if (!comm->comm && comm->world > 1)
+        return set_err(VICAN_ERR_ARG, "%s: a local communicator has no collective but the peer exchange (message larger than the mailboxes, or exchange disabled)", "vican_comm_allreduce_sum");
     if (comm->world == 1) {
         // one rank: the sum is the identity and nothing is enqueued - unless vican_comm_force_enqueue asked for the collective
         // to run anyway (tests, timing on a 1-GPU box).  RCCL itself elides an in-place ncclSum on a one-rank communicator
         // (no kernel, no copy), so the forced call asks for ncclAvg = sum x 1/world = x 1.0: the same bits, and RCCL's own
         // one-rank reduce kernel on the caller's stream.
-        if (!comm->force_enqueue) return VICAN_OK;
+        if (!comm->force_enqueue || !comm->comm) return VICAN_OK;
         const ncclResult_t e = rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclAvg, comm->comm, (hipStream_t)stream);
         return e == ncclSuccess ? VICAN_OK : rccl_err("vican_comm_allreduce_sum", e);
     }
@@ -103,8 +327,8 @@ extern "C" int vican_comm_force_enqueue(vican_comm_t* comm, int32_t on) {
 
 extern "C" int vican_comm_destroy(vican_comm_t* comm) {
     if (!comm) return VICAN_OK;
-    Rccl* r = rccl();
-    if (r && comm->comm) r->CommDestroy(comm->comm);
+    peer_release(comm);
+    if (comm->comm) { Rccl* r = rccl(); if (r) r->CommDestroy(comm->comm); }
     delete comm;
     return VICAN_OK;
 }

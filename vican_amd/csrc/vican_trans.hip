@@ -1240,10 +1240,12 @@ template <int COLS>
 __global__ __launch_bounds__(1024) void cg_fold2_kernel(const long long* __restrict__ part, int n_slab, int n_cam,
                                                         const double* __restrict__ p_t, const double* __restrict__ q_t, long long n_t, int n_pq,
                                                         double* __restrict__ pq_part, double* __restrict__ qcpq,
-                                                        const vican_cg_state_t* __restrict__ st) {
+                                                        const vican_cg_state_t* __restrict__ st, int n_pq_pad) {
     __shared__ long long sh[3][1024];
     __shared__ double red[16];
     if (st->done) return;
+    // (sharded runs all-reduce the slices element by element: the ones this rank does not fill must be zero every time)
+    if (blockIdx.x == 0 && (int)threadIdx.x >= n_pq && (int)threadIdx.x < n_pq_pad) pq_part[threadIdx.x] = 0.0;
     const long long n = 3LL * n_cam;
     const int lob = st->lo_bits;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1277,12 +1279,15 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
                                                        double* __restrict__ x_t, double* __restrict__ r_t, double* rr_part,
                                                        const double* __restrict__ pq_part, int n_pq,
                                                        double rtol, double n_add, vican_cg_state_t* st, unsigned int* ticket,
-                                                       double* hand) {
+                                                       double* hand, int rr_pad) {
     __shared__ double red[8];
     __shared__ double sh_beta;
     __shared__ int sh_go;
     if (st->done) return;
     const int nc = 3 * n_cam;
+    // (sharded runs all-reduce rr_part[0:rr_pad] element by element: the partials beyond this rank's blocks are zero every time)
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = (int)gridDim.x - 1 + (int)threadIdx.x; i < rr_pad; i += 256) rr_part[i] = 0.0;
     // alpha = rho / (p_t.q_t + p_c.q_c), by every workgroup for itself from the same numbers in the same order (as cg_step):
     // the partials of p_t.q_t that the fold's workgroups left (fixed slices, workgroup order) and the camera part
     __shared__ double sh_alpha;
@@ -1373,14 +1378,52 @@ extern "C" int vican_cg_iter_fused(const vican_graph_t* g, const double* w, cons
     const int n_fold = (int)((nc + 63) / 64);
     int n_pq = (int)((n + 8191) / 8192); if (n_pq < 1) n_pq = 1; if (n_pq > 96) n_pq = 96;       // slices of p_t.q_t (8 elements per thread and pass)
     hipLaunchKernelGGL(cg_fold2_kernel<64>, dim3((unsigned)(n_fold > n_pq ? n_fold : n_pq)), dim3(1024), 0, s, (const long long*)qc_part, (int)g->n_wg,
-                       (int)g->n_cam, p_t, q_t, n, n_pq, pq_part2, qcpq, st);
+                       (int)g->n_cam, p_t, q_t, n, n_pq, pq_part2, qcpq, st, 0);
     if (handover)
         hipLaunchKernelGGL(cg_step2_kernel<true>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
+                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32), 0);
     else
         hipLaunchKernelGGL(cg_step2_kernel<false>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32));
+                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32), 0);
     LAUNCH_CHECK("vican_cg_iter_fused");
+    return VICAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One CG iteration of a SHARDED solve behind one host call (timestep rows split over the ranks of `comm`, camera side
+// replicated): the single-rank sequence above with the two sums that cross ranks all-reduced in stream order -
+//   [cg_begin] sweep, cg_fold2 -> msg = [q_c partial (3C) | slices of p_t.q_t (VICAN_CG_PQ_SLICES, zero-padded)] -> all-reduce
+//   cg_step2 (alpha from the reduced message, by every workgroup for itself) -> rr_part[0:VICAN_CG_RR_SLICES] (zero-padded) -> all-reduce
+// and the next call's cg_begin closes the iteration from the reduced partials.  scipy's recurrence (two messages per
+// iteration, bipgo.py:477).  Every partial that enters a message is formed over FIXED slices in a fixed order and the peer
+// exchange sums ranks in rank order: the iterates are bit-reproducible from run to run and bit-identical on every rank.
+// first != 0: the call that follows vican_cg_init AND the all-reduce of the state's rr_time (the caller's).
+// msg: 3C + VICAN_CG_PQ_SLICES doubles.  The maxima that bound the fixed-point scale stay rank-local (each rank converts its
+// own partials to doubles before they travel).
+// ---------------------------------------------------------------------------
+extern "C" int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
+                                  double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
+                                  void* qc_part, double* pq_part, double* msg, double rtol, double* rr_part, int32_t part_cap,
+                                  double n_add, int32_t first, vican_cg_state_t* st, vican_comm_t* comm, void* stream) {
+    if (!g || !deg_c || !r_c || !p_c || !x_c || !r_t || !p_t || !q_t || !x_t || !msg || !rr_part || part_cap < 3 * CG_PARTS || !st)
+        return set_err(VICAN_ERR_ARG, "vican_cg_iter_comm: bad argument");
+    int rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = 3LL * g->n_time, nc = 3LL * g->n_cam;
+    int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
+    if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, first ? 0 : VICAN_CG_RR_SLICES, n_add, st, stream)) < 0) return rc;
+    if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
+    double* pq_slices = msg + nc;
+    const int n_fold = (int)((nc + 63) / 64);
+    int n_pq = (int)((n + 8191) / 8192); if (n_pq < 1) n_pq = 1; if (n_pq > VICAN_CG_PQ_SLICES) n_pq = VICAN_CG_PQ_SLICES;
+    hipLaunchKernelGGL(cg_fold2_kernel<64>, dim3((unsigned)(n_fold > n_pq ? n_fold : n_pq)), dim3(1024), 0, s, (const long long*)qc_part, (int)g->n_wg,
+                       (int)g->n_cam, p_t, q_t, n, n_pq, pq_slices, msg, st, VICAN_CG_PQ_SLICES);
+    LAUNCH_CHECK("vican_cg_iter_comm");
+    if (comm && (rc = vican_comm_allreduce_sum(comm, msg, nc + VICAN_CG_PQ_SLICES, stream)) < 0) return rc;
+    hipLaunchKernelGGL(cg_step2_kernel<false>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, msg, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                       rr_part, pq_slices, VICAN_CG_PQ_SLICES, rtol, n_add, st, (unsigned int*)nullptr, (double*)nullptr, VICAN_CG_RR_SLICES);
+    LAUNCH_CHECK("vican_cg_iter_comm");
+    if (comm && (rc = vican_comm_allreduce_sum(comm, rr_part, VICAN_CG_RR_SLICES, stream)) < 0) return rc;
     return VICAN_OK;
 }
 

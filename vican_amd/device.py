@@ -635,6 +635,21 @@ class HipBackend:
         self._ck(self.lib.vican_block_op_z(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx),
                                            _ptr(z_out), _stream()), "vican_block_op_z")
 
+    def block_op_comm(self, lamT_inv, x, z_out, comm):
+        """z_out = P x summed over the ranks of `comm` (solver.Comm): sweep, slab fold and the all-reduce behind ONE host call
+        where the communicator lives in the C library (include/vican_hip.h: vican_block_op_z_comm); else block_op + comm.allreduce."""
+        h = comm.native_handle() if hasattr(comm, "native_handle") else None
+        if h is None and z_out.is_cuda and not getattr(comm, "_native_tried", True):
+            comm._setup_native(z_out.device)                     # (first device message of the group: a collective set-up)
+            h = comm.native_handle()
+        if h is None or type(self).block_op is not HipBackend.block_op or z_out.numel() > getattr(comm, "PEER_MAX_DOUBLES", 0):
+            self.block_op(lamT_inv, x, z_out)
+            comm.allreduce(z_out)
+            return
+        self._ck(self.lib.vican_block_op_z_comm(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx),
+                                                _ptr(z_out), h, _stream()), "vican_block_op_z_comm")
+        comm.n_allreduce += 1
+
     def node_degrees(self, out):
         """Weighted degrees of all C+T nodes (cameras first) - bipgo.py:95."""
         out[: self.C].copy_(self.g.cam_sum_a)
@@ -745,6 +760,16 @@ class HipBackend:
                                               float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg,
                                               int(bool(first)) | (2 if self.cg_handover else 0),
                                               _ptr(st), _ptr(self._cg_ticket), _stream()), "vican_cg_iter_fused")
+
+    def cg_iter_comm(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, msg, rtol, st, first, comm):
+        """One CG iteration of a sharded solve behind one host call, both all-reduces enqueued from C in stream order
+        (include/vican_hip.h: vican_cg_iter_comm); comm: solver.Comm whose communicator lives in the C library, or a forced
+        one-rank Comm without one (identity collectives: the same launches minus the two messages).  msg: 3C + CG_PQ_SLICES."""
+        part = self.zpart[: self.cgl.n_wg * 6 * self.C]
+        self._ck(self.lib.vican_cg_iter_comm(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(r_c), _ptr(p_c), _ptr(x_c),
+                                             _ptr(r_t), _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(part), _ptr(self.pq_part), _ptr(msg),
+                                             float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg, int(bool(first)),
+                                             _ptr(st), comm.native_handle(), _stream()), "vican_cg_iter_comm")
 
     # one message per CG iteration (sharded solves; include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)
     def cg1_iter_local(self, deg_t, r_c, r_t, s_t, msg, st, n_rr_part):
@@ -1245,6 +1270,7 @@ class TiledBackend(HipBackend):
     no limit on the number of cameras.  No fused dual update (a performance feature of the untiled sweeps)."""
     fused_dual_ok = False
     cg_iter_fused = None           # (the tiled CG product is several launches: no fused iteration)
+    cg_iter_comm = None            # ... nor the sharded iteration behind one host call
     cg1_iter_local = None          # sharded tiled solves keep the two-message CG (the one-message product is an untiled sweep)
 
     def __init__(self, graph: TiledGraph):

@@ -35,10 +35,28 @@ import torch
 from ._lib import CG_F, CG_I, CG_STATE_DOUBLES, LSQR_F, LSQR_I, LSQR_STATE_DOUBLES
 
 
-class Comm:
-    """Sum-all-reduce over ranks; identity for a single rank."""
+_NATIVE_COMMS = {}       # (process group, device index) -> the C library's communicator of that group: made once per process
 
-    def __init__(self, group=None, native=None, force_sharded=False):
+
+class Comm:
+    """Sum-all-reduce over ranks; identity for a single rank.
+
+    Transport of the all-reduces of DEVICE tensors in a multi-rank group (``transport=`` / ``VICAN_COMM``; default "auto"):
+
+      "peer"   a communicator held by the C library (include/vican_hip.h: vican_comm_*), every collective enqueued from C on
+               the launch stream: the peer exchange (ONE launch of the library's own kernel over hipIpc-mapped mailboxes;
+               gateable, so sharded solves speculate like single-rank ones) with RCCL - where the group is an RCCL group -
+               behind it for messages larger than the mailboxes;
+      "rccl"   the same communicator, ncclAllReduce only;
+      "torch"  torch.distributed.all_reduce, issued by this Python code (what host tensors - the NumPy stand-in backend of the
+               CPU tests - always take).
+      "auto"   "peer" where it can be set up AND passes its self-test on every rank (a known message through the exchange,
+               bounded waits), else "rccl" on RCCL groups, else "torch".  A transport that fails is never an error.
+    """
+
+    PEER_MAX_DOUBLES = 131072            # mailbox capacity per message (9 C doubles: up to 14 000 cameras); larger messages: RCCL / torch
+
+    def __init__(self, group=None, native=None, force_sharded=False, transport=None):
         self.group = group
         self.world = 1
         self.rank = 0
@@ -46,72 +64,179 @@ class Comm:
             self.world = torch.distributed.get_world_size(group)
             self.rank = torch.distributed.get_rank(group)
         self.n_allreduce = 0
-        # force_sharded: take the sharded code paths (launch sequences, host-issued all-reduces, two-message CG) although this
+        # force_sharded: take the sharded code paths (launch sequences, all-reduces, two-message CG) although this
         # rank holds every row - how the multi-GPU schedule is exercised, timed and compared bit for bit on ONE GPU
         self.force_sharded = bool(force_sharded)
-        # native=True / VICAN_NATIVE_COMM=1: the all-reduces go through an RCCL communicator held by the C library
-        # (include/vican_hip.h: vican_comm_*; enqueued from C on the launch stream) instead of torch.distributed.  Off by
-        # default: torch's "nccl" backend IS RCCL and is the path every multi-rank test exercises; the native one has run on
-        # one GPU only (one-rank communicator: tests/test_comm_gpu.py, profiles/r05_rccl_onerank.txt).
-        self._native = None
-        if native is None:
-            native = os.environ.get("VICAN_NATIVE_COMM") == "1"
-        if native and self.world > 1 and self._device_collectives():
-            self._native = self._create_native()
+        if transport is None:
+            transport = os.environ.get("VICAN_COMM", "auto")
+        if native is not None:                                   # (round-5 spelling: native=True = RCCL from C, False = torch)
+            transport = "rccl" if native else "torch"
+        if os.environ.get("VICAN_NATIVE_COMM") == "1" and transport == "auto":
+            transport = "rccl"
+        if transport not in ("auto", "peer", "rccl", "torch"):
+            raise ValueError("Comm: unknown transport %r" % (transport,))
+        self.transport_wanted = transport
+        self.transport = "torch" if self.world > 1 else None      # what is in use (set by _setup_native on the first device message)
+        self._native, self._native_lib, self._native_tried = None, None, False
+        self.gateable = self.world == 1
+        self.notes = []
 
     @property
     def sharded(self):
         """True where the solver must take the sharded schedule (more than one rank, or forced on one)."""
         return self.world > 1 or getattr(self, "force_sharded", False)
 
-    def _create_native(self):
+    # -- the C library's communicator ------------------------------------------------------------------------------------
+    def native_handle(self):
+        """The vican_comm_t* whose collectives the C composites (vican_block_op_z_comm, vican_cg_iter_comm) enqueue
+        themselves, or None (torch transport, single rank without a forced transport)."""
+        return getattr(self, "_native", None)
+
+    def _setup_native(self, device):
+        """First device message of a multi-rank group: create the C library's communicator (a collective over the group -
+        every rank arrives here with the same message) and choose the transport."""
+        self._native_tried = True
+        want = self.transport_wanted
+        if want == "torch" or self.world == 1:
+            return
+        # one communicator (RCCL init, mailboxes, hipIpc mappings, self-test) per group, device and wanted transport for the
+        # life of the process: a drop-in call makes a fresh Comm, and every rank makes it at the same point
+        key = (self.group if self.group is not None else "world", device.index, want)
+        hit = _NATIVE_COMMS.get(key)
+        if hit is None:
+            self._create_native(device)
+            _NATIVE_COMMS[key] = (self._native, self._native_lib, self.transport, self.gateable, list(self.notes))
+        else:
+            self._native, self._native_lib, self.transport, self.gateable, self.notes = hit[0], hit[1], hit[2], hit[3], list(hit[4])
+        self._owns_native = False
+
+    def _create_native(self, device):
+        want = self.transport_wanted
         import ctypes
         from . import _lib
         lib = _lib.load()
-        ids = [None]
-        if self.rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            _lib.check(lib.vican_comm_unique_id(buf), "vican_comm_unique_id")
-            ids = [buf.raw]
-        src = torch.distributed.get_global_rank(self.group, 0) if self.group is not None else 0
-        torch.distributed.broadcast_object_list(ids, src=src, group=self.group)
+        dist = torch.distributed
+        rccl_group = self._device_collectives()
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+
+        def agree(ok):                                           # True iff every rank says True (host-side, any backend)
+            flags = [None] * self.world
+            dist.all_gather_object(flags, bool(ok), group=self.group)
+            return all(flags)
+
         h = ctypes.c_void_p()
-        _lib.check(lib.vican_comm_create(self.rank, self.world, ctypes.create_string_buffer(ids[0], 128), ctypes.byref(h)), "vican_comm_create")
-        self._native_lib = lib
-        return h
+        have = False
+        if rccl_group:
+            ids = [None]
+            if self.rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                ids = [buf.raw if lib.vican_comm_unique_id(buf) == 0 else None]
+            dist.broadcast_object_list(ids, src=src, group=self.group)
+            ok = ids[0] is not None and lib.vican_comm_create(self.rank, self.world, ctypes.create_string_buffer(ids[0], 128), ctypes.byref(h)) == 0
+            if not ok:
+                self.notes.append("vican_comm_create: %s" % (lib.vican_last_error() or b"?").decode())
+            # (a rank whose ncclCommInitRank failed while others succeeded cannot be repaired here: RCCL's init is itself a
+            #  collective and fails or succeeds for the group)
+            have = agree(ok)
+            if not have and ok:
+                lib.vican_comm_destroy(h)
+        elif want in ("auto", "peer") and self.world <= 8:
+            have = agree(lib.vican_comm_create_local(self.rank, self.world, ctypes.byref(h)) == 0)
+        if not have:
+            return
+        self._native, self._native_lib = h, lib
+        self.transport = "rccl" if rccl_group else "torch"
+        if want in ("auto", "peer") and self.world <= 8:
+            mine = ctypes.create_string_buffer(64)
+            ok = lib.vican_comm_peer_export(h, self.PEER_MAX_DOUBLES, mine) == 0
+            if not ok:
+                self.notes.append("vican_comm_peer_export: %s" % (lib.vican_last_error() or b"?").decode())
+            handles = [None] * self.world
+            dist.all_gather_object(handles, mine.raw if ok else None, group=self.group)
+            ok = all(x is not None for x in handles) and lib.vican_comm_peer_attach(h, ctypes.create_string_buffer(b"".join(handles), 64 * self.world)) == 0
+            if not ok and all(x is not None for x in handles):
+                self.notes.append("vican_comm_peer_attach: %s" % (lib.vican_last_error() or b"?").decode())
+            if agree(ok):
+                ok = agree(self._peer_selftest(device))
+                if ok:
+                    self.transport, self.gateable = "peer", True
+                else:
+                    self.notes.append("peer exchange failed its self-test: disabled")
+            if self.transport != "peer":
+                lib.vican_comm_peer_enable(h, 0)
+        if self.transport == "torch":                            # a local communicator without a working exchange serves nothing
+            lib.vican_comm_destroy(h)
+            self._native = None
+
+    def _peer_selftest(self, device):
+        """Known messages through the exchange (three sizes, both parities, bounded waits): rank r sends (r + 1)(i + 1) + r / 4."""
+        import ctypes
+        lib, h, W = self._native_lib, self._native, self.world
+        ok = True
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for n in (1, 700, min(self.PEER_MAX_DOUBLES, 9 * 1024 + 96)) * 2:
+                i = torch.arange(1, n + 1, dtype=torch.float64, device=device)
+                t = (self.rank + 1) * i + 0.25 * self.rank
+                ok = ok and lib.vican_comm_allreduce_sum(h, ctypes.c_void_p(t.data_ptr()), n, stream) == 0
+                torch.cuda.current_stream().synchronize()
+                want = (W * (W + 1) // 2) * i + 0.25 * (W * (W - 1) // 2)
+                ok = ok and bool(torch.equal(t, want)) and lib.vican_comm_peer_status(h) == 0
+        return ok
+
+    def check(self):
+        """Raise if a wait of the peer exchange timed out since the communicator was made (its messages came back as NaN)."""
+        if getattr(self, "_native", None) is not None and getattr(self, "transport", None) == "peer":
+            n = self._native_lib.vican_comm_peer_status(self._native)
+            if n > 0:
+                raise RuntimeError("peer exchange: %d element waits timed out on rank %d (a rank stopped, or left the collective "
+                                   "schedule); set VICAN_COMM=rccl to run without the exchange" % (n, self.rank))
 
     def __del__(self):
         try:
-            if getattr(self, "_native", None) is not None:
+            if getattr(self, "_native", None) is not None and getattr(self, "_owns_native", False):
                 self._native_lib.vican_comm_destroy(self._native)
                 self._native = None
         except Exception:                                       # noqa: BLE001  (interpreter shutdown)
             pass
 
     @classmethod
-    def single(cls, force_sharded=False, native=False):
+    def single(cls, force_sharded=False, native=False, peer=False):
         """A one-rank communicator even inside an initialised process group (replicated computations).
-        force_sharded: the solver takes its multi-rank schedule on it; native: the all-reduces of that schedule are REAL
-        ncclAllReduce calls on a one-rank RCCL communicator held by the C library (RCCL's one-rank kernel on the launch
-        stream: what one GPU can execute of the collective path; include/vican_hip_test.h: vican_comm_force_enqueue)."""
+        force_sharded: the solver takes its multi-rank schedule on it.  What one GPU can execute of the collective path:
+        native: the all-reduces of that schedule are REAL ncclAllReduce calls on a one-rank RCCL communicator held by the C
+        library (RCCL's one-rank kernel on the launch stream; include/vican_hip_test.h: vican_comm_force_enqueue);
+        peer: they are launches of the peer exchange with the rank's own mailbox slot as its peer (the same kernel, granules,
+        waits and epoch as with eight ranks - minus the links)."""
         c = cls.__new__(cls)
         c.group, c.world, c.rank, c.n_allreduce, c._native = None, 1, 0, 0, None
         c.force_sharded = bool(force_sharded)
-        if native:
+        c.transport_wanted, c.transport, c._native_tried, c.gateable, c.notes = "torch", None, True, True, []
+        if native or peer:
             import ctypes
             from . import _lib
             lib = _lib.load()
-            buf = ctypes.create_string_buffer(128)
-            _lib.check(lib.vican_comm_unique_id(buf), "vican_comm_unique_id")
             h = ctypes.c_void_p()
-            _lib.check(lib.vican_comm_create(0, 1, buf, ctypes.byref(h)), "vican_comm_create")
-            _lib.check(lib.vican_comm_force_enqueue(h, 1), "vican_comm_force_enqueue")
-            c._native_lib, c._native = lib, h
+            if peer:
+                _lib.check(lib.vican_comm_create_local(0, 1, ctypes.byref(h)), "vican_comm_create_local")
+                _lib.check(lib.vican_comm_peer_export(h, cls.PEER_MAX_DOUBLES, ctypes.create_string_buffer(64)), "vican_comm_peer_export")
+                _lib.check(lib.vican_comm_peer_attach(h, None), "vican_comm_peer_attach")
+                c.transport = "peer"
+            else:
+                buf = ctypes.create_string_buffer(128)
+                _lib.check(lib.vican_comm_unique_id(buf), "vican_comm_unique_id")
+                _lib.check(lib.vican_comm_create(0, 1, buf, ctypes.byref(h)), "vican_comm_create")
+                _lib.check(lib.vican_comm_force_enqueue(h, 1), "vican_comm_force_enqueue")
+                c.transport, c.gateable = "rccl", False
+            c._native_lib, c._native, c._owns_native = lib, h, True
         return c
 
     def allreduce(self, t):
         if self.sharded:
-            if self._native is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous():
+            if t.is_cuda and not getattr(self, "_native_tried", True):
+                self._setup_native(t.device)
+            if (getattr(self, "_native", None) is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                    and (self.transport != "peer" or t.numel() <= self.PEER_MAX_DOUBLES or self.world == 1 or self._device_collectives())):
                 import ctypes
                 from . import _lib
                 _lib.check(self._native_lib.vican_comm_allreduce_sum(self._native, ctypes.c_void_p(t.data_ptr()), t.numel(),
@@ -237,9 +362,18 @@ class RotationSolver:
         if not self.comm.sharded and self.fold_in_step and hasattr(self.K, "block_op_slabs"):
             self.K.block_op_slabs(self.lamT, x)
             return True
-        self.K.block_op(self.lamT, x, z)
-        self.comm.allreduce(z)
+        self._op_allreduce(self.lamT, x, z)
         return False
+
+    def _op_allreduce(self, lamT, x, z):
+        """z = P x summed over the ranks: sweep, slab fold and all-reduce behind ONE host call where the backend and the
+        communicator allow it (include/vican_hip.h: vican_block_op_z_comm)."""
+        fused = getattr(self.K, "block_op_comm", None)
+        if fused is not None and self.comm.sharded:
+            fused(lamT, x, z, self.comm)
+        else:
+            self.K.block_op(lamT, x, z)
+            self.comm.allreduce(z)
 
     # -- spectral step ---------------------------------------------------------
     def _seed_block(self, x0, with_z=False):
@@ -321,10 +455,12 @@ class RotationSolver:
                 if steps >= next_check or steps >= self.m_max:
                     handle = self._ritz(steps, first, level, gap=steps - prev_steps)
                     first = False
-                    # Sharded runs speculate only where a check is expected to pass (a step count remembered from an
-                    # earlier solve of this graph): the tail's all-reduces are issued by the host and cannot be gated, so
-                    # every failed check would pay for two collectives on cancelled data.
-                    speculate = not self.comm.sharded or (restart == 0 and it in self.pred_steps and steps >= self.pred_steps[it])
+                    # Sharded runs whose all-reduces cannot be gated (RCCL, torch.distributed: the collective runs whatever the
+                    # device decided) speculate only where a check is expected to pass (a step count remembered from an earlier
+                    # solve of this graph): every failed check would pay for two collectives on cancelled data.  The peer
+                    # exchange IS gated (a cancelled launch advances nothing on any rank): those runs speculate like one rank.
+                    speculate = (not self.comm.sharded or getattr(self.comm, "gateable", False)
+                                 or (restart == 0 and it in self.pred_steps and steps >= self.pred_steps[it]))
                     if speculate:
                         with K.gated(self.gate):               # speculative: runs iff the device says converged
                             K.tall_combine(n, self.V, ld, 3 * steps, self.Yd, self.X)
@@ -421,8 +557,7 @@ class RotationSolver:
         K, x = self.K, self.x0
         x.copy_(self._x_seed)
         for _ in range(self.prop_sweeps):
-            K.block_op(self.lamT, x, self.z)
-            self.comm.allreduce(self.z)
+            self._op_allreduce(self.lamT, x, self.z)
             K.polar_dual(self.z, x, None, 0)                    # (nearest rotation per camera, det fix: geometry.py:175-191)
             self.stats["sweeps"] += 1
         self.start_is_warm = True
@@ -433,8 +568,7 @@ class RotationSolver:
         update's own pass over the blocks (lamT_new Z_t is the polar factor of Z_t)."""
         K = self.K
         K.gauge_project(self.X, self.Xp)                        # bipgo.py:295-297
-        K.block_op(self.lamT, self.Xp, self.z)                  # bipgo.py:300
-        self.comm.allreduce(self.z)
+        self._op_allreduce(self.lamT, self.Xp, self.z)          # bipgo.py:300
         K.polar_dual(self.z, self.rc, self.lamC, 1)             # bipgo.py:306-315
         if fuse:
             K.dual_update_op(self.rc, self.Rt, self.lamT, self.zraw)   # bipgo.py:318-332 (+ :285-288 of the next iteration)
@@ -678,11 +812,19 @@ class TranslationSolver:
         # which the sequence below is not (its p.q partial depends on the sweep's ticket order).  VICAN_CG_FUSED=0: the sequence.
         fused = (not multi) and getattr(K, "cg_iter_fused", None) is not None and os.environ.get("VICAN_CG_FUSED", "1") != "0"
         handover = fused and bool(getattr(K, "cg_handover", False))     # (the step's last workgroup has run the next head already)
+        comm_iter = multi and self._comm_iter_ok()
 
         def one_iteration(n_part):
             if fused:
                 K.cg_iter_fused(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self.qcpq,
                                 self.rtol, st, first=(n_part is None))
+                return 0
+            if comm_iter:
+                # sharded: the same launches with the two sums that cross ranks all-reduced from C in stream order, partials over
+                # fixed slices (bit-reproducible, bit-identical on every rank) - include/vican_hip.h: vican_cg_iter_comm
+                K.cg_iter_comm(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self._msg,
+                               self.rtol, st, first=(n_part is None), comm=comm)
+                comm.n_allreduce += 2
                 return 0
             n_part = n_part or 0
             K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
@@ -746,6 +888,21 @@ class TranslationSolver:
         return self.x_c, self.x_t
 
 
+    def _comm_iter_ok(self):
+        """Sharded solve whose all-reduces the C library enqueues itself (solver.Comm with a native communicator, or a forced
+        one-rank Comm: identity) on a backend with vican_cg_iter_comm: one host call per iteration."""
+        K, comm = self.K, self.comm
+        if getattr(K, "cg_iter_comm", None) is None or not hasattr(comm, "native_handle") or os.environ.get("VICAN_CG_COMM_ITER", "1") == "0":
+            return False
+        if comm.world > 1 and not getattr(comm, "_native_tried", True):
+            comm._setup_native(self.st.device)
+        if comm.native_handle() is None and comm.world > 1:
+            return False
+        if getattr(self, "_msg", None) is None:
+            from ._lib import CG_PQ_SLICES
+            self._msg = K.zeros(3 * K.C + CG_PQ_SLICES)
+        return True
+
     def _solve_fixed(self, n_iter):
         """Exactly n_iter iterations of the recurrence this solver would run (resident kernel, launch sequence or the
         sharded runs' one-message arrangement), stopping test disabled (rtol = 0)."""
@@ -774,6 +931,15 @@ class TranslationSolver:
             return out
         if multi:
             comm.allreduce(st[CG_F["rr_time"]:CG_F["rr_time"] + 1])
+        if multi and self._comm_iter_ok():
+            for k in range(n_iter):
+                K.cg_iter_comm(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self._msg,
+                               0.0, st, first=(k == 0), comm=comm)
+                comm.n_allreduce += 2
+            s = self._state()
+            self.info = dict(cg_iters=n_iter, converged=False, fixed=True,
+                             relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
+            return self.x_c, self.x_t
         n_part = 0
         for _ in range(n_iter):
             K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, 0.0, st, n_part)
