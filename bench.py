@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse-capture measurement (detail.sparse) of the default run")
     ap.add_argument("--no-facade", action="store_true", help="skip the four-call C boundary timing (detail.facade) of the default run")
     ap.add_argument("--no-wide", action="store_true", help="skip the camera-tiled measurement (detail.wide: 4000 cameras) of the default run")
+    ap.add_argument("--no-strong", action="store_true", help="multi-GPU runs: skip the strong-scaling lines (detail.strong_scaling)")
     ap.add_argument("--no-sharded-schedule", action="store_true", help="skip the one-GPU cost of the multi-GPU schedule (detail.sharded_schedule) of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-threads", type=int, default=None, choices=[256, 512, 768, 1024])
@@ -446,15 +447,22 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
     """Build the synthetic graph of one workload in HBM, run `warmup` + `steps` full solves between barriers, and return
     value / ms_per_step / config / roofline / detail of it (the JSON line's fields)."""
     from vican_amd import synth
-    from vican_amd.bipgo import _shard_rows
+    from vican_amd.bipgo import _shard_rows, shard_policy
     from vican_amd.device import HipBackend, LocalGraph
-    from vican_amd.solver import RotationSolver, TranslationSolver
+    from vican_amd.solver import Comm, RotationSolver, TranslationSolver
+    policy = "single" if world == 1 else "sharded"
     if scaling == "weak":
         T_total, r0, Tl = Tn * world, rank * Tn, Tn
     else:                                               # one graph of Tn rows, split like solve_problem does
         T_total = Tn
-        r0, r1 = _shard_rows(Tn, world, rank)
+        policy = shard_policy(Tn * cpt, world)           # (as vican_amd.bipgo.solve_problem decides: small graphs are not sharded)
+        r0, r1 = _shard_rows(Tn, world, rank) if policy != "replicated" else (0, Tn)
         Tl = r1 - r0
+    group_world = world
+    if policy == "replicated":
+        # below the threshold every rank solves the WHOLE graph with the single-rank schedule (no collective): the job's
+        # throughput is that of one solve, whatever the number of GPUs
+        comm, world = Comm.single(), 1
     gr = synth.make_merged_graph_torch(C, Tl, cpt, dev, tdt, seed=0, t_offset=r0)
     g = LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"],
                    block_threads=args.block_threads, n_copy=args.n_copy)
@@ -539,7 +547,7 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if group_world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -567,9 +575,11 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
     barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if group_world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el.item())
+    if hasattr(comm, "check"):
+        comm.check()                                     # (a timed-out wait of the peer exchange is an error, never a number)
     if K.barrier_aborted() or K.coop_failures:
         print("bench.py: a cooperative kernel's grid barrier gave up during the run (%s): device shared?" % K.coop_failures, file=sys.stderr)
 
@@ -577,7 +587,7 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
     # remembered CG iteration count - every convergence check that fails is paid for) and one instrumented solve with events
     # on every heavy edge kernel; a short LSQR run (lsqr_solver="direct") for its fused pass
     cold_solve_ms, kernels = None, {}
-    if world == 1:
+    if group_world == 1:
         rot_w, tr_w = rot, tr
         rot, tr = RotationSolver(K, comm), TranslationSolver(K, comm)
         barrier()
@@ -645,8 +655,11 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
                                    cpt, E_total, E_local, args.maxiter, args.dtype),
                    "arithmetic": "%s block products, exact 64-bit fixed-point accumulation (double-word in the translation stage), "
                                  "f64 camera side and CG" % args.dtype,
-                   "parallelism": "timestep-sharded x%d, camera side replicated" % world,
-                   "devices": torch.cuda.device_count(), "dist_backend": backend if world > 1 else None},
+                   "parallelism": ("timestep-sharded x%d, camera side replicated" % world) if policy != "replicated" else
+                                  ("replicated x%d: %d merged edges are below the sharding threshold (vican_amd.bipgo.SHARD_MIN_EDGES), every rank "
+                                   "solves the whole graph with the single-rank schedule" % (group_world, Tn * cpt)),
+                   "policy": policy, "transport": getattr(comm, "transport", None), "comm_notes": getattr(comm, "notes", None),
+                   "devices": torch.cuda.device_count(), "dist_backend": backend if group_world > 1 else None},
         "roofline": {"bound": "hbm", "kernel": "%s_sweep_kernel<MODE=0> (vican_block_op)" % g.layout,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": op_bytes, "launches": int(len(kern_ms)), "cancelled_speculative_launches": n_cancelled,
@@ -668,7 +681,7 @@ def measure(args, dev, tdt, comm, workload, C, Tn, cpt, scaling, world, rank, st
                    # first_solve_ms: the very first solve on a fresh backend (lazy allocations included); cold_solve_ms: fresh
                    # solver objects on the warm backend (no schedule hints); ms_per_step above: warm re-solves (time series)
                    "first_solve_ms": first_solve_ms, "cold_solve_ms": cold_solve_ms,
-                   "cold_lanczos_steps": cold_steps if world == 1 else None,
+                   "cold_lanczos_steps": cold_steps if group_world == 1 else None,
                    # the other heavy edge kernels: HIP events on the kernel's own dispatch in one instrumented solve after
                    # the timed region; bytes = the algorithmic formulas of DESIGN.md section 5
                    "kernels": kernels},
@@ -755,6 +768,23 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": m["config"], "roofline": m["roofline"], "detail": m["detail"],
     }
+    if world > 1 and args.workload == "stress" and not args.no_strong:
+        # beside the weak-scaling headline: STRONG scaling on a graph where sharding can pay (the stress graph's rows split over
+        # the ranks) and on large_shop (40 000 merged edges: below the sharding threshold, every rank solves it whole - the
+        # job's wall-clock is one GPU's, not the ~2x longer sharded one).  Every rank takes part; rank 0 reports.
+        strong = {}
+        for name, (Cs, Ts, cs) in (("stress_rows_split", (C, Tn, cpt)), ("large_shop", (340, 10000, 4))):
+            try:
+                ms_ = measure(args, dev, tdt, comm, name, Cs, Ts, cs, "strong", world, rank, max(args.steps // 2, 3), 2, backend)
+                strong[name] = {"value_edges_per_s": ms_["value"], "ms_per_solve": ms_["ms_per_step"], "workload": ms_["config"]["workload"],
+                                "policy": ms_["config"]["policy"], "parallelism": ms_["config"]["parallelism"],
+                                "transport": ms_["config"]["transport"], "n_allreduce_per_solve": ms_["detail"]["n_allreduce_per_solve"],
+                                "edges_rank0": ms_["detail"]["edges_rank0"], "rows_rank0": ms_["detail"]["rows_rank0"],
+                                "cg_iters": ms_["detail"]["cg_iters"], "lanczos_steps": ms_["detail"]["lanczos_steps"],
+                                "roofline_frac": ms_["roofline"]["frac"], "scaling": "strong"}
+            except Exception as exc:
+                strong[name] = {"error": repr(exc)[:300]}
+        out["detail"]["strong_scaling"] = strong
     if rank == 0 and world == 1 and args.workload == "stress" and not args.no_large_shop:
         # second half of BASELINE.json's metric: wall-clock of a full solve of a large_shop-sized graph
         # (340 cameras x 10 000 timesteps x 4 cameras per timestep: cache-resident, latency-bound)

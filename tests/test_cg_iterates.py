@@ -28,7 +28,7 @@ import pytest
 import torch
 
 import golden_cases as gc
-from numpy_backend import NumpyBackend
+from vican_amd.backend_cpu import NumpyBackend
 from util import load_golden
 from vican_amd import frontend, synth
 from vican_amd.geometry import SE3, geodesic

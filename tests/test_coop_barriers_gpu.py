@@ -160,7 +160,7 @@ def test_dropin_solve_survives_a_busy_device():
 
 
 def _tiled_setup():
-    from numpy_backend import NumpyBackend
+    from vican_amd.backend_cpu import NumpyBackend
     from test_kernels_gpu import random_graph
     from vican_amd.device import TiledBackend, TiledGraph
     C_, T, tile = 600, 4000, 300

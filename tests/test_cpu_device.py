@@ -1,0 +1,83 @@
+"""BASELINE configs[0] as written ("... on CPU (plumbing, no GPU)"): the drop-in API with ``device="cpu"`` - the package's own
+NumPy backend (vican_amd/backend_cpu.py) under the same solver driver the GPU path uses - against the goldens of the REAL
+reference, with no GPU visible.  The path is explicit (never a fallback), is not the oracle, and the oracle is not imported by
+the product: all three are asserted here."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from util import e2e_translation_tol, expected, iteration_slack, load_golden, pose_errors, rebuild_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,dt", [("g1_object", "float64"), ("g1_object", "float32"), ("g2_small", "float64"), ("g2_small", "float32"),
+                                     ("g5_strings", "float64"), ("g3_medium", "float64")])
+def test_dropin_on_the_cpu_backend_matches_the_reference(name, dt):
+    from vican.bipgo import bipartite_se3sync, object_bipartite_se3sync      # the shim import path of main.ipynb
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "conjugate_gradient", dt)
+    dtype = np.dtype(dt).type
+    info = {}
+    if case["mode"] == "camera":
+        res = bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
+                                lsqr_solver="conjugate_gradient", dtype=dtype, info=info, device="cpu")
+    else:
+        res = object_bipartite_se3sync(src, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
+                                       lsqr_solver="conjugate_gradient", dtype=dtype, info=info, device="cpu")
+    rot, tr = pose_errors(res, exp)
+    assert info["device"] == "cpu" and info["layout"] == "numpy"
+    assert rot < (1e-7 if dt == "float64" else 5e-6), rot
+    assert tr < e2e_translation_tol(name, dt), tr
+    assert abs(info["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    first = next(iter(res.values()))
+    assert first.R().dtype == dtype and first.t().dtype == np.float64
+
+
+def test_lsqr_and_tight_on_the_cpu_backend():
+    from vican_amd.bipgo import bipartite_se3sync
+    g = load_golden("g2_small")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", g)
+    exp = expected(g, "direct", "float64")
+    res = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "direct", np.float64, device="cpu")
+    rot, tr = pose_errors(res, exp)
+    assert rot < 1e-7 and tr < 2e-6
+    expc = expected(g, "conjugate_gradient", "float64")
+    res = bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64, device="cpu", tight=True)
+    t = np.stack([np.asarray(v.t(), dtype=np.float64) for v in res.values()])
+    assert float(np.linalg.norm(t - (expc["t_tight"] - expc["t_tight"].mean(0)), axis=1).max()) < 1e-8
+    with pytest.raises(UnboundLocalError):
+        bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "cholesky", np.float64, device="cpu")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the behaviour of a box WITHOUT a GPU")
+def test_no_gpu_is_an_error_unless_the_cpu_backend_is_asked_for():
+    from vican_amd._lib import VicanError
+    from vican_amd.bipgo import bipartite_se3sync
+    g = load_golden("g2_small")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", g)
+    with pytest.raises(VicanError, match="no GPU visible"):
+        bipartite_se3sync(src, cons, nr, nt, ff, gc.MAXITER, "conjugate_gradient", np.float64)
+
+
+def test_the_product_never_touches_the_oracle_and_the_gpu_path_never_the_cpu_backend():
+    """grep-level guarantees the round's review asks for: no file of the product mentions oracle/; backend_cpu is imported in
+    ONE place, inside the device="cpu" branch; importing the GPU-side modules does not load it."""
+    pkg = os.path.join(ROOT, "vican_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "bipgo_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+                if f.endswith(".py") and f != "backend_cpu.py":
+                    n = txt.count("backend_cpu import") + txt.count("import backend_cpu")
+                    assert n == (1 if f == "bipgo.py" else 0), (f, n)
+    code = ("import sys; sys.path.insert(0, %r); import vican_amd, vican_amd.bipgo, vican_amd.solver, vican_amd.frontend, vican.bipgo; "
+            "assert 'vican_amd.backend_cpu' not in sys.modules and not any(m.startswith('oracle') for m in sys.modules)" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT).returncode == 0

@@ -1,5 +1,5 @@
 """Multi-rank path on CPU: timestep-sharded solve with world_size 2 over gloo, driven through the
-NumPy stand-in backend (tests/numpy_backend.py).  Checks that the sharding + all-reduce logic of
+NumPy stand-in backend (vican_amd/backend_cpu.py).  Checks that the sharding + all-reduce logic of
 vican_amd/solver.py reproduces the single-rank result and the reference goldens, and counts the
 collectives (camera-side partials only - no edge data moves)."""
 import os
@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import golden_cases as gc
-from numpy_backend import NumpyBackend
+from vican_amd.backend_cpu import NumpyBackend
 from test_solver_cpu import flatten_case, to_pose_arrays
 from util import expected, translation_tol
 from vican_amd.bipgo import _shard_rows

@@ -5,7 +5,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from numpy_backend import NumpyBackend                                   # noqa: E402
+from vican_amd.backend_cpu import NumpyBackend                                   # noqa: E402
 from test_kernels_gpu import make_backends                                 # noqa: E402
 from vican_amd import synth                                                # noqa: E402
 from vican_amd._lib import VicanError                                      # noqa: E402

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import golden_cases as gc
-from util import SelfMovement, rebuild_inputs
+from util import SelfMovement, load_golden, rebuild_inputs
 from vican_amd import frontend, synth
 from vican_amd.geometry import SE3
 from vican_amd.solver import with_cooperative_fallback
@@ -330,3 +330,32 @@ def test_c_passes_of_the_front_end_equal_the_python_path(monkeypatch):
     cols = frontend.EdgeColumns(list(src.values()))
     assert np.array_equal(cols["corners"], np.array([v["corners"] for v in src.values()], dtype=np.float64))
     assert np.array_equal(cols["reprojected_err"], np.array([v["reprojected_err"] for v in src.values()], dtype=np.float64))
+
+
+def test_column_form_weights_round_like_the_scalar_form_on_float32_rotations():
+    """numpy forms the reference's `k_r * R` (bipgo.py:213) in float32 when R is a float32 array (every SE3 built from a 4x4
+    matrix) and the weight a Python float: the column form of such a callable - one float64 array for all edges - must give
+    the same merged blocks to the bit (round-5 advisor finding: it formed float64 products, 7e-8 off), and a callable
+    that declares NumPy-scalar results (python_scalars=False) the float64 ones."""
+    g = load_golden("g2_small")
+    case, src, cons, (nr, nt, ff) = rebuild_inputs("g2_small", g)
+
+    def p4(v):
+        P = np.eye(4)
+        P[:3, :3], P[:3, 3] = v["pose"].R(), v["pose"].t()
+        return P
+    src32 = {k: dict(v, pose=SE3(pose=p4(v))) for k, v in src.items()}
+    assert next(iter(src32.values()))["pose"].R().dtype == np.float32
+    # (a weight both forms evaluate with IEEE operations only: math.exp and np.exp may differ in the last place)
+    scalar = lambda e: 1.0 / (1.0 + float(e["reprojected_err"]))
+    column = frontend.vectorized(lambda cols: 1.0 / (1.0 + cols["reprojected_err"]))(lambda e: 1.0 / (1.0 + float(e["reprojected_err"])))
+    p_s = frontend.flatten(src32, cons, scalar, nt, ff, np.float64)
+    p_c = frontend.flatten(src32, cons, column, nt, ff, np.float64)
+    assert np.array_equal(np.asarray(p_s.blk), np.asarray(p_c.blk)) and np.array_equal(np.asarray(p_s.a), np.asarray(p_c.a))
+    # NumPy-scalar weights (np.float64 is not a weak scalar: float64 products) - scalar and column form agree there too
+    scalar_np = lambda e: np.float64(1.0) / (1.0 + np.float64(e["reprojected_err"]))
+    column_np = frontend.vectorized(lambda cols: 1.0 / (1.0 + cols["reprojected_err"]), python_scalars=False)(scalar_np)
+    q_s = frontend.flatten(src32, cons, scalar_np, nt, ff, np.float64)
+    q_c = frontend.flatten(src32, cons, column_np, nt, ff, np.float64)
+    assert np.array_equal(np.asarray(q_s.blk), np.asarray(q_c.blk))
+    assert not np.array_equal(np.asarray(q_s.blk), np.asarray(p_s.blk))          # (the two roundings do differ on this data)

@@ -1,12 +1,12 @@
 """Per-kernel parity on the GPU: every HIP entry point vs the NumPy restatement
-(tests/numpy_backend.py) on seeded random inputs, through the C ABI."""
+(vican_amd/backend_cpu.py) on seeded random inputs, through the C ABI."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-from numpy_backend import NumpyBackend, svd_polar       # noqa: E402
+from vican_amd.backend_cpu import NumpyBackend, svd_polar       # noqa: E402
 from util import load_golden                            # noqa: E402
 from vican_amd import synth                             # noqa: E402
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import golden_cases as gc
-from numpy_backend import NumpyBackend
+from vican_amd.backend_cpu import NumpyBackend
 from oracle import bipgo_oracle as orc
 from util import load_golden, oracle_attempts, rebuild_inputs
 from vican_amd import frontend

@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import golden_cases as gc                                     # noqa: E402
-from numpy_backend import svd_polar                           # noqa: E402
+from vican_amd.backend_cpu import svd_polar                           # noqa: E402
 from test_kernels_gpu import CONFIGS, make_backends           # noqa: E402
 from test_so3sync_cpu import CASES, golden, inputs            # noqa: E402
 

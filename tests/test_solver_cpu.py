@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import golden_cases as gc
-from numpy_backend import NumpyBackend
+from vican_amd.backend_cpu import NumpyBackend
 from util import expected, iteration_slack, load_golden, rebuild_inputs, translation_tol
 from vican_amd import frontend
 from vican_amd.geometry import geodesic

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import golden_cases as gc                                                   # noqa: E402
-from numpy_backend import NumpyBackend                                      # noqa: E402
+from vican_amd.backend_cpu import NumpyBackend                                      # noqa: E402
 from test_kernels_gpu import random_graph                                   # noqa: E402
 from util import expected, load_golden, pose_errors, rebuild_inputs, translation_tol   # noqa: E402
 from vican_amd.solver import Comm, solve_on_backend                         # noqa: E402

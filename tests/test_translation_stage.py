@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import golden_cases as gc
-from numpy_backend import NumpyBackend
+from vican_amd.backend_cpu import NumpyBackend
 from test_solver_cpu import flatten_case
 from util import expected
 from vican_amd.solver import Comm, TranslationSolver

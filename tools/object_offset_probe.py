@@ -8,7 +8,7 @@ the scenes with the largest offsets and runs the rotation stage three ways ON TH
   eigs   the oracle's restatement of the reference: scipy eigs(L, k=5, sigma=-1e-6)  (bipgo.py:288), three runs
   eigh   the same iteration with the eigenvectors of a dense LAPACK eigh of L (the 3 smallest), nothing else changed
   lanczos the product's host solver (vican_amd.solver.RotationSolver: block Lanczos to its own tolerance) on the NumPy stand-in
-          backend (tests/numpy_backend.py) - the algorithm the GPU runs, in plain float64
+          backend (vican_amd/backend_cpu.py) - the algorithm the GPU runs, in plain float64
 
 and prints the largest geodesic distance between the camera-role rotations of each pair.  If eigh and lanczos agree far below
 the offset while eigs stands apart from both, the offset is ARPACK's (shift-invert with an LU of L + 1e-6 I next to three
@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_cases as gc                                   # noqa: E402
-from numpy_backend import NumpyBackend                      # noqa: E402
+from vican_amd.backend_cpu import NumpyBackend                      # noqa: E402
 from oracle import bipgo_oracle as orc                      # noqa: E402
 from test_random_parity_gpu import make_case                # noqa: E402
 from vican_amd import frontend, synth                       # noqa: E402

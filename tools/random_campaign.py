@@ -71,9 +71,9 @@ def stage_alone(src, cons, mode, fns, dt, ref):
         pos.update({str(s) + "_0": x_t.cpu().numpy()[i] for i, s in enumerate(prob.time_names)})
         t = np.stack([pos[str(k)] for k in ref])
         return float(np.linalg.norm(t - tr_, axis=1).max()), int(tr.info["cg_iters"])
-    # the same stage through the NumPy stand-in (tests/numpy_backend.py: plain f64 NumPy sums, no fixed point, no GPU) - an
+    # the same stage through the NumPy stand-in (vican_amd/backend_cpu.py: plain f64 NumPy sums, no fixed point, no GPU) - an
     # independent f64 implementation of the same recurrence: what IT does against the bound calibrates the bound
-    from numpy_backend import NumpyBackend
+    from vican_amd.backend_cpu import NumpyBackend
     N = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=dt, deg_t=prob.deg_t, deg_c=prob.deg_c)
     # ... and through the sharded runs' schedule, one rank holding every row: their default (scipy's recurrence, two messages per
     # iteration: vican_cg_iter_local / _finish / vican_cg_end) and the opt-in Chronopoulos-Gear arrangement (ONE message: vican_cg1_*)

@@ -3,7 +3,7 @@
 
 The campaign (tools/random_campaign.py) counts how often the translation stage - fed the oracle's rotations - lands outside
 4 x the oracle's own movement under 1e-15 perturbations, for the product AND for a plain-f64 NumPy stand-in of the same
-recurrence (tests/numpy_backend.py).  Round 3: product 51, stand-in 37 of 2168.  The stand-in sums a row's terms with np.add.at,
+recurrence (vican_amd/backend_cpu.py).  Round 3: product 51, stand-in 37 of 2168.  The stand-in sums a row's terms with np.add.at,
 i.e. sequentially in edge order - the order scipy's CSR product uses - and so shares most of the reference's roundings; the
 product's exact sums, rounded once, cannot.  This tool runs the SAME stand-in over the same camera-mode seeds with its
 translation-stage sums formed (a) in scipy's order, (b) in reverse order, (c) exactly (extended precision, rounded once), and
@@ -29,7 +29,7 @@ N_PERT = 8          # further "independent f64 implementations": scipy's order, 
 
 def one(seed):
     import golden_cases as gc
-    from numpy_backend import NumpyBackend
+    from vican_amd.backend_cpu import NumpyBackend
     from oracle import bipgo_oracle as orc
     from test_random_parity_gpu import make_case
     from util import SelfMovement
@@ -85,7 +85,7 @@ if __name__ == "__main__":
     with mp.Pool(procs) as pool:
         rows = [r for r in pool.imap_unordered(one, range(seed0, seed0 + N), chunksize=8) if r is not None]
     summary = dict(seeds=N, first_seed=seed0, compared=len(rows), seconds=time.time() - t0,
-                   note="translation stage of the NumPy stand-in (tests/numpy_backend.py), the oracle's rotations fed in, against "
+                   note="translation stage of the NumPy stand-in (vican_amd/backend_cpu.py), the oracle's rotations fed in, against "
                         "bound = max(1e-6 m, 4 x the oracle's self-movement under 1e-15 perturbations); sums of the stage formed in "
                         "scipy's order / reversed / exactly (extended precision, rounded once)")
     for order in ORDERS + tuple("ulp%d" % i for i in range(N_PERT)):

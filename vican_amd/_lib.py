@@ -332,7 +332,16 @@ def build_fastpath(force: bool = False) -> str:
     if res.returncode != 0:
         raise VicanError("building vican_fastpath.c failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, FASTPATH_SO)
+    # the module has no ABI tag in its name: record what it was built for, fastpath() refuses anything else
+    with open(FASTPATH_SO + ".stamp", "w") as f:
+        f.write(_fastpath_stamp())
     return FASTPATH_SO
+
+
+def _fastpath_stamp():
+    import sys
+    import numpy as np
+    return "cpython-%d.%d numpy-%s" % (sys.version_info[0], sys.version_info[1], np.__version__.split(".")[0])
 
 
 def fastpath():
@@ -342,6 +351,9 @@ def fastpath():
         _fastpath = None
         if os.environ.get("VICAN_FASTPATH", "1") != "0" and os.path.exists(FASTPATH_SO):
             try:
+                # (built for another interpreter / NumPy major version - it travels with repository snapshots: not loaded)
+                if open(FASTPATH_SO + ".stamp").read() != _fastpath_stamp():
+                    return _fastpath
                 import importlib.machinery
                 import importlib.util
                 loader = importlib.machinery.ExtensionFileLoader("_vican_fastpath", FASTPATH_SO)

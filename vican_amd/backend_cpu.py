@@ -1,16 +1,26 @@
-"""NumPy stand-in for ``vican_amd.device.HipBackend`` - TEST INFRASTRUCTURE ONLY.
+"""The solver's kernel interface (``vican_amd.device.HipBackend``) in plain NumPy: the GPU-less backend.
 
-Implements the same method surface on CPU torch tensors so that the host
-orchestration in ``vican_amd/solver.py`` (block Lanczos driver, CG state machine,
-timestep sharding + all-reduce) can be exercised without a GPU, single-process and
-with world_size-2 gloo.  It restates what each HIP kernel must compute (the
-formulas of SURVEY.md section 3.3) and doubles as the per-kernel oracle in
-``tests/test_kernels_gpu.py``.  The product never imports this file.
+BASELINE configs[0] ("cube_calib object_bipartite_se3sync ... on CPU (plumbing, no GPU)") and the reference itself
+(vican/bipgo.py:353-490: NumPy / SciPy only) run anywhere; so does this package when - and ONLY when - the caller asks for it:
+``bipartite_se3sync(..., device="cpu")`` / ``object_bipartite_se3sync(..., device="cpu")`` / ``solve_problem(..., device="cpu")``.
+
+  * never automatic: without ``device="cpu"`` a missing GPU or library raises ``VicanError`` as before - a GPU box must never
+    fall through to this file silently;
+  * never the oracle: this is the SAME algorithm the GPU runs (matrix-free block Lanczos on L = Lambda_C - P, device-style
+    Ritz verdict, Newton / SVD polar factors, scipy's CG recurrence with alpha / beta in a state vector) driven by the same
+    ``vican_amd/solver.py`` - not the reference's explicit-P / ARPACK / scipy.cg formulation that ``oracle/`` restates; nothing
+    here imports ``oracle/`` and the oracle does not import this;
+  * never on the GPU path: ``vican_amd.bipgo`` imports it inside the ``device="cpu"`` branch only; ``bench.py``'s timed region
+    and ``__graft_entry__.smoke()`` never touch it.
+
+Every method restates what one entry point of ``include/vican_hip.h`` computes (the formulas of SURVEY.md section 3.3) on
+CPU torch tensors; ``tests/test_kernels_gpu.py`` uses it as the per-kernel cross-check of the HIP kernels, the CPU tests
+(``tests/test_solver_cpu.py``, ``tests/test_dist_cpu.py``: world_size-2 gloo) pin it to the goldens of the real reference.
 """
 import numpy as np
 import torch
 
-from vican_amd._lib import CG_F, CG_I
+from ._lib import CG_F, CG_I
 
 
 def svd_polar(mats, mode):

@@ -6,7 +6,8 @@ poses are world<-node, gauge = lexicographically first camera at the identity
 rotation, translations of all nodes summing to zero (CG from x0 = 0).
 
 Everything numerical runs on the GPU through ``include/vican_hip.h``; there is no
-CPU fallback (a missing extension or GPU raises ``VicanError``).
+CPU FALLBACK (a missing extension or GPU raises ``VicanError``) - a GPU-less run exists
+only where the caller asks for it by name: ``device="cpu"`` (below).
 
 Extra keyword-only arguments (defaults reproduce the reference):
     info      dict that receives solver statistics (eigenvalues per iteration,
@@ -20,6 +21,12 @@ Extra keyword-only arguments (defaults reproduce the reference):
               validated.  Off by default: it deliberately breaks parity.
     cg_stop_at  (diagnostic) run exactly this many CG iterations instead of scipy's stopping test: lets a test compare
               iterate k with the reference's iterate k (tests/test_cg_iterates.py)
+    device    None (default): the current GPU.  "cpu": the same solver (vican_amd/solver.py: matrix-free block Lanczos, the
+              per-node polar factors, scipy's CG recurrence) on the package's own NumPy backend (vican_amd/backend_cpu.py),
+              host front-end included - what BASELINE configs[0] ("... on CPU (plumbing, no GPU)") and a box without a GPU
+              run, as the reference itself runs anywhere (bipgo.py:353-490 is NumPy / SciPy).  Explicit only: it is never
+              chosen for the caller, it is not the oracle, and nothing on the GPU path imports it.  Orders of magnitude
+              slower than the GPU path (plain NumPy, one core), sharded over `group` like the GPU path (gloo).
 """
 from __future__ import annotations
 
@@ -53,10 +60,14 @@ def _warn_if_disconnected(prob):
     return n
 
 
-def _device_merge():
-    """The numeric half of the front-end on the GPU (device.merge_edges); VICAN_HOST_MERGE=1 keeps it in NumPy."""
+def _is_cpu(device):
+    return device is not None and str(device).split(":")[0] == "cpu"
+
+
+def _device_merge(device=None):
+    """The numeric half of the front-end on the GPU (device.merge_edges); VICAN_HOST_MERGE=1 (and device="cpu") keep it in NumPy."""
     import os
-    if os.environ.get("VICAN_HOST_MERGE") == "1":
+    if os.environ.get("VICAN_HOST_MERGE") == "1" or _is_cpu(device):
         return None
     if not torch.cuda.is_available():
         raise VicanError("no GPU visible: vican_amd has no CPU fallback")
@@ -91,27 +102,29 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
                   group=None, info: Optional[dict] = None, device=None, eig_tol=1e-10, tight=False, cg_stop_at=None, comm=None):
     """Solve a flattened problem on this rank's GPU; returns host arrays
     (Rc [C,3,3], Rt [T,3,3] world<-node, p_c [C,3], p_t [T,3]).  comm: a ready solver.Comm (default: Comm(group))."""
-    from .device import TILE_CAMS, download, make_backend, upload      # needs the GPU + extension
-
     if lsqr_solver not in ("conjugate_gradient", "direct"):
         # the reference falls through both branches and dies on the unbound result (bipgo.py:476-487)
         raise UnboundLocalError("local variable 't_est' referenced before assignment")
     if maxiter < 1:
         # the reference's loop body never runs and `r_c` is unbound at bipgo.py:346
         raise UnboundLocalError("local variable 'r_c' referenced before assignment")
-    if not torch.cuda.is_available():
-        raise VicanError("no GPU visible: vican_amd has no CPU fallback")
-    comm = Comm(group) if comm is None else comm
+    cpu = _is_cpu(device)
+    if not cpu and not torch.cuda.is_available():
+        raise VicanError("no GPU visible: vican_amd has no CPU fallback (device=\"cpu\" asks for the NumPy backend explicitly)")
+    comm = (Comm(group, transport="torch") if cpu else Comm(group)) if comm is None else comm
     policy = shard_policy(prob.n_edges, comm.world)
     if policy == "replicated" and not getattr(comm, "force_sharded", False):
         comm = Comm.single()               # every rank solves the whole graph (small-graph policy above): no collective
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
     T = prob.n_time
     r0, r1 = _shard_rows(T, comm.world, comm.rank)
     rp_h = prob.host_csr()[0]
     e0, e1 = int(rp_h[r0]), int(rp_h[r1])
     t0 = time.perf_counter()
+    if cpu:
+        return _solve_problem_cpu(prob, maxiter, lsqr_solver, dtype, info, eig_tol, tight, cg_stop_at, comm, policy, (r0, r1, e0, e1), t0)
+    from .device import TILE_CAMS, download, make_backend, upload      # needs the GPU + extension
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
 
     # this rank's rows of the problem: host arrays of merge_host (ONE upload through page-locked staging, device.upload) or
     # device tensors of device.merge_edges.  The diagonal of the reference's J^T J as scipy forms it (frontend.merge_host)
@@ -197,6 +210,56 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
     return Rc, Rt, xc_h, xt_h
 
 
+def _solve_problem_cpu(prob, maxiter, lsqr_solver, dtype, info, eig_tol, tight, cg_stop_at, comm, policy, shard, t0):
+    """solve_problem(device="cpu"): this rank's rows on the NumPy backend (vican_amd/backend_cpu.py), the same stages."""
+    from .backend_cpu import NumpyBackend
+    r0, r1, e0, e1 = shard
+    T, nloc = prob.n_time, shard[1] - shard[0]
+    host = lambda a: a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    rp = host(prob.row_ptr)
+    deg_t = None if getattr(prob, "deg_t", None) is None else host(prob.deg_t)[r0:r1]
+    deg_c = None if getattr(prob, "deg_c", None) is None else (host(prob.deg_c) if comm.rank == 0 else np.zeros_like(host(prob.deg_c)))
+    K = NumpyBackend(prob.n_cam, rp[r0:r1 + 1] - rp[r0], host(prob.col)[e0:e1], host(prob.blk)[e0:e1], host(prob.a)[e0:e1], host(prob.w)[e0:e1],
+                     host(prob.u)[e0:e1], host(prob.v)[e0:e1], storage=np.dtype(dtype).type, deg_t=deg_t, deg_c=deg_c)
+    t1 = time.perf_counter()
+    bounds = [_shard_rows(T, comm.world, r)[0] for r in range(comm.world)] + [T]
+    gather = lambda loc, width: comm.gather_rows(loc.reshape(-1, width), nloc, bounds)
+    rot = RotationSolver(K, comm, eig_tol=eig_tol)
+    rc, Rt_loc = rot.run(maxiter)
+    t2 = time.perf_counter()
+    Rt_all = gather(Rt_loc.reshape(-1, 9)[:max(nloc, 1)], 9)
+    if tight:
+        tr = TightTranslationSolver(K, comm)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(3 * (prob.n_cam + T))
+        if not tr.info["converged"]:
+            raise AssertionError("tight CG did not converge")
+    elif lsqr_solver == "direct":                                            # bipgo.py:479-480
+        Rc_h = rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).numpy()
+        Rt_h = Rt_all.reshape(T, 3, 3).transpose(1, 2).numpy()
+        tr = LsqrTranslationSolver(K, comm)
+        x_c, x_t = tr.solve(rc, Rt_loc, 3 * (prob.n_cam + T), frontend.bnorm2(prob, Rc_h, Rt_h))
+    else:                                                                    # bipgo.py:476-478
+        tr = TranslationSolver(K, comm)
+        tr.setup(rc, Rt_loc)
+        x_c, x_t = tr.solve(3 * (prob.n_cam + T), stop_at=cg_stop_at)
+        if not tr.info["converged"] and cg_stop_at is None:
+            raise AssertionError("CG did not converge (scipy exit_code != 0, bipgo.py:478)")
+    t3 = time.perf_counter()
+    xt_all = gather(x_t.reshape(-1, 3)[:max(nloc, 1)], 3)
+    if info is not None:
+        info.update(evals=np.array(rot.stats["evals"]), lanczos_steps=list(rot.stats["lanczos_steps"]),
+                    eig_resid=list(rot.stats["resid"]), sweeps=rot.stats["sweeps"], restarts=rot.stats["restarts"],
+                    early_exit=rot.stats.get("early_exit"),
+                    cg_iters=tr.info.get("cg_iters"), cg_relres=tr.info.get("relres"), lsqr_iters=tr.info.get("lsqr_iters"),
+                    lsqr_istop=tr.info.get("istop"), n_cam=prob.n_cam, n_time=T, n_edges=prob.n_edges, n_src=prob.n_src, layout="numpy",
+                    t_pack=t1 - t0, t_rot=t2 - t1, t_trans=t3 - t2, world=comm.world, policy=policy, transport=getattr(comm, "transport", None),
+                    n_allreduce=getattr(comm, "n_allreduce", None), device="cpu")
+    return (np.ascontiguousarray(rc.reshape(prob.n_cam, 3, 3).transpose(1, 2).numpy()),           # bipgo.py:346
+            np.ascontiguousarray(Rt_all.reshape(T, 3, 3).transpose(1, 2).numpy()),                  # bipgo.py:348
+            x_c.numpy().copy(), xt_all.numpy().copy())
+
+
 def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
     """{node id: SE3(R in `dtype`, t float64)} in the reference's sorted node order (bipgo.py:485-487).  Ten thousand nodes:
     the arrays are scattered into node order at once and the SE3 objects are filled attribute by attribute (same contents as
@@ -221,15 +284,15 @@ def _pose_dict(prob, Rc, Rt, pc, pt, dtype):
 def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callable, noise_model_t: Callable,
                       edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
                       info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False,
-                      cg_stop_at: Optional[int] = None) -> dict:
+                      cg_stop_at: Optional[int] = None, device=None) -> dict:
     """SE(3) synchronisation of static cameras and a moving marker object
     (reference bipgo.py:353-490).  See module docstring."""
     t0 = time.perf_counter()
-    prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge())
+    prob = frontend.flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge(device))
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
-    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight, cg_stop_at=cg_stop_at)
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, device=device, tight=tight, cg_stop_at=cg_stop_at)
     local["t_flatten"] = t1 - t0
     out = _pose_dict(prob, Rc, Rt, pc, pt, dtype)
     if verbose:
@@ -241,7 +304,7 @@ def bipartite_se3sync(src_edges: dict, constraints: dict, noise_model_r: Callabl
 
 
 def bipartite_se3sync_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints: dict, maxiter: int, lsqr_solver: str,
-                             dtype=np.float32, *, info: Optional[dict] = None, group=None, tight: bool = False) -> dict:
+                             dtype=np.float32, *, info: Optional[dict] = None, group=None, tight: bool = False, device=None) -> dict:
     """``bipartite_se3sync`` for callers that hold their detections as ARRAYS (not in the reference; same mathematics,
     gauge, output dict and errors): one entry per kept source edge - camera id, timestamp, marker id (strings, the parts
     of the reference's key ``(cam, "<t>_<marker>")``), the marker's measured pose in the camera frame (R [n,3,3],
@@ -249,27 +312,27 @@ def bipartite_se3sync_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, cons
     is the caller's (drop the entries).  Skips the edge dict and its per-edge Python callables - the part of the
     drop-in call that dominates once the solve takes milliseconds."""
     t0 = time.perf_counter()
-    prob = frontend.flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype, merge=_device_merge())
+    prob = frontend.flatten_arrays(cam_ids, time_ids, marker_ids, R, t, k_r, k_t, constraints, dtype, merge=_device_merge(device))
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
-    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, device=device, tight=tight)
     local["t_flatten"] = t1 - t0
     return _pose_dict(prob, Rc, Rt, pc, pt, dtype)
 
 
 def object_bipartite_se3sync(src_edges: dict, noise_model_r: Callable, noise_model_t: Callable,
                              edge_filter: Callable, maxiter: int, lsqr_solver: str, dtype=np.float32, *,
-                             info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False) -> dict:
+                             info: Optional[dict] = None, group=None, verbose: bool = False, tight: bool = False, device=None) -> dict:
     """Object (marker cube) calibration from a moving camera (reference bipgo.py:493-545):
     markers take the camera role, frames the timestep role, every pose is inverted, the
     numerically smallest marker id is pinned to the identity; only marker poses are returned."""
     t0 = time.perf_counter()
-    root, prob = frontend.flatten_object(src_edges, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge())
+    root, prob = frontend.flatten_object(src_edges, noise_model_r, noise_model_t, edge_filter, dtype, merge=_device_merge(device))
     _warn_if_disconnected(prob)
     t1 = time.perf_counter()
     local = {} if info is None else info
-    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, tight=tight)
+    Rc, Rt, pc, pt = solve_problem(prob, maxiter, lsqr_solver, dtype, group, local, device=device, tight=tight)
     local["t_flatten"] = t1 - t0
     if verbose:
         print("vican_amd (object mode): %d markers, %d frames, %d merged edges | flatten %.3fs pack %.3fs rot %.3fs trans %.3fs" % (

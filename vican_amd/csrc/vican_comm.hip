@@ -8,6 +8,8 @@
 // behind the kernels that produced it, no host synchronisation.  RCCL is loaded at run time (dlopen of librccl.so.1): the
 // library has no link-time dependency on it, and single-GPU users never load it.
 #include <dlfcn.h>
+#include <mutex>
+#include <vector>
 #include <rccl/rccl.h>
 #include "vican_common.h"
 #include "vican_hip_test.h"
@@ -84,7 +86,7 @@ struct PeerArgs {
 struct vican_comm {
     ncclComm_t comm; int rank, world; int force_enqueue;
     // peer exchange
-    void* mb_local = nullptr; int64_t mb_cap = 0; bool mb_attached = false, mb_enabled = false;
+    void* mb_local = nullptr; int64_t mb_cap = 0; size_t mb_bytes = 0; bool mb_attached = false, mb_enabled = false;
     void* mb_opened[VICAN_PEER_MAX] = {};       // handles of the other ranks opened here (to be closed)
     PeerArgs pa = {};
     int device = -1;
@@ -226,12 +228,27 @@ extern "C" int vican_comm_create_local(int32_t rank, int32_t world, vican_comm_t
         }                                                                                                   \
     } while (0)
 
+// Mailboxes are NEVER handed back to the driver while the process lives: a freed one goes to a free list keyed by its size and
+// device and serves the next communicator (zeroed again).  Round 6 measured why: create -> exchange -> destroy -> create cycles
+// that hipFree'd the uncached allocation corrupted LATER allocations of the process (tensors that took over the address range
+// read back other bytes; now and then a memory fault) - one communicator kept for all solves never did, nor did communicators
+// that were made and destroyed without a launch having touched their mailbox.  (A communicator per process group lives as
+// long as the process anyway: vican_amd/solver.py keeps them; the churn comes from one-rank communicators of tests / timing.)
+struct PeerMem { void* mbox; unsigned int* state; unsigned int* status; size_t bytes; int device; };
+static std::vector<PeerMem>& peer_pool() { static std::vector<PeerMem> p; return p; }
+static std::mutex& peer_pool_mutex() { static std::mutex m; return m; }
+
 static void peer_release(vican_comm* c) {
     for (int r = 0; r < VICAN_PEER_MAX; ++r)
         if (c->mb_opened[r]) { (void)hipIpcCloseMemHandle(c->mb_opened[r]); c->mb_opened[r] = nullptr; }
-    if (c->mb_local) { (void)hipFree(c->mb_local); c->mb_local = nullptr; }
-    if (c->pa.state) { (void)hipFree(c->pa.state); c->pa.state = nullptr; }
-    if (c->pa.status) { (void)hipHostFree(c->pa.status); c->pa.status = nullptr; }
+    if (c->mb_local) {
+        // (a mailbox whose handle other processes may still hold open is not recycled: it is simply kept)
+        if (c->world == 1) {
+            std::lock_guard<std::mutex> lk(peer_pool_mutex());
+            peer_pool().push_back(PeerMem{c->mb_local, c->pa.state, c->pa.status, c->mb_bytes, c->device});
+        }
+        c->mb_local = nullptr; c->pa.state = nullptr; c->pa.status = nullptr;
+    }
     c->mb_attached = c->mb_enabled = false;
 }
 
@@ -248,12 +265,25 @@ extern "C" int vican_comm_peer_export(vican_comm_t* c, int64_t max_doubles, void
     const char* who = "vican_comm_peer_export";
     PEER_HIP(hipGetDevice(&c->device), who);
     const size_t bytes = (size_t)vican_comm_peer_bytes(c->world, max_doubles);
-    // uncached: a remote rank's stores must never meet a stale line of this GPU's L2 (and nothing of the mailbox is ever re-read)
-    PEER_HIP(hipExtMallocWithFlags(&c->mb_local, bytes, hipDeviceMallocUncached), who);
+    {
+        std::lock_guard<std::mutex> lk(peer_pool_mutex());
+        auto& pool = peer_pool();
+        for (size_t i = 0; i < pool.size(); ++i)
+            if (pool[i].bytes == bytes && pool[i].device == c->device) {
+                c->mb_local = pool[i].mbox; c->pa.state = pool[i].state; c->pa.status = pool[i].status;
+                pool.erase(pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!c->mb_local) {
+        // uncached: a remote rank's stores must never meet a stale line of this GPU's L2 (and nothing of the mailbox is ever re-read)
+        PEER_HIP(hipExtMallocWithFlags(&c->mb_local, bytes, hipDeviceMallocUncached), who);
+        PEER_HIP(hipMalloc((void**)&c->pa.state, 256), who);
+        PEER_HIP(hipHostMalloc((void**)&c->pa.status, 64, hipHostMallocMapped), who);
+    }
+    c->mb_bytes = bytes;
     PEER_HIP(hipMemset(c->mb_local, 0, bytes), who);
-    PEER_HIP(hipMalloc((void**)&c->pa.state, 256), who);
     PEER_HIP(hipMemset(c->pa.state, 0, 256), who);
-    PEER_HIP(hipHostMalloc((void**)&c->pa.status, 64, hipHostMallocMapped), who);
     memset(c->pa.status, 0, 64);
     PEER_HIP(hipDeviceSynchronize(), who);
     c->mb_cap = max_doubles;

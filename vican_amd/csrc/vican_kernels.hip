@@ -794,15 +794,8 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
             return set_err(VICAN_ERR_LAUNCH, "vican_lanczos_cam_coop: cannot raise dynamic LDS limit");
         configured = 128 * COOP_ROWS * 8;
     }
-    {   // co-residency of the grid on an idle device: checked whenever the LDS size or the grid exceeds what passed before
-        static size_t checked = 0;
-        static int checked_nwg = 0;
-        if (lds > checked || nwg > checked_nwg) {
-            if (int rc = vican_coresident_ok((const void*)lanczos_cam_coop_kernel, 256, lds, nwg, "vican_lanczos_cam_coop")) return rc;
-            checked = lds > checked ? lds : checked;
-            checked_nwg = nwg > checked_nwg ? nwg : checked_nwg;
-        }
-    }
+    // co-residency of the grid on an idle device (cached per kernel, LDS size, grid and device inside vican_coresident_ok)
+    if (int rc = vican_coresident_ok((const void*)lanczos_cam_coop_kernel, 256, lds, nwg, "vican_lanczos_cam_coop")) return rc;
     hipLaunchKernelGGL(lanczos_cam_coop_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, n_cam, lamC, V, ld, j, z, ws, Hcol,
                        beta, x_out, pivot_floor, sync_ws, (const long long*)zpart, n_slab, pa, pb, g_vican_abort_word,
                        g_vican_sync_ticks, (int)fenced);

@@ -43,12 +43,26 @@ extern "C" int vican_set_barrier_abort(uint32_t* abort_word, int64_t timeout_us)
 }
 // Can `grid` workgroups of this kernel be resident at once on an idle device?  (Necessary for its grid barriers; the
 // bounded spin of vican_grid_sync covers a device that is NOT idle.)
+// Every cooperative launcher asks on EVERY launch; the answer is a property of (kernel, block size, LDS bytes, device) - the
+// workgroups one compute unit holds - and is kept per such key (the occupancy query costs ~2 us of host time on the critical
+// path of an operator application; statics inside the launchers, as round 5 had them, were not keyed by the device).
 int vican_coresident_ok(const void* kernel, int block_threads, size_t lds_bytes, int grid, const char* who) {
-    int dev = 0, n_cu = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, lds_bytes) != hipSuccess)
-        return set_err(VICAN_ERR_LAUNCH, "%s: cannot query the occupancy of a cooperative kernel", who);
-    if ((long long)per_cu * n_cu < grid)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return set_err(VICAN_ERR_LAUNCH, "%s: cannot query the occupancy of a cooperative kernel", who);
+    struct Key { const void* k; int bt; size_t lds; int dev; long long capacity; };
+    static thread_local std::vector<Key> seen;              // (per host thread, like the gate and the launch timer: no lock)
+    long long capacity = -1;
+    for (const Key& e : seen)
+        if (e.k == kernel && e.bt == block_threads && e.lds == lds_bytes && e.dev == dev) { capacity = e.capacity; break; }
+    if (capacity < 0) {
+        int n_cu = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, lds_bytes) != hipSuccess)
+            return set_err(VICAN_ERR_LAUNCH, "%s: cannot query the occupancy of a cooperative kernel", who);
+        capacity = (long long)per_cu * n_cu;
+        if (seen.size() < 256) seen.push_back(Key{kernel, block_threads, lds_bytes, dev, capacity});
+    }
+    if (capacity < grid)
         return set_err(VICAN_ERR_CAPACITY, "%s: the grid of this cooperative kernel cannot be co-resident on the device", who);
     return VICAN_OK;
 }

@@ -36,7 +36,7 @@ class Problem:
         return len(self.col)
 
 
-def vectorized(columns_fn):
+def vectorized(columns_fn, python_scalars=True):
     """Decorator: give a per-edge callable (``edge_filter`` / ``noise_model_r`` / ``noise_model_t``: value dict -> bool / float,
     bipgo.py:204,212,449) a COLUMN form that the front-end calls once instead of once per edge:
 
@@ -46,9 +46,17 @@ def vectorized(columns_fn):
     ``columns_fn(cols)`` receives an ``EdgeColumns`` (``cols["reprojected_err"]`` [n], ``cols["corners"]`` [n,4,2],
     ``cols["R"]`` [n,3,3] / ``cols["t"]`` [n,3] of ``pose``, any other field as an object array; gathered on first use) and
     returns one value per edge (or a scalar).  The scalar form stays the definition - it is what the reference calls and what
-    runs when the attribute is absent; the two must agree (tests/test_frontend_cpu.py checks the shipped ones bit for bit)."""
+    runs when the attribute is absent; the two must agree (tests/test_frontend_cpu.py checks the shipped ones bit for bit).
+
+    One thing the column form cannot show is the TYPE the scalar form returns, and numpy's product `k_r * R` (bipgo.py:213)
+    depends on it when R is a float32 array (every pose built from a 4x4 matrix): a Python float is a weak scalar and gives a
+    float32 product, an np.float64 scalar a float64 one (f32_product_mask).  ``python_scalars`` says which: True (default) = the
+    scalar form returns Python floats (``math.exp(...)``, ``float(...)``, arithmetic on the dict's Python values) - a float64
+    column then counts as Python floats; False = it returns NumPy scalars (``np.exp(...)`` of a NumPy value) and the column's
+    own dtype decides, as it does for the arrays of ``flatten_arrays``."""
     def deco(fn):
         fn.vectorized = columns_fn
+        fn.vectorized_python_scalars = bool(python_scalars)
         return fn
     return deco
 
@@ -92,8 +100,8 @@ class EdgeColumns:
                     return self._cache[name]
                 if name == "R":
                     rl = self._pose_field("_R", "R")
-                    self._cache["r_is_f32"] = np.array([getattr(r, "dtype", None) == np.float32 for r in rl], dtype=bool) \
-                        if n and getattr(rl[0], "dtype", None) == np.float32 else np.zeros(n, dtype=bool)
+                    # (per-edge flags, whatever the first pose holds: a mixed list must not lose its float32 products)
+                    self._cache["r_is_f32"] = np.fromiter((getattr(r, "dtype", None) == np.float32 for r in rl), dtype=bool, count=n)
                     c = _stack_f64(rl, (3, 3)) if n else np.zeros((0, 3, 3))
                 else:
                     c = _stack_f64(self._pose_field("_t", "t"), (3,)) if n else np.zeros((0, 3))
@@ -162,7 +170,14 @@ def _call_columns(fn, cols, dtype):
     return out
 
 
-_CODES_CACHE = {"keys": None, "codes": None}        # the last kept key list and its index codes (time series: same keys, new values)
+# the last kept key list and its index codes (time series: same keys, new values) as ONE immutable pair, read and replaced in one
+# step each: concurrent flatten() calls can then at worst miss the cache, never pair one call's keys with another's codes.
+# clear_codes_cache() drops it (it pins the previous call's key list - ~80 000 tuples at large_shop size).
+_CODES_CACHE = [(None, None)]
+
+
+def clear_codes_cache():
+    _CODES_CACHE[0] = (None, None)
 
 
 def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, dtype=np.float32, merge=None) -> Problem:
@@ -197,12 +212,14 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
     if kr is None:
         kr_raw = [noise_model_r(v) for v in vals]
         kr = np.array(kr_raw, dtype=np.float64)
+    elif getattr(noise_model_r, "vectorized_python_scalars", True):
+        kr_raw = _PythonFloats(n)          # (the scalar form returns Python floats: weak scalars in numpy's k_r * R - `vectorized`)
     kt = _call_columns(noise_model_t, cols, np.float64)
     if kt is None:
         kt = np.array([noise_model_t(v) for v in vals], dtype=np.float64)
     R, t = cols["R"], cols["t"]
-    cache = _CODES_CACHE
-    codes = cache["codes"] if cache["keys"] is not None and len(cache["keys"]) == n and cache["keys"] == keys else None
+    ck, cc = _CODES_CACHE[0]
+    codes = cc if ck is not None and len(ck) == n and ck == keys else None
     if codes is None:
         cams = [k[0] for k in keys]
         tm = np.array([k[1] for k in keys])
@@ -215,7 +232,7 @@ def flatten(src_edges, constraints, noise_model_r, noise_model_t, edge_filter, d
             tsm = [k[1].split("_") for k in keys]
             times, marks = [a for a, _ in tsm], [b for _, b in tsm]
         codes = index_codes(cams, times, marks)
-        cache["keys"], cache["codes"] = keys, codes
+        _CODES_CACHE[0] = (keys, codes)
     # (float32 rotations - poses built from a 4x4 matrix: numpy weights them in float32, f32_product_mask; one dtype look-up for
     #  the usual float64 ones)
     kw = {}
@@ -382,6 +399,16 @@ def index_edges(cam_ids, time_ids, marker_ids, constraints, codes=None) -> EdgeI
     return ix
 
 
+class _PythonFloats:
+    """Stands for "n Python floats" in f32_product_mask without materialising them (a column-form weight whose scalar form
+    returns Python floats: frontend.vectorized)."""
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
 def f32_product_mask(weights, rotations):
     """Per kept source edge: does numpy form the reference's `k_r * v['pose'].R()` (bipgo.py:213) in float32?  It does when the
     rotation is a float32 array - every pose of object mode (SE3.inv() assembles a float32 4x4, geometry.py:239-243), poses
@@ -402,7 +429,9 @@ def f32_product_mask(weights, rotations):
     if not r32.any():
         return None
     probe = np.zeros(1, dtype=np.float32)
-    if isinstance(weights, np.ndarray):
+    if isinstance(weights, _PythonFloats):
+        k32 = np.full(n, (1.0 * probe).dtype == np.float32)
+    elif isinstance(weights, np.ndarray):
         k32 = np.full(n, (weights[:1] * probe).dtype == np.float32)
     else:
         types = list(map(type, weights))
@@ -518,7 +547,7 @@ def flatten_so3(src_edges, constraints, noise_model, edge_filter) -> Problem:
     Cm = np.stack([np.asarray(constraints[str(m)].R(), dtype=np.float64) @ r_root.T for m in mk_names])   # KeyError as bipgo.py:41
     Rl = [p.R() for p in poses]
     R = _stack_f64(Rl, (3, 3))
-    m32 = f32_product_mask(kr, Rl) if getattr(Rl[0], "dtype", None) == np.float32 else None      # (float32 rotations: numpy's float32 product)
+    m32 = f32_product_mask(kr, Rl)          # (float32 rotations - per edge, mixed lists included: numpy's float32 product)
     kr = np.asarray(kr, dtype=np.float64)
     A = kr[:, None, None] * R
     if m32 is not None:

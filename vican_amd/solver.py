@@ -169,19 +169,25 @@ class Comm:
             self._native = None
 
     def _peer_selftest(self, device):
-        """Known messages through the exchange (three sizes, both parities, bounded waits): rank r sends (r + 1)(i + 1) + r / 4."""
+        """Known messages through the exchange before any solve depends on it (three sizes; a synchronised exchange, then a
+        burst of 16 back-to-back ones without host synchronisation: both parities, the slot-reuse order; bounded waits):
+        rank r sends (r + 1)(i + 1) + r / 4, exactly representable, so the rank-ordered sum is known in closed form."""
         import ctypes
         lib, h, W = self._native_lib, self._native, self.world
         ok = True
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for n in (1, 700, min(self.PEER_MAX_DOUBLES, 9 * 1024 + 96)) * 2:
+            for n in (1, 700, min(self.PEER_MAX_DOUBLES, 9 * 1024 + 96)):
                 i = torch.arange(1, n + 1, dtype=torch.float64, device=device)
-                t = (self.rank + 1) * i + 0.25 * self.rank
-                ok = ok and lib.vican_comm_allreduce_sum(h, ctypes.c_void_p(t.data_ptr()), n, stream) == 0
-                torch.cuda.current_stream().synchronize()
+                mine = (self.rank + 1) * i + 0.25 * self.rank
                 want = (W * (W + 1) // 2) * i + 0.25 * (W * (W - 1) // 2)
-                ok = ok and bool(torch.equal(t, want)) and lib.vican_comm_peer_status(h) == 0
+                bufs = [mine.clone() for _ in range(17)]
+                ok = ok and lib.vican_comm_allreduce_sum(h, ctypes.c_void_p(bufs[0].data_ptr()), n, stream) == 0
+                torch.cuda.current_stream().synchronize()
+                for b in bufs[1:]:
+                    ok = ok and lib.vican_comm_allreduce_sum(h, ctypes.c_void_p(b.data_ptr()), n, stream) == 0
+                torch.cuda.current_stream().synchronize()
+                ok = ok and all(bool(torch.equal(b, want)) for b in bufs) and lib.vican_comm_peer_status(h) == 0
         return ok
 
     def check(self):

@@ -295,6 +295,10 @@ def make_merged_graph_torch(n_cam: int, n_time: int, cams_per_t: int, device,
         tt = torch.einsum("eij,ej->ei", RcT, p_obj[row[s:e]] - p_cam[col[s:e]])
         tt = tt + sigma_t * torch.randn((e - s, 3), generator=g2, device=device, dtype=f64)
         u[s:e] = tt * (a[s:e, None] ** 2)
+    # (a benchmark must never time a solve of garbage: round 6 met generated graphs with NaN blocks - memory handed out after a
+    #  freed uncached allocation, csrc/vican_comm.hip "Mailboxes are NEVER handed back" - and the solver dutifully "failed to converge")
+    if not bool(torch.isfinite(blk).all()) or not bool(torch.isfinite(u).all()):
+        raise FloatingPointError("make_merged_graph_torch: non-finite entries in the generated graph")
     return {
         "row_ptr": row_ptr, "col": col.to(torch.int32), "blk": blk,
         "a": a.to(dtype), "w": a * a, "u": u,
