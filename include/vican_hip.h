@@ -98,7 +98,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 28            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 29            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -110,7 +110,7 @@ int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the 
  * NULL (the default) disables gating.                                                        */
 int vican_set_gate(const int32_t* gate);
 
-/* Grid barriers of the cooperative kernels (vican_lanczos_cam_coop, vican_cg_resident, vican_lanczos_resident) - state of
+/* Grid barriers of the cooperative kernels (vican_lanczos_cam_coop, vican_cg_resident, vican_tiled_op) - state of
  * the calling host thread.  Those kernels spin on a device counter, which terminates only if every workgroup of the grid
  * is resident.  (1) Their launchers refuse grids that could not be co-resident on an idle device (occupancy query x
  * compute units -> VICAN_ERR_CAPACITY; the caller uses the launch-sequence entry points instead).  (2) Every spin is
@@ -372,19 +372,6 @@ int vican_chol_qr3(int32_t n, const double* R, const double* G, double* V, int32
 #define VICAN_SEED_MAX_N 16384
 int vican_lanczos_seed(int32_t n, const double* X0, double* V, int32_t ld, double* beta_out, double* x_out,
                        const double* Zraw, double* Z, void* coop_sync, void* stream);
-/* Block Lanczos steps j0 .. j1 - 1 (operator sweep vican_block_op + camera-side step vican_lanczos_cam_coop per step, i.e.
- * the ARPACK iteration behind eigs at bipgo.py:288) as ONE cooperative launch (vican_lres.hip) for wave-layout graphs whose
- * grid is co-resident, C <= 512: blocks of the first two chunks per wavefront stay in registers, the basis rows of the
- * camera workgroups in LDS, five grid barriers per step.  Bit-identical to the two-launch sequence.  V: column-major basis
- * [3 (m + 1)][ld] with blocks 0 .. j0 filled; xrow [3C][3]: block j0 (in) -> block j1 (out); HB [m][hb_stride]: row j gets
- * the projected column (9 (j + 1) doubles) and beta_j at offset hw (the layout vican_ritz reads); zpart: n_wg * 9C words;
- * ws: vican_lanczos_resident_ws_doubles() doubles; sync_ws: the two barrier words of vican_lanczos_cam_coop (zeroed by
- * vican_lanczos_seed at the start of every eigen-solve); fx as for vican_block_op.                                       */
-int64_t vican_lanczos_resident_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t storage, int32_t n_copy, int32_t j1);
-int64_t vican_lanczos_resident_ws_doubles(int32_t n_cam);
-int vican_lanczos_resident(const vican_graph_t* g, const double* lamT_inv, const double* lamC, double* V, int32_t ld,
-                           int32_t j0, int32_t j1, double* xrow, double* HB, int32_t hb_stride, int32_t hw, void* zpart,
-                           double* ws, uint32_t* sync_ws, const double* fx, double pivot_floor, void* stream);
 /* X[n][3] (row-major) = V[:, :ka] Y[ka][3] */
 int vican_tall_combine(int32_t n, const double* V, int32_t ld, int32_t ka, const double* Y,
                        double* X, void* stream);
@@ -607,15 +594,12 @@ int vican_cg_iter_finish(int32_t n_cam, int32_t n_time, const double* deg_c, con
 /* Single rank: one CG iteration behind one host call - vican_cg_begin + vican_cg_sweep + a fold that also forms p_t.q_t over
  * fixed slices (bit-reproducible from run to run: the sweep's own partial depends on the order of its chunk tickets) + the
  * step.  Same recurrence as (vican_cg_iter_local, vican_cg_iter_finish): iterates agree to the rounding of the differently
- * grouped p_t.q_t; poll st->done as there.  first: bit 0 = the call that follows vican_cg_init; bit 1 = hand-over mode - the
- * step's LAST workgroup (agent-scope ticket, no workgroup waits for another) runs the next iteration's vican_cg_begin, three
- * launches per iteration instead of four (measured slower on large graphs: profiles/r05_cg_tail.txt; every call of a solve
- * must use the same mode).  ticket: 1024 zeroed bytes owned by the solve, 128-byte aligned (tickets, hand-over words, p.q
- * partials); rr_part >= 1536 doubles.  scipy cg, bipgo.py:477.                                                            */
+ * grouped p_t.q_t; poll st->done as there.  first != 0: the call that follows vican_cg_init.  ws: 1024 bytes owned by the solve
+ * (the fold's p.q partials); rr_part >= 1536 doubles.  scipy cg, bipgo.py:477.                                              */
 int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
                         double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
                         void* qc_part, double* pq_part, double* qcpq, double rtol, double* rr_part, int32_t part_cap,
-                        double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ticket, void* stream);
+                        double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ws, void* stream);
 
 /* ONE message per CG iteration for timestep-sharded solves (replaces the two reductions per iteration of the pair above;
  * scipy.sparse.linalg.cg at bipgo.py:476-478 on a sharded graph): the Chronopoulos-Gear arrangement - the product is formed

@@ -404,6 +404,73 @@ def unit_scale_case():
     np.savez_compressed(os.path.join(HERE, "g11_unit_scale.npz"), **out)
 
 
+def cube_calib_case():
+    """G12: the reference's object calibration at the notebook's size and weights (golden_cases.CUBE_CALIB; main.ipynb:74-80).
+    Besides the returned marker poses: the eigenvalues per iteration, the CG iteration count, the converged solution of the
+    reference's own system for the marker nodes (`t_tight`: its node order comes from the inner bipartite_se3sync call, whose
+    full output dict is observed, not altered) and the reference's own reproducibility - eight repeats of its cg call on
+    right-hand sides perturbed by one unit in the last place (movement of the MARKER translations, iteration counts)."""
+    import time
+    case = gc.CUBE_CALIB
+    scene, flat = gc.build_flat(case)
+    src = synth.edges_to_dict(flat, ref_geometry.SE3)
+    nr, nt, ff = (gc.CALLABLES[case[k]] for k in ("noise_r", "noise_t", "filt"))
+    out = {"digest": input_digest(flat)}
+    inner, seen = ref_bipgo.bipartite_se3sync, {}
+    cg_inner = ref_bipgo.cg                                     # (= _cg above: records iterations, relres, t_tight)
+
+    def spy(*a, **k):
+        res = inner(*a, **k)
+        seen["keys"] = [str(x) for x in res.keys()]
+        return res
+
+    def cg_spy(A, b, *a, **k):
+        x, info = cg_inner(A, b, *a, **k)
+        rng = np.random.default_rng(12345)
+        xs, its = [], []
+        for _ in range(8):
+            n = [0]
+            xt, _ = _orig_cg(A, b * (1.0 + 1e-15 * rng.standard_normal(b.shape)), *a, callback=lambda _x: n.__setitem__(0, n[0] + 1), **k)
+            xs.append(np.asarray(xt, dtype=np.float64).reshape(-1, 3)); its.append(n[0])
+        seen["trials"], seen["trial_iters"], seen["x"] = xs, its, np.asarray(x, dtype=np.float64).reshape(-1, 3)
+        return x, info
+    ref_bipgo.bipartite_se3sync, ref_bipgo.cg = spy, cg_spy
+    try:
+        for solver, dt in case["runs"]:
+            _rec.update(evals=[], cg_iters=None, cg_relres=None, t_tight=None)
+            t0 = time.time()
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                res = ref_bipgo.object_bipartite_se3sync(src, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
+                                                         lsqr_solver=solver, dtype=np.dtype(dt).type)
+            wall = time.time() - t0
+            tag = "out_%s_%s_" % (solver, dt)
+            keys = [str(k) for k in res.keys()]
+            rows = np.array([seen["keys"].index(k) for k in keys])          # marker nodes inside the inner call's node order
+            t = np.stack([np.asarray(res[k].t(), dtype=np.float64) for k in res.keys()])
+            assert np.array_equal(seen["x"][rows], t)
+            out[tag + "keys"] = np.array(keys)
+            out[tag + "R"] = np.stack([np.asarray(res[k].R(), dtype=np.float64) for k in res.keys()])
+            out[tag + "t"] = t
+            out[tag + "evals"] = np.stack(_rec["evals"])
+            out[tag + "cg_iters"] = np.int64(_rec["cg_iters"])
+            out[tag + "cg_relres"] = np.float64(_rec["cg_relres"])
+            out[tag + "t_tight"] = _rec["t_tight"][rows]
+            out[tag + "dist_tight"] = np.float64(np.linalg.norm(t - _rec["t_tight"][rows], axis=1).max())
+            out[tag + "self_move"] = np.array([float(np.linalg.norm(xt[rows] - t, axis=1).max()) for xt in seen["trials"]])
+            out[tag + "self_move_all_nodes"] = np.array([float(np.linalg.norm(xt - seen["x"], axis=1).max()) for xt in seen["trials"]])
+            out[tag + "iters"] = np.array([_rec["cg_iters"]] + seen["trial_iters"], dtype=np.int64)
+            out[tag + "n_nodes"] = np.int64(len(seen["keys"]))
+            out[tag + "ref_wall_s"] = np.float64(wall)
+            print("  g12_cube_calib %-20s %-8s markers=%d nodes=%d src_edges=%d cg_iters=%s (trials %s) relres %.1e dist_tight=%.3e m "
+                  "self-movement of the marker translations %s m  reference wall %.1f s" % (
+                      solver, dt, len(keys), len(seen["keys"]), len(src), _rec["cg_iters"], seen["trial_iters"], _rec["cg_relres"], out[tag + "dist_tight"],
+                      " ".join("%.1e" % v for v in out[tag + "self_move"]), wall))
+    finally:
+        ref_bipgo.bipartite_se3sync, ref_bipgo.cg = inner, cg_inner
+    out["versions"] = np.array(["numpy " + np.__version__, "scipy " + scipy.__version__, "python " + sys.version.split()[0]])
+    np.savez_compressed(os.path.join(HERE, "g12_cube_calib.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, case in gc.CASES.items():
@@ -424,3 +491,5 @@ if __name__ == "__main__":
         cg_iterates_case()
     if "g11_unit_scale" in only:
         unit_scale_case()
+    if "g12_cube_calib" in only:
+        cube_calib_case()

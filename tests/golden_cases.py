@@ -38,8 +38,20 @@ def w_area_heavy_t(edge):       # notebook-like: 0.001*area^2 (ill-conditioned)
     return 0.001 * _area(edge) ** 2
 
 
+def w_area_sq_r(edge):          # main.ipynb:75 (object calibration): 0.01 * area^2
+    return 0.01 * _area(edge) ** 2
+
+
+def w_area_p6_t(edge):          # main.ipynb:76 (object calibration): 0.001 * area^6 - heavy-tailed over ~12 decades
+    return 0.001 * _area(edge) ** 6
+
+
 def f_all(edge):
     return True
+
+
+def f_err01(edge):              # main.ipynb:77
+    return edge["reprojected_err"] < 0.1
 
 
 def f_err(edge):
@@ -47,7 +59,7 @@ def f_err(edge):
 
 
 CALLABLES = {f.__name__: f for f in
-             (w_unit, w_area_mild, w_area_mild_t, w_area_heavy_r, w_area_heavy_t, f_all, f_err)}
+             (w_unit, w_area_mild, w_area_mild_t, w_area_heavy_r, w_area_heavy_t, w_area_sq_r, w_area_p6_t, f_all, f_err, f_err01)}
 
 
 # -- case table ---------------------------------------------------------------
@@ -119,6 +131,17 @@ UNIT_SCALE = {
                                  noise_r="w_unit", noise_t="w_unit", filt="f_all",
                                  runs=[("conjugate_gradient", "float32"), ("conjugate_gradient", "float64")]),
 }
+
+
+# G12: BASELINE configs[0] at its REAL size and in the notebook's own regime (main.ipynb:74-80): object calibration, 24 markers x
+# 2000 frames x 4 detections per frame, dtype float64, weights 0.01 area^2 / 0.001 area^6 on the synthetic detections' marker
+# areas (apparent squares of 60 px / distance: the sixth power spreads the translation weights over ~12 decades), the
+# notebook's reprojection filter.  Outputs + input digest only; with the reference's own reproducibility under 1e-15
+# perturbations and the converged solution of its system (`t_tight`) for the marker nodes.
+CUBE_CALIB = dict(mode="object", scene=dict(n_cam=1, n_time=2000, n_marker=24, seed=121),
+                  edges=dict(mpv=4, sigma_r=1e-3, sigma_t=1e-3, seed=122),
+                  noise_r="w_area_sq_r", noise_t="w_area_p6_t", filt="f_err01",
+                  runs=[("conjugate_gradient", "float64")])
 
 
 def build_flat(case: dict):

@@ -268,6 +268,8 @@ def test_dropin_matches_reference_on_unit_weight_scenes_at_dataset_size(name, dt
     rot, tr = float(geodesic(R, np.asarray(e["R"], dtype=np.float64)).max()), dist(t, e["t"])
     print("%s %s: rot %.2e rad, trans %.2e m, cg %d vs %d (reference %.1f s, drop-in solve %.1f ms)" % (
         name, dt, rot, tr, info["cg_iters"], int(e["cg_iters"]), float(e["ref_wall_s"]), 1e3 * (info["t_rot"] + info["t_trans"])))
+    from conftest import record_parity
+    record_parity("g11_" + name, dt, "drop-in", rot, tr, 2e-5 if dt == "float32" else 1e-6, info["cg_iters"], int(e["cg_iters"]))
     assert rot < (5e-6 if dt == "float32" else 1e-7), rot
     assert tr < (2e-5 if dt == "float32" else 1e-6), tr
     assert info["cg_iters"] == int(e["cg_iters"])

@@ -32,6 +32,8 @@ def test_dropin_on_the_cpu_backend_matches_the_reference(name, dt):
         res = object_bipartite_se3sync(src, noise_model_r=nr, noise_model_t=nt, edge_filter=ff, maxiter=gc.MAXITER,
                                        lsqr_solver="conjugate_gradient", dtype=dtype, info=info, device="cpu")
     rot, tr = pose_errors(res, exp)
+    from conftest import record_parity
+    record_parity(name, dt, "device=cpu", rot, tr, e2e_translation_tol(name, dt), info["cg_iters"], int(exp["cg_iters"]))
     assert info["device"] == "cpu" and info["layout"] == "numpy"
     assert rot < (1e-7 if dt == "float64" else 5e-6), rot
     assert tr < e2e_translation_tol(name, dt), tr

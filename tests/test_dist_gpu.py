@@ -50,12 +50,20 @@ def test_sharded_large_shop_golden_matches_the_reference(nranks):
     (rotations 1e-7 / 5e-6 rad, translations inside the reference's own reproducibility band, CG iterations inside its
     101..106 window +- 1), and against the single-rank solve of the same processes."""
     port = _free_port()
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "g9.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_g9.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dist_g9.py"), out]
     res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     print(res.stdout[-3000:])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert "dist g9: mismatches 0" in res.stdout
+    rep = json.load(open(out))
+    from conftest import record_parity
+    for dt in ("float64", "float32"):
+        r = rep[dt]
+        record_parity("g9_large_shop", dt, "%d ranks (%s)" % (nranks, r.get("transport")), r["rot_vs_reference_rad"], r["trans_vs_reference_m"],
+                      r["tol_trans"], r["cg_iters"], r["cg_reference"])
 
 
 @pytest.mark.parametrize("workload,scaling,gpus,min_edges", [("large_shop", "strong", 2, 0), ("stress", "weak", 2, None), ("large_shop", "strong", 4, 0),

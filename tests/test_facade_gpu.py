@@ -70,6 +70,8 @@ def test_four_calls_reproduce_the_reference(name, dt):
     r_err, t_err = float(geodesic(R, exp["R"]).max()), float(np.linalg.norm(t - exp["t"], axis=1).max())
     print("%s %s through the four calls: rot %.2e rad, trans %.2e m, %d Lanczos steps, %d sweeps, cg %d vs %d, layout %s" % (
         name, dt, r_err, t_err, info.lanczos_steps, info.sweeps, info.cg_iters, int(exp["cg_iters"]), "wave" if graph.layout == 1 else "block"))
+    from conftest import record_parity
+    record_parity(name, dt, "facade", r_err, t_err, e2e_translation_tol(name, dt), info.cg_iters, int(exp["cg_iters"]))
     assert r_err < (5e-6 if dt == "float32" else 1e-7), r_err
     assert t_err < e2e_translation_tol(name, dt), t_err
     assert abs(info.cg_iters - int(exp["cg_iters"])) <= iteration_slack(name, dt)

@@ -210,18 +210,15 @@ def test_translation_kernels_and_cg(cfg):
 
 @pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[8], CONFIGS[10], CONFIGS[11], CONFIGS[12], (1000, 3000, 250, 250, "wave12", None, False)])
 @pytest.mark.parametrize("rtol", [1e-5, 1e-9])
-@pytest.mark.parametrize("handover", [False, True])
-def test_fused_cg_iteration(cfg, rtol, handover, monkeypatch):
-    """vican_cg_iter_fused (sweep, a fold whose LAST workgroup forms alpha, a step whose last workgroup runs the next iteration's
-    head: three launches, hand-overs by agent-scope ticket, p_t.q_t over fixed slices) against the four-launch sequence
+def test_fused_cg_iteration(cfg, rtol):
+    """vican_cg_iter_fused (begin, sweep, a fold that forms p_t.q_t over fixed slices, the step) against the launch sequence
     vican_cg_iter_local / vican_cg_iter_finish.
-      * the hand-overs are exercised under UNEVEN load (a filler kernel occupies part of the chip on another stream while the
-        iterations run) and the iterates must be bit-identical from run to run - a stale or early read of a hand-over word
-        would show as a different iterate;
+      * run under UNEVEN load (a filler kernel occupies part of the chip on another stream while the iterations run) the
+        iterates must be bit-identical from run to run - the sweep's own p.q partial (ticket order) was not;
       * against the sequence: the same recurrence, the timestep part of p.q grouped differently (and, in the sequence, in the
         order the sweep's tickets happened to fall): same iterates to rounding, same iteration count on these well-conditioned
-        systems, and after every iteration the state of the fused path equals the sequence's state after ITS next head;
-      * the tickets are left at zero; iteration budget as scipy's range(maxiter)."""
+        systems;
+      * iteration budget as scipy's range(maxiter)."""
     from test_coop_barriers_gpu import occupy
     from vican_amd.solver import Comm, TranslationSolver
     C, T, lo, hi, bt, nwg, er = cfg
@@ -231,7 +228,6 @@ def test_fused_cg_iteration(cfg, rtol, handover, monkeypatch):
         dtp = np.float64
     H, N, g = make_backends(C, T, lo, hi, 300 + C, dtp, bt, nwg, False)
     H._cgres_ok = False                                          # (capture-sized graphs: the launch paths, not the resident kernel)
-    H.cg_handover = handover                                     # (True: the step's last workgroup runs the next head - VICAN_CG_HANDOVER=1)
     rng = np.random.default_rng(3)
     rc = synth.random_rotations(rng, C).reshape(3 * C, 3)
     rt = synth.random_rotations(rng, T).reshape(T, 9)
@@ -252,7 +248,6 @@ def test_fused_cg_iteration(cfg, rtol, handover, monkeypatch):
                 torch.cuda.synchronize()
                 states.append(([getattr(ts, nm).clone() for nm in names], ts._state()))
         torch.cuda.synchronize()
-        assert int(H._cg_ticket[:2].abs().sum().item()) == 0
         return states
     ref = run_fused(10, False)
     for rep in range(4):
@@ -274,22 +269,19 @@ def test_fused_cg_iteration(cfg, rtol, handover, monkeypatch):
         H.cg_begin(tq.r_c, tq.p_c, rtol, tq.st, n_part)
         torch.cuda.synchronize()
         sf, sq = tf._state(), tq._state()
-        # (without hand-over the fused call has not run the next head yet: p_c and the head's scalars are compared a call later)
-        for nm in (names if handover else [x for x in names if x != "p_c"]):
+        # (the fused call has not run the next head yet: p_c and the head's scalars are compared a call later)
+        for nm in [x for x in names if x != "p_c"]:
             a, b = getattr(tf, nm), getattr(tq, nm)
             assert float((a - b).abs().max()) <= 1e-11 * max(float(b.abs().max()), 1e-300), (k, nm)
-        keys = ("rho", "alpha", "beta", "pq", "rr_cam", "rr_time", "pmax", "qscale") if handover else ("alpha", "pq", "rr_cam")
-        if handover:
-            assert sf["iter"] == sq["iter"] == k + 1 and sf["done"] == sq["done"] and sf["lo_bits"] == sq["lo_bits"]
-        for key in keys:
+        for key in ("alpha", "pq", "rr_cam"):
             assert abs(sf[key] - sq[key]) <= 1e-11 * abs(sq[key]), (k, key, sf[key], sq[key])
         if sq["done"]:
             break
     # whole solves: the polled driver on either path
     outs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("VICAN_CG_FUSED", fused)
+    for fused in (True, False):
         ts = TranslationSolver(H, Comm.single(), rtol=rtol, poll_every=4)
+        ts.use_fused = fused                                     # (False: the launch sequence the camera-tiled backends take)
         ts.setup(H.from_numpy(rc), H.from_numpy(rt))
         x_c, x_t = ts.solve(3 * (C + T))
         outs.append((x_c.clone(), x_t.clone(), dict(ts.info)))
@@ -298,7 +290,6 @@ def test_fused_cg_iteration(cfg, rtol, handover, monkeypatch):
         scale = max(float(outs[1][1].abs().max()), 1.0)
         assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e3 * rtol * scale and float((outs[0][1] - outs[1][1]).abs().max()) < 1e3 * rtol * scale
     # iteration budget (scipy: range(maxiter), no test behind the last update)
-    monkeypatch.setenv("VICAN_CG_FUSED", "1")
     ts = TranslationSolver(H, Comm.single(), rtol=1e-14)
     ts.setup(H.from_numpy(rc), H.from_numpy(rt))
     ts.solve(3 * (C + T), maxiter=3)
@@ -452,53 +443,6 @@ def test_cooperative_step_repeats_bit_identically():
     x0 = H.from_numpy(rng.standard_normal((n, 3)))
     H.lanczos_seed(x0, V, n, beta, x)
     assert int(H._coop_sync.abs().sum()) == 0
-
-
-@pytest.mark.parametrize("cfg", [(100, 4000, 2, 9, None), (340, 10000, 2, 6, None), (37, 300, 1, 12, None), (300, 3000, 20, 60, None),
-                                 (5, 40, 1, 3, None), (300, 900, 60, 128, 9)])
-@pytest.mark.parametrize("dt", [np.float64, np.float32])
-def test_lanczos_resident_matches_the_launch_pairs(cfg, dt):
-    """vican_lanczos_resident (a run of Lanczos steps as one cooperative launch, vican_lres.hip) against the sequence of
-    vican_block_op + vican_lanczos_cam_coop launches: basis, projected columns, beta blocks and the next sweep input
-    bit-identical - in one run, split into two runs (j0 > 0), and on repeats."""
-    C, T, lo, hi, nwg = cfg
-    H, N, g = make_backends(C, T, lo, hi, 900 + C, dt, "wave", nwg)
-    m = min(10, C - 1)
-    if nwg is not None and nwg < -(-C // 32):
-        assert H.lanczos_resident_steps(m, force=True) == 0     # (fewer workgroups than camera slices: not eligible)
-        return
-    assert H.lanczos_resident_steps(m, force=True) == m
-    n, ld, hw = 3 * C, 3 * C, 3 * (m + 1) * 3
-    rng = np.random.default_rng(5)
-    lam, cd, lamC = H.empty(T, 9), H.empty(C), H.empty(C, 9)
-    H.init_duals(lam, cd)
-    H.scaled_identity(cd, lamC)
-    x0 = H.from_numpy(rng.standard_normal((n, 3)))
-
-    def fresh():
-        V, HB, xrow, beta0 = H.zeros(3 * (m + 1) * n), H.zeros(m, hw + 9), H.empty(n, 3), H.empty(9)
-        assert H.lanczos_seed(x0, V, ld, beta0, xrow)
-        return V, HB, xrow
-
-    # the launch pairs
-    V1, HB1, x1 = fresh()
-    R, Hs, G, z = H.zeros(3 * n), H.zeros(3 * (m + 1) * 3), H.zeros(9), H.empty(n, 3)
-    for j in range(m):
-        H.block_op_slabs(lam, x1)
-        H.lanczos_cam_step(lamC, V1, ld, j, z, R, Hs, G, HB1[j, :hw], HB1[j, hw:], x1, 0.0, from_slabs=True)
-    # one resident run, two resident runs, a repeat
-    outs = []
-    for cuts in ((0, m), (0, 3, m), (0, m)):
-        V2, HB2, x2 = fresh()
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            if b > a:
-                H.lanczos_resident(lam, lamC, V2, ld, a, b, x2, HB2, hw, 0.0)
-        outs.append((V2, HB2, x2))
-    torch.cuda.synchronize()
-    for V2, HB2, x2 in outs:
-        assert torch.equal(V1, V2) and torch.equal(HB1, HB2) and torch.equal(x1, x2)
-    q = V1.cpu().numpy().reshape(3 * (m + 1), n)
-    assert np.abs(q @ q.T - np.eye(3 * (m + 1))).max() < 1e-10                 # (the basis is orthonormal)
 
 
 def _ritz_inputs(steps, m, seed, dead_at=None, gap=True):

@@ -66,6 +66,8 @@ def test_dropin_matches_reference_at_large_shop_scale(case, dt):
     print("large_shop scale %s: rot %.2e rad, trans %.3e m (the reference moves by up to %.1e m against itself), cg %d vs %d, "
           "solve %.1f ms (reference %.1f s)" % (dt, rot, tr, float(cg_sensitivity("g9_large_shop", dt)[0].max()), info["cg_iters"],
                                                int(exp["cg_iters"]), 1e3 * (info["t_rot"] + info["t_trans"]), float(exp["ref_wall_s"])))
+    from conftest import record_parity
+    record_parity("g9_large_shop", dt, "drop-in", rot, tr, min(translation_tol("g9_large_shop", dt), G9_TR_BOUND), info["cg_iters"], int(exp["cg_iters"]))
     assert rot < (5e-6 if dt == "float32" else 1e-7), rot               # north star: 1e-4 rad
     assert tr < min(translation_tol("g9_large_shop", dt), G9_TR_BOUND), tr
     # scipy's stopping rule is reproduced; the reference itself stops anywhere between 101 and 106 iterations under

@@ -29,6 +29,8 @@ def test_dropin_api_matches_reference(name, dt):
         res = object_bipartite_se3sync(src, noise_model_r=nr, noise_model_t=nt, edge_filter=ff,
                                        maxiter=gc.MAXITER, lsqr_solver="conjugate_gradient", dtype=dtype, info=info)
     rot, tr = pose_errors(res, exp)
+    from conftest import record_parity
+    record_parity(name, dt, "drop-in", rot, tr, e2e_translation_tol(name, dt), info["cg_iters"], int(exp["cg_iters"]))
     assert rot < ROT_TOL[dt] <= 1e-4, rot
     assert tr < e2e_translation_tol(name, dt), tr
     if name == "g4_illcond" and info["cg_iters"] == int(exp["cg_iters"]):
@@ -235,6 +237,8 @@ def test_dropin_direct_lsqr_matches_reference(name, dt):
     res = bipartite_se3sync(src, constraints=cons, noise_model_r=nr, noise_model_t=nt, edge_filter=ff,
                             maxiter=gc.MAXITER, lsqr_solver="direct", dtype=np.dtype(dt).type, info=info)
     rot, tr = pose_errors(res, exp)
+    from conftest import record_parity
+    record_parity(name, dt, "drop-in LSQR", rot, tr, 2e-6 if dt == "float64" else 5e-4, info["lsqr_iters"], None)
     assert rot < ROT_TOL[dt]
     assert tr < (2e-6 if dt == "float64" else 5e-4), tr
     assert info["lsqr_istop"] in (1, 2) and info["lsqr_iters"] > 0

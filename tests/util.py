@@ -104,7 +104,8 @@ def oracle_attempts(run, check, n=4):
             res = run()
             check(res)
             return res
-        except (AssertionError, ArithmeticError, RuntimeError) as exc:      # (ArpackError derives from RuntimeError)
+        # (ArpackError derives from RuntimeError; a stray start can also hand back a singular V[0:3] - LinAlgError, met on g12)
+        except (AssertionError, ArithmeticError, RuntimeError, np.linalg.LinAlgError) as exc:
             last = exc
     raise last
 

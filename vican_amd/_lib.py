@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so")      # VICAN_LIB: diagnostic builds (tools/)
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
-           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_lres.hip"), os.path.join(CSRC, "vican_merge.hip"),
+           os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_merge.hip"),
            os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip"), os.path.join(CSRC, "vican_tcg.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
 HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), os.path.join(CSRC, "vican_cgw_impl.h"), WSWEEP]
@@ -163,9 +163,6 @@ PROTOTYPES = {
     "vican_cg_resident_lds_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vican_cg_resident_ws_doubles": (_i64, [_i32, _i32]),
     "vican_cg_resident": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _f64, _i32, _vp, _vp]),
-    "vican_lanczos_resident_lds_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
-    "vican_lanczos_resident_ws_doubles": (_i64, [_i32]),
-    "vican_lanczos_resident": (C.c_int, [_G, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp]),
     "vican_merge_ws_bytes": (_i64, [_i64, _i32, _i32]),
     "vican_merge_edges": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -84,9 +84,11 @@ def _shard_rows(T, world, rank):
 # camera side (Lanczos steps, Ritz, per-camera SVDs: most of a capture-sized solve) is replicated either way.  Below the
 # threshold every rank solves the WHOLE graph with the single-rank schedule - no collective at all, the same bits on every
 # rank (the single-rank solve is bit-reproducible), 1.0 x the one-GPU time instead of the measured ~0.5 x.  Measured on one
-# MI355X (tools/shard_threshold.py, profiles/r06_shard_threshold.txt): the break-even of an 8-way split lies between 2 M and
-# 4 M merged edges.  VICAN_SHARD_MIN_EDGES overrides (0: always shard).
-SHARD_MIN_EDGES = 3_000_000
+# MI355X (tools/shard_threshold.py, profiles/r06_shard_threshold.txt: single-rank solve of E edges against the sharded schedule on
+# E / N edges + 3 us per collective for the link): at 4 M merged edges a 2 / 4 / 8-way split is predicted at 0.96-1.04 / 0.82-1.02 /
+# 0.79-1.10 x, at 8 M at 1.10-1.13 / 1.26-1.27 / 1.09 x (at 25 M: 1.4 / 1.7-2.0 / 2.1-2.4 x).  VICAN_SHARD_MIN_EDGES overrides
+# (0: always shard).
+SHARD_MIN_EDGES = 6_000_000
 
 
 def shard_policy(n_edges_total, world):

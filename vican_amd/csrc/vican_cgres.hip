@@ -117,12 +117,6 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         if (wg == 0 && tid == 0) { st->done = -1; st->iter = 0; }
         return false;
     };
-#ifdef VICAN_CGRSTAMP   /* diagnostic build: wall-clock per phase (100 MHz ticks) of workgroup 0 -> ws tail */
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memrealtime();
-#define RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define RSTAMP(i) do {} while (0)
-#endif
 
     const int c0 = (int)(((long long)wg * g.n_chunk) / nwg), c1 = (int)(((long long)(wg + 1) * g.n_chunk) / nwg);
     const int row0 = g.chunk_row0[c0];
@@ -195,7 +189,6 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         if (!first)
             for (int i = tid; i < ni; i += CGR_THREADS) pts[i] = mul_add_2r(beta, pts[i], rts[i]);
         __syncthreads();
-        RSTAMP(0);
 
         // ---- sweep of this workgroup's chunks: a wavefront per chunk (the arithmetic of cg_wsweep_kernel)
         double pqs = 0.0;
@@ -279,13 +272,10 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             for (kc += CGR_NW; kc < c1; kc += CGR_NW) { CgrEdges<EPL> e; load_edges(e, kc); chunk(e, kc); }
         }
         __syncthreads();
-        RSTAMP(1);
         for (int j = tid; j < 2 * n3; j += CGR_THREADS) cgr_st(slab + (size_t)wg * 2 * n3 + j, qc[j]);
         const double pq_loc = cgr_sum(pqs, red);
         if (tid == 0) cgr_st(part + 4 * wg + 2, pq_loc);
-        RSTAMP(2);
         if (!gsync()) return;
-        RSTAMP(3);
 
         // ---- fold this workgroup's slice of the camera sums over all slabs (8 lanes per element; exact, overflow-proof integer sums)
         for (int e = j0 + (tid >> 3); e < j1; e += CGR_THREADS / 8) {
@@ -295,9 +285,7 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             const u64 st_ = stripe_sum((u64)a.top, 8), sb_ = stripe_sum((u64)a.bot, 8), sl_ = stripe_sum((u64)a.lo, 8);
             if ((tid & 7) == 0) { cgr_st(qc_sum + e, st_); cgr_st(qc_sum + n3 + e, sb_); cgr_st(qc_sum + 2 * n3 + e, sl_); }
         }
-        RSTAMP(4);
         if (!gsync()) return;
-        RSTAMP(5);
 
         // ---- alpha, x += alpha p, r -= alpha q (camera side replicated, timestep side on the own rows)
         double sq = tid < nwg ? cgr_ld(part + 4 * tid + 2) : 0.0;               // p.q: timestep partials + camera terms
@@ -307,7 +295,6 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             qcs[j] = q; sq += pcs[j] * q;
         }
         pq = cgr_sum(sq, red);
-        RSTAMP(6);
         alpha = rho / pq;
         double sr = 0.0, mr = 0.0, mpc = 0.0;
         for (int j = tid; j < n3; j += CGR_THREADS) {
@@ -337,19 +324,13 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             __syncthreads();
             pcmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         }
-        RSTAMP(7);
         if (!gsync()) return;
-        RSTAMP(8);
         t = cgr_reduce6(tid < nwg ? cgr_ld(part + 4 * tid) : 0.0, 0.0, 0.0, tid < nwg ? cgr_ld(part + 4 * tid + 1) : 0.0,
                         tid < nwg ? cgr_ld(part + 4 * tid + 3) : 0.0, 0.0, red);
         rr_time = t.s0; rmax_time = t.a; pmax_time = t.b;
         rho_prev = rho;
         ++iter;
-        RSTAMP(9);
     }
-#ifdef VICAN_CGRSTAMP
-    if (wg == 0 && tid == 0) { double* o = (double*)(sync + 2); for (int i = 0; i < 10; ++i) o[i] = (double)st_acc[i] / (iter > 0 ? iter : 1); }
-#endif
 
     // ---- results: the solution and the state (workgroup 0); the barrier counter is re-armed by the last one out
     for (int i = tid; i < ni; i += CGR_THREADS) x_t[i0 + i] = xts[i];

@@ -3,11 +3,6 @@
 #pragma once
 #include "vican_sweep_common.h"
 
-#ifndef CSTAMP0
-#define CSTAMP0() do {} while (0)
-#define CSTAMP(i) do {} while (0)
-#endif
-
 template <int EPL>
 struct CgWRegs { double w[EPL]; uint32_t id[EPL]; };
 
@@ -35,11 +30,6 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
     __shared__ double red[16];
     __shared__ int s_ticket;
     if (st->done) return;
-#ifdef VICAN_CGWSTAMP
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = 0;
-    int n_done = 0;
-#endif
     const int C = g.n_cam, ncopy = g.n_copy, cmask = ncopy - 1, RW = g.max_rows;
     const int tid = threadIdx.x, lane = tid & 63, lane_copy = lane & cmask;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,28 +103,12 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
     // k + NW (row bounds `vnext`, loaded a body ago) and the row bounds of chunk k + 2 NW (returned)
     auto body = [&](CgWRegs<EPL>& cur, CgWRegs<EPL>& nxt, RowVals& rv, RowVals& rvn, const int2 vrow, const int2 vnext, const int k_next,
                     const int k_after) -> int2 {
-        CSTAMP0();
         const int r0 = __builtin_amdgcn_readfirstlane(vrow.x), n3 = 3 * (__builtin_amdgcn_readfirstlane(vrow.y) - r0);
         const int2 vnn = load_rows(k_after);
         load_rowvals(rvn, vnext);
         __builtin_amdgcn_sched_barrier(0);
         load_edges(nxt, k_next);
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
-#pragma unroll
-        for (int t = 0; t < TRIPS; ++t) asm volatile("" :: "v"(rv.p[t]), "v"(rv.r[t]), "v"(rv.d[t]));
-        return vnn;
-#endif
-        CSTAMP(0);                      // row bounds (a wait), issue of the prefetches
-#ifdef VICAN_CGWSTAMP                   /* wait for this chunk's data here so that the wait is booked separately */
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
-#pragma unroll
-        for (int t = 0; t < TRIPS; ++t) asm volatile("" :: "v"(rv.p[t]), "v"(rv.r[t]), "v"(rv.d[t]));
-        CSTAMP(1);
-        ++n_done;
-#endif
+        // row bounds (a wait), issue of the prefetches
         if (n3 == 3) {
             // ONE row in the chunk (dense rows: every lane's slots belong to it): no LDS staging, no row accumulators, no fold -
             // lanes 0..2 hold p / r / deg of the row's three components, the row sum sum_c w p_c is a wave reduction of the
@@ -142,7 +116,6 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
             const double pn = upd ? mul_add_2r(beta, rv.p[0], rv.r[0]) : rv.p[0];
             if (upd && lane < 3) p_t[(size_t)r0 * 3 + lane] = pn;
             const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
-            CSTAMP(2);
             uint32_t cam[EPL];
             double wj[EPL], acc[3] = {0, 0, 0};
 #pragma unroll
@@ -168,8 +141,6 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
                 q_t[(size_t)r0 * 3 + lane] = qv;
                 pq += pn * qv;
             }
-            CSTAMP(3);
-            CSTAMP(4);
             return vnn;
         }
         // commit this chunk's rows: p (updated), deg p into the wavefront's staging; the updated p back to memory
@@ -183,7 +154,7 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
             }
         }
         __builtin_amdgcn_wave_barrier();
-        CSTAMP(2);                      // commit
+        // commit
         // edges.  LDS operations of a wavefront return in order, so a read issued after an atomic waits for it: all the
         // reads of the lane's EPL edges first (camera values; the row's p where the row changes), then the arithmetic,
         // then nothing but atomics - camera contributions one by one, same-row contributions of a lane pre-summed.
@@ -227,20 +198,10 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
         for (int j = 0; j < EPL; ++j) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
-                asm volatile("" :: "v"(fc[j][i].hi), "v"(fc[j][i].lo));
-#else
                 lds_add_fix(&qc[i * CP + cam[j]], fc[j][i].hi);
-#if !defined(VICAN_CGWABLATE) || VICAN_CGWABLATE != 3     /* 3: hi words only (cost of the second word) */
                 lds_add_fix(&qc[lo_c + i * CP + cam[j]], fc[j][i].lo);
-#endif
-#endif
             }
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 4      /* no row atomics (upper bound of a register-resident row side) */
-            if (false) {
-#else
             if (j == EPL - 1 || row[j] != row[j + 1]) {
-#endif
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const Fix2 f = to_fix2(ar[j][i], scale, lo_scale);
@@ -250,15 +211,10 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
             }
         }
         __builtin_amdgcn_wave_barrier();
-        CSTAMP(3);                      // edges
+        // edges
         // fold this chunk's row sums (exact integer sums of the stripes), q_t, p.q: one lane per (item, stripe) word,
         // the n_copy words of an item summed across neighbouring lanes
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 4
-        if (lane < n3) { const double qv = dps[lane] - ar[EPL - 1][0]; q_t[(size_t)r0 * 3 + lane] = qv; pq += pts[lane] * qv; }
-        for (int base = 0; false && base < n3 * ncopy; base += 64) {
-#else
         for (int base = 0; base < n3 * ncopy; base += 64) {
-#endif
             const int a = base + lane;
             const bool live = a < n3 * ncopy;
             u64 sum = 0ull, slo = 0ull;
@@ -276,12 +232,9 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
             }
         }
         __builtin_amdgcn_wave_barrier();
-        CSTAMP(4);                      // fold
+        // fold
         return vnn;
     };
-#ifdef VICAN_CGWSTAMP
-    const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
-#endif
     auto draw = [&]() -> int {
         int t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -299,21 +252,10 @@ __device__ __forceinline__ void cg_wsweep_impl(const vican_graph_t& g, const dou
         // rotate the row-bound registers: (v0, v1, v2) hold the bounds of (kb, -, k) -> bring them back to (k, kb)
         const int2 tmp = v0; v0 = v2; v1 = tmp;
     }
-#ifdef VICAN_CGWSTAMP
-    const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
-#endif
     __syncthreads();
     for (int pl = 0; pl < 6; ++pl)                             // the slab keeps planes of stride C ([2][3][C]: cg_fold_kernel)
         for (int i = tid; i < C; i += NW * 64) qc_part[((size_t)wg * 6 + pl) * C + i] = qc[pl * CP + i];
     const double t = block_sum(pq, red);
     if (tid == 0 && !partial) pq_part[wg] = t;
-#ifdef VICAN_CGWSTAMP
-    if (lane == 0 && cgw_stamp_buf) {
-        double* o = cgw_stamp_buf + ((size_t)wg * NW + wave) * 10;
-        o[0] = (double)rt_begin; o[1] = (double)rt_loop0; o[2] = (double)rt_loop1; o[3] = (double)__builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 5; ++i) o[4 + i] = (double)st_acc[i];
-        o[9] = (double)n_done;
-    }
-#endif
 }
 

@@ -55,7 +55,7 @@ static inline int64_t rhs_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_c
 // (double-word camera sums [2][3][C] + p_c planes; double-buffered double-word row stripes + two staging arrays)
 static inline int64_t cg_lds_bytes(int32_t n_cam, int32_t max_rows, int32_t n_copy) { return 72LL * n_cam + (int64_t)max_rows * (96LL * n_copy + 96) + 256; }
 // ---------------------------------------------------------------------------
-// Grid barriers of the cooperative kernels (lanczos_cam_coop_kernel, cg_resident_kernel, lanczos_resident_kernel)
+// Grid barriers of the cooperative kernels (lanczos_cam_coop_kernel, cg_resident_kernel, tiled_sweep_kernel)
 // ---------------------------------------------------------------------------
 // These kernels spin on a device counter, which only terminates if every workgroup of the grid is resident.  Three
 // layers make that safe:

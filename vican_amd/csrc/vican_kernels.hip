@@ -629,13 +629,6 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
     __shared__ long long zred[8][9 * COOP_CAMS];         // slab fold (zpart != NULL): partial sums of 8 slab groups
     __shared__ double zl[9 * COOP_CAMS];                 // ... and this workgroup's rows of z
     const int nwg = (int)gridDim.x, wg = (int)blockIdx.x, tid = threadIdx.x;
-#ifdef COOP_STAMP
-    unsigned long long ts[12]; int nts = 0;
-#define CSTAMP() do { if (nts < 12) ts[nts++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CSTAMP() do {} while (0)
-#endif
-    CSTAMP();
     const int ka = 3 * (j + 1), hs = 3 * ka;
     const int c0 = (int)(((long long)wg * n_cam) / nwg), c1 = (int)(((long long)(wg + 1) * n_cam) / nwg);
     const int row0 = 3 * c0, nsl = 3 * (c1 - c0);
@@ -703,11 +696,8 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
     for (int pass = 0; pass < 2; ++pass) {
         double* part = pass ? part2 : part1;
         double* hh = pass ? h2 : h;
-        CSTAMP();
         coop_gram(vs, ka, nsl, rs, part, nwg, wg);
-        CSTAMP();
         if (!vican_grid_sync(sy, (unsigned)((pass + 1) * nwg), fenced != 0)) return;
-        CSTAMP();
         coop_reduce(part, hs, nwg, stage, hh);
         if (tid < nsl) {
             double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
@@ -735,9 +725,7 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         __syncthreads();
         if (tid < 6) st_agent(partG + (size_t)tid * nwg + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
     }
-    CSTAMP();
     if (!vican_grid_sync(sy, (unsigned)(3 * nwg), fenced != 0)) return;
-    CSTAMP();
     coop_reduce(partG, 6, nwg, stage, G6s);
     // upper Cholesky G = beta^T beta, Q = R beta^-1  (same pivot rule as chol_qr3_kernel)
     const double g00 = G6s[0], g01 = G6s[1], g02 = G6s[2], g11 = G6s[3], g12 = G6s[4], g22 = G6s[5];
@@ -760,14 +748,6 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         V[(size_t)col0 * ld + i] = q0; V[(size_t)(col0 + 1) * ld + i] = q1; V[(size_t)(col0 + 2) * ld + i] = q2;
         x_out[(size_t)i * 3] = q0; x_out[(size_t)i * 3 + 1] = q1; x_out[(size_t)i * 3 + 2] = q2;
     }
-#ifdef COOP_STAMP
-    CSTAMP();
-    if (wg == 3 && tid == 0) {
-        printf("COOP j=%d ticks(10ns):", j);
-        for (int i = 1; i < nts; ++i) printf(" %llu", ts[i] - ts[i - 1]);
-        printf("\n");
-    }
-#endif
     // the last workgroup out re-arms the barrier counter for the next launch
     if (tid == 0 && __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nwg - 1u) {
         __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1021,13 +1001,6 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
     __shared__ int s_fast;
     __shared__ double s_tau, s_gl, s_gu, s_piv;
     if (tid == 0) s_fast = 0;
-#ifdef RITZ_STAMP       /* diagnostic build: 100 MHz ticks per phase -> Y behind the Ritz vectors (tools/ritz_bench.py --stamp) */
-    unsigned long long rst_t = __builtin_amdgcn_s_memrealtime();
-    int rst_n = 0;
-#define RSTAMP() do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (tid == 0 && rst_n < 8) Y[9 * steps + rst_n] = (double)(t_ - rst_t); ++rst_n; rst_t = t_; } while (0)
-#else
-#define RSTAMP() do {} while (0)
-#endif
     if (n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX && fast_lds) {
         double* fd = (double*)((((size_t)(cs + 2 * half)) + (size_t)half * sizeof(int) + 15) & ~(size_t)15);
         double* fe = fd + N; double* fe2 = fe + N; double* fv = fe2 + N; double* fp = fv + N; double* fg = fp + N;
@@ -1093,7 +1066,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
             }
             __syncthreads();
         }
-        RSTAMP();       // 0: tridiagonalisation
+        // 0: tridiagonalisation
         if (tid == 0) {
             fd[n - 2] = A[(n - 2) * ld + n - 2]; fe[n - 2] = A[(n - 1) * ld + n - 2];
             fd[n - 1] = A[(n - 1) * ld + n - 1]; fe[n - 1] = 0.0;
@@ -1117,7 +1090,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
             }
         }
         __syncthreads();
-        RSTAMP();       // 1: Gershgorin
+        // 1: Gershgorin
         auto small_solve = [&](auto ns_) {                  // NS register slots per lane: 1 for n <= 64, 2 up to 128
             constexpr int NS = decltype(ns_)::value;
         {   // bisection, 64 trial shifts per round: a wavefront per wanted eigenvalue
@@ -1143,7 +1116,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
             }
         }
         __syncthreads();
-        RSTAMP();       // 2: bisection
+        // 2: bisection
         // inverse iteration for the three smallest pairs (dlagtf / dlagts: LU with partial pivoting of T - theta I), one
         // wavefront per pair, element i of every array in the REGISTERS of lane i % 64 (slot i / 64): the serial recurrences
         // read their operands with v_readlane and write back under a lane predicate - no memory latency in the chain
@@ -1232,7 +1205,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
         }
         };
         if (n <= 64) small_solve(std::integral_constant<int, 1>()); else small_solve(std::integral_constant<int, 2>());
-        RSTAMP();       // 3: inverse iteration
+        // 3: inverse iteration
         // back-transformation y = Q z, then validation against T itself
         for (int idx = tid >> 3; idx < 3 * n; idx += B >> 3) {
             const int k = idx / n, i = idx - k * n;
@@ -1278,7 +1251,7 @@ __global__ __launch_bounds__(1024) void ritz_kernel(const double* __restrict__ H
             s_fast = ok ? 1 : 0;
         }
         __syncthreads();
-        RSTAMP();       // 4: back-transformation + validation
+        // 4: back-transformation + validation
         if (s_fast) {
             // hand the result to the common tail in the Jacobi layout: eigenvalue k on the diagonal, its vector in column k
             for (int idx = tid; idx < 3 * n; idx += B) { const int k = idx / n, i = idx - k * n; V[i * ld + k] = ys[k * N + i]; }
@@ -1402,9 +1375,7 @@ extern "C" int vican_ritz(const double* HB, int32_t row_stride, int32_t hw, int3
         return set_err(VICAN_ERR_ARG, "vican_ritz: bad argument");
     const int n = 3 * steps, N = n + (n & 1), ld = N | 1, half = N / 2;
     size_t lds = ((size_t)2 * N * ld + 2 * half) * sizeof(double) + (size_t)half * sizeof(int) + 16;
-    static int fast_env = -1;
-    if (fast_env < 0) { const char* e = getenv("VICAN_RITZ_FAST"); fast_env = (e && e[0] == '0') ? 0 : 1; }
-    const int fast_lds = fast_env && n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX;     // workspace of the tridiagonalisation path
+    const int fast_lds = n >= RITZ_FAST_NMIN && n <= RITZ_FAST_NMAX;     // workspace of the tridiagonalisation path
     if (fast_lds) lds += ((size_t)12 * N + 8) * sizeof(double) + 32;   // d, e, e^2, v, p, g, 8 eigenvalues, z[3], y[3]
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {

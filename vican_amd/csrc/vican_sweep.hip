@@ -567,13 +567,11 @@ extern "C" int vican_pack_edges(const vican_graph_t* g, const int32_t* row_ptr, 
     dim3 grid((g->slots + 255) / 256, g->n_chunk), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int epl = (g->storage == VICAN_STORE_F32) ? 4 : 2;
-    static const int wave1 = getenv("VICAN_SLOT_WAVE1") ? atoi(getenv("VICAN_SLOT_WAVE1")) : 1;     // (0: A/B against the class order)
-    static const int rows_greedy = getenv("VICAN_SLOT_ROWS_GREEDY") ? atoi(getenv("VICAN_SLOT_ROWS_GREEDY")) : 1;     // (0: plain CSR order)
-    if (g->slot_order == 1 && rows_greedy && g->layout == VICAN_LAYOUT_WAVE && g->slots == 64 * epl)
+    if (g->slot_order == 1 && g->layout == VICAN_LAYOUT_WAVE && g->slots == 64 * epl)
         hipLaunchKernelGGL(plan_slots_rows_greedy_kernel, dim3((g->n_chunk + 63) / 64), dim3(64), 0, st, *g, row_ptr, col, perm_ws, epl);
     else if (g->slot_order == 1)
         hipLaunchKernelGGL(plan_slots_rows_kernel, grid, block, 0, st, *g, row_ptr, perm_ws);
-    else if (wave1 && g->layout == VICAN_LAYOUT_WAVE && g->n_chunk == g->n_time && g->slots == 64 * epl)
+    else if (g->layout == VICAN_LAYOUT_WAVE && g->n_chunk == g->n_time && g->slots == 64 * epl)
         hipLaunchKernelGGL(plan_slots_wave1_kernel, dim3((g->n_chunk + 63) / 64), dim3(64), 0, st, *g, row_ptr, col, perm_ws, epl);
     else
         hipLaunchKernelGGL(plan_slots_kernel, dim3(g->n_chunk), dim3(64), (size_t)g->slots * 4, st, *g, row_ptr, col, perm_ws, epl);
@@ -869,10 +867,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                                                             const double* __restrict__ rnorm,
                                                             double* __restrict__ fx) {
     GATE_RETURN(gate);
-#ifdef VICAN_STAMP
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
-    unsigned long long rt_loop0 = 0, rt_loop1 = 0;
-#endif
     constexpr int EPL = Vec<S>::N;
     constexpr int NWAVE = BLOCK / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -959,22 +953,10 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
     if ((MODE == 0 || MODE == 2) && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;       // omega bound: raised by dual_svd_kernel afterwards
 
-#ifdef VICAN_STAMP
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t;
-#define STAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP0() do {} while (0)
-#define STAMP(i) do {} while (0)
-#endif
     // Register ring: DEPTH chunks in flight ahead of the one being processed.  512-thread workgroups
     // have 256 VGPRs per lane and keep two chunks in flight (the memory system then always has work
     // from this CU); 768/1024-thread workgroups only have room for one.
 
-    STAMP0();
-#ifdef VICAN_STAMP
-    rt_loop0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // body: process chunk k (registers `cur`), prefetch chunk kpref into `nxt`, draw the ticket for the chunk
     // the NEXT body will prefetch; returns that chunk index (>= nchunk: nothing left / cap reached)
     auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int k, const int kpref) -> int {
@@ -1003,20 +985,7 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         //      then ONE striped fixed-point atomic group per (lane,row).  Padding slots carry zero
         //      blocks and are processed like edges of (row 0, camera lane%32): no branches; the
         //      x gather of edge j+1 is in flight while edge j is multiplied.
-#if defined(VICAN_ABLATE) && VICAN_ABLATE == 3      /* loads only: pure streaming rate of this access pattern */
-        {
-            float keep = 0.f;
-#pragma unroll
-            for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
-            if (keep == 123.456f && cur.id[0] == 77u) zs[0] = 1ull;
-            if (tid == 0) s_knext = taken < cap ? (DEPTH + 1) * nwg + (int)ticket : 0x7fffffff;
-            __syncthreads();
-            const int kn_ = __builtin_amdgcn_readfirstlane(s_knext);
-            __syncthreads();
-            return kn_;
-        }
-#endif
-        STAMP(5);                       // inter-chunk prologue: descriptors, dual loads, prefetch issue
+        // inter-chunk prologue: descriptors, dual loads, prefetch issue
         uint32_t cam[EPL], row[EPL];
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
@@ -1055,13 +1024,13 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                 }
             }
         }
-        STAMP(0);                       // phase 1 (incl. waiting for this chunk's loads)
+        // phase 1 (incl. waiting for this chunk's loads)
         if (tid == 0) s_knext = taken < cap ? (DEPTH + 1) * nwg + (int)ticket : 0x7fffffff;
         __syncthreads();
         // read between the two barriers of this body (rewritten after the second); wave-uniform -> scalar register,
         // so that the chunk addresses derived from it are scalar arithmetic
         const int knew = __builtin_amdgcn_readfirstlane(s_knext);
-        STAMP(1);                       // barrier A
+        // barrier A
 
         // ---- phase 2: one wavefront per row: fold the striped copies (exact integer sum, copy index
         //      rotated by the accumulator index => distinct banks), re-zero them, then
@@ -1161,9 +1130,9 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
             }
         }
         // all rows folded and re-zeroed before anyone starts the next phase 1 / reads w
-        STAMP(2);                       // phase 2
+        // phase 2
         __syncthreads();
-        STAMP(3);                       // barrier B
+        // barrier B
         if (HAS_Z) {
             // ---- phase 3: z_cam += M w_row   (blocks still in registers: read from HBM once)
             S w[9];
@@ -1185,17 +1154,11 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
                     for (int b = 0; b < 3; ++b) {
                         const S v = dot3<S>(vget<S>(cur.m[i * 3 + 0], j), w[b], vget<S>(cur.m[i * 3 + 1], j), w[3 + b],
                                             vget<S>(cur.m[i * 3 + 2], j), w[6 + b]);
-#if defined(VICAN_ABLATE) && VICAN_ABLATE == 1      /* no phase-3 atomics */
-                        asm volatile("" :: "v"(v));
-#elif defined(VICAN_ABLATE) && VICAN_ABLATE == 2    /* phase-3 atomics without the products */
-                        lds_add_fix(&zc[(i * 3 + b) * CP], (u64)(camj + i));
-#else
                         lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
-#endif
                     }
             }
         }
-        STAMP(4);                       // phase 3
+        // phase 3
         // (the barrier after the next chunk's phase 1 separates this chunk's phase 3 reads of wv
         //  from the next phase 2 writes; ys is already re-zeroed for the next phase 1)
         return knew;
@@ -1229,11 +1192,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sched[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#ifdef VICAN_STAMP
-    rt_loop1 = __builtin_amdgcn_s_memrealtime();
-    if (MODE == 0 && Rt_out && (tid == 0 || tid == BLOCK - 64))
-        for (int i = 0; i < 6; ++i) Rt_out[((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 6 + i] = (double)st_acc[i];
-#endif
     if (HAS_Z) {
         __syncthreads();
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout stays [9][C]
@@ -1241,12 +1199,6 @@ __global__ __launch_bounds__(BLOCK) void block_sweep_kernel(const int32_t* __res
         for (int q = 0; q < 9; ++q)
             for (int c = tid; c < C; c += BLOCK) zp[q * C + c] = (u64)fix_total<S>((long long)zs[q * CP + c]);
     }
-#ifdef VICAN_STAMP
-    if (MODE == 0 && Rt_out && tid == 0) {                 // wall-clock structure of the launch, per workgroup
-        double* w = Rt_out + 4096 * 12 + (size_t)blockIdx.x * 4;
-        w[0] = (double)rt_begin; w[1] = (double)rt_loop0; w[2] = (double)rt_loop1; w[3] = (double)__builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 #endif  // hot kernel
@@ -1370,50 +1322,11 @@ extern "C" int vican_block_op(const vican_graph_t* g, const double* lamT_inv, co
                               double* fx, void* stream) {
     if (int rc = vican_check_graph(g, "vican_block_op")) return rc;
     if (!lamT_inv || !x || !zpart || !fx) return set_err(VICAN_ERR_ARG, "vican_block_op: null pointer");
-#ifdef VICAN_STAMP
-    static double* stamp_buf = nullptr;                 // diagnostic builds only: per-workgroup phase cycles
-    if (!stamp_buf) hipMalloc(&stamp_buf, 4096 * 16 * sizeof(double));
-    if (int rc = dispatch_sweep<0>(g, lamT_inv, x, (u64*)zpart, stamp_buf, nullptr, nullptr, fx, stream)) return rc;
-    if (getenv("VICAN_STAMP_DUMP")) {
-        hipStreamSynchronize((hipStream_t)stream);
-        static double host[4096 * 12];
-        hipMemcpy(host, stamp_buf, sizeof(double) * g->n_wg * 12, hipMemcpyDeviceToHost);
-        double sum[2][6] = {{0}};
-        for (int w = 0; w < g->n_wg; ++w) for (int h = 0; h < 2; ++h) for (int i = 0; i < 6; ++i) sum[h][i] += host[(w * 2 + h) * 6 + i];
-        {   // wall-clock structure of the launch (100 MHz ticks -> us), over workgroups
-            static double rt[4096 * 4];
-            hipMemcpy(rt, stamp_buf + 4096 * 12, sizeof(double) * g->n_wg * 4, hipMemcpyDeviceToHost);
-            double b0 = 1e300, b1 = 0, l0min = 1e300, l0max = 0, l1min = 1e300, l1max = 0, emax = 0, pro = 0, loop = 0, epi = 0;
-            for (int w = 0; w < g->n_wg; ++w) {
-                const double* r = rt + w * 4;
-                b0 = fmin(b0, r[0]); b1 = fmax(b1, r[0]); l0min = fmin(l0min, r[1]); l0max = fmax(l0max, r[1]);
-                l1min = fmin(l1min, r[2]); l1max = fmax(l1max, r[2]); emax = fmax(emax, r[3]);
-                pro += r[1] - r[0]; loop += r[2] - r[1]; epi += r[3] - r[2];
-            }
-            fprintf(stderr, "WALL us: first start 0, last start %.2f | loop start %.2f..%.2f | loop end %.2f..%.2f | last end %.2f | mean prologue %.2f loop %.2f epilogue %.2f\n",
-                    (b1 - b0) / 100, (l0min - b0) / 100, (l0max - b0) / 100, (l1min - b0) / 100, (l1max - b0) / 100, (emax - b0) / 100,
-                    pro / g->n_wg / 100, loop / g->n_wg / 100, epi / g->n_wg / 100);
-        }
-        for (int h = 0; h < 2; ++h)
-            fprintf(stderr, "STAMP wave%s: prologue %.0f phase1 %.0f barA %.0f phase2 %.0f barB %.0f phase3 %.0f  (mean cycles per workgroup)\n",
-                    h ? "-last" : "0", sum[h][5] / g->n_wg, sum[h][0] / g->n_wg, sum[h][1] / g->n_wg, sum[h][2] / g->n_wg, sum[h][3] / g->n_wg, sum[h][4] / g->n_wg);
-    }
-#else
     if (int rc = sweep_any<0>(g, lamT_inv, x, (u64*)zpart, nullptr, nullptr, nullptr, fx, stream)) return rc;
-#endif
     LAUNCH_CHECK("vican_block_op");
     return VICAN_OK;
 }
 
-#ifdef VICAN_WSTAMP
-// diagnostic builds only (tools/wsweep_time.py --stamp): the wave sweep with its wall-clock stamps -> stamp_out
-extern "C" int vican_block_op_stamp(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx,
-                                    double* stamp_out, void* stream) {
-    if (int rc = vican_check_graph(g, "vican_block_op_stamp")) return rc;
-    if (g->layout != VICAN_LAYOUT_WAVE) return set_err(VICAN_ERR_ARG, "vican_block_op_stamp: wave layout only");
-    return vican_wsweep(0, g, lamT_inv, x, (u64*)zpart, stamp_out, fx, stream);
-}
-#endif
 
 // Both halves of R~ [x_cam; x_time] (non-eliminated solver): y_time[t] = sum_c M_ct^T x_cam[c] (exact fixed-point
 // row sums -> f64), z_cam = slab-reduced sum_t M_ct x_time[t].  fx must hold the scales of vican_bip_scales.

@@ -7,7 +7,6 @@
 // grid - the same device function (cg_wsweep_impl, vican_cgw_impl.h) in its `partial` mode, one launch.
 // The tiles' descriptors travel BY VALUE in the kernel arguments (up to four): pointers that reach a kernel through memory are
 // generic pointers to the compiler and every access through them a FLAT instruction (vican_tsweep.hip).
-#undef VICAN_CGWSTAMP
 #include "vican_cgw_impl.h"
 
 struct tcg_tile_t { vican_graph_t g; const double* w; const double* p_c; double* acc_t; u64* qc_part; };

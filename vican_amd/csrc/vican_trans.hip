@@ -329,14 +329,7 @@ __device__ __forceinline__ void cg_close_iteration(const double* __restrict__ rr
 // into registers before the first use: same expressions, same per-thread order of the floating-point sums, same bits.
 // ---------------------------------------------------------------------------
 #define CG_CAMK 12
-template <bool HANDOVER>
-__device__ __forceinline__ double cg_ld(const double* p) {      // HANDOVER: written by ANOTHER workgroup of this launch (sc1 store)
-    if (HANDOVER) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-__device__ __forceinline__ void cg_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // this thread's part of p_c . q_c, q_c = deg_c p_c - qc  (cg_cam_step / cg_step / cg_fold2)
-template <bool QC_HANDOVER>
 __device__ __forceinline__ double cg_cam_dot(int nc, const double* __restrict__ deg_c, const double* __restrict__ p_c, const double* qc) {
     double s = 0.0;
     for (int base = 0; base < nc; base += 256 * CG_CAMK) {
@@ -345,7 +338,7 @@ __device__ __forceinline__ double cg_cam_dot(int nc, const double* __restrict__ 
         for (int k = 0; k < CG_CAMK; ++k) {
             const int i = base + (int)threadIdx.x + 256 * k;
             const bool in = i < nc;
-            pv[k] = in ? p_c[i] : 0.0; dv[k] = in ? deg_c[i / 3] : 0.0; qv[k] = in ? cg_ld<QC_HANDOVER>(qc + i) : 0.0;
+            pv[k] = in ? p_c[i] : 0.0; dv[k] = in ? deg_c[i / 3] : 0.0; qv[k] = in ? qc[i] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < CG_CAMK; ++k) {
@@ -355,9 +348,7 @@ __device__ __forceinline__ double cg_cam_dot(int nc, const double* __restrict__ 
     }
     return s;
 }
-// x_c += alpha p_c, r_c -= alpha q_c; this thread's parts of r_c . r_c and max |r_c|.  RC_HANDOVER: r_c is stored for another
-// workgroup of this launch (cg_step2: the next iteration's head runs in whichever workgroup finishes last)
-template <bool RC_HANDOVER>
+// x_c += alpha p_c, r_c -= alpha q_c; this thread's parts of r_c . r_c and max |r_c|
 __device__ __forceinline__ void cg_cam_update(int nc, double alpha, const double* __restrict__ deg_c, const double* __restrict__ qc,
                                               const double* __restrict__ p_c, double* x_c, double* r_c, double& rr, double& mx) {
     for (int base = 0; base < nc; base += 256 * CG_CAMK) {
@@ -376,7 +367,7 @@ __device__ __forceinline__ void cg_cam_update(int nc, double alpha, const double
                 const double q = dv[k] * p - qv[k];
                 x_c[i] = mul_add_2r(alpha, p, xv[k]);
                 const double r = mul_add_2r(-alpha, q, rv[k]);
-                if (RC_HANDOVER) cg_st(&r_c[i], r); else r_c[i] = r;
+                r_c[i] = r;
                 rr += r * r; mx = fmax(mx, fabs(r));
             }
         }
@@ -385,17 +376,13 @@ __device__ __forceinline__ void cg_cam_update(int nc, double alpha, const double
 
 // top of an iteration: (optionally close the previous one), convergence test, beta, p_c update,
 // and the fixed-point scale of this iteration's sweep from the running bound on max|p|
-// HANDOVER: the body runs in the LAST workgroup of the launch that produced rr_part, r_c and st->rr_cam (cg_step2_kernel):
-// those were stored with agent-scope (sc1) stores and are read here with agent-scope loads - a workgroup's vector L1 is never
-// refreshed by another workgroup's stores.  Same thread mapping, same summation orders, same bits as the stand-alone kernel.
-template <bool HANDOVER>
 __device__ __forceinline__ void cg_begin_body(int n_cam, const double* __restrict__ r_c, double* p_c, double rtol,
                                               const double* __restrict__ rr_part, int n_part, double n_add, vican_cg_state_t* st,
-                                              double* red /* [8] */, double* sh_beta, int* sh_go, const double* hand = nullptr) {
+                                              double* red /* [8] */, double* sh_beta, int* sh_go) {
     // close the previous iteration: fixed-order block reduction of the partials (sum, max |r_t|, max |p_t|)
     double ps = 0.0, pm = 0.0, pp = 0.0;
     for (int i = threadIdx.x; i < n_part; i += 256) {
-        ps += cg_ld<HANDOVER>(rr_part + i); pm = fmax(pm, cg_ld<HANDOVER>(rr_part + CG_PARTS + i)); pp = fmax(pp, cg_ld<HANDOVER>(rr_part + 2 * CG_PARTS + i));
+        ps += rr_part[i]; pm = fmax(pm, rr_part[CG_PARTS + i]); pp = fmax(pp, rr_part[2 * CG_PARTS + i]);
     }
     const double tsum = block_sum(ps, red);
 #pragma unroll
@@ -409,9 +396,6 @@ __device__ __forceinline__ void cg_begin_body(int n_cam, const double* __restric
             st->pmax_time = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
             st->iter += 1; st->rho_prev = st->rho; st->first = 0;
         }
-        // (HANDOVER: r_c.r_c and max |r_c| of the camera workgroup arrive in words of their own - the state's cache lines
-        //  were read with plain loads at the top of the launch and may sit, stale, in this XCD's L2)
-        if (HANDOVER) { st->rr_cam = cg_ld<true>(hand); st->rmax_cam = cg_ld<true>(hand + 1); }
         const double rho = st->rr_cam + st->rr_time;
         if (st->iter == 0 && st->first) { st->bnorm2 = rho; st->atol2 = rtol * rtol * rho; }
         st->rho = rho;
@@ -434,7 +418,7 @@ __device__ __forceinline__ void cg_begin_body(int n_cam, const double* __restric
         for (int k = 0; k < CG_CAMK; ++k) {
             const int i = base + (int)threadIdx.x + 256 * k;
             const bool in = i < 3 * n_cam;
-            pv[k] = in ? p_c[i] : 0.0; rv[k] = (in && go) ? cg_ld<HANDOVER>(r_c + i) : 0.0;
+            pv[k] = in ? p_c[i] : 0.0; rv[k] = (in && go) ? r_c[i] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < CG_CAMK; ++k) {
@@ -475,7 +459,7 @@ __global__ __launch_bounds__(256) void cg_begin_kernel(int n_cam, const double* 
     __shared__ int sh_go;
     __shared__ double red[8];
     if (st->done) return;
-    cg_begin_body<false>(n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, red, &sh_beta, &sh_go);
+    cg_begin_body(n_cam, r_c, p_c, rtol, rr_part, n_part, n_add, st, red, &sh_beta, &sh_go);
 }
 extern "C" int vican_cg_begin(int32_t n_cam, const double* r_c, double* p_c, double rtol, const double* rr_part,
                               int32_t n_part, double n_add, vican_cg_state_t* st, void* stream) {
@@ -780,7 +764,7 @@ __global__ __launch_bounds__(256) void cg_cam_step_kernel(int n_cam, const doubl
     __shared__ double sh_alpha;
     if (st->done) return;
     const int n = 3 * n_cam;
-    const double s = cg_cam_dot<false>(n, deg_c, p_c, qc_sum);
+    const double s = cg_cam_dot(n, deg_c, p_c, qc_sum);
     const double pqc = block_sum(s, red);
     if (threadIdx.x == 0) {
         const double pq = *pq_time + pqc;
@@ -792,7 +776,7 @@ __global__ __launch_bounds__(256) void cg_cam_step_kernel(int n_cam, const doubl
     __syncthreads();
     const double alpha = sh_alpha;
     double rr = 0.0, m = 0.0;
-    cg_cam_update<false>(n, alpha, deg_c, qc_sum, p_c, x_c, r_c, rr, m);
+    cg_cam_update(n, alpha, deg_c, qc_sum, p_c, x_c, r_c, rr, m);
     const double t = block_sum(rr, red);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
@@ -862,7 +846,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     __shared__ double sh_alpha;
     if (st->done) return;
     const int nc = 3 * n_cam;
-    const double s = cg_cam_dot<false>(nc, deg_c, p_c, qc_sum);
+    const double s = cg_cam_dot(nc, deg_c, p_c, qc_sum);
     const double pqc = block_sum(s, red);
     if (threadIdx.x == 0) {
         const double pq = *pq_time + pqc;
@@ -894,7 +878,7 @@ __global__ __launch_bounds__(256) void cg_step_kernel(int n_cam, long long n, co
     return;
     }
     double rc2 = 0.0, mc = 0.0;
-    cg_cam_update<false>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);
+    cg_cam_update(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);
     const double tc = block_sum(rc2, red);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
@@ -1195,43 +1179,20 @@ extern "C" int vican_cg_fold_tiles(const void* const* qc_parts, const int32_t* n
 }
 
 // ---------------------------------------------------------------------------
-// Single-rank iteration in THREE launches instead of four (begin, sweep, fold, step), bit-reproducible from run to run:
+// Single-rank iteration behind one host call (begin, sweep, fold, step), bit-reproducible from run to run:
 //   sweep                      (unchanged)
 //   cg_fold2  = cg_fold + partials of p_t.q_t over FIXED slices (the sweep's own partial depends on the order in which its
 //               wavefronts drew their chunk tickets: the only sum of the iteration that was not reproducible)
-//   cg_step2  = cg_step (alpha by every workgroup for itself) + cg_begin of the NEXT iteration by the workgroup that finishes last
+//   cg_step2  = cg_step with alpha from those slices (by every workgroup for itself)
 // Measured on the stress graph (profiles/r05_cg_tail.txt): the tail kernels are bound by their own dependent memory round
-// trips, not by launch gaps (1.3 us each) - a first version that also formed alpha once, in the fold's last workgroup, was
-// SLOWER (fold 9.7 -> 14.7 us, and nothing of the step's 10 us went away); what made the tail shorter was staging the
-// camera-side loops (cg_cam_dot / cg_cam_update: cg_begin 9.4 -> 8.2 us, cg_step 13.3 -> 10.6 us).
-// No workgroup ever waits for another one (no spin, nothing to co-schedule): the hand-over goes to whoever draws the last
-// ticket.  What crosses workgroups inside a launch travels as agent-scope (sc1) stores, every storing wave drains its stores
-// (s_waitcnt vmcnt(0)) in front of the workgroup barrier that precedes the ticket, and the last workgroup reads with
-// agent-scope loads after its ticket has returned (MI355X guide, inter-workgroup visibility: per-XCD L2s are not coherent,
-// a CU's L1 is never refreshed).  Same thread mappings, summation orders and expressions as the four kernels => same bits
-// (tests/test_kernels_gpu.py::test_fused_cg_iteration_is_bit_identical).
+// trips, not by launch gaps (1.3 us each).  A version in which the step's last workgroup (agent-scope ticket, sc1 hand-over
+// words) also ran the next iteration's head - three launches instead of four - was built in round 5, tested bit-identical, measured
+// SLOWER (the head's 8 us of dependent round trips stay serial behind the last step workgroup, the ticket adds 3 us) and
+// removed in round 6 (tools/lab_patches/cg_handover.patch keeps it).  What made the tail shorter was staging the camera-side
+// loops (cg_cam_dot / cg_cam_update: cg_begin 9.4 -> 8.2 us, cg_step 13.3 -> 10.6 us).
+// Same thread mappings, summation orders and expressions as the four kernels => same bits
+// (tests/test_kernels_gpu.py::test_fused_cg_iteration).
 // ---------------------------------------------------------------------------
-// true in every thread of the workgroup that arrives last; the counter is left at zero for the next launch
-__device__ __forceinline__ bool cg_last_arrival(unsigned int* ticket, unsigned int n_arrive) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's hand-over stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#ifdef VICAN_CG_HAND_RELEASE                                   /* diagnostic: the portable form (agent-scope release / acquire) */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == n_arrive - 1u;
-        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef VICAN_CG_HAND_ACQUIRE
-        if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
 // p_t . q_t is formed HERE, over fixed slices in a fixed order, not taken from the sweep's pq_part: the sweeps hand their chunks
 // to wavefronts by ticket, so which wavefront adds which rows' p q - and with it the last bits of the workgroup's floating-
 // point partial - depends on timing (every other sum of the sweep is an exact integer sum).  4.8 MB of extra reads on the
@@ -1272,17 +1233,13 @@ __global__ __launch_bounds__(1024) void cg_fold2_kernel(const long long* __restr
     }
 }
 
-template <bool HANDOVER>
 __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, const double* __restrict__ deg_c,
                                                        const double* __restrict__ qc_sum, double* p_c, double* x_c, double* r_c,
                                                        const double* __restrict__ p_t, const double* __restrict__ q_t,
                                                        double* __restrict__ x_t, double* __restrict__ r_t, double* rr_part,
                                                        const double* __restrict__ pq_part, int n_pq,
-                                                       double rtol, double n_add, vican_cg_state_t* st, unsigned int* ticket,
-                                                       double* hand, int rr_pad) {
+                                                       vican_cg_state_t* st, int rr_pad) {
     __shared__ double red[8];
-    __shared__ double sh_beta;
-    __shared__ int sh_go;
     if (st->done) return;
     const int nc = 3 * n_cam;
     // (sharded runs all-reduce rr_part[0:rr_pad] element by element: the partials beyond this rank's blocks are zero every time)
@@ -1296,7 +1253,7 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
         for (int k = threadIdx.x; k < n_pq; k += 256) tq += pq_part[k];     // (n_pq <= 192: at most one term per thread)
         __shared__ double pqs[256];
         pqs[threadIdx.x] = tq;
-        const double sdot = cg_cam_dot<false>(nc, deg_c, p_c, qc_sum);
+        const double sdot = cg_cam_dot(nc, deg_c, p_c, qc_sum);
         const double pqc = block_sum(sdot, red);           // (its barriers also publish pqs)
         if (threadIdx.x == 0) {
             double pq_time = 0.0;
@@ -1329,12 +1286,11 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
         __syncthreads();
         if (threadIdx.x == 0) {
             const double rm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), pm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-            if (HANDOVER) { cg_st(&rr_part[blockIdx.x], t); cg_st(&rr_part[CG_PARTS + blockIdx.x], rm); cg_st(&rr_part[2 * CG_PARTS + blockIdx.x], pm); }
-            else { rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = rm; rr_part[2 * CG_PARTS + blockIdx.x] = pm; }
+            rr_part[blockIdx.x] = t; rr_part[CG_PARTS + blockIdx.x] = rm; rr_part[2 * CG_PARTS + blockIdx.x] = pm;
         }
     } else {
         double rc2 = 0.0, mc = 0.0;
-        cg_cam_update<HANDOVER>(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);  // (HANDOVER: r_c is read by whoever runs the head below)
+        cg_cam_update(nc, alpha, deg_c, qc_sum, p_c, x_c, r_c, rc2, mc);
         const double tc = block_sum(rc2, red);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mc = fmax(mc, __shfl_down(mc, o, 64));
@@ -1343,48 +1299,36 @@ __global__ __launch_bounds__(256) void cg_step2_kernel(int n_cam, long long n, c
         __syncthreads();
         if (threadIdx.x == 0) {
             const double rm = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-            if (HANDOVER) { cg_st(hand, tc); cg_st(hand + 1, rm); } else { st->rr_cam = tc; st->rmax_cam = rm; }
+            st->rr_cam = tc; st->rmax_cam = rm;
         }
     }
-    if (!HANDOVER) return;                                 // (the next call's vican_cg_begin closes this iteration)
-    if (!cg_last_arrival(ticket, gridDim.x)) return;
-    // ---- the last workgroup: head of the next iteration (cg_begin with n_part = nb) ----
-    cg_begin_body<true>(n_cam, r_c, p_c, rtol, rr_part, nb, n_add, st, red, &sh_beta, &sh_go, hand);
 }
 
-// One CG iteration of a single rank: [cg_begin (first iteration only)] + sweep + cg_fold2 + cg_step2.  `first` != 0: the
-// call that follows vican_cg_init.  ticket: 1024 zeroed bytes owned by this solve, 128-byte aligned - two 32-bit tickets (left at
-// zero by every launch) on the first cache line, two doubles of hand-over on the second (r_c.r_c, max |r_c|: a line that no
-// plain load ever touches), from byte 256 the fold's partials of p_t.q_t.
+// One CG iteration of a single rank: cg_begin + sweep + cg_fold2 + cg_step2.  `first` != 0: the call that follows
+// vican_cg_init.  ws: 1024 bytes owned by this solve, 8-byte aligned - from byte 256 the fold's partials of p_t.q_t (the first
+// 256 bytes are unused: the hand-over words of round 5's variant lived there).
 // The state after k calls equals the state after k x (vican_cg_iter_local, vican_cg_iter_finish) plus the vican_cg_begin
 // of the next call, bit for bit.
 extern "C" int vican_cg_iter_fused(const vican_graph_t* g, const double* w, const double* deg_t, const double* deg_c,
                                    double* r_c, double* p_c, double* x_c, double* r_t, double* p_t, double* q_t, double* x_t,
                                    void* qc_part, double* pq_part, double* qcpq, double rtol, double* rr_part, int32_t part_cap,
-                                   double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ticket, void* stream) {
-    if (!g || !deg_c || !r_c || !p_c || !x_c || !r_t || !p_t || !q_t || !x_t || !qcpq || !rr_part || part_cap < 3 * CG_PARTS || !st || !ticket)
+                                   double n_add, int32_t first, vican_cg_state_t* st, uint32_t* ws, void* stream) {
+    if (!g || !deg_c || !r_c || !p_c || !x_c || !r_t || !p_t || !q_t || !x_t || !qcpq || !rr_part || part_cap < 3 * CG_PARTS || !st || !ws)
         return set_err(VICAN_ERR_ARG, "vican_cg_iter_fused: bad argument");
     int rc;
     hipStream_t s = (hipStream_t)stream;
     const long long n = 3LL * g->n_time, nc = 3LL * g->n_cam;
     int nb = (int)((n + 1023) / 1024); if (nb < 1) nb = 1; if (nb > CG_PARTS) nb = CG_PARTS;        // as vican_cg_time_step
-    const int handover = first & 2;
-    // the head of this iteration: its own launch - or, with hand-over, already run by the previous call's last workgroup
-    if ((first & 1) || !handover)
-        if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, (first & 1) ? 0 : nb, n_add, st, stream)) < 0) return rc;
+    if ((rc = vican_cg_begin(g->n_cam, r_c, p_c, rtol, rr_part, (first & 1) ? 0 : nb, n_add, st, stream)) < 0) return rc;
     if ((rc = vican_cg_sweep(g, w, deg_t, p_c, r_t, p_t, q_t, qc_part, pq_part, st, stream)) < 0) return rc;
-    // partials of p_t . q_t, one per workgroup of the fold (<= 96: C <= 2048): doubles 32.. of the solve's ticket workspace
-    double* pq_part2 = (double*)(ticket + 64);
+    // partials of p_t . q_t, one per workgroup of the fold (<= 96: C <= 2048): doubles 32.. of the solve's workspace
+    double* pq_part2 = (double*)(ws + 64);
     const int n_fold = (int)((nc + 63) / 64);
     int n_pq = (int)((n + 8191) / 8192); if (n_pq < 1) n_pq = 1; if (n_pq > 96) n_pq = 96;       // slices of p_t.q_t (8 elements per thread and pass)
     hipLaunchKernelGGL(cg_fold2_kernel<64>, dim3((unsigned)(n_fold > n_pq ? n_fold : n_pq)), dim3(1024), 0, s, (const long long*)qc_part, (int)g->n_wg,
                        (int)g->n_cam, p_t, q_t, n, n_pq, pq_part2, qcpq, st, 0);
-    if (handover)
-        hipLaunchKernelGGL(cg_step2_kernel<true>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32), 0);
-    else
-        hipLaunchKernelGGL(cg_step2_kernel<false>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                           rr_part, pq_part2, n_pq, rtol, n_add, st, ticket + 1, (double*)(ticket + 32), 0);
+    hipLaunchKernelGGL(cg_step2_kernel, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, qcpq, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                       rr_part, pq_part2, n_pq, st, 0);
     LAUNCH_CHECK("vican_cg_iter_fused");
     return VICAN_OK;
 }
@@ -1420,8 +1364,8 @@ extern "C" int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const
                        (int)g->n_cam, p_t, q_t, n, n_pq, pq_slices, msg, st, VICAN_CG_PQ_SLICES);
     LAUNCH_CHECK("vican_cg_iter_comm");
     if (comm && (rc = vican_comm_allreduce_sum(comm, msg, nc + VICAN_CG_PQ_SLICES, stream)) < 0) return rc;
-    hipLaunchKernelGGL(cg_step2_kernel<false>, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, msg, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
-                       rr_part, pq_slices, VICAN_CG_PQ_SLICES, rtol, n_add, st, (unsigned int*)nullptr, (double*)nullptr, VICAN_CG_RR_SLICES);
+    hipLaunchKernelGGL(cg_step2_kernel, dim3(nb + 1), dim3(256), 0, s, (int)g->n_cam, n, deg_c, msg, p_c, x_c, r_c, p_t, q_t, x_t, r_t,
+                       rr_part, pq_slices, VICAN_CG_PQ_SLICES, st, VICAN_CG_RR_SLICES);
     LAUNCH_CHECK("vican_cg_iter_comm");
     if (comm && (rc = vican_comm_allreduce_sum(comm, rr_part, VICAN_CG_RR_SLICES, stream)) < 0) return rc;
     return VICAN_OK;

@@ -71,9 +71,6 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                                                              const double* __restrict__ x, u64* __restrict__ zpart,
                                                              double* __restrict__ lamT_out, double* __restrict__ fx) {
     GATE_RETURN(gate);
-#ifdef VICAN_WSTAMP     /* diagnostic build: wall-clock structure of the launch -> lamT_out (unused by MODE 0), 100 MHz ticks */
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-#endif
     constexpr int EPL = Vec<S>::N, BLOCK = NW * 64;
     constexpr bool HAS_Z = (MODE == 0 || MODE == 3 || MODE == 4);
     // TRIPS: (row, dual-block row) items per lane in phase 2 = ceil(3 max_rows / 64), 1..3 (max_rows <= 64)
@@ -226,21 +223,12 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     if ((MODE == 0 || MODE == 4) && blockIdx.x == 0 && tid == 0) fx[7] = 1.0 / up;
     if ((MODE == 1 || MODE == 3) && blockIdx.x == 0 && tid == 0) fx[4] = 0.0;   // omega bound: raised by dual_svd_kernel
 
-#ifdef VICAN_WSTAMP
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
-#define WSTAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define WSTAMP0() do {} while (0)
-#define WSTAMP(i) do {} while (0)
-#endif
     // body: this wavefront processes the chunk held in `cur` (its row bounds in `vrow`, loaded a body ago), prefetches
     // chunk kpref into `nxt` and requests kpref's row bounds (returned; consumed by the next body).  Every
     // vector-memory operation of the body is UNCONDITIONAL (indices clamped instead): results retire in issue order,
     // and a load that may or may not have been issued makes the compiler wait for vmcnt(0) - i.e. for the whole
     // prefetch - wherever an older result is needed.
     auto body = [&](ChunkRegs<S, EPL>& cur, ChunkRegs<S, EPL>& nxt, const int2 vrow, const int kpref, int& ticket) -> int2 {
-        WSTAMP0();
         ticket = draw();                                       // for the chunk after next; resolved after the body
         const int r0 = __builtin_amdgcn_readfirstlane(vrow.x);
         const int nrows = __builtin_amdgcn_readfirstlane(vrow.y) - r0;
@@ -274,21 +262,8 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         __builtin_amdgcn_sched_barrier(0);
         load_chunk16<S, EPL, NT>(nxt, g, kp, lane);
 
-#if defined(VICAN_WABLATE) && VICAN_WABLATE == 1      /* loads only: streaming rate of this access pattern */
-        {
-            float keep = 0.f;
-#pragma unroll
-            for (int p = 0; p < 9; ++p) keep += (float)vget<S>(cur.m[p], 0) + (float)vget<S>(cur.m[p], EPL - 1);
-            if (keep == 123.456f && cur.id[0] == 77u) ys[0] = 1ull;
-            return vnext;
-        }
-#endif
         // ---- phase 1
-        WSTAMP(0);                      // descriptors, dual loads, prefetch issue
-#ifdef VICAN_WSTAMP                     /* wait for this chunk's data here so that the wait is booked separately */
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        WSTAMP(1);
-#endif
+        // descriptors, dual loads, prefetch issue
         // LEAN (16 wavefronts = 128 VGPRs): no double-buffered x gather, camera / row indices re-derived in phase 3
         constexpr bool LEAN = NW >= 16;
         auto cam_of = [&](uint32_t id) -> uint32_t { return id == VICAN_PAD_SLOT ? pad_cam : (id & 0xFFFFu); };
@@ -319,13 +294,8 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                 const bool last = !ONE && ((j == EPL - 1) || row[j + 1 < EPL ? j + 1 : j] != row[j]);
                 if (last) {
                     u64* yr = ys + (size_t)(row[j] * 9) * ncopy + lane_copy;
-#if defined(VICAN_WABLATE) && (VICAN_WABLATE == 4 || VICAN_WABLATE == 5)    /* no phase-1 atomics */
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) asm volatile("" :: "v"(acc[q]));
-#else
 #pragma unroll
                     for (int q = 0; q < 9; ++q) lds_add_fix(yr + q * ncopy, fix_of<S>(acc[q], y_scale));
-#endif
                 }
                 if (j + 1 < EPL) {
 #pragma unroll
@@ -340,10 +310,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             }
         }
         __builtin_amdgcn_wave_barrier();
-        WSTAMP(2);                      // phase 1
-#if defined(VICAN_WABLATE) && VICAN_WABLATE == 2      /* phase 1 only */
-        return vnext;
-#endif
+        // phase 1
 
         // ---- phase 2
         S w1[9];                                               // ONE: the phase-3 operand, wave-uniform
@@ -390,19 +357,6 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
             }
         } else {
         // ---- phase 2 (this wavefront's rows only; LDS operations of a wavefront execute in order)
-#if defined(VICAN_WABLATE) && VICAN_WABLATE == 6      /* no fold, no y round trip through LDS (timing only: wrong results) */
-        if (MODE == 0) {
-#pragma unroll
-            for (int t = 0; t < TRIPS; ++t) {
-                const int j = lane + 64 * t;
-                if (j < nrows * 3) {
-#pragma unroll
-                    for (int b3 = 0; b3 < 3; ++b3)
-                        wv[j * 3 + b3] = pre_scale<S>(dot3<double>(L[t][0], L[t][1], L[t][1], L[t][2], L[t][2], L[t][0]), z_scale);
-                }
-            }
-        }
-#else
         if (MODE == 4) {
 #pragma unroll
             for (int t = 0; t < 3 * TRIPS; ++t) {
@@ -432,7 +386,6 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                 }
             }
         }
-#endif
         if (MODE == 3) {
             for (int r = lane; r < nrows; r += 64) {
                 double R[9];
@@ -449,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         }
         }
         __builtin_amdgcn_wave_barrier();
-        WSTAMP(3);                      // phase 2
+        // phase 2
 
         if (HAS_Z) {
             // ---- phase 3
@@ -473,31 +426,16 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                     for (int b = 0; b < 3; ++b) {
                         const S v = dot3<S>(vget<S>(cur.m[i * 3 + 0], j), w[b], vget<S>(cur.m[i * 3 + 1], j), w[3 + b],
                                             vget<S>(cur.m[i * 3 + 2], j), w[6 + b]);
-#if defined(VICAN_WABLATE) && (VICAN_WABLATE == 3 || VICAN_WABLATE == 5)    /* no phase-3 atomics */
-                        asm volatile("" :: "v"(v));
-#else
                         lds_add_fix(&zc[(i * 3 + b) * CP], fix_of<S>(v, z_scale));
-#endif
                     }
             }
         }
         __builtin_amdgcn_wave_barrier();
-#ifdef VICAN_WSTAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // book the drain of this chunk's LDS atomics to phase 3
-#endif
-        WSTAMP(4);                      // phase 3
+        // phase 3
         return vnext;
     };
 
-#ifdef VICAN_WSTAMP
-    const unsigned long long rt_loop0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef VICAN_WSTAMP
-    int n_done = 0;
-#define WCOUNT() (++n_done)
-#else
 #define WCOUNT() ((void)0)
-#endif
 #pragma unroll 1
     while (kc != NONE) {
         int t;
@@ -516,23 +454,12 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
         __hip_atomic_store(&sched[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sched[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#ifdef VICAN_WSTAMP
-    const unsigned long long rt_loop1 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (HAS_Z) {
         u64* zp = zpart + (size_t)blockIdx.x * 9 * C;          // slab layout [9][C]
 #pragma unroll
         for (int q = 0; q < 9; ++q)
             for (int c = tid; c < C; c += BLOCK) zp[q * C + c] = (u64)fix_total<S>((long long)zs[q * CP + c]);
     }
-#ifdef VICAN_WSTAMP
-    if (MODE == 0 && lamT_out && lane == 0) {
-        double* o = lamT_out + ((size_t)blockIdx.x * NW + wave) * 10;
-        o[0] = (double)rt_begin; o[1] = (double)rt_loop0; o[2] = (double)rt_loop1; o[3] = (double)__builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 5; ++i) o[4 + i] = (double)st_acc[i];
-        o[9] = (double)n_done;
-    }
-#endif
 }
 
 static thread_local const int32_t* w_gate_override = nullptr;     // the redo launch of MODE 3 runs under its own gate
@@ -561,9 +488,8 @@ static int launch_wsweep4(const vican_graph_t* g, const double* lamT_inv, const 
 template <typename S, int NW, int MODE, int CP, bool FB>
 static int launch_wsweep3(const vican_graph_t* g, const double* lamT_inv, const double* x, u64* zpart, double* lamT_out,
                           double* fx, hipStream_t st) {
-    // one row per chunk everywhere (n_chunk == n_time): the accumulator-free instantiation (VICAN_SWEEP_ONE_ROW=0: A/B)
-    static const int one_row_ok = getenv("VICAN_SWEEP_ONE_ROW") ? atoi(getenv("VICAN_SWEEP_ONE_ROW")) : 1;
-    if (NW >= 8 && NW <= 12 && one_row_ok && g->n_chunk == g->n_time)
+    // one row per chunk everywhere (n_chunk == n_time): the accumulator-free instantiation
+    if (NW >= 8 && NW <= 12 && g->n_chunk == g->n_time)
         return launch_wsweep4<S, NW, MODE, CP, 1, FB, true>(g, lamT_inv, x, zpart, lamT_out, fx, st);
     // TRIPS = ceil(3 max_rows / 64) row items per lane: dual-block rows (MODE 0) / thirds of the given row operands (MODE 4)
     if ((MODE != 0 && MODE != 4) || 3 * g->max_rows <= 64) return launch_wsweep4<S, NW, MODE, CP, 1, FB>(g, lamT_inv, x, zpart, lamT_out, fx, st);

@@ -18,17 +18,6 @@ extern "C" int64_t vican_cg_wsweep_lds_bytes(int32_t n_cam, int32_t max_rows, in
     return 72LL * plane_stride(n_cam) + (int64_t)n_waves * per_wave + 256;       // nine camera planes of compile-time stride
 }
 
-#ifdef VICAN_CGWSTAMP   /* diagnostic build (tools/cgsweep_time.py --stamp): wall-clock structure of the launch, per wavefront */
-__device__ double* cgw_stamp_buf = nullptr;
-extern "C" int vican_cgw_stamp_buffer(double* buf) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(cgw_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? VICAN_OK : VICAN_ERR_ARG;
-}
-#define CSTAMP0() do { __builtin_amdgcn_sched_barrier(0); st_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define CSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define CSTAMP0() do {} while (0)
-#define CSTAMP(i) do {} while (0)
-#endif
 
 #include "vican_cgw_impl.h"
 
@@ -124,10 +113,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         const size_t gi = (size_t)k * 3 + l3;
         rv.p = p_t[gi]; rv.r = r_t[gi]; rv.d = deg_t[k + vzero];
     };
-#ifndef CGW1_SETS
-#define CGW1_SETS 3                    /* register sets: chunks in flight + 1 (4: three chunks ahead - diagnostic builds) */
-#endif
-    if (tid == 0) s_ticket = c0 + (CGW1_SETS + 1) * NW;
+    if (tid == 0) s_ticket = c0 + 4 * NW;        // (three register sets: two chunks in flight beside the one being processed)
     __syncthreads();
 
     // chunks of the workgroup's range by LDS ticket (the first four rounds are static); a ticket is drawn three bodies before
@@ -137,24 +123,12 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
     RowVals ra, rb, rc;
     load_edges(ea, q0); load_rowvals(ra, q0);
     load_edges(eb, q1); load_rowvals(rb, q1);
-#if CGW1_SETS == 4
-    int q4 = q3 + NW;
-    CgW1Regs<EPL, W32> ed;
-    RowVals rd;
-    load_edges(ec, q2); load_rowvals(rc, q2);
-#endif
     double pq = 0.0;
 
     auto body = [&](const CgW1Regs<EPL, W32>& cur, const RowVals& rv, CgW1Regs<EPL, W32>& fill, RowVals& rvf, const int k, const int k_fill) {
         load_rowvals(rvf, k_fill);
         load_edges(fill, k_fill);
         __builtin_amdgcn_sched_barrier(0);
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 1      /* loads only: streaming rate of this access pattern */
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) asm volatile("" :: "v"(cur.id[j]), "v"(cur.w[j]));
-        asm volatile("" :: "v"(rv.p), "v"(rv.r), "v"(rv.d));
-        return;
-#endif
         const double pn = upd ? mul_add_2r(beta, rv.p, rv.r) : rv.p;
         if (upd && lane < 3) p_t[(size_t)k * 3 + lane] = pn;
         const double prow[3] = {lane_bcast(pn, 0), lane_bcast(pn, 1), lane_bcast(pn, 2)};
@@ -174,11 +148,7 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const Fix2 f = to_fix2(wj[j] * prow[i], scale, lo_scale);
-#if defined(VICAN_CGWABLATE) && VICAN_CGWABLATE == 2      /* no camera atomics */
-                asm volatile("" :: "v"(f.hi), "v"(f.lo));
-#else
                 lds_add_fix(&qc[i * CP + cam[j]], f.hi); lds_add_fix(&qc[lo_c + i * CP + cam[j]], f.lo);
-#endif
             }
         }
         const double srow = wave_total3(acc[0], acc[1], acc[2], lane);         // lanes 0, 1, 2: the three row sums
@@ -193,27 +163,6 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         if (lane == 0) t = __hip_atomic_fetch_add(&s_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t;
     };
-#if CGW1_SETS == 4
-#define CGW1_NEXT(t) do { q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = __builtin_amdgcn_readfirstlane(t); } while (0)
-#pragma unroll 1
-    while (q0 < c1) {
-        int t = draw();
-        body(ea, ra, ed, rd, q0, q3);
-        CGW1_NEXT(t);
-        if (q0 >= c1) break;
-        t = draw();
-        body(eb, rb, ea, ra, q0, q3);
-        CGW1_NEXT(t);
-        if (q0 >= c1) break;
-        t = draw();
-        body(ec, rc, eb, rb, q0, q3);
-        CGW1_NEXT(t);
-        if (q0 >= c1) break;
-        t = draw();
-        body(ed, rd, ec, rc, q0, q3);
-        CGW1_NEXT(t);
-    }
-#else
 #define CGW1_NEXT(t) do { q0 = q1; q1 = q2; q2 = q3; q3 = __builtin_amdgcn_readfirstlane(t); } while (0)
 #pragma unroll 1
     while (q0 < c1) {
@@ -229,7 +178,6 @@ __global__ __launch_bounds__(NW * 64) void cg_wsweep1_kernel(vican_graph_t g, co
         body(ec, rc, eb, rb, q0, q2);
         CGW1_NEXT(t);
     }
-#endif
 #undef CGW1_NEXT
     __syncthreads();
     for (int pl = 0; pl < 6; ++pl)
@@ -405,7 +353,6 @@ extern "C" __attribute__((visibility("hidden"))) int vican_trans_wrhs(const vica
     const int epl = g->slots / 64, trips = (9 * g->max_rows + 63) / 64;
     // (measured: 8 wavefronts beat 12 even where 12 fit the register budget: stress 240 vs 253 us, sparse 207 vs 302 us)
     int nw = g->wg_waves >= 8 ? 8 : 4;
-    if (const char* ev = getenv("VICAN_WRHS_WAVES")) { const int v = atoi(ev); if (v == 4 || v == 8 || v == 12) nw = v; }     // A/B
     while (nw > 4 && wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw) > vican_lds_limit_bytes()) nw -= 4;
     const size_t lds = (size_t)wrhs_lds_bytes(g->n_cam, g->max_rows, g->n_copy, nw);
     if ((int64_t)lds > vican_lds_limit_bytes()) return set_err(VICAN_ERR_CAPACITY, "%s: camera tables / row staging do not fit in LDS", "vican_trans_rhs (wave layout)");
@@ -746,11 +693,9 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
     const int epl = g->slots / 64, trips = (3 * g->max_rows + 63) / 64, cp = (int)plane_stride(g->n_cam);
     const bool nt = g->stream_nt != 0;
     hipStream_t s = (hipStream_t)stream;
-    static const int one_row_ok = getenv("VICAN_CG_ONE_ROW") ? atoi(getenv("VICAN_CG_ONE_ROW")) : 1;      // (0: A/B against the general kernel)
-    if (one_row_ok && g->n_chunk == g->n_time && nw >= 8 && !partial && g->idx16) {
+    if (g->n_chunk == g->n_time && nw >= 8 && !partial && g->idx16) {
         // every chunk is one row: the specialised kernel (no row staging: LDS = the nine camera planes)
         const size_t lds1 = (size_t)72 * cp + 256;
-        static const int nw1 = getenv("VICAN_CG_ONE_ROW_WAVES") ? atoi(getenv("VICAN_CG_ONE_ROW_WAVES")) : 12;
         // (float32 weight stream: only for the very array w32 was made from, 4 edges per lane)
         const bool w32 = g->w32 != nullptr && g->w32_src == w && epl == 4;
 #define CGW1_LAUNCH_(NW_, E_, CP_, NT_)                                                                                   \
@@ -770,7 +715,7 @@ extern "C" __attribute__((visibility("hidden"))) int vican_cg_wsweep(const vican
             if (epl == 4) { if (cp == 256) CGW1_LAUNCH(NW_, 4, 256); else if (cp == 512) CGW1_LAUNCH(NW_, 4, 512); else CGW1_LAUNCH(NW_, 4, 1024); } \
             else          { if (cp == 256) CGW1_LAUNCH(NW_, 2, 256); else if (cp == 512) CGW1_LAUNCH(NW_, 2, 512); else CGW1_LAUNCH(NW_, 2, 1024); } \
         } while (0)
-        if (nw1 == 16) CGW1_PICK(16); else if (nw1 == 8) CGW1_PICK(8); else CGW1_PICK(12);
+        CGW1_PICK(12);                  // (12 wavefronts per workgroup: 8 and 16 measured slower - profiles/NOTES.md, round 4)
 #undef CGW1_PICK
 #undef CGW1_LAUNCH
 #undef CGW1_LAUNCH_

@@ -297,9 +297,6 @@ class _Layout:
         if blk is None:                                      # translation layout: index + weight words of the CG sweep
             stream_bytes = self.nslot * 12
         self.stream_nt = int(stream_bytes > STREAM_NT_BYTES)
-        import os
-        if blk is None and os.environ.get("VICAN_TL_NT") is not None:       # A/B switch for the translation kernels
-            self.stream_nt = int(os.environ["VICAN_TL_NT"])
         self.desc = _lib.Graph(n_cam, self.n_time, self.n_chunk, self.slots, self.max_rows, storage, self.block_threads,
                                self.n_wg, self.n_copy, self.wg_chunk_cap, _lib.LAYOUT_WAVE if self.kind == "wave" else _lib.LAYOUT_BLOCK,
                                self.wg_waves, self.stream_nt, self.slot_order, None if blk is None else blk.data_ptr(), self.idx.data_ptr(),
@@ -705,34 +702,6 @@ class HipBackend:
                                                  0 if ws is None else ws.numel(), _stream()),
                  "vican_lanczos_cam_step")
 
-    def lanczos_resident_steps(self, j1_want, force=False):
-        """Largest j1 <= j1_want for which Lanczos steps .. j1 - 1 can run as one cooperative launch (vican_lres.hip); 0 if
-        this graph does not qualify (wave layout, C <= 512, co-resident grid that holds the camera workgroups).
-        The solver uses it only when VICAN_LANCZOS_RESIDENT=1: measured 27-32 us per step against ~30 us for the pair of
-        launches - not worth a second code path by default."""
-        if getattr(self, "_lres_ok", None) is None:
-            g = self.g
-            self._lres_ok = bool(self.layout == "wave" and self.C <= 512 and g.n_chunk > 0 and g.n_wg <= n_cu() and
-                                 -(-self.C // 32) <= g.n_wg and g.max_rows <= 64)
-        if not self._lres_ok or not (force or os.environ.get("VICAN_LANCZOS_RESIDENT", "0") == "1"):
-            return 0
-        g, st = self.g, (_lib.STORE_F64 if self.storage_f64 else _lib.STORE_F32)
-        j1 = min(int(j1_want), 64)
-        while j1 > 0 and int(self.lib.vican_lanczos_resident_lds_bytes(self.C, g.max_rows, st, g.n_copy, j1)) + 14 * 1024 > 160 * 1024:
-            j1 -= 1
-        return j1
-
-    def lanczos_resident(self, lamT_inv, lamC, V, ld, j0, j1, xrow, HB, hw, pivot_floor):
-        """Lanczos steps j0 .. j1 - 1 (sweep + camera-side step each) in one launch; HB row j = [projected column | beta_j]."""
-        if getattr(self, "_lres_ws", None) is None:
-            self._lres_ws = torch.zeros(int(self.lib.vican_lanczos_resident_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
-        if self._coop_sync is None:                 # (the barrier words shared with the cooperative camera-side step)
-            self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        self._ck(self.lib.vican_lanczos_resident(self._gref, _ptr(lamT_inv), _ptr(lamC), _ptr(V), ld, int(j0), int(j1), _ptr(xrow),
-                                                 _ptr(HB), int(HB.stride(0)), int(hw), _ptr(self.zpart), _ptr(self._lres_ws),
-                                                 _ptr(self._coop_sync), _ptr(self.g.fx), float(pivot_floor), _stream()),
-                 "vican_lanczos_resident")
-
     def cg_iter_local(self, deg_t, r_c, p_c, r_t, p_t, q_t, qcpq, rtol, st, n_rr_part):
         part = self.zpart[: self.cgl.n_wg * 6 * self.C]            # double-word camera partials: (hi, lo) planes per workgroup
         self._ck(self.lib.vican_cg_iter_local(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(r_c), _ptr(p_c), _ptr(r_t),
@@ -745,20 +714,16 @@ class HipBackend:
                                                       _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(r_t), _ptr(self.rr_part),
                                                       self.rr_part.numel(), _ptr(st), _stream()), "vican_cg_iter_finish")
 
-    # VICAN_CG_HANDOVER=1: the step's last workgroup runs the next iteration's head (three launches per iteration instead of
-    # four); measured SLOWER on the stress graph (profiles/r05_cg_tail.txt) - the default keeps the head in its own launch
-    cg_handover = os.environ.get("VICAN_CG_HANDOVER") == "1"
-
     def cg_iter_fused(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, qcpq, rtol, st, first):
         """One single-rank CG iteration behind one host call, bit-reproducible from run to run (p_t.q_t over fixed slices):
         include/vican_hip.h vican_cg_iter_fused; same recurrence as cg_iter_local + cg_iter_finish."""
         if getattr(self, "_cg_ticket", None) is None:
-            self._cg_ticket = torch.zeros(256, dtype=torch.int32, device=self.dev)    # line 0: tickets [2]; line 1: hand-over doubles [2]; byte 256..: p.q partials
+            self._cg_ticket = torch.zeros(256, dtype=torch.int32, device=self.dev)    # workspace of the fused iteration: byte 256..: p.q partials
         part = self.zpart[: self.cgl.n_wg * 6 * self.C]
         self._ck(self.lib.vican_cg_iter_fused(self._gref_cg, _ptr(self._cg_w), _ptr(deg_t), _ptr(deg_c), _ptr(r_c), _ptr(p_c), _ptr(x_c),
                                               _ptr(r_t), _ptr(p_t), _ptr(q_t), _ptr(x_t), _ptr(part), _ptr(self.pq_part), _ptr(qcpq),
                                               float(rtol), _ptr(self.rr_part), self.rr_part.numel(), self.n_add_cg,
-                                              int(bool(first)) | (2 if self.cg_handover else 0),
+                                              int(bool(first)),
                                               _ptr(st), _ptr(self._cg_ticket), _stream()), "vican_cg_iter_fused")
 
     def cg_iter_comm(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, msg, rtol, st, first, comm):
@@ -939,7 +904,7 @@ class HipBackend:
         if getattr(self, "_cgres_ok", None) is None:
             l = self.cgl
             self._cgres_ok = bool(
-                os.environ.get("VICAN_CG_RESIDENT", "1") != "0" and self.layout == "wave" and self._gref_cg is self._gref and
+                self.layout == "wave" and self._gref_cg is self._gref and
                 l.n_chunk > 0 and l.n_wg <= min(n_cu(), 128) and        # (a grid barrier costs 1 us at 40 workgroups, 2 at 128,
                                                                          #  3.8 at 256: measured CG stage 0.35 / 0.49 ms at 40
                                                                          #  workgroups, 0.44 / 0.50 at 98, 0.72 / 0.60 at 235)
@@ -1161,7 +1126,7 @@ class TiledGraph:
                 # integer effect: 3 or 4 rows); chunks of many short rows fill well in any order: a smaller pool there, none
                 # beyond 32 rows per chunk
                 rows_est = max(1.0, slots / max(1.0, max(float(r[-1]) for r in rps_host) / T))
-                window = int(os.environ.get("VICAN_TILE_PACK_WINDOW", 0)) or (512 if rows_est <= 8 else 128 if rows_est <= 32 else 1)
+                window = 512 if rows_est <= 8 else 128 if rows_est <= 32 else 1
                 nch = _lib.check(lib.vican_plan_rows_multi(T, len(parts), C.cast(ptrs, C.c_void_p), slots, cap_rows, window,
                                                             C.c_void_p(perm.ctypes.data), C.c_void_p(c0s.ctypes.data), T + 2),
                                  "vican_plan_rows_multi")
@@ -1293,7 +1258,7 @@ class TiledBackend(HipBackend):
         self.zero_rows = torch.zeros(T1, 9, dtype=torch.float64, device=self.dev)
         self.scratch_c = [torch.zeros(3 * (b1 - b0), 3, dtype=torch.float64, device=self.dev) for b0, b1 in zip(graph.bounds[:-1], graph.bounds[1:])]
         self._fused = None
-        if getattr(graph, "shared_chunks", None) is not None and os.environ.get("VICAN_TILE_FUSED", "1") != "0":
+        if getattr(graph, "shared_chunks", None) is not None:
             self._setup_fused()
         if graph.tiles[0].w is not None:
             self.n_add_cg = float(max(max(t.tl.rows_per_wg_max, t.tl.slots) for t in graph.tiles) + 1)
@@ -1306,7 +1271,7 @@ class TiledBackend(HipBackend):
             # the tiles' CG products in ONE launch (vican_cg_sweep_tiles: 2..4 wave-layout tiles of one launch shape; the
             # launcher refuses anything else and the per-tile launches take over)
             self._tcg = None
-            if 2 <= nt <= 4 and all(K.layout == "wave" for K in self.tiles) and os.environ.get("VICAN_TILE_CG_FUSED", "1") != "0":
+            if 2 <= nt <= 4 and all(K.layout == "wave" for K in self.tiles):
                 t = _LsqrCtx()
                 t.nwgt = max(1, n_cu() // nt)
                 t.host = (_lib.CgTile * nt)()
@@ -1599,7 +1564,7 @@ def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None
     tile = int(os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
     if n_cam > tile:
         g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c,
-                       permute_rows=os.environ.get("VICAN_TILE_PERMUTE", "1") != "0")
+                       permute_rows=True)
         return g, TiledBackend(g)
     g = LocalGraph(n_cam, row_ptr, col, blk, a, w, u, v, deg_t=deg_t, deg_c=deg_c, row_ptr_host=row_ptr_host)
     return g, HipBackend(g)

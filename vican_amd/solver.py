@@ -71,8 +71,6 @@ class Comm:
             transport = os.environ.get("VICAN_COMM", "auto")
         if native is not None:                                   # (round-5 spelling: native=True = RCCL from C, False = torch)
             transport = "rccl" if native else "torch"
-        if os.environ.get("VICAN_NATIVE_COMM") == "1" and transport == "auto":
-            transport = "rccl"
         if transport not in ("auto", "peer", "rccl", "torch"):
             raise ValueError("Comm: unknown transport %r" % (transport,))
         self.transport_wanted = transport
@@ -436,28 +434,16 @@ class RotationSolver:
             while True:
                 j = steps
                 in_slabs = False
-                # capture-sized graphs, single rank: all steps up to the next check as ONE cooperative launch (sweep and
-                # camera-side step per Lanczos step, vican_lres.hip) - bit-identical to the launch pairs below
-                j_res = 0
-                if (not self.comm.sharded and self.small_graph and self.N == getattr(K, "C", -1) and hasattr(K, "lanczos_resident_steps")
-                        and not (j == 0 and have_z)):
-                    j_res = K.lanczos_resident_steps(min(max(next_check, j + 1), self.m_max))
-                if j_res > j:
-                    K.lanczos_resident(self.lamT, self.lamC, self.V, ld, j, j_res, self.xrow, self.HB, self.hw, self.pivot_floor)
-                    self.stats["sweeps"] += j_res - j
-                    total_steps += j_res - j
-                    steps = j_res
-                else:
-                    if not (j == 0 and have_z):
-                        # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
-                        #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
-                        in_slabs = bool(self.apply_P(self.xrow, self.z))
-                    # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
-                    # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
-                    K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
-                                       self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
-                    steps += 1
-                    total_steps += 1
+                if not (j == 0 and have_z):
+                    # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
+                    #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
+                    in_slabs = bool(self.apply_P(self.xrow, self.z))
+                # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
+                # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
+                K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
+                                   self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
+                steps += 1
+                total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
                     handle = self._ritz(steps, first, level, gap=steps - prev_steps)
                     first = False
@@ -815,9 +801,9 @@ class TranslationSolver:
         n_part, it_launched, s = None, 0, None          # (None: the first iteration)
 
         # single rank: one host call per iteration with p_t.q_t formed over fixed slices - bit-reproducible from run to run,
-        # which the sequence below is not (its p.q partial depends on the sweep's ticket order).  VICAN_CG_FUSED=0: the sequence.
-        fused = (not multi) and getattr(K, "cg_iter_fused", None) is not None and os.environ.get("VICAN_CG_FUSED", "1") != "0"
-        handover = fused and bool(getattr(K, "cg_handover", False))     # (the step's last workgroup has run the next head already)
+        # which the sequence below is not (its p.q partial depends on the sweep's ticket order).  use_fused = False: the sequence
+        # (what backends without the fused call - camera tiles - take; the tests compare the two)
+        fused = (not multi) and getattr(K, "cg_iter_fused", None) is not None and getattr(self, "use_fused", True)
         comm_iter = multi and self._comm_iter_ok()
 
         def one_iteration(n_part):
@@ -859,7 +845,7 @@ class TranslationSolver:
                 # the same system was solved before (time series, benchmark loop): launch exactly as many iterations
                 # as it took then, plus the one that detects convergence, before the first poll
                 # (the fused iteration detects convergence in the launch that made the last update)
-                burst = min(max(self._last_iters + (0 if handover else 1), 1), 64, maxiter - it_launched)
+                burst = min(max(self._last_iters + 1, 1), 64, maxiter - it_launched)
             first_burst = False
             left = burst
             if it_launched == 0:                                  # the first iteration passes other arguments
@@ -886,8 +872,6 @@ class TranslationSolver:
             if s["done"] or it_launched >= maxiter:
                 break
             self.poll_every = min(self.poll_every * 2, 64)
-        if handover and s["done"] == 1 and s["iter"] >= maxiter:
-            s["done"] = 0              # (found by the head that rides with the LAST allowed update: scipy does not test there)
         self._last_iters = int(s["iter"]) if s["done"] == 1 else None
         self.info = dict(cg_iters=s["iter"] if s["done"] else it_launched, converged=s["done"] == 1,
                          relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
@@ -898,7 +882,7 @@ class TranslationSolver:
         """Sharded solve whose all-reduces the C library enqueues itself (solver.Comm with a native communicator, or a forced
         one-rank Comm: identity) on a backend with vican_cg_iter_comm: one host call per iteration."""
         K, comm = self.K, self.comm
-        if getattr(K, "cg_iter_comm", None) is None or not hasattr(comm, "native_handle") or os.environ.get("VICAN_CG_COMM_ITER", "1") == "0":
+        if getattr(K, "cg_iter_comm", None) is None or not hasattr(comm, "native_handle"):
             return False
         if comm.world > 1 and not getattr(comm, "_native_tried", True):
             comm._setup_native(self.st.device)
