@@ -780,6 +780,14 @@ int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges, int32_t st
                       const int32_t* col, const void* blk, const void* a, const double* w, const double* u, const double* v,
                       const double* deg_t, const double* deg_c, void* stream, vican_plan_t** plan_out);
 int vican_plan_describe(const vican_plan_t* plan, vican_graph_t* g_out);   /* the layout that was planned (sizes; device pointers) */
+/* One rank of a timestep-sharded solve (the north star's partitioning; the reference has no distributed code): the plan was
+ * created from THIS rank's rows (its slice of the timesteps with all their edges, all C cameras; deg_c = this rank's share of the
+ * camera diagonal: the whole vector on one rank and zeros on the others, or NULL).  After this call vican_solve_rot /
+ * vican_solve_trans all-reduce the camera-side partials through `comm` (vican_comm_*: peer exchange or RCCL) in stream order -
+ * one all-reduce per operator application, two per CG iteration - and every rank of the group must make the same calls;
+ * rc_out / x_c are identical on all ranks, Rt_out / x_t are this rank's rows.  One collective inside: the graph constants that
+ * must be global.  vican_solve_trans_lsqr stays single-rank.  comm = NULL: back to a single-rank plan.                        */
+int vican_plan_set_comm(vican_plan_t* plan, vican_comm_t* comm, void* stream);
 int vican_solve_rot(vican_plan_t* plan, int32_t maxiter, double eig_tol, double* rc_out, double* Rt_out,
                     vican_solve_info_t* info, void* stream);
 int vican_solve_trans(vican_plan_t* plan, const double* rc, const double* Rt, double rtol, int64_t maxiter, double* x_c,

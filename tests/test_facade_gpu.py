@@ -16,7 +16,8 @@ from vican_amd.geometry import geodesic
 pytestmark = pytest.mark.gpu
 
 
-def solve_through_the_facade(prob, dt, maxiter=gc.MAXITER):
+def solve_through_the_facade(prob, dt, maxiter=gc.MAXITER, comm=None):
+    """comm: a vican_comm_t* - the plan then is ONE RANK of a sharded solve (vican_plan_set_comm)."""
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     tdt = torch.float32 if dt == "float32" else torch.float64
@@ -36,6 +37,8 @@ def solve_through_the_facade(prob, dt, maxiter=gc.MAXITER):
         g = _lib.Graph()
         assert lib.vican_plan_describe(plan, C.byref(g)) == 0
         assert g.n_cam == Cn and g.n_time == T and g.n_chunk >= 1 and g.n_wg >= 1
+        if comm is not None:
+            assert lib.vican_plan_set_comm(plan, comm, stream) == 0, lib.vican_last_error()
         rcs, Rt = torch.empty(3 * Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 9, dtype=torch.float64, device=dev)
         x_c, x_t = torch.empty(Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 3, dtype=torch.float64, device=dev)
         info = _lib.SolveInfo()
@@ -79,11 +82,50 @@ def test_four_calls_reproduce_the_reference(name, dt):
     assert np.abs(np.sort(np.array(info.evals[:3])) - evr).max() < (1e-4 if dt == "float32" else 1e-7) * np.abs(exp["evals"]).max()
 
 
+@pytest.mark.parametrize("name,dt", [("g3_medium", "float64"), ("g3_medium", "float32"), ("g2_small", "float64")])
+def test_the_sharded_schedule_through_the_four_calls(name, dt):
+    """vican_plan_set_comm: the plan as one rank of a timestep-sharded solve - here the ONLY rank, with a communicator whose
+    all-reduces are launches of the peer exchange (vican_comm_create_local + vican_comm_peer_export / _attach, ctypes alone: the
+    rank's own mailbox slot is its peer).  Every sweep's camera partial and both messages of every CG iteration go through the
+    exchange; poses against the real reference's, and against the single-rank facade solve of the same plan inputs."""
+    lib = _lib.load()
+    g = load_golden(name)
+    case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "conjugate_gradient", dt)
+    prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
+    comm = C.c_void_p()
+    assert lib.vican_comm_create_local(0, 1, C.byref(comm)) == 0
+    assert lib.vican_comm_peer_export(comm, 9 * 1024 + 96, C.create_string_buffer(64)) == 0, lib.vican_last_error()
+    assert lib.vican_comm_peer_attach(comm, None) == 0, lib.vican_last_error()
+    try:
+        Rc, Rt, pc, pt, info, graph = solve_through_the_facade(prob, dt, comm=comm)
+        assert lib.vican_comm_peer_status(comm) == 0
+    finally:
+        lib.vican_comm_destroy(comm)
+    Rc1, Rt1, pc1, pt1, info1, _ = solve_through_the_facade(prob, dt)
+    rot, pos = {}, {}
+    for i, c in enumerate(prob.cam_names):
+        rot[str(c)], pos[str(c)] = Rc[i], pc[i]
+    for i, s_ in enumerate(prob.time_names):
+        rot[str(s_) + "_0"], pos[str(s_) + "_0"] = Rt[i], pt[i]
+    keys = [str(k) for k in exp["keys"]]
+    R = np.stack([rot[k] for k in keys]); t = np.stack([pos[k] for k in keys])
+    r_err, t_err = float(geodesic(R, exp["R"]).max()), float(np.linalg.norm(t - exp["t"], axis=1).max())
+    from conftest import record_parity
+    record_parity(name, dt, "facade, sharded schedule", r_err, t_err, e2e_translation_tol(name, dt), info.cg_iters, int(exp["cg_iters"]))
+    assert r_err < (5e-6 if dt == "float32" else 1e-7), r_err
+    assert t_err < e2e_translation_tol(name, dt), t_err
+    assert abs(info.cg_iters - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    # against the single-rank schedule of the same boundary: the same answer to the eigen-solver's tolerance
+    assert float(geodesic(Rc, Rc1).max()) < (2e-6 if dt == "float32" else 1e-9) and abs(info.cg_iters - info1.cg_iters) <= 1
+
+
 def test_bad_arguments_are_refused():
     lib = _lib.load()
     plan = C.c_void_p()
     assert lib.vican_plan_create(0, 1, 1, 0, None, None, None, None, None, None, None, None, None, None, C.byref(plan)) == _lib.ERR_ARG
     assert lib.vican_solve_rot(None, 4, 1e-10, None, None, None, None) == _lib.ERR_ARG
+    assert lib.vican_plan_set_comm(None, None, None) == _lib.ERR_ARG
     assert lib.vican_plan_destroy(None) == 0
 
 

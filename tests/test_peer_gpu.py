@@ -144,3 +144,23 @@ def test_sharded_golden_over_the_peer_exchange_between_processes(nranks, tmp_pat
     if rep["float64"]["transport"] != "peer":
         pytest.skip("same-device hipIpc mapping refused on this box")
     assert "dist g9: mismatches 0" in res.stdout
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_the_c_boundary_as_ranks_of_one_sharded_solve(nranks, tmp_path):
+    """tools/facade_dist.py: vican_plan_create on each rank's slice of the rows + vican_plan_set_comm + the two solve calls, the
+    communicator made from ctypes alone (vican_comm_create_local, 64-byte mailbox handles) - goldens g3 (both dtypes) and g9
+    (large_shop scale) against the real reference's poses."""
+    out = str(tmp_path / "facade.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "facade_dist.py"), out]
+    res = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(res.stdout[-3000:])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "facade dist: mismatches 0" in res.stdout
+    rep = json.load(open(out))
+    from conftest import record_parity
+    for key, r in rep.items():
+        if isinstance(r, dict) and "rot_rad" in r:
+            name, dt = key.rsplit("_", 1)
+            record_parity(name, dt, "facade, %d ranks" % nranks, r["rot_rad"], r["trans_m"], r["bound_m"], r["cg_iters"], r["cg_reference"])

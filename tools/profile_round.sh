@@ -7,7 +7,7 @@ TAG=${1:-r01}
 O=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse --no-wide --no-facade"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-large-shop --no-sparse --no-wide --no-facade --no-sharded-schedule"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 1 --warmup 0 > $O/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 1 --warmup 0 > $O/bench_write.log 2>&1

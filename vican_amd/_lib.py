@@ -188,6 +188,7 @@ PROTOTYPES = {
     # the four-call boundary (csrc/vican_facade.hip)
     "vican_plan_create": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "vican_plan_describe": (C.c_int, [_vp, _G]),
+    "vican_plan_set_comm": (C.c_int, [_vp, _vp, _vp]),
     "vican_solve_rot": (C.c_int, [_vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "vican_solve_trans": (C.c_int, [_vp, _vp, _vp, _f64, _i64, _vp, _vp, _vp, _vp]),
     "vican_solve_trans_lsqr": (C.c_int, [_vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _vp, _vp, _vp, _vp]),

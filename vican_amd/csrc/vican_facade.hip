@@ -7,9 +7,11 @@
 // stopping rules - with the plain schedule: layout planning as device.py's _Layout (wave layout where every row fits a
 // 64-lane chunk, else block layout), block Lanczos with a convergence check (device Ritz step, one blocking 128-byte read) every
 // few steps, launch-sequence camera-side step, the fused dual update, CG iterations (vican_cg_iter_fused) in bursts of eight
-// with the state polled in between.  No speculation, no cooperative kernels, no HIP graphs, single rank, C <= 1024: the Python driver remains the
-// fast path (and the only sharded / tiled / LSQR one); this one is the small stable surface.  The library owns the plan's
-// device memory (one arena); inputs and outputs are the caller's.
+// with the state polled in between.  No speculation, no HIP graphs, C <= 1024.  vican_plan_set_comm turns the same plan into ONE RANK
+// of a timestep-sharded solve (the plan holds this rank's rows; every camera-side quantity is replicated): the sweeps' camera
+// partials are all-reduced from C in stream order (vican_block_op_z_comm), the CG runs vican_cg_iter_comm - the schedule
+// vican_amd/solver.py takes for sharded runs.  The Python driver remains the fast path (and the only camera-tiled one); this
+// one is the small stable surface.  The library owns the plan's device memory (one arena); inputs and outputs are the caller's.
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -78,6 +80,11 @@ struct vican_plan {
     uint32_t* cg_ticket = nullptr;
     double* status_host = nullptr;      // pinned
     // LSQR workspace (lsqr_solver="direct"): its own allocation, made by the first vican_solve_trans_lsqr (24 bytes per edge slot)
+    // one rank of a timestep-sharded solve (vican_plan_set_comm): the communicator, the CG message, the GLOBAL graph sizes
+    vican_comm_t* comm = nullptr;
+    double* msg = nullptr;
+    double* setup_msg = nullptr;
+    bool comm_ready = false;
     unsigned char* lsqr_base = nullptr;
     double *lu = nullptr, *lsw = nullptr, *lpart = nullptr, *lslab = nullptr, *lv_c = nullptr, *lw_c = nullptr, *lv_t = nullptr, *lw_t = nullptr,
            *lz_t = nullptr, *lacc = nullptr, *lpart2 = nullptr, *lwp_c = nullptr, *lwp_t = nullptr, *ls2 = nullptr;
@@ -214,8 +221,10 @@ size_t carve(vican_plan* P, size_t n_row0) {
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
         P->pq_part = A.take<double>(std::max(P->g.n_wg, 1)); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
         P->st = (vican_cg_state_t*)A.take<double>(19);
-        P->cg_ticket = A.take<uint32_t>(256);        // (vican_cg_iter_fused: tickets, hand-over words, p.q partials; zeroed with the arena)
+        P->cg_ticket = A.take<uint32_t>(256);        // (vican_cg_iter_fused: the fold's p.q partials; zeroed with the arena)
+        P->msg = A.take<double>(3 * (size_t)C + VICAN_CG_PQ_SLICES);      // (vican_cg_iter_comm: [q_c partial | slices of p_t.q_t])
     }
+    P->setup_msg = A.take<double>((size_t)C + 4);
     return A.used + 256;
 }
 
@@ -324,6 +333,35 @@ extern "C" int vican_plan_describe(const vican_plan_t* P, vican_graph_t* g_out) 
     return VICAN_OK;
 }
 
+// One rank of a timestep-sharded solve: the plan was created from THIS rank's rows (row_ptr / col / blk ... of its slice of the
+// timesteps, all C cameras; deg_c: this rank's share of the diagonal - the whole vector on one rank, zeros on the others - or NULL:
+// the local camera sums).  From here on vican_solve_rot / vican_solve_trans all-reduce the camera-side partials through `comm`
+// (vican_comm_*: peer exchange or RCCL) in stream order; every rank must make the same calls.  One collective here: the graph
+// constants that must be GLOBAL (camera degrees -> pivot floor, edge and row counts -> propagation sweeps).  comm NULL: back to
+// a single-rank plan.
+extern "C" int vican_plan_set_comm(vican_plan_t* P, vican_comm_t* comm, void* stream) {
+    if (!P) return ferr(VICAN_ERR_ARG, "vican_plan_set_comm: NULL plan");
+    P->comm = comm; P->comm_ready = false;
+    if (!comm) return VICAN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = P->C;
+    std::vector<double> h((size_t)C + 2);
+    HIPCK(hipMemcpyAsync(P->setup_msg, P->cam_sum_a, (size_t)C * 8, hipMemcpyDeviceToDevice, s), "vican_plan_set_comm");
+    const double cnt[2] = {(double)P->E, (double)P->T};
+    HIPCK(hipMemcpyAsync(P->setup_msg + C, cnt, 16, hipMemcpyHostToDevice, s), "vican_plan_set_comm");
+    HIPCK(hipStreamSynchronize(s), "vican_plan_set_comm");          // (cnt is a stack object)
+    CK(vican_comm_allreduce_sum(comm, P->setup_msg, C + 2, stream));
+    HIPCK(hipMemcpyAsync(h.data(), P->setup_msg, h.size() * 8, hipMemcpyDeviceToHost, s), "vican_plan_set_comm");
+    HIPCK(hipStreamSynchronize(s), "vican_plan_set_comm");
+    P->lscale = *std::max_element(h.begin(), h.begin() + C);
+    const double n_e = h[C], n_t = std::max(h[C + 1], 1.0);
+    const double hops1 = (n_e / C) * std::max(n_e / n_t - 1.0, 0.0) / C;
+    P->prop_sweeps = hops1 >= 4.0 ? 1 : (hops1 >= 0.5 ? 2 : 3);
+    for (int& v : P->pred_steps) v = 0;
+    P->comm_ready = true;
+    return VICAN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // rotation stage: reference large_bipartite_so3sync, bipgo.py:279-348 (schedule of vican_amd/solver.py RotationSolver, plain form)
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -338,15 +376,18 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
     const int min_steps = small ? 8 : 4, warm_min = small ? 4 : 2, check_every = small ? 4 : 2, max_restarts = 20;
     const double floor_tol = P->storage == VICAN_STORE_F64 ? 1e-13 : 1e-7, pivot_floor = (1e-12 * P->lscale) * (1e-12 * P->lscale);
     vican_solve_info_t inf{};
+    vican_comm_t* comm = P->comm_ready ? P->comm : nullptr;       // (one rank of a sharded solve: camera partials all-reduced in stream order)
+    auto op_z = [&](const double* x, double* z) { return vican_block_op_z_comm(g, P->lamT, x, P->zpart, P->fx, z, comm, stream); };
     // duals, Lambda_C = (weighted camera degree) I  (bipgo.py:271-276)
     CK(vican_init_duals(T, P->row_sum_a, P->rnorm, P->lamT, P->fx, stream));
     CK(fx_finish(P, stream));
     HIPCK(hipMemcpyAsync(P->cam_deg, P->cam_sum_a, (size_t)C * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
+    if (comm) CK(vican_comm_allreduce_sum(comm, P->cam_deg, C, stream));
     CK(vican_scaled_identity(C, P->cam_deg, P->lamC, stream));
     // start block: rotations propagated from the gauge camera through the power graph (solver.py: _propagated_start)
     hipLaunchKernelGGL(facade_seed_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, n, P->x0);
     for (int k = 0; k < P->prop_sweeps; ++k) {
-        CK(vican_block_op_z(g, P->lamT, P->x0, P->zpart, P->fx, P->z, stream));
+        CK(op_z(P->x0, P->z));
         CK(vican_polar_dual(C, P->z, P->x0, nullptr, 0, stream));
         ++inf.sweeps;
     }
@@ -385,10 +426,10 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
                 const int j = steps;
                 // camera side of the step as ONE cooperative launch (vican_lanczos_cam_coop; with few slabs it folds them itself:
                 // the sweep's result stays in fixed point) - the launch sequence (7 kernels per step) where that grid is refused
-                const bool sweep = !(j == 0 && have_z), from_slabs = sweep && P->coop_ok && g->n_wg <= 64;
+                const bool sweep = !(j == 0 && have_z), from_slabs = sweep && !comm && P->coop_ok && g->n_wg <= 64;
                 if (sweep) {
                     if (from_slabs) CK(vican_block_op(g, P->lamT, P->xrow, P->zpart, P->fx, stream));
-                    else CK(vican_block_op_z(g, P->lamT, P->xrow, P->zpart, P->fx, P->z, stream));
+                    else CK(op_z(P->xrow, P->z));
                     ++inf.sweeps;
                 }
                 bool done_step = false;
@@ -434,9 +475,13 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
         inf.eig_resid = st[0];
         // X = V3 V3[0:3]^-1, per-camera projection, Y = P X, camera duals, timestep duals (bipgo.py:295-334)
         CK(vican_gauge_project(C, P->X, P->Xp, stream));
-        CK(vican_block_op_z(g, P->lamT, P->Xp, P->zpart, P->fx, P->z, stream));
+        CK(op_z(P->Xp, P->z));
         CK(vican_polar_dual(C, P->z, P->rc, P->lamC, 1, stream));
-        if (!last) { CK(vican_dual_update_op(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, P->zpart, P->zraw, stream)); z_ready = true; }
+        if (!last) {
+            CK(vican_dual_update_op(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, P->zpart, P->zraw, stream));
+            if (comm) CK(vican_comm_allreduce_sum(comm, P->zraw, 9LL * C, stream));
+            z_ready = true;
+        }
         else CK(vican_dual_update(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, stream));
         CK(fx_finish(P, stream));
         inf.sweeps += 2;
@@ -460,9 +505,19 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     const int C = P->C, T = P->T;
     if (maxiter <= 0) maxiter = 10LL * 3 * (C + T);              // scipy's default
     vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
+    vican_comm_t* comm = P->comm_ready ? P->comm : nullptr;
     CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
+    const double* deg_c = P->cam_sum_w;
+    if (comm) {
+        // the camera side of the system is a sum over all ranks' rows: right-hand side and diagonal (the caller's deg_c was this
+        // rank's SHARE); the reduced diagonal in its own buffer - the plan's stays this rank's share for the next solve
+        CK(vican_comm_allreduce_sum(comm, P->b_c, 3LL * C, stream));
+        HIPCK(hipMemcpyAsync(P->setup_msg, P->cam_sum_w, (size_t)C * 8, hipMemcpyDeviceToDevice, s), "vican_solve_trans");
+        CK(vican_comm_allreduce_sum(comm, P->setup_msg, C, stream));
+        deg_c = P->setup_msg;
+    }
     vican_cg_state_t h{};
-    if (P->cgres_ok) {
+    if (P->cgres_ok && !comm) {
         // capture-sized graphs: the whole solve as ONE cooperative launch (vican_cg_resident; an iteration of the launch sequence is
         // three dependent launches of a few microseconds each there)
         const int rc_ = vican_cg_resident(&P->g, P->w, P->row_sum_w, P->cam_sum_w, P->b_c, P->b_t, x_c, x_t, P->zpart, P->cgres_ws, rtol,
@@ -484,13 +539,19 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
         }
     }
     CK(vican_cg_init(C, T, P->b_c, P->b_t, x_c, x_t, P->r_c, P->r_t, P->p_c, P->p_t, P->st, P->ws, P->wmax, stream));
+    if (comm) CK(vican_comm_allreduce_sum(comm, &P->st->rr_time, 1, stream));
     long long launched = 0;
     int burst = 8;
     for (;;) {
         // (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x; no test behind the last one)
-        for (int i = 0; i < burst && launched < maxiter; ++i, ++launched)
-            CK(vican_cg_iter_fused(&P->g, P->w, P->row_sum_w, P->cam_sum_w, P->r_c, P->p_c, x_c, P->r_t, P->p_t, P->q_t, x_t, P->zpart,
-                                   P->pq_part, P->qcpq, rtol, P->rr_part, 1536, P->n_add_cg, launched == 0, P->st, P->cg_ticket, stream));
+        for (int i = 0; i < burst && launched < maxiter; ++i, ++launched) {
+            if (comm)
+                CK(vican_cg_iter_comm(&P->g, P->w, P->row_sum_w, deg_c, P->r_c, P->p_c, x_c, P->r_t, P->p_t, P->q_t, x_t, P->zpart, P->pq_part,
+                                      P->msg, rtol, P->rr_part, 1536, P->n_add_cg, launched == 0, P->st, comm, stream));
+            else
+                CK(vican_cg_iter_fused(&P->g, P->w, P->row_sum_w, P->cam_sum_w, P->r_c, P->p_c, x_c, P->r_t, P->p_t, P->q_t, x_t, P->zpart,
+                                       P->pq_part, P->qcpq, rtol, P->rr_part, 1536, P->n_add_cg, launched == 0, P->st, P->cg_ticket, stream));
+        }
         HIPCK(hipMemcpyAsync(P->status_host + 16, P->st, sizeof(vican_cg_state_t), hipMemcpyDeviceToHost, s), "vican_solve_trans");
         HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
         std::memcpy(&h, P->status_host + 16, sizeof(h));
