@@ -706,7 +706,7 @@ int vican_lsqr_update_st(int64_t n, double* v, double* w, double* x, double* par
  *                   (hipIpc handles; xGMI between the GPUs of a node): every rank pushes its partial into its slot of every
  *                   mailbox as self-validating 8-byte granules {32 data bits | epoch tag} and sums the slots of its own mailbox
  *                   in rank order - one hop, the same bits on every rank, no ordering between payload and flag relied on, bounded
- *                   waits.  The launch honours vican_set_gate (a speculative tail that the device cancels advances nothing on
+ *                   waits (30 s: a peer may arrive seconds late; vican_comm_peer_set_timeout).  The launch honours vican_set_gate (a speculative tail that the device cancels advances nothing on
  *                   any rank), so sharded solves speculate like single-rank ones.  Messages up to `max_doubles`; <= 8 ranks.
  *   vican_comm_unique_id   128 bytes (ncclUniqueId) written by ONE rank, handed to the others by any means
  *   vican_comm_create      collective over the group: every rank calls it with the same id (ncclCommInitRank)
@@ -739,6 +739,7 @@ int64_t vican_comm_peer_bytes(int32_t world, int64_t max_doubles);
 int vican_comm_peer_export(vican_comm_t* comm, int64_t max_doubles, void* handle_out /* 64 bytes, host */);
 int vican_comm_peer_attach(vican_comm_t* comm, const void* handles /* [world][64], host */);
 int vican_comm_peer_enable(vican_comm_t* comm, int32_t on);
+int vican_comm_peer_set_timeout(vican_comm_t* comm, int64_t microseconds);   /* bound of every wait of the exchange (default 30 s) */
 int vican_comm_peer_status(vican_comm_t* comm);
 int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream);
 int vican_comm_destroy(vican_comm_t* comm);

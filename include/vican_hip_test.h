@@ -20,6 +20,10 @@ int vican_test_occupy(int32_t n_wg, int32_t threads, int32_t lds_bytes, int64_t 
  * that produced the message (tests/test_comm_gpu.py, tools/rccl_onerank.py).  The buffer keeps its bits.                */
 int vican_comm_force_enqueue(vican_comm_t* comm, int32_t on);
 
+/* Counts one timed-out wait of the peer exchange without there having been one (vican_comm_peer_status > 0 afterwards): the tests
+ * walk the recovery path - the whole group falls back to RCCL / torch.distributed - on hardware where the exchange works.       */
+int vican_comm_peer_inject_fault(vican_comm_t* comm);
+
 /* ---- LSQR, two-pass form (cross-checks; reference bipgo.py:479-480) -------------------------------------------- */
 /* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
 int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,

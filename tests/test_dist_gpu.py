@@ -88,6 +88,13 @@ def test_bench_launches_its_own_ranks(workload, scaling, gpus, min_edges):
         return
     assert out["detail"]["n_allreduce_per_solve"] > 0 and out["config"]["policy"] == "sharded"
     print(out["config"]["transport"], out["config"]["comm_notes"])
+    demoted = any("switched off" in n for n in (out["config"]["comm_notes"] or []))
+    if demoted:
+        # N processes time-share ONE GPU here: on a crowded box a rank's exchange kernel can wait past its bound for a peer that
+        # is not scheduled.  The run then fell back to the group's other transport before its timed region (bench.py) - which
+        # is what this branch sees; the collective count of the warm-up no longer matches the formula below
+        assert out["config"]["transport"] in ("torch", "rccl")
+        return
     if scaling == "strong":
         assert out["detail"]["rows_rank0"] == 10000 // gpus
         # collectives per solve: one all-reduce per operator application (propagated start + Lanczos steps + the tails'

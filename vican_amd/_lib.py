@@ -180,6 +180,7 @@ PROTOTYPES = {
     "vican_comm_peer_export": (C.c_int, [_vp, _i64, _vp]),
     "vican_comm_peer_attach": (C.c_int, [_vp, _vp]),
     "vican_comm_peer_enable": (C.c_int, [_vp, _i32]),
+    "vican_comm_peer_set_timeout": (C.c_int, [_vp, _i64]),
     "vican_comm_peer_status": (C.c_int, [_vp]),
     "vican_comm_allreduce_sum": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vican_comm_destroy": (C.c_int, [_vp]),
@@ -211,6 +212,7 @@ class LsqrInfo(C.Structure):
 # include/vican_hip_test.h: diagnostics / cross-check entry points, not part of the boundary
 TEST_PROTOTYPES = {
     "vican_comm_force_enqueue": (C.c_int, [_vp, _i32]),
+    "vican_comm_peer_inject_fault": (C.c_int, [_vp]),
     "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),

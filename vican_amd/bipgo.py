@@ -189,6 +189,13 @@ def solve_problem(prob: frontend.Problem, maxiter: int, lsqr_solver: str, dtype=
 
     # (a cooperative kernel whose grid barrier timed out - device shared - makes the stages run again on the launch sequences)
     rot, tr, rc, Rt_all, Rt_loc, x_c, x_t = with_cooperative_fallback(K, comm, stages)
+    if comm.world > 1 and hasattr(comm, "healthy") and not getattr(comm, "_verified", False):
+        # the first sharded solve of a communicator ends with ONE collective health check: if a wait of the peer exchange timed
+        # out on any rank (its messages came back as NaN) the group falls back to RCCL / torch on every rank and the solve runs again
+        if not comm.healthy():
+            warnings.warn("vican_amd: " + "; ".join(comm.notes), RuntimeWarning, stacklevel=2)
+            rot, tr, rc, Rt_all, Rt_loc, x_c, x_t = with_cooperative_fallback(K, comm, stages)
+        comm._verified = True
     if hasattr(comm, "check"):
         comm.check()                       # (a timed-out wait of the peer exchange: NaN messages - an error, never a silent result)
     t2 = tm["t2"]

@@ -70,8 +70,8 @@ int rccl_err(const char* who, ncclResult_t e) {
 //   epoch            : a DEVICE word, advanced by the launch itself (its last workgroup) - a launch that the solver's gate
 //                      cancels on the device (speculative tails) advances nothing, on any rank; parities alternate with it, so
 //                      a source can overwrite a slot only after the owner has collected it (it needs the owner's NEXT push first)
-//   waits            : bounded (vican_set_barrier_abort's limit); a timeout raises the host-visible status word, the message
-//                      is left as NaN, and the exchange is disabled for this communicator (vican_comm_peer_status)
+//   waits            : bounded (30 s; vican_comm_peer_set_timeout); a timeout raises the host-visible status word, the message
+//                      is left as NaN, and the caller switches the group to its fall-back transport (vican_comm_peer_status)
 // ---------------------------------------------------------------------------------------------------------------------------
 #define VICAN_PEER_MAX 8
 #define VICAN_PEER_WG 1024
@@ -309,9 +309,18 @@ extern "C" int vican_comm_peer_attach(vican_comm_t* c, const void* handles) {
         c->pa.mbox[r] = (unsigned long long*)p;
     }
     c->pa.rank = c->rank; c->pa.world = c->world; c->pa.cap = c->mb_cap;
-    c->pa.limit = g_vican_sync_ticks ? g_vican_sync_ticks : 200000000ull;          // (2 s of the 100 MHz counter)
+    // waits of the exchange: 30 s by default - a rank may reach a collective seconds after its peers (packing, a first-call
+    // module load): RCCL's kernels would wait for it indefinitely; this bound only ends waits for a rank that is gone
+    // (the 2 s bound of the cooperative kernels' grid barriers guards something else: a grid that is not co-resident)
+    c->pa.limit = 3000000000ull;
     c->mb_attached = true;
     c->mb_enabled = true;
+    return VICAN_OK;
+}
+
+extern "C" int vican_comm_peer_set_timeout(vican_comm_t* c, int64_t microseconds) {
+    if (!c || microseconds <= 0) return set_err(VICAN_ERR_ARG, "%s: bad argument", "vican_comm_peer_set_timeout");
+    c->pa.limit = (unsigned long long)microseconds * 100ull;            // ticks of the 100 MHz real-time counter
     return VICAN_OK;
 }
 
@@ -346,6 +355,14 @@ extern "C" int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t
     }
     const ncclResult_t e = rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, comm->comm, (hipStream_t)stream);
     return e == ncclSuccess ? VICAN_OK : rccl_err("vican_comm_allreduce_sum", e);
+}
+
+// test hook (include/vican_hip_test.h): count one timed-out wait without there having been one - lets a test walk the recovery
+// path (solver.Comm.healthy: the whole group falls back to RCCL / torch.distributed) on hardware where the exchange works
+extern "C" int vican_comm_peer_inject_fault(vican_comm_t* c) {
+    if (!c || !c->mb_attached) return set_err(VICAN_ERR_ARG, "%s: no exchange attached", "vican_comm_peer_inject_fault");
+    *(volatile unsigned int*)c->pa.status += 1u;
+    return VICAN_OK;
 }
 
 // test / timing switch (include/vican_hip_test.h): a one-rank communicator really calls ncclAllReduce

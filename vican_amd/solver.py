@@ -103,10 +103,22 @@ class Comm:
         hit = _NATIVE_COMMS.get(key)
         if hit is None:
             self._create_native(device)
-            _NATIVE_COMMS[key] = (self._native, self._native_lib, self.transport, self.gateable, list(self.notes))
+            hit = _NATIVE_COMMS[key] = dict(native=self._native, lib=self._native_lib, transport=self.transport, gateable=self.gateable,
+                                            notes=list(self.notes), verified=False)
         else:
-            self._native, self._native_lib, self.transport, self.gateable, self.notes = hit[0], hit[1], hit[2], hit[3], list(hit[4])
+            self._native, self._native_lib, self.transport, self.gateable, self.notes = (hit["native"], hit["lib"], hit["transport"],
+                                                                                           hit["gateable"], list(hit["notes"]))
+        self._shared = hit                                       # (state of the group's communicator, shared by every Comm of the group)
         self._owns_native = False
+
+    @property
+    def _verified(self):
+        return bool(getattr(self, "_shared", {}).get("verified", False))
+
+    @_verified.setter
+    def _verified(self, v):
+        if getattr(self, "_shared", None) is not None:
+            self._shared["verified"] = bool(v)
 
     def _create_native(self, device):
         want = self.transport_wanted
@@ -155,7 +167,11 @@ class Comm:
             if not ok and all(x is not None for x in handles):
                 self.notes.append("vican_comm_peer_attach: %s" % (lib.vican_last_error() or b"?").decode())
             if agree(ok):
+                # (the self-test runs right behind a collective that aligned the ranks: a short bound ends a broken mapping quickly;
+                #  solves get the long one - a rank may reach its first collective seconds after the others)
+                lib.vican_comm_peer_set_timeout(h, 2_000_000)
                 ok = agree(self._peer_selftest(device))
+                lib.vican_comm_peer_set_timeout(h, int(os.environ.get("VICAN_PEER_TIMEOUT_US", 30_000_000)))
                 if ok:
                     self.transport, self.gateable = "peer", True
                 else:
@@ -187,6 +203,33 @@ class Comm:
                 torch.cuda.current_stream().synchronize()
                 ok = ok and all(bool(torch.equal(b, want)) for b in bufs) and lib.vican_comm_peer_status(h) == 0
         return ok
+
+    def healthy(self):
+        """COLLECTIVE (every rank of the group calls it at the same point): True iff no wait of the peer exchange has timed out on
+        any rank.  On False the group's communicator is demoted on EVERY rank - the exchange is switched off, the all-reduces go
+        through RCCL from C (RCCL groups) or torch.distributed, speculation through collectives stops - and stays demoted for
+        the life of the process: the caller re-runs what it computed since the last healthy point.  Cheap to call between solves
+        (one tiny host-side all-gather); never called inside a timed region."""
+        if self.world == 1 or getattr(self, "_native", None) is None or getattr(self, "transport", None) != "peer":
+            return True
+        bad = self._native_lib.vican_comm_peer_status(self._native) > 0
+        flags = [None] * self.world
+        torch.distributed.all_gather_object(flags, bool(bad), group=self.group)
+        if not any(flags):
+            return True
+        self._demote("a wait of the peer exchange timed out on rank(s) %s" % [r for r, f in enumerate(flags) if f])
+        return False
+
+    def _demote(self, why):
+        self.notes.append("peer exchange switched off: " + why)
+        self._native_lib.vican_comm_peer_enable(self._native, 0)
+        self.gateable = False
+        if self._device_collectives():
+            self.transport = "rccl"
+        else:                                                   # a local communicator has no other collective: torch carries them
+            self.transport, self._native = "torch", None
+        if getattr(self, "_shared", None) is not None:           # later Comm objects of this group start demoted
+            self._shared.update(native=self._native, transport=self.transport, gateable=False, notes=list(self.notes))
 
     def check(self):
         """Raise if a wait of the peer exchange timed out since the communicator was made (its messages came back as NaN)."""
