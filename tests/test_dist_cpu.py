@@ -49,6 +49,11 @@ def _worker(rank, world, port, name, dt, out_q, tight=False, messages=None):
         full[r0:r1, :9] = Rt[: r1 - r0]
         full[r0:r1, 9:] = x_t[: r1 - r0]
         comm.allreduce(full)
+        # the replicated camera side must be the SAME BITS on every rank (rank-ordered / fixed-slice sums behind every collective)
+        import hashlib
+        sums = [None] * world
+        dist.all_gather_object(sums, hashlib.sha1(rc.numpy().tobytes() + x_c.numpy().tobytes()).hexdigest())
+        assert len(set(sums)) == 1, "camera-side results differ between ranks: %s" % sums
         if rank == 0:
             out_q.put(dict(rc=rc.numpy().copy(), Rt=full[:, :9].numpy().copy(), x_c=x_c.numpy().copy(),
                            x_t=full[:, 9:].numpy().copy(), cg_iters=stats["cg_iters"], sweeps=stats["sweeps"],

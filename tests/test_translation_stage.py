@@ -50,11 +50,13 @@ class LoneShardComm(Comm):
         return t
 
 
-def run_stage(K, prob, exp, comm=None, one_message=None):
+def run_stage(K, prob, exp, comm=None, one_message=None, comm_iter=None):
     rc, rt = reference_rotations(prob, exp)
     tr = TranslationSolver(K, comm or Comm.single())
     if one_message is not None:
         tr.one_message = bool(one_message)
+    if comm_iter is not None:
+        tr.use_comm_iter = bool(comm_iter)
     tr.setup(K.from_numpy(rc), K.from_numpy(rt))
     x_c, x_t = tr.solve(3 * (prob.n_cam + prob.n_time))
     pos = {str(c): x_c.cpu().numpy()[i] for i, c in enumerate(prob.cam_names)}
@@ -98,12 +100,19 @@ def test_sharded_default_is_scipys_recurrence_numpy_backend(name, dt):
     mk = lambda: NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.dtype(dt).type,
                               deg_t=prob.deg_t, deg_c=prob.deg_c)
     comm = LoneShardComm()
-    dist, info = run_stage(mk(), prob, exp, comm)
+    dist, info = run_stage(mk(), prob, exp, comm, comm_iter=False)
     dist1, info1 = run_stage(mk(), prob, exp)
     assert not info.get("one_message")
     assert dist == dist1 and info["cg_iters"] == info1["cg_iters"]
     # set-up message + r.r of the start + two per launched iteration (bursts overshoot by at most 64 iterations)
     assert 2 * info["cg_iters"] <= comm.n_allreduce <= 2 + 2 * (info["cg_iters"] + 1 + 64)
+    # round 6: the same recurrence behind ONE call per iteration with the two cross-rank sums travelling as fixed slices
+    # (vican_cg_iter_comm; the default where the backend offers it) - other groupings of the same sums: the golden's bounds,
+    # the iteration count within the reference's own spread, the same two messages per iteration
+    comm2 = LoneShardComm()
+    dist2, info2 = run_stage(mk(), prob, exp, comm2)
+    assert dist2 < stage_tol(name, dt) and abs(info2["cg_iters"] - int(exp["cg_iters"])) <= iteration_slack(name, dt)
+    assert 2 * info2["cg_iters"] <= comm2.n_allreduce <= 2 + 2 * (info2["cg_iters"] + 1 + 64)
 
 
 def hip_backend(prob, dt):

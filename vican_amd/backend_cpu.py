@@ -466,6 +466,50 @@ class NumpyBackend:
         self.cg_cam_step(deg_c, qcpq, p_c, x_c, r_c, st)
         return self.cg_time_step(p_t, q_t, x_t, r_t, st)
 
+    # the sharded iteration behind one call (include/vican_hip.h: vican_cg_iter_comm): scipy's recurrence with the two sums that
+    # cross ranks travelling as FIXED slices - msg = [q_c partial | slices of p_t.q_t], then the slices of r_t.r_t - all-reduced
+    # element by element and summed in a fixed order behind the collective: the same bits on every rank.  This backend issues
+    # the two all-reduces through comm.allreduce itself (comm_iter_host): the HIP backend's are enqueued by the C library.
+    comm_iter_host = True
+    CG_RR_SLICES = 512
+
+    def cg_iter_comm(self, deg_t, deg_c, r_c, p_c, x_c, r_t, p_t, q_t, x_t, msg, rtol, st, first, comm):
+        from ._lib import CG_PQ_SLICES
+        f, i = self._st(st)
+        T, C3 = self.T, 3 * self.C
+        if getattr(self, "_rr_slices", None) is None:
+            self._rr_slices = torch.zeros(self.CG_RR_SLICES, dtype=torch.float64)
+        rr = self._rr_slices
+        if not i[CG_I["done"]]:
+            if not first:                                       # close the previous iteration from the REDUCED slices of r.r
+                f[CG_F["rr_time"]] = float(np.add.reduce(rr.numpy()))      # (fixed order: sequential over the slices)
+                i[CG_I["iter"]] += 1
+                f[CG_F["rho_prev"]] = f[CG_F["rho"]]
+                i[CG_I["first"]] = 0
+            self.cg_begin(r_c, p_c, rtol, st, 0)
+        m = msg.numpy()
+        if not i[CG_I["done"]]:
+            self.cg_sweep(deg_t, p_c, r_t, p_t, q_t, msg[: C3 + 1], st)
+            pq = (p_t.numpy()[:T] * q_t.numpy()[:T]).reshape(-1)
+            sl = np.zeros(CG_PQ_SLICES)
+            n_sl = max(1, min(CG_PQ_SLICES, -(-len(pq) // 8192)))
+            for k in range(n_sl):                               # slice k = elements k, k + n_sl, ... blocks of 1024 (the kernel's map)
+                sl[k] = float(pq.reshape(-1)[k::n_sl].sum()) if len(pq) else 0.0
+            m[C3:] = sl
+        comm.allreduce(msg)
+        if not i[CG_I["done"]]:
+            qcpq = torch.from_numpy(np.concatenate([m[:C3], [float(np.add.reduce(m[C3:]))]]))
+            self.cg_cam_step(deg_c, qcpq, p_c, x_c, r_c, st)
+            a = f[CG_F["alpha"]]
+            x_t.numpy()[:T] += a * p_t.numpy()[:T]
+            r_t.numpy()[:T] -= a * q_t.numpy()[:T]
+            r2 = (r_t.numpy()[:T] ** 2).reshape(-1)
+            nb = max(1, min(self.CG_RR_SLICES, -(-len(r2) // 1024)))
+            rr.zero_()
+            for k in range(nb):
+                rr.numpy()[k] = float(r2[k::nb].sum()) if len(r2) else 0.0
+        comm.allreduce(rr)
+
     # one message per CG iteration (include/vican_hip.h: vican_cg1_iter_local / vican_cg1_iter_finish)
     def cg1_iter_local(self, deg_t, r_c, r_t, s_t, msg, st, n_rr_part):
         f, i = self._st(st)

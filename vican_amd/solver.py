@@ -859,7 +859,8 @@ class TranslationSolver:
                 # fixed slices (bit-reproducible, bit-identical on every rank) - include/vican_hip.h: vican_cg_iter_comm
                 K.cg_iter_comm(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self._msg,
                                self.rtol, st, first=(n_part is None), comm=comm)
-                comm.n_allreduce += 2
+                if not getattr(K, "comm_iter_host", False):     # (the C library's all-reduces are not seen by comm.allreduce)
+                    comm.n_allreduce += 2
                 return 0
             n_part = n_part or 0
             K.cg_iter_local(self.deg_t, self.r_c, self.p_c, self.r_t, self.p_t, self.q_t, self.qcpq, self.rtol, st, n_part)
@@ -925,11 +926,12 @@ class TranslationSolver:
         """Sharded solve whose all-reduces the C library enqueues itself (solver.Comm with a native communicator, or a forced
         one-rank Comm: identity) on a backend with vican_cg_iter_comm: one host call per iteration."""
         K, comm = self.K, self.comm
-        if getattr(K, "cg_iter_comm", None) is None or not hasattr(comm, "native_handle"):
-            return False
-        if comm.world > 1 and not getattr(comm, "_native_tried", True):
+        if getattr(K, "cg_iter_comm", None) is None or not hasattr(comm, "native_handle") or not getattr(self, "use_comm_iter", True):
+            return False                                         # (use_comm_iter = False: the launch sequence with host-issued all-reduces)
+        host_side = bool(getattr(K, "comm_iter_host", False))   # (the backend issues the two all-reduces through comm.allreduce itself)
+        if comm.world > 1 and not getattr(comm, "_native_tried", True) and not host_side:
             comm._setup_native(self.st.device)
-        if comm.native_handle() is None and comm.world > 1:
+        if comm.native_handle() is None and comm.world > 1 and not host_side:
             return False
         if getattr(self, "_msg", None) is None:
             from ._lib import CG_PQ_SLICES
@@ -968,7 +970,8 @@ class TranslationSolver:
             for k in range(n_iter):
                 K.cg_iter_comm(self.deg_t, self.deg_c, self.r_c, self.p_c, self.x_c, self.r_t, self.p_t, self.q_t, self.x_t, self._msg,
                                0.0, st, first=(k == 0), comm=comm)
-                comm.n_allreduce += 2
+                if not getattr(K, "comm_iter_host", False):
+                    comm.n_allreduce += 2
             s = self._state()
             self.info = dict(cg_iters=n_iter, converged=False, fixed=True,
                              relres=float(np.sqrt(s["rho"] / s["bnorm2"])) if s["bnorm2"] > 0 else 0.0)
