@@ -445,6 +445,41 @@ def test_cooperative_step_repeats_bit_identically():
     assert int(H._coop_sync.abs().sum()) == 0
 
 
+def test_wave_sweeps_repeat_bit_identically():
+    """The sweeps' sums are fixed-point, so their results do not depend on which workgroup took which chunk - as long as
+    every chunk is taken exactly once.  The range scheduler of wave_sweep_kernel once published "queue exhausted" BEFORE the
+    last range (two LDS stores in the wrong order): a wavefront polling between them left with its ticket inside that range
+    and the chunk's rows were missing from the sums, in about one sweep of 10^4 on the stress graph (a Lanczos solve then
+    needed extra steps; results still converged).  Tens of thousands of back-to-back sweeps on the same inputs must
+    reproduce the first result bit for bit, for the operator sweep (MODE 0 + fold) and the fused dual update (MODE 3)."""
+    from vican_amd.device import HipBackend, LocalGraph
+    dev = torch.device("cuda:0")
+    C, T, cpt = 1000, 20000, 250
+    gr = synth.make_merged_graph_torch(C, T, cpt, dev, torch.float32, seed=5)
+    K = HipBackend(LocalGraph(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"]))
+    del gr
+    assert K.g.layout == "wave"
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    rc = torch.randn(3 * C, 3, dtype=torch.float64, device=dev, generator=gen)
+    Rt, lamT, z = K.empty(T, 9), K.empty(T, 9), K.empty(3 * C, 3)
+    K.dual_update_op(rc, Rt, lamT, z)
+    x, z0 = torch.randn(3 * C, 3, dtype=torch.float64, device=dev, generator=gen), K.empty(3 * C, 3)
+    lam_keep = lamT.clone()
+
+    def repeat(fn, outs, n):
+        fn(); torch.cuda.synchronize()
+        ref = [o.clone() for o in outs]
+        cnt = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(n):
+            fn()
+            for o, r in zip(outs, ref):
+                cnt += (o != r).any()
+        return int(cnt)
+
+    assert repeat(lambda: K.block_op(lam_keep, x, z0), [z0], 30000) == 0
+    assert repeat(lambda: K.dual_update_op(rc, Rt, lamT, z), [Rt, lamT, z], 15000) == 0
+
+
 def _ritz_inputs(steps, m, seed, dead_at=None, gap=True):
     """HB rows as vican_lanczos_cam_step writes them, for a random symmetric projected matrix."""
     rng = np.random.default_rng(seed)

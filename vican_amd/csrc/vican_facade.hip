@@ -71,6 +71,7 @@ struct vican_plan {
     float* w32 = nullptr; int32_t* w32_flag = nullptr;     // float32 copy of the CG weights (vican_graph_t.w32) where they are float32 values
     bool coop_ok = true, cgres_ok = false;                  // (dropped for the rest of the plan's life once a launch is refused)
     int pred_steps[64] = {0};                               // Lanczos steps that sufficed in primal-dual iteration `it` of the previous solve
+    int pred_fail[64] = {0};                                // ... and consecutive solves whose first check at that count failed
     double floor_level[64];                                 // ... and the residual level its f32 rounding floor sat at (< 0: none met)
     int hw = 0, hb_stride = 0, ld = 0;
     // translation workspace
@@ -358,6 +359,7 @@ extern "C" int vican_plan_set_comm(vican_plan_t* P, vican_comm_t* comm, void* st
     const double hops1 = (n_e / C) * std::max(n_e / n_t - 1.0, 0.0) / C;
     P->prop_sweeps = hops1 >= 4.0 ? 1 : (hops1 >= 0.5 ? 2 : 3);
     for (int& v : P->pred_steps) v = 0;
+    for (int& v : P->pred_fail) v = 0;
     P->comm_ready = true;
     return VICAN_OK;
 }
@@ -456,11 +458,18 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
                 HIPCK(hipStreamSynchronize(s), "vican_solve_rot");
                 conv = st[3] != 0.0;
                 const bool floor_hit = st[4] != 0.0;
-                if (floor_hit && restart == 0 && it < 64) {     // where the floor was first reached (the earlier of the two checks), its level
+                if (floor_hit && restart == 0 && it < 64 && !(remembered > 0 && steps > remembered)) {     // where the floor was first reached (the earlier of the two checks), its level
                     P->floor_level[it] = prev_res >= 0.0 ? std::max(st[0], prev_res) : std::max(st[0], P->floor_level[it]);
                     floor_at = (prev_res >= 0.0 && prev_res <= 2.0 * P->floor_level[it]) ? prev_steps : steps;
                 }
-                if (conv && restart == 0 && it < 64) P->pred_steps[it] = floor_hit && floor_at > 0 ? floor_at : steps;
+                if (conv && restart == 0 && it < 64) {
+                    // (a larger count than the remembered one is adopted only when the first check at the remembered count failed
+                    //  in two solves in a row: about one solve in a few hundred runs into a stalled residual and takes 3-6 extra
+                    //  steps - vican_amd/solver.py, RotationSolver.spectral)
+                    const int want = floor_hit && floor_at > 0 ? floor_at : steps, have = P->pred_steps[it];
+                    if (have <= 0 || want <= have) { P->pred_steps[it] = want; P->pred_fail[it] = 0; }
+                    else if (++P->pred_fail[it] >= 2) { P->pred_steps[it] = want; P->pred_fail[it] = 0; }
+                }
                 prev_res = st[0]; prev_steps = steps;
                 if (st[2] != 0.0) break;                       // stop (converged, noise floor, step budget or exhausted Krylov space)
                 const bool near_floor = floor_tol > 1e-12 && st[0] <= floor_tol;
