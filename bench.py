@@ -849,7 +849,14 @@ def main():
     if rank == 0 and world == 1 and args.workload == "stress" and not args.no_facade:
         # the four-call C boundary on the same graphs, next to the Python driver's numbers
         try:
-            f = facade_timing(args, dev, tdt, {"stress": (C, Tn, cpt, 5), "large_shop": (340, 10000, 4, 10)})
+            shapes = {"stress": (C, Tn, cpt, 5), "large_shop": (340, 10000, 4, 10)}
+            if not args.no_wide:
+                shapes["wide"] = (4000, 100000, 250, 2)          # camera tiles behind the same four calls (csrc/vican_facade_tiles.hip)
+            f = facade_timing(args, dev, tdt, shapes)
+            wd = out["detail"].get("wide", {})
+            if "ms_per_solve" in f.get("wide", {}) and "ms_per_solve" in wd:
+                f["wide"]["python_driver_ms_per_solve"] = wd["ms_per_solve"]
+                f["wide"]["ratio_to_python_driver"] = f["wide"]["ms_per_solve"] / wd["ms_per_solve"]
             if "ms_per_solve" in f.get("stress", {}):
                 f["stress"]["python_driver_ms_per_solve"] = m["ms_per_step"]
                 f["stress"]["ratio_to_python_driver"] = f["stress"]["ms_per_solve"] / m["ms_per_step"]

@@ -98,7 +98,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 29            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 30            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -754,9 +754,14 @@ int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const double* de
  * For a maintainer who wants the numerics of the reference's two stages behind ONE handle: everything above composed by host
  * code inside the library (csrc/vican_facade.hip) with the plain schedule - chunked layout planned as vican_amd/device.py does,
  * block Lanczos with a convergence check (vican_ritz + one blocking 128-byte read) every few steps, the fused dual update, CG in
- * bursts with the state polled in between.  Single rank, C <= 1024, CG only (lsqr_solver="direct", sharded and camera-tiled
- * runs: the granular entry points, as vican_amd/solver.py drives them).  The library owns the plan's device memory; inputs and
- * outputs are the caller's device buffers; every call synchronises `stream` before it returns.
+ * bursts with the state polled in between.  The library owns the plan's device memory; inputs and outputs are the caller's device
+ * buffers; every call synchronises `stream` before it returns.
+ * More than 1024 cameras (the reference has no camera limit, bipgo.py:225-232; one LDS table of the sweeps holds 1024): the plan
+ * cuts the cameras into <= 64 tiles of equal width that share one chunking of the timestep rows and runs the tiled schedule
+ * (csrc/vican_facade_tiles.hip, as vican_amd/tiled.py: the operator as one launch that reads every block once, dual update / J^T b /
+ * CG product tile by tile, rows summed in tile order) - same calls, same outputs, vican_plan_set_comm included.  VICAN_ERR_CAPACITY
+ * where a timestep row has more than 256 (f32) / 128 (f64) edges inside one tile or a tile has no edges at all (layouts only the
+ * host driver vican_amd.tiled plans), and from vican_solve_trans_lsqr on a tiled plan.
  *
  * vican_plan_create  replaces bipgo.py:244-276 (COO triplets -> CSR, degrees, power-graph constants): the merged timestep-major
  *     CSR problem (row_ptr [T+1], col [E] ascending inside a row, blk [E][9] and a [E] in the storage type; optionally the

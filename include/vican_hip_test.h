@@ -24,6 +24,10 @@ int vican_comm_force_enqueue(vican_comm_t* comm, int32_t on);
  * walk the recovery path - the whole group falls back to RCCL / torch.distributed - on hardware where the exchange works.       */
 int vican_comm_peer_inject_fault(vican_comm_t* comm);
 
+/* Cameras per tile of the plans vican_plan_create makes from now on (1..1024; default 1024 = one LDS table of the sweeps): the tests
+ * force the camera-tiled schedule (csrc/vican_facade_tiles.hip) on golden cases of a few dozen cameras.  Process-wide.           */
+int vican_facade_set_tile_cams(int32_t n_cam_per_tile);
+
 /* ---- LSQR, two-pass form (cross-checks; reference bipgo.py:479-480) -------------------------------------------- */
 /* u <- s (v_t - v_c) - coef * u ;  *nrm2_out = |u|^2 */
 int vican_lsqr_u_step(const vican_graph_t* g, const double* sw, const double* v_c, const double* v_t,

@@ -120,6 +120,141 @@ def test_the_sharded_schedule_through_the_four_calls(name, dt):
     assert float(geodesic(Rc, Rc1).max()) < (2e-6 if dt == "float32" else 1e-9) and abs(info.cg_iters - info1.cg_iters) <= 1
 
 
+def _poses_against_reference(prob, exp, Rc, Rt, pc, pt):
+    rot, pos = {}, {}
+    for i, c in enumerate(prob.cam_names):
+        rot[str(c)], pos[str(c)] = Rc[i], pc[i]
+    for i, s_ in enumerate(prob.time_names):
+        rot[str(s_) + "_0"], pos[str(s_) + "_0"] = Rt[i], pt[i]
+    keys = [str(k) for k in exp["keys"]]
+    R = np.stack([rot[k] for k in keys]); t = np.stack([pos[k] for k in keys])
+    return float(geodesic(R, exp["R"]).max()), float(np.linalg.norm(t - exp["t"], axis=1).max())
+
+
+@pytest.fixture
+def tile_cams():
+    """vican_facade_set_tile_cams (include/vican_hip_test.h): plans made inside the test cut their cameras into tiles this wide."""
+    lib = _lib.load()
+
+    def set_(n):
+        assert lib.vican_facade_set_tile_cams(n) == 0, lib.vican_last_error()
+    yield set_
+    lib.vican_facade_set_tile_cams(1024)
+
+
+@pytest.mark.parametrize("name,dt,tile", [("g3_medium", "float64", 16), ("g3_medium", "float32", 16), ("g2_small", "float64", 3),
+                                          ("g2_small", "float32", 3), ("g9_large_shop", "float32", 128)])
+@pytest.mark.parametrize("sharded", [False, True])
+def test_camera_tiles_behind_the_four_calls(name, dt, tile, sharded, tile_cams):
+    """More cameras than a tile holds (csrc/vican_facade_tiles.hip; forced here on golden cases: 40 cameras in tiles of 16, 6 in
+    tiles of 3, large_shop's 340 in tiles of 128): the same four calls, poses against the REAL reference's.  sharded: the tiled
+    plan as the only rank of a sharded solve - its all-reduces (operator result, both CG messages) through the peer exchange."""
+    lib = _lib.load()
+    g = load_golden(name)
+    if name == "g9_large_shop":             # (inputs regenerated from their seed, as tests/test_large_shop_scale.py does)
+        from vican_amd import synth
+        from vican_amd.geometry import SE3
+        scene, flat = gc.build_flat(gc.LARGE_SHOP)
+        src, cons = synth.edges_to_dict(flat, SE3), synth.constraints_from_scene(scene, SE3)
+        nr, nt, ff = (gc.CALLABLES[gc.LARGE_SHOP[k]] for k in ("noise_r", "noise_t", "filt"))
+    else:
+        case, src, cons, (nr, nt, ff) = rebuild_inputs(name, g)
+    exp = expected(g, "conjugate_gradient", dt)
+    prob = frontend.flatten(src, cons, nr, nt, ff, np.dtype(dt).type)
+    tile_cams(tile)
+    comm = None
+    if sharded:
+        comm = C.c_void_p()
+        assert lib.vican_comm_create_local(0, 1, C.byref(comm)) == 0
+        assert lib.vican_comm_peer_export(comm, 9 * 1024 + 96, C.create_string_buffer(64)) == 0, lib.vican_last_error()
+        assert lib.vican_comm_peer_attach(comm, None) == 0, lib.vican_last_error()
+    try:
+        Rc, Rt, pc, pt, info, graph = solve_through_the_facade(prob, dt, comm=comm)
+        if sharded:
+            assert lib.vican_comm_peer_status(comm) == 0
+    finally:
+        if sharded:
+            lib.vican_comm_destroy(comm)
+    assert graph.n_cam == prob.n_cam and graph.n_wg >= 2             # (describe: the shared chunking, all tiles' workgroups)
+    r_err, t_err = _poses_against_reference(prob, exp, Rc, Rt, pc, pt)
+    print("%s %s through the four calls on tiles of %d cameras%s: rot %.2e rad, trans %.2e m, %d Lanczos steps, cg %d vs %d" % (
+        name, dt, tile, " (sharded schedule)" if sharded else "", r_err, t_err, info.lanczos_steps, info.cg_iters, int(exp["cg_iters"])))
+    from conftest import record_parity
+    record_parity(name, dt, "facade, camera tiles" + (", sharded" if sharded else ""), r_err, t_err, e2e_translation_tol(name, dt),
+                  info.cg_iters, int(exp["cg_iters"]))
+    assert r_err < (5e-6 if dt == "float32" else 1e-7), r_err
+    assert t_err < (2e-3 if name == "g9_large_shop" else e2e_translation_tol(name, dt)), t_err
+    assert abs(info.cg_iters - int(exp["cg_iters"])) <= iteration_slack(name, dt, **({"extra": 2} if name == "g9_large_shop" else {}))
+
+
+def test_1500_cameras_behind_the_four_calls_match_the_python_driver():
+    """A graph that NEEDS tiles (1500 cameras: 2 x 752), synthetic, both storage types: vican_plan_create at its default tile width
+    against the Python driver's tiled solve (vican_amd.tiled through bipgo.solve_problem's backend choice) of the same arrays."""
+    from vican_amd import synth
+    from vican_amd.solver import Comm, RotationSolver, TranslationSolver
+    from vican_amd.tiled import TiledBackend, TiledGraph
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Cn, T, cpt = 1500, 3000, 60
+    for tdt in (torch.float32, torch.float64):
+        gr = synth.make_merged_graph_torch(Cn, T, cpt, dev, tdt, seed=11)
+        E = int(gr["col"].numel())
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        plan = C.c_void_p()
+        rc = lib.vican_plan_create(Cn, T, E, _lib.STORE_F32 if tdt == torch.float32 else _lib.STORE_F64, p(gr["row_ptr"]), p(gr["col"]), p(gr["blk"]),
+                                   p(gr["a"]), p(gr["w"]), p(gr["u"]), p(gr["v"]), None, None, stream, C.byref(plan))
+        assert rc == 0, lib.vican_last_error()
+        try:
+            rcs, Rt = torch.empty(3 * Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 9, dtype=torch.float64, device=dev)
+            x_c, x_t = torch.empty(Cn, 3, dtype=torch.float64, device=dev), torch.empty(T, 3, dtype=torch.float64, device=dev)
+            info = _lib.SolveInfo()
+            assert lib.vican_solve_rot(plan, 4, 1e-10, p(rcs), p(Rt), C.byref(info), stream) == 0, lib.vican_last_error()
+            assert lib.vican_solve_trans(plan, p(rcs), p(Rt), 1e-5, 0, p(x_c), p(x_t), C.byref(info), stream) == 0, lib.vican_last_error()
+            assert info.cg_converged == 1 and float(rcs.abs().max()) > 0.5
+            # LSQR on tiles is the host driver's: refused, with the reason
+            assert lib.vican_solve_trans_lsqr(plan, p(rcs), p(Rt), 0.0, 1e-6, 1e-6, 1e8, 0, p(x_c.clone()), p(x_t.clone()), None, stream) == _lib.ERR_CAPACITY
+            assert b"camera-tiled" in lib.vican_last_error()
+        finally:
+            assert lib.vican_plan_destroy(plan) == 0
+        K = TiledBackend(TiledGraph(Cn, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"]))
+        rot = RotationSolver(K, Comm(), eig_tol=1e-10)
+        rc_ref, Rt_ref = rot.run(4)
+        tr = TranslationSolver(K, Comm())
+        tr.setup(rc_ref, Rt_ref)
+        xc_ref, xt_ref = tr.solve(3 * (Cn + T))
+        tol_r = 2e-5 if tdt == torch.float32 else 1e-8
+        d_rc = float((rcs - rc_ref.reshape(3 * Cn, 3)).abs().max()); d_rt = float((Rt - Rt_ref.reshape(T, 9)).abs().max())
+        d_x = float((x_c - xc_ref.reshape(Cn, 3)).abs().max()); d_t = float((x_t - xt_ref[:T].reshape(T, 3)).abs().max())
+        print("1500 cameras, %s: facade against the Python driver: rc %.2e Rt %.2e x_c %.2e x_t %.2e, cg %d vs %d" % (
+            str(tdt), d_rc, d_rt, d_x, d_t, info.cg_iters, tr.info["cg_iters"]))
+        assert d_rc < tol_r and d_rt < tol_r, (d_rc, d_rt)
+        scale = float(xc_ref.abs().max())
+        assert d_x < 1e-4 * scale and d_t < 1e-4 * scale, (d_x, d_t, scale)
+        assert abs(info.cg_iters - tr.info["cg_iters"]) <= 1
+        del K, rot, tr, gr
+
+
+def test_tile_layouts_the_boundary_does_not_plan_are_refused_with_the_reason(tile_cams):
+    """A tile without edges (cameras 8..15 never seen) is a layout only the host driver plans: VICAN_ERR_CAPACITY and a message."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(0)
+    Cn, T = 16, 50
+    cols = np.stack([np.sort(rng.choice(8, 3, replace=False)) for _ in range(T)]).reshape(-1).astype(np.int32)
+    rp = (np.arange(T + 1) * 3).astype(np.int32)
+    E = len(cols)
+    up = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(dev, d)
+    blk = up(np.tile(np.eye(3).reshape(9), (E, 1)), torch.float64); a = up(np.ones(E), torch.float64)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    tile_cams(8)
+    plan = C.c_void_p()
+    rc = lib.vican_plan_create(Cn, T, E, _lib.STORE_F64, p(up(rp, torch.int32)), p(up(cols, torch.int32)), p(blk), p(a), None, None, None, None, None,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(plan))
+    assert rc == _lib.ERR_CAPACITY and b"has no edges" in lib.vican_last_error(), lib.vican_last_error()
+    assert not plan.value
+
+
 def test_bad_arguments_are_refused():
     lib = _lib.load()
     plan = C.c_void_p()

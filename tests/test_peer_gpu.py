@@ -152,7 +152,7 @@ def test_sharded_golden_over_the_peer_exchange_between_processes(nranks, tmp_pat
 def test_the_c_boundary_as_ranks_of_one_sharded_solve(nranks, tmp_path):
     """tools/facade_dist.py: vican_plan_create on each rank's slice of the rows + vican_plan_set_comm + the two solve calls, the
     communicator made from ctypes alone (vican_comm_create_local, 64-byte mailbox handles) - goldens g3 (both dtypes) and g9
-    (large_shop scale) against the real reference's poses."""
+    (large_shop scale) against the real reference's poses, untiled and with every rank's cameras cut into tiles."""
     out = str(tmp_path / "facade.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "facade_dist.py"), out]
@@ -167,7 +167,9 @@ def test_the_c_boundary_as_ranks_of_one_sharded_solve(nranks, tmp_path):
     for key, r in rep.items():
         if isinstance(r, dict) and "rot_rad" in r:
             name, dt = key.rsplit("_", 1)
-            record_parity(name, dt, "facade, %d ranks" % nranks, r["rot_rad"], r["trans_m"], r["bound_m"], r["cg_iters"], r["cg_reference"])
+            tiles = name.endswith("@tiles")
+            name = name[:-6] if tiles else name
+            record_parity(name, dt, "facade, %s%d ranks" % ("camera tiles, " if tiles else "", nranks), r["rot_rad"], r["trans_m"], r["bound_m"], r["cg_iters"], r["cg_reference"])
 
 
 def test_a_failing_exchange_demotes_the_whole_group_and_the_solve_runs_again():

@@ -7,7 +7,8 @@ numerics; torch.distributed only carries the 64-byte handles and, at the end, ga
     VICAN_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/facade_dist.py [out.json]
 
 Golden g3 (40 cameras x 400 timesteps, non-unit weights, reprojection filter) in both dtypes and the large_shop-scale golden g9
-in float64, against the REAL reference's poses.  Prints "facade dist: mismatches <n>"."""
+in float64, against the REAL reference's poses; then g3 and g9 again with the cameras cut into TILES (16 / 128 cameras wide: the
+camera-tiled schedule of csrc/vican_facade_tiles.hip, every rank tiling its own rows).  Prints "facade dist: mismatches <n>"."""
 import ctypes as C
 import json
 import os
@@ -89,7 +90,9 @@ def compare(name, prob, exp, dt, out):
 
 
 report, bad = {"world": world}, 0
-for name, dt in (("g3_medium", "float64"), ("g3_medium", "float32"), ("g9_large_shop", "float64")):
+for name, dt, tile in (("g3_medium", "float64", 0), ("g3_medium", "float32", 0), ("g9_large_shop", "float64", 0),
+                       ("g3_medium", "float64", 16), ("g9_large_shop", "float32", 128)):
+    _lib.check(lib.vican_facade_set_tile_cams(tile or 1024), "vican_facade_set_tile_cams")
     if name == "g9_large_shop":
         g = load_golden(name)
         scene, flat = gc.build_flat(gc.LARGE_SHOP)
@@ -105,10 +108,10 @@ for name, dt in (("g3_medium", "float64"), ("g3_medium", "float32"), ("g9_large_
     r_err, t_err, cg = compare(name, prob, exp, dt, solve(prob, dt))
     ok = r_err < (5e-6 if dt == "float32" else 1e-7) and t_err < tol and abs(cg - int(exp["cg_iters"])) <= 6
     bad += not ok
-    report["%s_%s" % (name, dt)] = dict(rot_rad=r_err, trans_m=t_err, bound_m=tol, cg_iters=cg, cg_reference=int(exp["cg_iters"]), ok=bool(ok))
+    report["%s%s_%s" % (name, "@tiles" if tile else "", dt)] = dict(tile_cams=tile, rot_rad=r_err, trans_m=t_err, bound_m=tol, cg_iters=cg, cg_reference=int(exp["cg_iters"]), ok=bool(ok))
     if rank == 0:
-        print("%s %s through the four calls on %d ranks: rot %.2e rad, trans %.2e m (< %.1e), cg %d vs %d%s" % (
-            name, dt, world, r_err, t_err, tol, cg, int(exp["cg_iters"]), "" if ok else "   <-- MISMATCH"), flush=True)
+        print("%s %s through the four calls on %d ranks%s: rot %.2e rad, trans %.2e m (< %.1e), cg %d vs %d%s" % (
+            name, dt, world, " (camera tiles of %d)" % tile if tile else "", r_err, t_err, tol, cg, int(exp["cg_iters"]), "" if ok else "   <-- MISMATCH"), flush=True)
 st_all = [None] * world
 dist.all_gather_object(st_all, int(lib.vican_comm_peer_status(comm)))
 report["peer_status"] = int(max(st_all))

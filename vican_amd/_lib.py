@@ -19,9 +19,9 @@ LIB_PATH = os.environ.get("VICAN_LIB") or os.path.join(CSRC, "libvican_hip.so") 
 SOURCES = [os.path.join(CSRC, "vican_sweep.hip"), os.path.join(CSRC, "vican_kernels.hip"),
            os.path.join(CSRC, "vican_trans.hip"), os.path.join(CSRC, "vican_lsqr.hip"), os.path.join(CSRC, "vican_wtrans.hip"),
            os.path.join(CSRC, "vican_cgres.hip"), os.path.join(CSRC, "vican_merge.hip"),
-           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip"), os.path.join(CSRC, "vican_tcg.hip")]
+           os.path.join(CSRC, "vican_facade.hip"), os.path.join(CSRC, "vican_facade_tiles.hip"), os.path.join(CSRC, "vican_comm.hip"), os.path.join(CSRC, "vican_tsweep.hip"), os.path.join(CSRC, "vican_tcg.hip")]
 WSWEEP = os.path.join(CSRC, "vican_wsweep.hip")
-HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), os.path.join(CSRC, "vican_cgw_impl.h"), WSWEEP]
+HEADERS = [os.path.join(CSRC, "vican_common.h"), os.path.join(CSRC, "vican_sweep_common.h"), os.path.join(CSRC, "vican_cgw_impl.h"), os.path.join(CSRC, "vican_facade_impl.h"), WSWEEP]
 FX_DOUBLES = 20
 GRAM_WS_DOUBLES = 128 * 192 * 3     # VICAN_GRAM_WS_DOUBLES
 SEED_MAX_N = 16384                  # VICAN_SEED_MAX_N
@@ -213,6 +213,7 @@ class LsqrInfo(C.Structure):
 TEST_PROTOTYPES = {
     "vican_comm_force_enqueue": (C.c_int, [_vp, _i32]),
     "vican_comm_peer_inject_fault": (C.c_int, [_vp]),
+    "vican_facade_set_tile_cams": (C.c_int, [_i32]),
     "vican_test_occupy": (C.c_int, [_i32, _i32, _i32, _i64, _vp]),
     "vican_lsqr_u_step": (C.c_int, [_G, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp]),
     "vican_lsqr_v_step": (C.c_int, [_G, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(C.c_double), _vp]),

@@ -7,90 +7,12 @@
 // stopping rules - with the plain schedule: layout planning as device.py's _Layout (wave layout where every row fits a
 // 64-lane chunk, else block layout), block Lanczos with a convergence check (device Ritz step, one blocking 128-byte read) every
 // few steps, launch-sequence camera-side step, the fused dual update, CG iterations (vican_cg_iter_fused) in bursts of eight
-// with the state polled in between.  No speculation, no HIP graphs, C <= 1024.  vican_plan_set_comm turns the same plan into ONE RANK
+// with the state polled in between.  No speculation, no HIP graphs.  More than 1024 cameras: the plan cuts the cameras into tiles
+// and runs the tiled schedule (vican_facade_tiles.hip; wave-layout tiles with a shared chunking).  vican_plan_set_comm turns the same plan into ONE RANK
 // of a timestep-sharded solve (the plan holds this rank's rows; every camera-side quantity is replicated): the sweeps' camera
 // partials are all-reduced from C in stream order (vican_block_op_z_comm), the CG runs vican_cg_iter_comm - the schedule
-// vican_amd/solver.py takes for sharded runs.  The Python driver remains the fast path (and the only camera-tiled one); this
-// one is the small stable surface.  The library owns the plan's device memory (one arena); inputs and outputs are the caller's.
-#include <vector>
-#include <algorithm>
-#include <cmath>
-#include <cstring>
-#include <cstdarg>
-#include <cstdio>
-#include "vican_sweep_common.h"
-
-namespace {
-
-int ferr(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
-int ferr(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_vican_err, sizeof(g_vican_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-constexpr double X_BOUND = 1.7320508075688772;          // |x_c|_F of every sweep input (device.py: X_BOUND)
-constexpr size_t STREAM_NT_BYTES = (size_t)192 << 20;   // device.py: STREAM_NT_BYTES
-constexpr int M_MAX = 32;                               // VICAN_RITZ_MAX_STEPS
-
-struct Arena {
-    unsigned char* base = nullptr;
-    size_t size = 0, used = 0;
-    template <typename T> T* take(size_t n) {
-        used = (used + 255) & ~(size_t)255;
-        T* p = base ? (T*)(base + used) : nullptr;
-        used += n * sizeof(T);
-        return p;
-    }
-};
-
-}  // namespace
-
-struct vican_plan {
-    int C = 0, T = 0, storage = 0, epl = 4;
-    long long E = 0;
-    vican_graph_t g{};
-    int rows_per_wg_max = 1, rows_per_wg_sweep = 1;
-    double n_add = 1, n_add_cg = 1, wmax = 1, gmax = 1, lscale = 1;
-    bool have_t = false;
-    int prop_sweeps = 3;
-    Arena ar;
-    // layout arrays
-    int32_t* idx = nullptr; int32_t* chunk_row0 = nullptr; void* blk = nullptr; void* a = nullptr; uint16_t* idx16 = nullptr;
-    double *w = nullptr, *u = nullptr, *v = nullptr;
-    // graph constants
-    double *row_sum_a = nullptr, *cam_sum_a = nullptr, *rnorm = nullptr, *fx = nullptr, *row_sum_w = nullptr, *cam_sum_w = nullptr;
-    // solver workspace (names as in vican_amd/solver.py)
-    double *zpart = nullptr, *V = nullptr, *R = nullptr, *H = nullptr, *G = nullptr, *beta0 = nullptr, *HB = nullptr, *Yd = nullptr,
-           *status = nullptr, *xrow = nullptr, *z = nullptr, *X = nullptr, *Xp = nullptr, *x0 = nullptr, *rc = nullptr, *lamC = nullptr,
-           *cam_deg = nullptr, *lamT = nullptr, *Rt = nullptr, *zraw = nullptr;
-    int32_t* gate = nullptr; int32_t* coop_sync = nullptr;
-    double *coop_ws = nullptr, *cgres_ws = nullptr;        // workspaces of the cooperative camera-side step / of the resident CG
-    float* w32 = nullptr; int32_t* w32_flag = nullptr;     // float32 copy of the CG weights (vican_graph_t.w32) where they are float32 values
-    bool coop_ok = true, cgres_ok = false;                  // (dropped for the rest of the plan's life once a launch is refused)
-    int pred_steps[64] = {0};                               // Lanczos steps that sufficed in primal-dual iteration `it` of the previous solve
-    int pred_fail[64] = {0};                                // ... and consecutive solves whose first check at that count failed
-    double floor_level[64];                                 // ... and the residual level its f32 rounding floor sat at (< 0: none met)
-    int hw = 0, hb_stride = 0, ld = 0;
-    // translation workspace
-    double *b_c = nullptr, *b_t = nullptr, *r_c = nullptr, *p_c = nullptr, *r_t = nullptr, *p_t = nullptr, *q_t = nullptr, *qcpq = nullptr,
-           *pq_part = nullptr, *rr_part = nullptr, *ws = nullptr;
-    vican_cg_state_t* st = nullptr;
-    uint32_t* cg_ticket = nullptr;
-    double* status_host = nullptr;      // pinned
-    // LSQR workspace (lsqr_solver="direct"): its own allocation, made by the first vican_solve_trans_lsqr (24 bytes per edge slot)
-    // one rank of a timestep-sharded solve (vican_plan_set_comm): the communicator, the CG message, the GLOBAL graph sizes
-    vican_comm_t* comm = nullptr;
-    double* msg = nullptr;
-    double* setup_msg = nullptr;
-    bool comm_ready = false;
-    unsigned char* lsqr_base = nullptr;
-    double *lu = nullptr, *lsw = nullptr, *lpart = nullptr, *lslab = nullptr, *lv_c = nullptr, *lw_c = nullptr, *lv_t = nullptr, *lw_t = nullptr,
-           *lz_t = nullptr, *lacc = nullptr, *lpart2 = nullptr, *lwp_c = nullptr, *lwp_t = nullptr, *ls2 = nullptr;
-    vican_lsqr_state_t* lst = nullptr;
-};
+// vican_amd/solver.py takes for sharded runs.  The Python driver remains the fast path; this one is the small stable surface.  The library owns the plan's device memory (one arena); inputs and outputs are the caller's.
+#include "vican_facade_impl.h"
 
 namespace {
 
@@ -115,11 +37,7 @@ __global__ void facade_seed_kernel(int n, double* x) {         // identity at ca
     if (i < 3 * n) x[i] = (i < 9 && i / 3 == i % 3) ? 1.0 : 0.0;
 }
 
-int n_cu() {
-    int dev = 0; hipGetDevice(&dev);
-    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-}
+using vican_facade::n_cu;
 
 // device.py _Layout: sizes of the chunked layout for this graph
 int plan_layout(vican_plan* P, const std::vector<int32_t>& rp, std::vector<int32_t>& chunk_row0) {
@@ -195,15 +113,17 @@ size_t carve(vican_plan* P, size_t n_row0) {
     Arena& A = P->ar;
     A.used = 0;
     const int C = P->C, T1 = std::max(P->T, 1), n = 3 * C;
-    const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, s = P->storage == VICAN_STORE_F32 ? 4 : 8;
+    const bool tiled = !P->tiles.empty();                    // (the graph arrays of a tiled plan are its tiles': vican_facade_tiles_carve)
+    const size_t nslot = tiled ? 0 : (size_t)std::max(1, P->g.n_chunk) * P->g.slots, s = P->storage == VICAN_STORE_F32 ? 4 : 8;
+    const int n_wg = tiled ? 1 : std::max(P->g.n_wg, 1);
     P->idx = A.take<int32_t>(nslot); P->chunk_row0 = A.take<int32_t>(n_row0);
     // (wave layout: the 2-byte index the edge sweeps stream, vican_graph_t.idx16)
-    P->idx16 = P->g.layout == VICAN_LAYOUT_WAVE ? A.take<uint16_t>(nslot) : nullptr;
+    P->idx16 = P->g.layout == VICAN_LAYOUT_WAVE && !tiled ? A.take<uint16_t>(nslot) : nullptr;
     P->blk = A.take<unsigned char>(9 * nslot * s); P->a = A.take<unsigned char>(nslot * s);
     if (P->have_t) { P->w = A.take<double>(nslot); P->u = A.take<double>(3 * nslot); P->v = A.take<double>(3 * nslot); }
     P->row_sum_a = A.take<double>(T1); P->cam_sum_a = A.take<double>(C); P->rnorm = A.take<double>(T1); P->fx = A.take<double>(20);
     if (P->have_t) { P->row_sum_w = A.take<double>(T1); P->cam_sum_w = A.take<double>(C); }
-    P->zpart = A.take<double>((size_t)std::max(P->g.n_wg, 1) * 9 * C);
+    P->zpart = A.take<double>((size_t)n_wg * 9 * C);
     const int m = std::max(1, std::min(M_MAX, n / 3));
     P->ld = n; P->hw = 3 * (m + 1) * 3; P->hb_stride = P->hw + 9;
     P->V = A.take<double>((size_t)3 * (m + 1) * n); P->R = A.take<double>(3 * (size_t)n); P->H = A.take<double>(3 * (m + 1) * 3);
@@ -215,24 +135,28 @@ size_t carve(vican_plan* P, size_t n_row0) {
     P->Rt = A.take<double>(9 * (size_t)T1); P->zraw = A.take<double>(3 * (size_t)n);
     P->coop_ws = A.take<double>((size_t)vican_lanczos_coop_ws_doubles(C));
     if (P->have_t) {
-        P->cgres_ws = A.take<double>((size_t)vican_cg_resident_ws_doubles(C, std::max(P->g.n_wg, 1)));
+        P->cgres_ws = A.take<double>(tiled ? 1 : (size_t)vican_cg_resident_ws_doubles(C, n_wg));
         P->w32 = A.take<float>(nslot); P->w32_flag = A.take<int32_t>(4);
         P->b_c = A.take<double>(3 * (size_t)C); P->b_t = A.take<double>(3 * (size_t)T1); P->r_c = A.take<double>(3 * (size_t)C);
         P->p_c = A.take<double>(3 * (size_t)C); P->r_t = A.take<double>(3 * (size_t)T1); P->p_t = A.take<double>(3 * (size_t)T1);
         P->q_t = A.take<double>(3 * (size_t)T1); P->qcpq = A.take<double>(3 * (size_t)C + 1);
-        P->pq_part = A.take<double>(std::max(P->g.n_wg, 1)); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
+        P->pq_part = A.take<double>(tiled ? 1024 : n_wg); P->rr_part = A.take<double>(1536); P->ws = A.take<double>(1024);
         P->st = (vican_cg_state_t*)A.take<double>(19);
         P->cg_ticket = A.take<uint32_t>(256);        // (vican_cg_iter_fused: the fold's p.q partials; zeroed with the arena)
         P->msg = A.take<double>(3 * (size_t)C + VICAN_CG_PQ_SLICES);      // (vican_cg_iter_comm: [q_c partial | slices of p_t.q_t])
     }
     P->setup_msg = A.take<double>((size_t)C + 4);
+    if (tiled) vican_facade_tiles_carve(P);
     return A.used + 256;
 }
 
 #define CK(call) do { const int rc_ = (call); if (rc_ < 0) return rc_; } while (0)
 #define HIPCK(call, what) do { if ((call) != hipSuccess) return ferr(VICAN_ERR_LAUNCH, "%s: %s failed", what, #call); } while (0)
 
-int fx_finish(vican_plan* P, void* stream) { return vican_fx_finish(P->fx, X_BOUND, (double)P->rows_per_wg_sweep + 1.0, P->storage, stream); }
+int fx_finish(vican_plan* P, void* stream) {
+    if (!P->tiles.empty()) return vican_facade_tiles_refresh(P, stream);
+    return vican_fx_finish(P->fx, X_BOUND, (double)P->rows_per_wg_sweep + 1.0, P->storage, stream);
+}
 
 }  // namespace
 
@@ -244,7 +168,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (n_cam <= 0 || n_time <= 0 || n_edges <= 0 || !row_ptr || !col || !blk || !a || (storage != VICAN_STORE_F32 && storage != VICAN_STORE_F64) ||
         ((w || u || v) && !(w && u && v)))
         return ferr(VICAN_ERR_ARG, "vican_plan_create: bad argument");
-    if (n_cam > 1024) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: more than 1024 cameras need the camera-tiled host driver (vican_amd.device.TiledBackend)");
+    if (n_cam > 65535) return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: more than 65535 cameras are not supported by the packed edge index");
     hipStream_t s = (hipStream_t)stream;
     vican_plan* P = new vican_plan();
     for (double& f : P->floor_level) f = -1.0;
@@ -254,8 +178,10 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (hipMemcpyAsync(rp.data(), row_ptr, rp.size() * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: cannot read row_ptr"));
     if (rp[0] != 0 || rp[n_time] != n_edges) return fail(ferr(VICAN_ERR_ARG, "vican_plan_create: row_ptr does not span n_edges"));
-    int rc = plan_layout(P, rp, c0);
+    const bool tiled = n_cam > vican_facade_tile_cams();
+    int rc = tiled ? vican_facade_tiles_layout(P, rp, row_ptr, col, stream) : plan_layout(P, rp, c0);
     if (rc < 0) return fail(rc);
+    if (tiled) c0.assign(1, 0);
     const size_t bytes = carve(P, c0.size());
     if (hipMalloc((void**)&P->ar.base, bytes) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc of %zu bytes failed", bytes));
     P->ar.size = bytes;
@@ -263,17 +189,32 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
     if (hipHostMalloc((void**)&P->status_host, 2048 * sizeof(double)) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipHostMalloc failed"));
     if (hipMemsetAsync(P->ar.base, 0, bytes, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: memset failed"));
     if (hipMemcpyAsync(P->chunk_row0, c0.data(), c0.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed"));
-    P->g.blk = P->blk; P->g.idx = (const uint32_t*)P->idx; P->g.chunk_row0 = P->chunk_row0;
-    P->n_add = (double)std::max(P->rows_per_wg_max, P->g.slots) + 1.0; P->n_add_cg = P->n_add;
-    {   // the whole CG as one cooperative launch on capture-sized graphs (device.py HipBackend.cg_resident_ok, solver.py small_graph)
+    if (!tiled) {
+        P->g.blk = P->blk; P->g.idx = (const uint32_t*)P->idx; P->g.chunk_row0 = P->chunk_row0;
+        P->n_add = (double)std::max(P->rows_per_wg_max, P->g.slots) + 1.0; P->n_add_cg = P->n_add;
+    }
+    int32_t* perm = nullptr;
+    if (tiled) {
+        // camera tiles: maxima over the whole edge set (bounds of the fixed-point scales), every tile packed, constants summed
+        P->coop_ok = n_cam <= 8192; P->cgres_ok = false;
+        double* mx = P->ws ? P->ws : P->G;
+        hipLaunchKernelGGL(facade_maxima_kernel, dim3(256), dim3(256), 0, s, (long long)n_edges, storage, a, w, u, v, mx);
+        double h[3] = {1, 1, 1};
+        if (hipMemcpyAsync(h, mx, 24, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: maxima read failed"));
+        hipMemsetAsync(mx, 0, 24, s);
+        if (P->have_t) { P->wmax = h[1]; P->gmax = h[2]; }
+        rc = vican_facade_tiles_pack(P, row_ptr, col, blk, a, w, u, v, h[0], stream);
+        if (rc >= 0 && P->have_t && deg_t) hipMemcpyAsync(P->row_sum_w, deg_t, (size_t)n_time * 8, hipMemcpyDeviceToDevice, s);
+        if (rc >= 0 && P->have_t && deg_c) hipMemcpyAsync(P->cam_sum_w, deg_c, (size_t)n_cam * 8, hipMemcpyDeviceToDevice, s);
+        if (rc < 0) return fail(rc);
+    } else {   // the whole CG as one cooperative launch on capture-sized graphs (device.py HipBackend.cg_resident_ok, solver.py small_graph)
         int dev_ = 0, ncu_ = 0;
         hipGetDevice(&dev_); hipDeviceGetAttribute(&ncu_, hipDeviceAttributeMultiprocessorCount, dev_);
         P->cgres_ok = P->have_t && P->g.layout == VICAN_LAYOUT_WAVE && n_edges < 2000000 && P->g.n_chunk > 0 && P->g.n_wg <= std::min(ncu_, 128) &&
                       vican_cg_resident_lds_bytes(n_cam, P->g.max_rows, P->g.n_copy, P->rows_per_wg_max) <= vican_lds_limit_bytes();
         P->coop_ok = n_cam <= 8192;
-    }
     // pack: CSR order -> chunked slot order (one scratch array of slot indices)
-    int32_t* perm = nullptr;
     const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots;
     if (hipMalloc((void**)&perm, nslot * 4) != hipSuccess) return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: hipMalloc failed"));
     double* mx = P->ws ? P->ws : P->G;           // three doubles of scratch (zeroed by the memset)
@@ -305,6 +246,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
             }
         }
     }
+    }   // (untiled)
     // |L| <~ 2 max camera degree: sizes the pivot floor of the Cholesky-QR (solver.py: RotationSolver.init)
     std::vector<double> cs((size_t)n_cam);
     if (rc >= 0 && (hipMemcpyAsync(cs.data(), P->cam_sum_a, cs.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
@@ -379,9 +321,14 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
     const double floor_tol = P->storage == VICAN_STORE_F64 ? 1e-13 : 1e-7, pivot_floor = (1e-12 * P->lscale) * (1e-12 * P->lscale);
     vican_solve_info_t inf{};
     vican_comm_t* comm = P->comm_ready ? P->comm : nullptr;       // (one rank of a sharded solve: camera partials all-reduced in stream order)
-    auto op_z = [&](const double* x, double* z) { return vican_block_op_z_comm(g, P->lamT, x, P->zpart, P->fx, z, comm, stream); };
+    const bool tiled = !P->tiles.empty();
+    auto op_z = [&](const double* x, double* z) {
+        if (!tiled) return vican_block_op_z_comm(g, P->lamT, x, P->zpart, P->fx, z, comm, stream);
+        const int rc_ = vican_facade_tiles_op_z(P, x, z, stream);
+        return rc_ < 0 || !comm ? rc_ : vican_comm_allreduce_sum(comm, z, 9LL * P->C, stream);
+    };
     // duals, Lambda_C = (weighted camera degree) I  (bipgo.py:271-276)
-    CK(vican_init_duals(T, P->row_sum_a, P->rnorm, P->lamT, P->fx, stream));
+    CK(vican_init_duals(T, P->row_sum_a, P->rnorm, P->lamT, tiled ? P->tiles[0].fx : P->fx, stream));
     CK(fx_finish(P, stream));
     HIPCK(hipMemcpyAsync(P->cam_deg, P->cam_sum_a, (size_t)C * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
     if (comm) CK(vican_comm_allreduce_sum(comm, P->cam_deg, C, stream));
@@ -428,7 +375,7 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
                 const int j = steps;
                 // camera side of the step as ONE cooperative launch (vican_lanczos_cam_coop; with few slabs it folds them itself:
                 // the sweep's result stays in fixed point) - the launch sequence (7 kernels per step) where that grid is refused
-                const bool sweep = !(j == 0 && have_z), from_slabs = sweep && !comm && P->coop_ok && g->n_wg <= 64;
+                const bool sweep = !(j == 0 && have_z), from_slabs = sweep && !comm && !tiled && P->coop_ok && g->n_wg <= 64;
                 if (sweep) {
                     if (from_slabs) CK(vican_block_op(g, P->lamT, P->xrow, P->zpart, P->fx, stream));
                     else CK(op_z(P->xrow, P->z));
@@ -439,7 +386,7 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
                     const int rc_ = vican_lanczos_cam_coop(C, P->lamC, P->V, ld, j, P->z, P->coop_ws, P->HB + (size_t)j * P->hb_stride,
                                                            P->HB + (size_t)j * P->hb_stride + P->hw, P->xrow, pivot_floor, (uint32_t*)P->coop_sync,
                                                            from_slabs ? P->zpart : nullptr, from_slabs ? g->n_wg : 0, from_slabs ? P->fx + 3 : nullptr,
-                                                           from_slabs ? P->fx + 7 : nullptr, g->n_wg <= 64 ? 1 : 0, stream);
+                                                           from_slabs ? P->fx + 7 : nullptr, !tiled && g->n_wg <= 64 ? 1 : 0, stream);
                     if (rc_ == VICAN_ERR_CAPACITY) {
                         P->coop_ok = false;
                         if (from_slabs) CK(vican_slab_reduce_fx(P->zpart, g->n_wg, C, 9, 1.0, P->fx + 3, P->fx + 7, P->z, stream));
@@ -486,7 +433,8 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
         CK(vican_gauge_project(C, P->X, P->Xp, stream));
         CK(op_z(P->Xp, P->z));
         CK(vican_polar_dual(C, P->z, P->rc, P->lamC, 1, stream));
-        if (!last) {
+        if (tiled) CK(vican_facade_tiles_dual_update(P, P->rc, stream));      // (no fused dual update on tiles: the next solve sweeps for its z)
+        else if (!last) {
             CK(vican_dual_update_op(g, P->rc, P->Rt, P->lamT, P->rnorm, P->fx, P->zpart, P->zraw, stream));
             if (comm) CK(vican_comm_allreduce_sum(comm, P->zraw, 9LL * C, stream));
             z_ready = true;
@@ -515,7 +463,9 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     if (maxiter <= 0) maxiter = 10LL * 3 * (C + T);              // scipy's default
     vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
     vican_comm_t* comm = P->comm_ready ? P->comm : nullptr;
-    CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
+    const bool tiled = !P->tiles.empty();
+    if (tiled) CK(vican_facade_tiles_rhs(P, rc, Rt, stream));
+    else CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
     const double* deg_c = P->cam_sum_w;
     if (comm) {
         // the camera side of the system is a sum over all ranks' rows: right-hand side and diagonal (the caller's deg_c was this
@@ -550,11 +500,23 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     CK(vican_cg_init(C, T, P->b_c, P->b_t, x_c, x_t, P->r_c, P->r_t, P->p_c, P->p_t, P->st, P->ws, P->wmax, stream));
     if (comm) CK(vican_comm_allreduce_sum(comm, &P->st->rr_time, 1, stream));
     long long launched = 0;
-    int burst = 8;
+    int burst = 8, n_part = 0;
     for (;;) {
         // (scipy: `for iteration in range(maxiter)` - at most maxiter updates of x; no test behind the last one)
         for (int i = 0; i < burst && launched < maxiter; ++i, ++launched) {
-            if (comm)
+            if (tiled) {
+                // camera tiles: the product tile by tile, then the step (vican_amd/solver.py, the two-call iteration; sharded: its two
+                // messages [q_c | p_t.q_t] and r_t.r_t)
+                CK(vican_facade_tiles_cg_local(P, rtol, n_part, stream));
+                if (comm) CK(vican_comm_allreduce_sum(comm, P->qcpq, 3LL * C + 1, stream));
+                n_part = vican_cg_iter_finish(C, T, deg_c, P->qcpq, P->p_c, x_c, P->r_c, P->p_t, P->q_t, x_t, P->r_t, P->rr_part, 1536, P->st, stream);
+                if (n_part < 0) return n_part;
+                if (comm) {
+                    CK(vican_cg_end(P->rr_part, n_part, P->st, stream));
+                    CK(vican_comm_allreduce_sum(comm, &P->st->rr_time, 1, stream));
+                    n_part = 0;
+                }
+            } else if (comm)
                 CK(vican_cg_iter_comm(&P->g, P->w, P->row_sum_w, deg_c, P->r_c, P->p_c, x_c, P->r_t, P->p_t, P->q_t, x_t, P->zpart, P->pq_part,
                                       P->msg, rtol, P->rr_part, 1536, P->n_add_cg, launched == 0, P->st, comm, stream));
             else
@@ -609,6 +571,7 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
                                       double conlim, int64_t iter_lim, double* x_c, double* x_t, vican_lsqr_info_t* info, void* stream) {
     if (!P || !rc || !Rt || !x_c || !x_t || !(atol >= 0) || !(btol >= 0)) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: bad argument");
     if (!P->have_t) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: the plan was created without translation arrays (w, u, v)");
+    if (!P->tiles.empty()) return ferr(VICAN_ERR_CAPACITY, "vican_solve_trans_lsqr: a camera-tiled plan (more than %d cameras) solves its translations with vican_solve_trans; LSQR on tiles is the host driver's (vican_amd.tiled)", P->tile_width);
     CK(lsqr_workspace(P));
     hipStream_t s = (hipStream_t)stream;
     const int C = P->C, T = P->T, C3 = 3 * C;

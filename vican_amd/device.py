@@ -581,6 +581,7 @@ def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None
     deg_t / deg_c: diagonal of the translation system for this rank's rows / this rank's share of the camera diagonal
     (default: sums of w)."""
     import os
+    from .tiled import TILE_CAMS, TiledBackend, TiledGraph
     tile = int(os.environ.get("VICAN_TILE_CAMS") or TILE_CAMS)
     if n_cam > tile:
         g = TiledGraph(n_cam, row_ptr, col, blk, a, w, u, v, tile=tile, deg_t=deg_t, deg_c=deg_c,
@@ -591,4 +592,12 @@ def make_backend(n_cam, row_ptr, col, blk, a, w=None, u=None, v=None, deg_t=None
 
 
 from .merge import merge_edges                                      # noqa: E402,F401
-from .tiled import TILE_CAMS, TiledBackend, TiledGraph                # noqa: E402,F401
+
+
+def __getattr__(name):
+    # TILE_CAMS / TiledBackend / TiledGraph live in tiled.py (which imports THIS module): resolved on first use, whichever of the
+    # two modules is imported first
+    if name in ("TILE_CAMS", "TiledBackend", "TiledGraph"):
+        from . import tiled
+        return getattr(tiled, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
