@@ -81,7 +81,7 @@ def test_graph_struct_in_the_header_the_ctypes_mirror_and_the_documented_stub_ag
     # every entry point the document names exists in one of the two headers; every argtypes list it shows has the bound arity
     named = set(re.findall(r"\bvican_[a-z0-9_]+\b", md))
     known = set(header_symbols()) | set(header_symbols("vican_hip_test.h"))
-    types = {"vican_graph_t", "vican_lsqr_state_t", "vican_amd", "vican_hip", "vican_facade", "vican_plan_t", "vican_solve_info_t", "vican_comm_t", "vican_cg_state_t"}
+    types = {"vican_graph_t", "vican_lsqr_state_t", "vican_amd", "vican_hip", "vican_facade", "vican_facade_tiles", "vican_plan_t", "vican_solve_info_t", "vican_comm_t", "vican_cg_state_t"}
     patterns = {n for n in named if n.endswith("_")}          # prefixes like vican_comm_ in prose
     unknown = {n for n in named - known - types - patterns if not any(k.startswith(n) for k in known)}
     assert not unknown, "INTEGRATION.md names entry points the headers do not declare: %s" % sorted(unknown)
