@@ -739,7 +739,10 @@ int64_t vican_comm_peer_bytes(int32_t world, int64_t max_doubles);
 int vican_comm_peer_export(vican_comm_t* comm, int64_t max_doubles, void* handle_out /* 64 bytes, host */);
 int vican_comm_peer_attach(vican_comm_t* comm, const void* handles /* [world][64], host */);
 int vican_comm_peer_enable(vican_comm_t* comm, int32_t on);
-int vican_comm_peer_set_timeout(vican_comm_t* comm, int64_t microseconds);   /* bound of every wait of the exchange (default 30 s) */
+/* bound of every wait of the exchange (default 30 s).  A wait that ran into it poisons the communicator: results are NaN from there
+ * on, vican_comm_peer_status > 0, and every later launch gives a missing granule only 1/256 of the bound (a solve in flight drains
+ * in seconds; the group then falls back - vican_amd.solver.Comm.healthy).                                                          */
+int vican_comm_peer_set_timeout(vican_comm_t* comm, int64_t microseconds);
 int vican_comm_peer_status(vican_comm_t* comm);
 int vican_comm_allreduce_sum(vican_comm_t* comm, double* buf, int64_t n, void* stream);
 int vican_comm_destroy(vican_comm_t* comm);

@@ -29,7 +29,8 @@ def _free_port():
 
 
 def _env(**kw):
-    env = dict(os.environ, VICAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    # (the ranks of these tests time-share ONE GPU: a wait of the peer exchange that stalls there is given 5 s, not 30)
+    env = dict(os.environ, VICAN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **{"VICAN_PEER_TIMEOUT_US": os.environ.get("VICAN_PEER_TIMEOUT_US", "5000000"), **kw})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return env

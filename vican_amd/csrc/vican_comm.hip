@@ -79,7 +79,7 @@ struct PeerArgs {
     unsigned long long* mbox[VICAN_PEER_MAX];   // every rank's mailbox as mapped in THIS process ([rank] = the local one)
     int rank, world;
     long long cap;                              // doubles per message
-    unsigned int* state;                        // device: [0] epoch, [1] arrival ticket
+    unsigned int* state;                        // device: [0] epoch, [1] arrival ticket, [2] a wait of this communicator has timed out
     unsigned int* status;                       // host-visible (pinned): [0] timed-out waits
     unsigned long long limit;                   // spin bound, ticks of the 100 MHz counter
 };
@@ -105,6 +105,10 @@ __global__ __launch_bounds__(VICAN_PEER_WG) void peer_allreduce_kernel(const int
     GATE_RETURN(gate);
     __shared__ int s_last;
     const unsigned int epoch = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a wait that timed out poisons the communicator (its results are NaN from there on, the host sees status != 0 and the group
+    // falls back): later launches keep the protocol going - they push, they advance the epoch - but give a missing granule only
+    // 1/256 of the bound, so that a solve in flight (a hundred exchanges) drains in seconds instead of a hundred full bounds
+    const unsigned long long limit = __hip_atomic_load(a.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? (a.limit >> 8) + 100000ull : a.limit;
     const unsigned int tag = (epoch & 0x7FFFFFFFu) + 1u;
     const long long par = epoch & 1u;
     const long long slot = 2 * a.cap;                                    // granules per (parity, source)
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(VICAN_PEER_WG) void peer_allreduce_kernel(const int
                 if (pending) {
                     if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
                     __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > a.limit) timed_out = true;
+                    if ((++spins & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > limit) timed_out = true;
                 }
             }
             double acc = __longlong_as_double(0x7FF8000000000000LL);
@@ -158,7 +162,10 @@ __global__ __launch_bounds__(VICAN_PEER_WG) void peer_allreduce_kernel(const int
             buf[i] = acc;
         }
     }
-    if (timed_out) __hip_atomic_fetch_add(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (timed_out) {
+        __hip_atomic_fetch_add(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.state + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- the workgroup that finishes last advances the epoch (every workgroup has read it by then)
     __syncthreads();
     if (threadIdx.x == 0) {
