@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
     // ticket -> chunk.  Tickets are unique in the workgroup; entries are published in ticket order.
     auto resolve = [&](const int v) -> int {
         for (;;) {
-            const int npub = __hip_atomic_load(&s_npub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int npub = __hip_atomic_load(&s_npub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");                       // (the entries are read after the count that covers them)
 #define LDSV(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)     /* never cached in a register */
             while (my_r < npub - 1 && v >= LDSV(s_v1[my_r & (RING - 1)])) ++my_r;
             const int e = my_r & (RING - 1), v0 = LDSV(s_v0[e]), v1 = LDSV(s_v1[e]);
@@ -142,15 +143,21 @@ __global__ __launch_bounds__(NW * 64) void wave_sweep_kernel(const int32_t* __re
                         // range published (it reads s_done first, s_npub second: below).  With s_done stored first, a wavefront
                         // polling between the two stores saw "done, nothing new" and left with its ticket inside the range
                         // being published: that chunk's rows were missing from the sums (about one sweep in 10^4).
-                        if (nl > 0) __hip_atomic_store(&s_npub, npub + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (done) __hip_atomic_store(&s_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (LDS operations of one wavefront execute in order; the compiler barriers keep the stores in THIS order - a
+                        //  release store would also wait for the wavefront's prefetch of the next chunk, vmcnt(0))
+                        asm volatile("" ::: "memory");
+                        if (nl > 0) __hip_atomic_store(&s_npub, npub + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        asm volatile("" ::: "memory");
+                        if (done) __hip_atomic_store(&s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 return k;
             }
             if (my_r < npub - 1) continue;                     // (entries were published meanwhile)
-            if (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) &&
-                __hip_atomic_load(&s_npub, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == npub) return NONE;
+            // (s_done FIRST, s_npub second - the order of the two stores reversed; loads of one wavefront return in order)
+            const int done_now = __hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            if (done_now && __hip_atomic_load(&s_npub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == npub) return NONE;
             __builtin_amdgcn_s_sleep(8);                       // the next range is on its way
         }
     };
