@@ -762,7 +762,8 @@ int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const double* de
  * More than 1024 cameras (the reference has no camera limit, bipgo.py:225-232; one LDS table of the sweeps holds 1024): the plan
  * cuts the cameras into <= 64 tiles of equal width that share one chunking of the timestep rows and runs the tiled schedule
  * (csrc/vican_facade_tiles.hip, as vican_amd/tiled.py: the operator as one launch that reads every block once, dual update / J^T b /
- * CG product tile by tile, rows summed in tile order) - same calls, same outputs, vican_plan_set_comm included.  VICAN_ERR_CAPACITY
+ * CG product tile by tile, rows summed in tile order; the rows packed for the shared chunking in an order of the plan's own, per-row
+ * arguments translated at the boundary) - same calls, same outputs, vican_plan_set_comm included.  VICAN_ERR_CAPACITY
  * where a timestep row has more than 256 (f32) / 128 (f64) edges inside one tile or a tile has no edges at all (layouts only the
  * host driver vican_amd.tiled plans), and from vican_solve_trans_lsqr on a tiled plan.
  *

@@ -217,12 +217,17 @@ def test_1500_cameras_behind_the_four_calls_match_the_python_driver():
             assert b"camera-tiled" in lib.vican_last_error()
         finally:
             assert lib.vican_plan_destroy(plan) == 0
-        K = TiledBackend(TiledGraph(Cn, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"]))
+        # (rows packed for the shared chunking on both sides: vican_plan_rows_multi - the plan and the TiledGraph keep their rows in
+        #  the same order of their own and hand per-row results back in the caller's)
+        G = TiledGraph(Cn, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"], permute_rows=True)
+        assert G.row_perm is not None
+        K = TiledBackend(G)
         rot = RotationSolver(K, Comm(), eig_tol=1e-10)
         rc_ref, Rt_ref = rot.run(4)
         tr = TranslationSolver(K, Comm())
         tr.setup(rc_ref, Rt_ref)
         xc_ref, xt_ref = tr.solve(3 * (Cn + T))
+        Rt_ref, xt_ref = G.unpermute_rows(Rt_ref.reshape(-1, 9)[:T]), G.unpermute_rows(xt_ref.reshape(-1, 3)[:T])
         tol_r = 2e-5 if tdt == torch.float32 else 1e-8
         d_rc = float((rcs - rc_ref.reshape(3 * Cn, 3)).abs().max()); d_rt = float((Rt - Rt_ref.reshape(T, 9)).abs().max())
         d_x = float((x_c - xc_ref.reshape(Cn, 3)).abs().max()); d_t = float((x_t - xt_ref[:T].reshape(T, 3)).abs().max())
@@ -249,7 +254,8 @@ def test_tile_layouts_the_boundary_does_not_plan_are_refused_with_the_reason(til
     p = lambda t: C.c_void_p(t.data_ptr())
     tile_cams(8)
     plan = C.c_void_p()
-    rc = lib.vican_plan_create(Cn, T, E, _lib.STORE_F64, p(up(rp, torch.int32)), p(up(cols, torch.int32)), p(blk), p(a), None, None, None, None, None,
+    rp_d, col_d = up(rp, torch.int32), up(cols, torch.int32)
+    rc = lib.vican_plan_create(Cn, T, E, _lib.STORE_F64, p(rp_d), p(col_d), p(blk), p(a), None, None, None, None, None,
                                C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(plan))
     assert rc == _lib.ERR_CAPACITY and b"has no edges" in lib.vican_last_error(), lib.vican_last_error()
     assert not plan.value

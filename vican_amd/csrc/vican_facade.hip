@@ -205,8 +205,12 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
         hipMemsetAsync(mx, 0, 24, s);
         if (P->have_t) { P->wmax = h[1]; P->gmax = h[2]; }
         rc = vican_facade_tiles_pack(P, row_ptr, col, blk, a, w, u, v, h[0], stream);
-        if (rc >= 0 && P->have_t && deg_t) hipMemcpyAsync(P->row_sum_w, deg_t, (size_t)n_time * 8, hipMemcpyDeviceToDevice, s);
+        if (rc >= 0 && P->have_t && deg_t) {                 // (into the plan's row order)
+            const double* d = vican_facade_tiles_rows_in(P, deg_t, 1, P->t_rows9, stream);
+            hipMemcpyAsync(P->row_sum_w, d, (size_t)n_time * 8, hipMemcpyDeviceToDevice, s);
+        }
         if (rc >= 0 && P->have_t && deg_c) hipMemcpyAsync(P->cam_sum_w, deg_c, (size_t)n_cam * 8, hipMemcpyDeviceToDevice, s);
+        if (rc >= 0 && hipStreamSynchronize(s) != hipSuccess) rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: packing failed");
         if (rc < 0) return fail(rc);
     } else {   // the whole CG as one cooperative launch on capture-sized graphs (device.py HipBackend.cg_resident_ok, solver.py small_graph)
         int dev_ = 0, ncu_ = 0;
@@ -445,7 +449,8 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
         ++inf.iterations;
     }
     if (rc_out) HIPCK(hipMemcpyAsync(rc_out, P->rc, (size_t)3 * n * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
-    if (Rt_out) HIPCK(hipMemcpyAsync(Rt_out, P->Rt, (size_t)9 * T * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
+    if (Rt_out && tiled) vican_facade_tiles_rows_out(P, P->Rt, 9, Rt_out, stream);     // (the caller's row order)
+    else if (Rt_out) HIPCK(hipMemcpyAsync(Rt_out, P->Rt, (size_t)9 * T * 8, hipMemcpyDeviceToDevice, s), "vican_solve_rot");
     HIPCK(hipStreamSynchronize(s), "vican_solve_rot");
     if (info) *info = inf;
     return VICAN_OK;
@@ -464,7 +469,14 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
     vican_solve_info_t inf = info ? *info : vican_solve_info_t{};
     vican_comm_t* comm = P->comm_ready ? P->comm : nullptr;
     const bool tiled = !P->tiles.empty();
-    if (tiled) CK(vican_facade_tiles_rhs(P, rc, Rt, stream));
+    // a tiled plan may keep its rows in an order of its own: Rt comes in, x_t goes out through it (the CG runs on the plan's q_t-sized
+    // buffer t_rows9, which is free again once J^T b is formed)
+    double* const x_t_caller = x_t;
+    const bool reorder = tiled && P->t_perm_dev != nullptr;
+    if (tiled) {
+        CK(vican_facade_tiles_rhs(P, rc, vican_facade_tiles_rows_in(P, Rt, 9, P->t_rows9, stream), stream));
+        if (reorder) x_t = P->t_rows9;
+    }
     else CK(vican_trans_rhs(&P->g, P->u, P->v, rc, Rt, P->b_t, P->b_c, P->zpart, P->gmax, P->n_add, stream));
     const double* deg_c = P->cam_sum_w;
     if (comm) {
@@ -528,6 +540,10 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
         std::memcpy(&h, P->status_host + 16, sizeof(h));
         if (h.done || launched >= maxiter) break;
         burst = std::min(2 * burst, 64);
+    }
+    if (reorder) {                                           // x_t back in the caller's row order
+        vican_facade_tiles_rows_out(P, x_t, 3, x_t_caller, stream);
+        HIPCK(hipStreamSynchronize(s), "vican_solve_trans");
     }
     inf.cg_iters = h.done == 1 ? h.iter : (int32_t)std::min<long long>(launched, 2147483647LL); inf.cg_converged = h.done == 1;
     inf.cg_relres = h.bnorm2 > 0 ? std::sqrt(h.rho / h.bnorm2) : 0.0;

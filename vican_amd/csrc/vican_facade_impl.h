@@ -97,6 +97,9 @@ struct vican_plan {
     // camera tiles (C > the tile width; vican_facade_tiles.hip): empty for an untiled plan
     std::vector<vican_tile_plan> tiles;
     std::vector<int32_t> t_chunks;                          // the shared chunking (host)
+    std::vector<int32_t> t_perm;                            // t_perm[new] = old row where the plan keeps its rows in an order of its own (else empty)
+    int32_t* t_perm_dev = nullptr;
+    double* t_rows9 = nullptr;
     std::vector<vican_tile_t> t_host;                       // descriptors of the one-launch operator
     vican_tile_t* t_dev = nullptr;
     int32_t* t_chunk_row0 = nullptr;
@@ -121,3 +124,5 @@ int vican_facade_tiles_op_z(vican_plan* P, const double* x, double* z, void* str
 int vican_facade_tiles_dual_update(vican_plan* P, const double* rc, void* stream);
 int vican_facade_tiles_rhs(vican_plan* P, const double* rc, const double* Rt, void* stream);
 int vican_facade_tiles_cg_local(vican_plan* P, double rtol, int n_part, void* stream);
+const double* vican_facade_tiles_rows_in(vican_plan* P, const double* src, int width, double* scratch, void* stream);
+void vican_facade_tiles_rows_out(vican_plan* P, const double* src, int width, double* dst, void* stream);

@@ -8,8 +8,11 @@
 //   J^T b         per tile, rows summed in tile order
 //   CG product    the tiles' sweeps in one launch (vican_cg_sweep_tiles, 2..4 tiles) or tile by tile, rows combined in tile order
 // Everything camera-sided (Lanczos step, Ritz, gauge, polar) has no camera limit and stays in vican_facade.hip.
-// Not here (the Python driver's): tiles in the block layout (a tile row of more than 64 * EPL edges, a tile without edges), the
-// row permutation that packs the shared chunking tighter (vican_plan_rows_multi), LSQR on tiles.
+// The timestep rows live in an ORDER OF THE PLAN'S OWN where that packs the shared chunking tighter (vican_plan_rows_multi: 1.33 ->
+// 1.03 slots per edge on 4 tiles x 62 edges per row); everything per row inside the plan is in that order, the calls translate
+// their per-row arguments (deg_t, Rt, x_t) at the boundary.
+// Not here (the Python driver's): tiles in the block layout (a tile row of more than 64 * EPL edges, a tile without edges),
+// LSQR on tiles.
 #include "vican_facade_impl.h"
 
 namespace {
@@ -38,8 +41,9 @@ __global__ void tile_count_kernel(int T, int nt, int tile, const int32_t* __rest
 }
 
 // the edges of ONE tile (cameras [c0, c1)) as CSR arrays of their own, rows and the order inside a row kept: one wavefront per row
+// (perm != NULL: row t of the tile = row perm[t] of the caller's arrays)
 template <typename S>
-__global__ void tile_gather_kernel(int T, int c0, int c1, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+__global__ void tile_gather_kernel(int T, int c0, int c1, const int32_t* __restrict__ perm, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                    const S* __restrict__ blk, const S* __restrict__ a, const double* __restrict__ w,
                                    const double* __restrict__ u, const double* __restrict__ v, const int32_t* __restrict__ rp_k,
                                    int32_t* __restrict__ col_k, S* __restrict__ blk_k, S* __restrict__ a_k, double* __restrict__ w_k,
@@ -47,7 +51,8 @@ __global__ void tile_gather_kernel(int T, int c0, int c1, const int32_t* __restr
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= T) return;
-    const int e0 = row_ptr[t], e1 = row_ptr[t + 1];
+    const int ts = perm ? perm[t] : t;
+    const int e0 = row_ptr[ts], e1 = row_ptr[ts + 1];
     int base = rp_k[t];
     for (int e = e0; e < e1; e += 64) {
         const int i = e + lane;
@@ -67,6 +72,15 @@ __global__ void tile_gather_kernel(int T, int c0, int c1, const int32_t* __restr
             }
         }
         base += __popcll(m);
+    }
+}
+
+// dst[r] = src[perm[r]] (gather: the caller's order -> the plan's) or dst[perm[r]] = src[r] (scatter: back), rows of `width` doubles
+__global__ void rows_permute_kernel(long long n, int width, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                                    double* __restrict__ dst, int scatter) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n * width; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / width, q = i - r * width, o = (long long)perm[r] * width + q;
+        if (scatter) dst[o] = src[i]; else dst[i] = src[o];
     }
 }
 
@@ -140,7 +154,33 @@ int vican_facade_tiles_layout(vican_plan* P, const std::vector<int32_t>& rp, con
     std::vector<const int32_t*> ptrs(nt);
     for (int k = 0; k < nt; ++k) ptrs[k] = P->tiles[k].rp.data();
     P->t_chunks.assign((size_t)T + 2, 0);
-    const int nchunk = vican_plan_chunks_multi(T, nt, ptrs.data(), slots, cap_rows, P->t_chunks.data(), T + 2);
+    // rows in a better order for the shared chunking (tiled.py: a pool of 512 rows where few rows fill a chunk - the integer effect -
+    // 128 up to 32 rows per chunk, none beyond: chunks of many short rows fill well in any order)
+    long long e_max = 0;
+    for (const vican_tile_plan& t : P->tiles) e_max = std::max(e_max, t.E);
+    const double rows_est = std::max(1.0, slots / std::max(1.0, (double)e_max / T));
+    const int window = rows_est <= 8 ? 512 : (rows_est <= 32 ? 128 : 1);
+    P->t_perm.clear();
+    int nchunk = -1;
+    if (window > 1 && nt > 1) {
+        std::vector<int32_t> perm((size_t)T), c0s((size_t)T + 2);
+        const int n = vican_plan_rows_multi(T, nt, ptrs.data(), slots, cap_rows, window, perm.data(), c0s.data(), T + 2);
+        bool identity = n >= 0;
+        for (int r = 0; identity && r < T; ++r) identity = perm[r] == r;
+        if (n >= 0 && identity) { nchunk = n; P->t_chunks = c0s; }
+        else if (n >= 0) {
+            // the tiles' row_ptr in the new order
+            for (int k = 0; k < nt; ++k) {
+                vican_tile_plan& t = P->tiles[k];
+                std::vector<int32_t> rpn((size_t)T + 1, 0);
+                for (int r = 0; r < T; ++r) rpn[r + 1] = rpn[r] + (t.rp[perm[r] + 1] - t.rp[perm[r]]);
+                t.rp.swap(rpn);
+            }
+            nchunk = n; P->t_chunks = c0s; P->t_perm.swap(perm);
+        }
+    }
+    for (int k = 0; k < nt; ++k) ptrs[k] = P->tiles[k].rp.data();
+    if (nchunk < 0) nchunk = vican_plan_chunks_multi(T, nt, ptrs.data(), slots, cap_rows, P->t_chunks.data(), T + 2);
     if (nchunk == VICAN_ERR_CAPACITY)
         return ferr(VICAN_ERR_CAPACITY, "vican_plan_create: a timestep row has more than %d edges inside one camera tile: block-layout tiles are the host driver's (vican_amd.tiled)", slots);
     if (nchunk < 0) return nchunk;
@@ -217,6 +257,10 @@ void vican_facade_tiles_carve(vican_plan* P) {
     P->t_wrow = A.take<double>((size_t)T1 * 9);
     if (P->have_t) P->t_acc = A.take<double>((size_t)nt * T1 * 3);
     P->t_dev = A.take<vican_tile_t>(nt);
+    if (!P->t_perm.empty()) {
+        P->t_perm_dev = A.take<int32_t>(P->t_perm.size());
+        P->t_rows9 = A.take<double>((size_t)T1 * 9);         // a per-row argument in the plan's row order (Rt in, x_t out)
+    }
 }
 
 // ---- pack: every tile's edges out of the caller's CSR arrays into its chunked planes; graph constants ----------------------------------
@@ -248,16 +292,18 @@ int vican_facade_tiles_pack(vican_plan* P, const int32_t* row_ptr, const int32_t
     int rc = VICAN_OK;
     if (hipMemcpyAsync(P->t_chunk_row0, P->t_chunks.data(), P->t_chunks.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess)
         rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed");
+    if (rc >= 0 && P->t_perm_dev && hipMemcpyAsync(P->t_perm_dev, P->t_perm.data(), P->t_perm.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+        rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed");
     double* rows_a = P->t_rows; double* rows_n = P->t_rows + (size_t)nt * T1; double* rows_w = P->t_rows + (size_t)2 * nt * T1;
     for (int k = 0; k < nt && rc >= 0; ++k) {
         vican_tile_plan& t = P->tiles[k];
         t.g.blk = t.blk; t.g.idx = (const uint32_t*)t.idx; t.g.chunk_row0 = P->t_chunk_row0;
         if (hipMemcpyAsync(rp_k, t.rp.data(), t.rp.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess) { rc = ferr(VICAN_ERR_LAUNCH, "vican_plan_create: copy failed"); break; }
         if (storage == VICAN_STORE_F32)
-            hipLaunchKernelGGL(tile_gather_kernel<float>, dim3((T + 3) / 4), dim3(256), 0, s, T, t.c0, t.c1, row_ptr, col, (const float*)blk, (const float*)a, w, u, v,
+            hipLaunchKernelGGL(tile_gather_kernel<float>, dim3((T + 3) / 4), dim3(256), 0, s, T, t.c0, t.c1, P->t_perm_dev, row_ptr, col, (const float*)blk, (const float*)a, w, u, v,
                                rp_k, col_k, (float*)blk_k, (float*)a_k, w_k, u_k, v_k);
         else
-            hipLaunchKernelGGL(tile_gather_kernel<double>, dim3((T + 3) / 4), dim3(256), 0, s, T, t.c0, t.c1, row_ptr, col, (const double*)blk, (const double*)a, w, u, v,
+            hipLaunchKernelGGL(tile_gather_kernel<double>, dim3((T + 3) / 4), dim3(256), 0, s, T, t.c0, t.c1, P->t_perm_dev, row_ptr, col, (const double*)blk, (const double*)a, w, u, v,
                                rp_k, col_k, (double*)blk_k, (double*)a_k, w_k, u_k, v_k);
         rc = vican_pack_edges(&t.g, rp_k, col_k, blk_k, a_k, w ? w_k : nullptr, w ? u_k : nullptr, w ? v_k : nullptr, t.a, t.w, t.u, t.v, perm, stream);
         if (rc >= 0) rc = vican_pack_idx16(&t.g, t.idx16, stream);
@@ -383,4 +429,19 @@ int vican_facade_tiles_cg_local(vican_plan* P, double rtol, int n_part, void* st
     const int nb = vican_cg_combine_rows(P->T, nt, (int64_t)T1 * 3, P->row_sum_w, P->p_t, P->t_acc, P->q_t, P->pq_part, 1024, P->st, stream);
     if (nb < 0) return nb;
     return vican_cg_reduce_pq(P->pq_part, nb, P->qcpq + (size_t)3 * C, P->st, stream);
+}
+
+// Per-row arrays at the boundary of a plan whose rows are in an order of its own (no-ops otherwise): `to_plan` copies the caller's
+// [T][width] array into the plan's order (returns the array to use), `to_caller` writes a plan-order array back in the caller's order
+const double* vican_facade_tiles_rows_in(vican_plan* P, const double* src, int width, double* scratch, void* stream) {
+    if (!P->t_perm_dev) return src;
+    hipLaunchKernelGGL(rows_permute_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (long long)P->T, width, P->t_perm_dev, src, scratch, 0);
+    return scratch;
+}
+void vican_facade_tiles_rows_out(vican_plan* P, const double* src, int width, double* dst, void* stream) {
+    if (!P->t_perm_dev) {
+        if (src != dst) hipMemcpyAsync(dst, src, (size_t)P->T * width * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return;
+    }
+    hipLaunchKernelGGL(rows_permute_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (long long)P->T, width, P->t_perm_dev, src, dst, 1);
 }
