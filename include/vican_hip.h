@@ -765,7 +765,7 @@ int vican_cg_iter_comm(const vican_graph_t* g, const double* w, const double* de
  * CG product tile by tile, rows summed in tile order; the rows packed for the shared chunking in an order of the plan's own, per-row
  * arguments translated at the boundary) - same calls, same outputs, vican_plan_set_comm included.  VICAN_ERR_CAPACITY
  * where a timestep row has more than 256 (f32) / 128 (f64) edges inside one tile or a tile has no edges at all (layouts only the
- * host driver vican_amd.tiled plans), and from vican_solve_trans_lsqr on a tiled plan.
+ * host driver vican_amd.tiled plans).
  *
  * vican_plan_create  replaces bipgo.py:244-276 (COO triplets -> CSR, degrees, power-graph constants): the merged timestep-major
  *     CSR problem (row_ptr [T+1], col [E] ascending inside a row, blk [E][9] and a [E] in the storage type; optionally the

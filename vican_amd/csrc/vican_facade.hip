@@ -563,12 +563,19 @@ extern "C" int vican_solve_trans(vican_plan_t* P, const double* rc, const double
 namespace {
 int lsqr_workspace(vican_plan* P) {
     if (P->lsqr_base) return VICAN_OK;
-    const size_t nslot = (size_t)std::max(1, P->g.n_chunk) * P->g.slots, C = P->C, T1 = std::max(P->T, 1);
+    const bool tiled = !P->tiles.empty();
+    const size_t nslot = tiled ? 0 : (size_t)std::max(1, P->g.n_chunk) * P->g.slots, C = P->C, T1 = std::max(P->T, 1);
     Arena A;
     auto carve = [&]() {
         A.used = 0;
         P->lu = A.take<double>(3 * nslot); P->lsw = A.take<double>(nslot); P->lpart = A.take<double>(std::max<size_t>(P->g.n_wg, 1024));
-        P->lslab = A.take<double>((size_t)std::max(P->g.n_wg, 1) * 6 * C);
+        P->lslab = A.take<double>(tiled ? 1 : (size_t)std::max(P->g.n_wg, 1) * 6 * C);
+        for (vican_tile_plan& t : P->tiles) {                 // camera tiles: every tile keeps its own edge vector u~ (tiled.py lsqr_*)
+            const size_t ns = (size_t)t.g.n_chunk * t.g.slots;
+            t.lu = A.take<double>(3 * ns); t.lsw = A.take<double>(ns); t.lpart = A.take<double>(std::max<size_t>(t.g.n_wg, 1024));
+            t.lslab = A.take<double>((size_t)t.g.n_wg * 6 * (t.c1 - t.c0));
+        }
+        P->ltmp = A.take<double>(P->tiles.size() + 1);
         P->lv_c = A.take<double>(3 * C); P->lw_c = A.take<double>(3 * C); P->lv_t = A.take<double>(3 * T1); P->lw_t = A.take<double>(3 * T1);
         P->lz_t = A.take<double>(3 * T1); P->lacc = A.take<double>(3 * C + 2); P->lpart2 = A.take<double>(1025);
         P->lwp_c = A.take<double>(1024); P->lwp_t = A.take<double>(1024); P->ls2 = A.take<double>(4);
@@ -587,7 +594,6 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
                                       double conlim, int64_t iter_lim, double* x_c, double* x_t, vican_lsqr_info_t* info, void* stream) {
     if (!P || !rc || !Rt || !x_c || !x_t || !(atol >= 0) || !(btol >= 0)) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: bad argument");
     if (!P->have_t) return ferr(VICAN_ERR_ARG, "vican_solve_trans_lsqr: the plan was created without translation arrays (w, u, v)");
-    if (!P->tiles.empty()) return ferr(VICAN_ERR_CAPACITY, "vican_solve_trans_lsqr: a camera-tiled plan (more than %d cameras) solves its translations with vican_solve_trans; LSQR on tiles is the host driver's (vican_amd.tiled)", P->tile_width);
     CK(lsqr_workspace(P));
     hipStream_t s = (hipStream_t)stream;
     const int C = P->C, T = P->T, C3 = 3 * C;
@@ -606,7 +612,39 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
         return true;
     };
     // u~_1 = b~ (unnormalised), beta_1 = |b~|
-    CK(vican_lsqr_init_u(&P->g, P->w, P->u, P->v, rc, Rt, P->lu, P->lsw, P->lpart, P->ls2, stream));
+    // camera tiles: every pass over the edges tile by tile - a tile's sweep yields its row sums (added in tile order), the complete
+    // camera sums of its own cameras and its part of |u^|^2 (vican_amd/tiled.py lsqr_init_u / lsqr_step); per-row arguments in the
+    // plan's row order
+    const bool tiled = !P->tiles.empty(), reorder = tiled && P->t_perm_dev != nullptr;
+    const int nt = (int)P->tiles.size();
+    const size_t T1 = std::max(T, 1);
+    double* const x_t_caller = x_t;
+    auto sum_parts = [&](double* out) { return vican_sum_apply3(1, 1, nullptr, P->ltmp, nt, 1, out, stream); };
+    auto edge_step = [&]() -> int {
+        if (!tiled) return vican_lsqr_step(&P->g, P->lsw, P->lu, P->lv_c, P->lv_t, P->lz_t, P->lslab, P->lpart, P->lacc, P->lst, stream);
+        for (int k = 0; k < nt; ++k) {
+            const vican_tile_plan& t = P->tiles[k];
+            // (the tile writes its camera sums into its slice of lacc and its part of |u^|^2 right behind the slice)
+            CK(vican_lsqr_step(&t.g, t.lsw, t.lu, P->lv_c + (size_t)3 * t.c0, P->lv_t, P->t_acc + (size_t)k * T1 * 3, t.lslab, t.lpart,
+                               P->lacc + (size_t)3 * t.c0, P->lst, stream));
+            HIPCK(hipMemcpyAsync(P->ltmp + k, P->lacc + (size_t)3 * t.c1, 8, hipMemcpyDeviceToDevice, s), "vican_solve_trans_lsqr");
+        }
+        CK(sum_parts(P->lacc + C3));
+        return vican_sum_apply3(T, 3, nullptr, P->t_acc, nt, (int64_t)T1 * 3, P->lz_t, stream);
+    };
+    if (tiled) {
+        const double* Rt_plan = vican_facade_tiles_rows_in(P, Rt, 9, P->t_rows9, stream);
+        for (int k = 0; k < nt; ++k) {
+            const vican_tile_plan& t = P->tiles[k];
+            CK(vican_lsqr_init_u(&t.g, t.w, t.u, t.v, rc + (size_t)9 * t.c0, Rt_plan, t.lu, t.lsw, t.lpart, P->ltmp + k, stream));
+        }
+        CK(sum_parts(P->ls2));
+        if (reorder) {                                          // (t_rows9 is free again: the iteration's x_t in the plan's row order)
+            x_t = P->t_rows9;
+            if (!zero(x_t, 3 * (size_t)T)) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: memset failed");
+        }
+    } else
+        CK(vican_lsqr_init_u(&P->g, P->w, P->u, P->v, rc, Rt, P->lu, P->lsw, P->lpart, P->ls2, stream));
     double h4[4];
     if (!read(P->ls2, h4, 1)) return ferr(VICAN_ERR_LAUNCH, "vican_solve_trans_lsqr: read failed");
     const double beta = std::sqrt(h4[0]);
@@ -620,7 +658,7 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
     st.coef = -1.0; st.smax = smax; st.n_add = n_add; st.lo_bits = lo_bits;
     st.qscale = fix_scale(smax * beta, n_add, &inv, 49); st.qinv = inv;
     HIPCK(hipMemcpyAsync(P->lst, &st, sizeof(st), hipMemcpyHostToDevice, s), "vican_solve_trans_lsqr");
-    CK(vican_lsqr_step(&P->g, P->lsw, P->lu, P->lv_c, P->lv_t, P->lz_t, P->lslab, P->lpart, P->lacc, P->lst, stream));
+    CK(edge_step());
     int nb = vican_lsqr_nodes(C, T, P->lz_t, P->lacc, P->lv_t, P->lv_c, P->lpart2, P->lst, stream);
     if (nb < 0) return nb;
     std::vector<double> hp(1025);
@@ -646,7 +684,7 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
     for (;;) {
         const long long todo = std::min<long long>(burst, std::max<long long>(iter_lim - launched, 1));
         for (long long i = 0; i < todo; ++i, ++launched) {
-            CK(vican_lsqr_step(&P->g, P->lsw, P->lu, P->lv_c, P->lv_t, P->lz_t, P->lslab, P->lpart, P->lacc, P->lst, stream));
+            CK(edge_step());
             nb = vican_lsqr_nodes(C, T, P->lz_t, P->lacc, P->lv_t, P->lv_c, P->lpart2, P->lst, stream);
             if (nb < 0) return nb;
             CK(vican_lsqr_scalars(C, P->lacc, P->lpart2, nb, nullptr, wpart_t, n_wt, wpart_c, n_wc, nullptr, P->lst, stream));
@@ -661,6 +699,10 @@ extern "C" int vican_solve_trans_lsqr(vican_plan_t* P, const double* rc, const d
         std::memcpy(&hst, P->status_host + 32, sizeof(hst));
         if (hst.done || launched >= iter_lim) break;
         burst = std::min(2 * burst, 64);
+    }
+    if (reorder) {                                           // x_t back in the caller's row order
+        vican_facade_tiles_rows_out(P, x_t, 3, x_t_caller, stream);
+        HIPCK(hipStreamSynchronize(s), "vican_solve_trans_lsqr");
     }
     inf.itn = hst.itn; inf.istop = hst.istop; inf.rnorm = hst.rnorm; inf.arnorm = hst.arnorm; inf.anorm = hst.anorm; inf.acond = hst.acond;
     inf.xnorm = hst.xnorm;

@@ -54,6 +54,7 @@ struct vican_tile_plan {
     double n_add = 1;
     int32_t* idx = nullptr; uint16_t* idx16 = nullptr; void* blk = nullptr; void* a = nullptr;
     double *w = nullptr, *u = nullptr, *v = nullptr, *fx = nullptr, *zpart = nullptr, *zpart_f = nullptr;
+    double *lu = nullptr, *lsw = nullptr, *lpart = nullptr, *lslab = nullptr;       // LSQR workspace of the tile (vican_solve_trans_lsqr)
 };
 
 struct vican_plan {
@@ -110,6 +111,7 @@ struct vican_plan {
     double *lu = nullptr, *lsw = nullptr, *lpart = nullptr, *lslab = nullptr, *lv_c = nullptr, *lw_c = nullptr, *lv_t = nullptr, *lw_t = nullptr,
            *lz_t = nullptr, *lacc = nullptr, *lpart2 = nullptr, *lwp_c = nullptr, *lwp_t = nullptr, *ls2 = nullptr;
     vican_lsqr_state_t* lst = nullptr;
+    double* ltmp = nullptr;                                 // per-tile parts of |u^|^2
 };
 
 

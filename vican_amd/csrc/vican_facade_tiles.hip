@@ -11,8 +11,8 @@
 // The timestep rows live in an ORDER OF THE PLAN'S OWN where that packs the shared chunking tighter (vican_plan_rows_multi: 1.33 ->
 // 1.03 slots per edge on 4 tiles x 62 edges per row); everything per row inside the plan is in that order, the calls translate
 // their per-row arguments (deg_t, Rt, x_t) at the boundary.
-// Not here (the Python driver's): tiles in the block layout (a tile row of more than 64 * EPL edges, a tile without edges),
-// LSQR on tiles.
+//   LSQR          vican_solve_trans_lsqr (vican_facade.hip): every pass over the edges tile by tile, each tile its own edge vector
+// Not here (the Python driver's): tiles in the block layout (a tile row of more than 64 * EPL edges, a tile without edges).
 #include "vican_facade_impl.h"
 
 namespace {
