@@ -224,6 +224,17 @@ def test_1500_cameras_behind_the_four_calls_match_the_python_driver():
             assert d_l < 2e-3 * float(x_c.abs().max())
         finally:
             assert lib.vican_plan_destroy(plan) == 0
+        # a rotation-only plan of the same graph (no translation arrays): the same rotations to the bit, translations refused
+        plan = C.c_void_p()
+        assert lib.vican_plan_create(Cn, T, E, _lib.STORE_F32 if tdt == torch.float32 else _lib.STORE_F64, p(gr["row_ptr"]), p(gr["col"]), p(gr["blk"]),
+                                     p(gr["a"]), None, None, None, None, None, stream, C.byref(plan)) == 0, lib.vican_last_error()
+        try:
+            rc2, Rt2 = torch.empty_like(rcs), torch.empty_like(Rt)
+            assert lib.vican_solve_rot(plan, 4, 1e-10, p(rc2), p(Rt2), None, stream) == 0, lib.vican_last_error()
+            assert torch.equal(rc2, rcs) and torch.equal(Rt2, Rt)
+            assert lib.vican_solve_trans(plan, p(rc2), p(Rt2), 1e-5, 0, p(x_c.clone()), p(x_t.clone()), None, stream) == _lib.ERR_ARG
+        finally:
+            assert lib.vican_plan_destroy(plan) == 0
         # (rows packed for the shared chunking on both sides: vican_plan_rows_multi - the plan and the TiledGraph keep their rows in
         #  the same order of their own and hand per-row results back in the caller's)
         G = TiledGraph(Cn, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"], permute_rows=True)
