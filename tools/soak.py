@@ -2,7 +2,7 @@
 """Soak: thousands of WHOLE warm solves (rotation loop + translation CG, Python driver) per shape, every output compared with the
 first solve's bit for bit on the device, Lanczos step counts and CG iterations with it, cooperative-kernel failures listed.
 
-    python tools/soak.py          (GPU; ~1 minute)
+    python tools/soak.py [scale]  (GPU; ~1 minute at scale 1)
 
 Output of the round-6 library: profiles/r06_determinism.txt (second half)."""
 import os
@@ -14,7 +14,9 @@ from vican_amd import synth
 from vican_amd.device import make_backend
 from vican_amd.solver import Comm, RotationSolver, TranslationSolver
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0        # python tools/soak.py 15  -> fifteen times as many solves
 for (C, T, cpt, n_sol, tag) in ((340, 10000, 4, 20000, "large_shop"), (1000, 100000, 250, 4000, "stress"), (100, 200000, 8, 4000, "sparse-like"), (4000, 30000, 250, 1500, "tiled")):
+    n_sol = int(n_sol * SCALE)
     gr = synth.make_merged_graph_torch(C, T, cpt, dev, torch.float32, seed=0)
     g, K = make_backend(C, gr["row_ptr"], gr["col"], gr["blk"], gr["a"], gr["w"], gr["u"], gr["v"])
     del gr

@@ -179,7 +179,7 @@ extern "C" int vican_plan_create(int32_t n_cam, int32_t n_time, int64_t n_edges,
         return fail(ferr(VICAN_ERR_LAUNCH, "vican_plan_create: cannot read row_ptr"));
     if (rp[0] != 0 || rp[n_time] != n_edges) return fail(ferr(VICAN_ERR_ARG, "vican_plan_create: row_ptr does not span n_edges"));
     const bool tiled = n_cam > vican_facade_tile_cams();
-    int rc = tiled ? vican_facade_tiles_layout(P, rp, row_ptr, col, stream) : plan_layout(P, rp, c0);
+    int rc = tiled ? vican_facade_tiles_layout(P, row_ptr, col, stream) : plan_layout(P, rp, c0);
     if (rc < 0) return fail(rc);
     if (tiled) c0.assign(1, 0);
     const size_t bytes = carve(P, c0.size());

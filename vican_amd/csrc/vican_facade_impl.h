@@ -117,7 +117,7 @@ struct vican_plan {
 
 // camera tiles (vican_facade_tiles.hip)
 int vican_facade_tile_cams();
-int vican_facade_tiles_layout(vican_plan* P, const std::vector<int32_t>& rp, const int32_t* row_ptr, const int32_t* col, void* stream);
+int vican_facade_tiles_layout(vican_plan* P, const int32_t* row_ptr, const int32_t* col, void* stream);
 void vican_facade_tiles_carve(vican_plan* P);
 int vican_facade_tiles_pack(vican_plan* P, const int32_t* row_ptr, const int32_t* col, const void* blk, const void* a, const double* w,
                             const double* u, const double* v, double amax, void* stream);

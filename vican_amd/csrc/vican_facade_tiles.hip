@@ -118,7 +118,7 @@ extern "C" int vican_facade_set_tile_cams(int32_t n) {
 int vican_facade_tile_cams() { return g_tile_cams; }
 
 // ---- planning: tiles, the shared chunking, every tile's descriptor (host; one small kernel for the per-tile row lengths) ----------
-int vican_facade_tiles_layout(vican_plan* P, const std::vector<int32_t>& rp, const int32_t* row_ptr, const int32_t* col, void* stream) {
+int vican_facade_tiles_layout(vican_plan* P, const int32_t* row_ptr, const int32_t* col, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int C = P->C, T = P->T, storage = P->storage, epl = P->epl, ncu = vican_facade::n_cu();
     // tiles of EQUAL width (4000 cameras: 4 x 1000, not 3 x 1024 + 928): a row's edges split evenly and the shared chunking fills
@@ -136,7 +136,6 @@ int vican_facade_tiles_layout(vican_plan* P, const std::vector<int32_t>& rp, con
     const bool ok = hipMemcpyAsync(h.data(), cnt, h.size() * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     hipFree(cnt);
     if (!ok) return ferr(VICAN_ERR_LAUNCH, "vican_plan_create: cannot count the tiles' edges");
-    (void)rp;
     int slots = 64 * epl, cap_rows = 64;
     for (int k = 0; k < nt; ++k) {
         vican_tile_plan& t = P->tiles[k];
