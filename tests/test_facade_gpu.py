@@ -143,11 +143,13 @@ def tile_cams():
 
 
 @pytest.mark.parametrize("name,dt,tile", [("g3_medium", "float64", 16), ("g3_medium", "float32", 16), ("g2_small", "float64", 3),
-                                          ("g2_small", "float32", 3), ("g9_large_shop", "float32", 128)])
+                                          ("g2_small", "float32", 3), ("g9_large_shop", "float32", 128),
+                                          # more than four tiles: the CG product tile by tile, the operator's share reload loop
+                                          ("g3_medium", "float64", 6), ("g3_medium", "float32", 5)])
 @pytest.mark.parametrize("sharded", [False, True])
 def test_camera_tiles_behind_the_four_calls(name, dt, tile, sharded, tile_cams):
     """More cameras than a tile holds (csrc/vican_facade_tiles.hip; forced here on golden cases: 40 cameras in tiles of 16, 6 in
-    tiles of 3, large_shop's 340 in tiles of 128): the same four calls, poses against the REAL reference's.  sharded: the tiled
+    tiles of 3, large_shop's 340 in tiles of 128; 40 in tiles of 6 / 5 = seven / eight tiles): the same four calls, poses against the REAL reference's.  sharded: the tiled
     plan as the only rank of a sharded solve - its all-reduces (operator result, both CG messages) through the peer exchange."""
     lib = _lib.load()
     g = load_golden(name)
