@@ -387,7 +387,7 @@ int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t
                            double* ws, int64_t ws_doubles, void* stream);
 
 /* The same step as ONE cooperative kernel: <= 32 workgroups (32 cameras each, all resident) that meet at
- * three device-side grid barriers instead of seven dependent launches.  ws: scratch of
+ * two device-side grid barriers instead of seven dependent launches.  ws: scratch of
  * vican_lanczos_coop_ws_doubles(n_cam) doubles; sync_ws: two 32-bit words, zero before the first call
  * (the kernel leaves them zero).  n_cam <= 8192 (256 workgroups of 32 cameras; VICAN_ERR_CAPACITY if that grid is not co-resident).  Results equal vican_lanczos_cam_step up to the order
  * of the (fixed-order, deterministic) partial sums.

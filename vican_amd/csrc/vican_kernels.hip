@@ -516,7 +516,8 @@ __global__ __launch_bounds__(1024) void lanczos_cam_fused_kernel(int n_cam, cons
 // ---------------------------------------------------------------------------
 // Cooperative camera-side Lanczos step: the seven launches of the fine-grained sequence (each a few
 // microseconds of work behind ~5 us of launch latency) as ONE kernel of <= 32 co-resident workgroups that
-// meet at three grid barriers (device counter + spin; the grid is far smaller than the chip, so all
+// meet at two grid barriers (one per Gram-Schmidt pass; the 3x3 Gram of the final block rides on the second - device counter + spin;
+// the grid is far smaller than the chip, so all
 // workgroups are resident).  Each workgroup owns a slice of <= 32 cameras (96 rows of the 3C x 3 block):
 // its rows of R live in LDS for the whole step; only the Gram partials (3 ka doubles per workgroup and pass)
 // and the 3x3 Gram of R cross workgroups, summed in a fixed order => deterministic.
@@ -692,13 +693,31 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
                                      (zpart ? zl[tid * 9 + i * 3 + b] : z[(size_t)(3 * c + i) * 3 + b]);
     }
     __syncthreads();
-    // two Gram-Schmidt passes against the whole basis
+    // two Gram-Schmidt passes against the whole basis.  G = R^T R of the FINAL block rides on the second pass's barrier: with an
+    // orthonormal basis (R' - V h2)^T (R' - V h2) = R'^T R' - h2^T h2, and h2 - what the first pass left along the basis - is
+    // rounding-sized against R' (no cancellation: the correction is ~1e-32 of the leading term; where the Krylov space is exhausted
+    // both forms sit far below the pivot floor).  Two grid barriers per step instead of three.
     for (int pass = 0; pass < 2; ++pass) {
         double* part = pass ? part2 : part1;
         double* hh = pass ? h2 : h;
         coop_gram(vs, ka, nsl, rs, part, nwg, wg);
+        if (pass == 1) {                                       // slice partial of R'^T R' (six numbers) -> all workgroups
+            double g[6] = {0, 0, 0, 0, 0, 0};
+            if (tid < nsl) {
+                const double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
+                g[0] = r0 * r0; g[1] = r0 * r1; g[2] = r0 * r2; g[3] = r1 * r1; g[4] = r1 * r2; g[5] = r2 * r2;
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
+            if ((tid & 63) == 0)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) g6[tid >> 6][q] = g[q];
+            __syncthreads();
+            if (tid < 6) st_agent(partG + (size_t)tid * nwg + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
+        }
         if (!vican_grid_sync(sy, (unsigned)((pass + 1) * nwg), fenced != 0)) return;
         coop_reduce(part, hs, nwg, stage, hh);
+        if (pass == 1) coop_reduce(partG, 6, nwg, stage, G6s);
         if (tid < nsl) {
             double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
             for (int k = 0; k < ka; ++k) {
@@ -710,25 +729,14 @@ __global__ __launch_bounds__(256) void lanczos_cam_coop_kernel(int n_cam, const 
         __syncthreads();
     }
     if (wg == 0) for (int t = tid; t < hs; t += blockDim.x) Hcol[t] = h[t] + h2[t];
-    // G = R^T R: slice partial -> all workgroups
-    {
-        double g[6] = {0, 0, 0, 0, 0, 0};
-        if (tid < nsl) {
-            const double r0 = rs[0][tid], r1 = rs[1][tid], r2 = rs[2][tid];
-            g[0] = r0 * r0; g[1] = r0 * r1; g[2] = r0 * r2; g[3] = r1 * r1; g[4] = r1 * r2; g[5] = r2 * r2;
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) g[q] = wave_sum(g[q]);
-        if ((tid & 63) == 0)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) g6[tid >> 6][q] = g[q];
-        __syncthreads();
-        if (tid < 6) st_agent(partG + (size_t)tid * nwg + wg, (g6[0][tid] + g6[1][tid]) + (g6[2][tid] + g6[3][tid]));
+    // G = R'^T R' - h2^T h2 (every workgroup for itself, from the same numbers in the same order)
+    double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    for (int k = 0; k < ka; ++k) {
+        const double a = h2[k * 3], b = h2[k * 3 + 1], c = h2[k * 3 + 2];
+        c00 += a * a; c01 += a * b; c02 += a * c; c11 += b * b; c12 += b * c; c22 += c * c;
     }
-    if (!vican_grid_sync(sy, (unsigned)(3 * nwg), fenced != 0)) return;
-    coop_reduce(partG, 6, nwg, stage, G6s);
     // upper Cholesky G = beta^T beta, Q = R beta^-1  (same pivot rule as chol_qr3_kernel)
-    const double g00 = G6s[0], g01 = G6s[1], g02 = G6s[2], g11 = G6s[3], g12 = G6s[4], g22 = G6s[5];
+    const double g00 = G6s[0] - c00, g01 = G6s[1] - c01, g02 = G6s[2] - c02, g11 = G6s[3] - c11, g12 = G6s[4] - c12, g22 = G6s[5] - c22;
     const double tr = g00 + g11 + g22, floor_ = fmax(1e-28 * tr, pivot_floor);
     double b00 = 0, b01 = 0, b02 = 0, b11 = 0, b12 = 0, b22 = 0, i00 = 0, i11 = 0, i22 = 0;
     if (g00 > floor_) { b00 = sqrt(g00); i00 = 1.0 / b00; b01 = g01 * i00; b02 = g02 * i00; }
