@@ -158,7 +158,10 @@ def large_shop_wall_clock(args, dev, tdt, comm):
         rot2, tr2 = RotationSolver(K2, comm), TranslationSolver(K2, comm)
         solve(rot2, tr2, K2)
         cold.append(time.perf_counter() - t0)
-    for _ in range(2):
+    cold_steps = list(rot2.stats["lanczos_steps"])
+    # (warm = later solves of the SAME solver object - a time series: the check positions are remembered and, on capture-sized graphs,
+    #  walked down one step per solve to the smallest counts that pass; settled after at most five solves - solver.py, spectral)
+    for _ in range(7):
         solve(rot2, tr2, K2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -167,7 +170,10 @@ def large_shop_wall_clock(args, dev, tdt, comm):
     torch.cuda.synchronize()
     res = {"ms_per_solve": (time.perf_counter() - t0) / 5 * 1e3, "cold_ms": min(cold[1:]) * 1e3, "first_call_ms": cold[0] * 1e3,
            "t_pack_ms": t_pack * 1e3, "cameras": Cl, "timesteps": Tl2, "merged_edges": g2.n_edges,
-           "lanczos_steps": rot2.stats["lanczos_steps"], "cg_iters": tr2.info.get("cg_iters"), "solves_timed": 5}
+           "lanczos_steps": rot2.stats["lanczos_steps"], "cold_lanczos_steps": cold_steps, "cg_iters": tr2.info.get("cg_iters"), "solves_timed": 5,
+           "schedule": "warm: the solver object remembers where its Ritz checks passed and, checking every fourth step on capture-sized graphs, "
+                       "tries one step fewer per solve until a check fails; every solve ends on a passed check of the same rule (cold: a fresh "
+                       "solver object, no hints)"}
     try:                                                 # host front-end on an edge dict of this size (2 markers per view)
         from vican_amd.geometry import SE3
         scene = synth.make_scene(n_cam=Cl, n_time=Tl2, n_marker=6, seed=0)
@@ -250,7 +256,8 @@ def facade_timing(args, dev, tdt, shapes):
             def solve():
                 _lib.check(lib.vican_solve_rot(plan, args.maxiter, 1e-10, p(rcs), p(Rt), C.byref(info), stream), "vican_solve_rot")
                 _lib.check(lib.vican_solve_trans(plan, p(rcs), p(Rt), 1e-5, 0, p(x_c), p(x_t), C.byref(info), stream), "vican_solve_trans")
-            solve()
+            for _ in range(1 if E >= 2000000 else 7):            # (capture-sized graphs: the plan's check positions settle over a few solves)
+                solve()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n_solves):
@@ -361,7 +368,7 @@ def sharded_schedule(args, dev, tdt, shapes):
                     tr.setup(rc, Rt)
                     tr.solve(3 * (Cn + Tn))
                     K.synchronize()
-                for _ in range(3):
+                for _ in range(3 if g.n_edges >= 2000000 else 8):    # (capture-sized graphs: the check positions settle over a few solves)
                     solve()
                 n0 = comm.n_allreduce
                 torch.cuda.synchronize()

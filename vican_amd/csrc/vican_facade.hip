@@ -302,10 +302,12 @@ extern "C" int vican_plan_set_comm(vican_plan_t* P, vican_comm_t* comm, void* st
     HIPCK(hipStreamSynchronize(s), "vican_plan_set_comm");
     P->lscale = *std::max_element(h.begin(), h.begin() + C);
     const double n_e = h[C], n_t = std::max(h[C + 1], 1.0);
+    P->e_global = n_e;
     const double hops1 = (n_e / C) * std::max(n_e / n_t - 1.0, 0.0) / C;
     P->prop_sweeps = hops1 >= 4.0 ? 1 : (hops1 >= 0.5 ? 2 : 3);
     for (int& v : P->pred_steps) v = 0;
     for (int& v : P->pred_fail) v = 0;
+    for (bool& v : P->probe_done) v = false;
     P->comm_ready = true;
     return VICAN_OK;
 }
@@ -320,7 +322,8 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
     const int C = P->C, T = P->T, n = 3 * C, ld = P->ld, m_max = std::max(1, std::min(M_MAX, n / 3));
     const vican_graph_t* g = &P->g;
     vican_set_gate(nullptr);
-    const bool small = P->E < 2000000;
+    // (one rank of a sharded solve: the GLOBAL edge count, the same on every rank - the check schedule decides when collectives run)
+    const bool small = (P->comm_ready && P->comm ? P->e_global : (double)P->E) < 2000000.0;
     const int min_steps = small ? 8 : 4, warm_min = small ? 4 : 2, check_every = small ? 4 : 2, max_restarts = 20;
     const double floor_tol = P->storage == VICAN_STORE_F64 ? 1e-13 : 1e-7, pivot_floor = (1e-12 * P->lscale) * (1e-12 * P->lscale);
     vican_solve_info_t inf{};
@@ -369,6 +372,11 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
             //  last time instead of paying for checks known to fail; schedule only, every step is executed - solver.py pred_steps)
             const int remembered = restart == 0 && it < 64 ? P->pred_steps[it] : 0;
             int next_check = std::min(remembered > 0 ? remembered : (restart == 0 ? warm_min : min_steps), m_max), prev_steps = 0;
+            // capture-sized graphs are checked every four steps, so the remembered count is a multiple of that spacing that sufficed, not
+            // the smallest count: later solves of the plan try ONE STEP FEWER each until a first check fails (that solve takes the step
+            // back and checks again - one Ritz call more, once); every solve still ends on a passed check (solver.py, spectral)
+            bool probing = false;
+            if (small && remembered > 1 && it < 64 && !P->probe_done[it]) { --next_check; probing = true; }
             // residual level of the rounding floor: remembered per iteration index, else the one met by the previous iteration (a
             // property of the f32 products, not of the iterate) - lets the FIRST check recognise a stalled residual (solver.py)
             const double level = restart == 0 && it < 64 ? (P->floor_level[it] >= 0.0 ? P->floor_level[it] : (it > 0 ? P->floor_level[it - 1] : -1.0)) : -1.0;
@@ -419,9 +427,16 @@ extern "C" int vican_solve_rot(vican_plan_t* P, int32_t maxiter, double eig_tol,
                     //  steps - vican_amd/solver.py, RotationSolver.spectral)
                     const int want = floor_hit && floor_at > 0 ? floor_at : steps, have = P->pred_steps[it];
                     if (have <= 0 || want <= have) { P->pred_steps[it] = want; P->pred_fail[it] = 0; }
-                    else if (++P->pred_fail[it] >= 2) { P->pred_steps[it] = want; P->pred_fail[it] = 0; }
+                    else if (++P->pred_fail[it] >= 2) { P->pred_steps[it] = want; P->pred_fail[it] = 0; P->probe_done[it] = true; }
                 }
                 prev_res = st[0]; prev_steps = steps;
+                if (probing) {                                 // (the first check of this run was the probe)
+                    probing = false;
+                    if (!(st[2] != 0.0 && conv)) {
+                        P->probe_done[it] = true;              // one step fewer does not do: the remembered count is the smallest
+                        if (st[2] == 0.0) { next_check = std::min(steps + 1, m_max); continue; }
+                    }
+                }
                 if (st[2] != 0.0) break;                       // stop (converged, noise floor, step budget or exhausted Krylov space)
                 const bool near_floor = floor_tol > 1e-12 && st[0] <= floor_tol;
                 next_check = std::min(steps + ((steps < 8 && !small) || near_floor || remembered > 0 ? 1 : check_every), m_max);

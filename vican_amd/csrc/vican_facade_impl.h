@@ -60,6 +60,7 @@ struct vican_tile_plan {
 struct vican_plan {
     int C = 0, T = 0, storage = 0, epl = 4;
     long long E = 0;
+    double e_global = 0;                                    // merged edges of ALL ranks (vican_plan_set_comm)
     vican_graph_t g{};
     int rows_per_wg_max = 1, rows_per_wg_sweep = 1;
     double n_add = 1, n_add_cg = 1, wmax = 1, gmax = 1, lscale = 1;
@@ -80,7 +81,8 @@ struct vican_plan {
     float* w32 = nullptr; int32_t* w32_flag = nullptr;     // float32 copy of the CG weights (vican_graph_t.w32) where they are float32 values
     bool coop_ok = true, cgres_ok = false;                  // (dropped for the rest of the plan's life once a launch is refused)
     int pred_steps[64] = {0};                               // Lanczos steps that sufficed in primal-dual iteration `it` of the previous solve
-    int pred_fail[64] = {0};                                // ... and consecutive solves whose first check at that count failed
+    int pred_fail[64] = {0};
+    bool probe_done[64] = {false};                          // ... and whether the remembered count is known to be the smallest (capture-sized graphs)                                // ... and consecutive solves whose first check at that count failed
     double floor_level[64];                                 // ... and the residual level its f32 rounding floor sat at (< 0: none met)
     int hw = 0, hb_stride = 0, ld = 0;
     // translation workspace
