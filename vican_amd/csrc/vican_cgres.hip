@@ -10,10 +10,11 @@
 //     compute unit's own L1 without any cross-workgroup coherence traffic;
 //   * the camera vectors (3C numbers each) are replicated: every workgroup keeps p_c, r_c, x_c in LDS and performs
 //     the same camera-side updates from the same inputs in the same order, so they agree to the bit;
-//   * three device-side grid barriers per iteration carry what has to cross workgroups: the fixed-point camera partials
-//     sum_t w p_t (slab per workgroup -> each workgroup folds a slice of the cameras -> everybody reads the 3C sums) and
-//     the partial dot products / maxima.  Everything that crosses is written and read with agent-scope atomics
-//     (write-through / L1-bypassing), the barrier is the relaxed counter of lanczos_cam_coop_kernel.
+//   * two device-side grid barriers per iteration carry what has to cross workgroups: the fixed-point camera partials
+//     sum_t w p_t (every workgroup ADDS its sums into one of two global accumulator sets with integer atomics - exact, any
+//     order - and everybody reads the 3C totals behind the barrier; round 5: slab per workgroup, barrier, a slice folded per
+//     workgroup, barrier) and the partial dot products / maxima.  Everything that crosses is written and read with agent-scope
+//     atomics (write-through / L1-bypassing), the barrier is the relaxed counter of lanczos_cam_coop_kernel.
 // Arithmetic is that of the multi-kernel path: contributions w p in f64, exact double-word fixed-point accumulation (to_fix2:
 // hi word 49 bits below wmax * max(max|p_c|, max|r_t| + beta max|p_t|) as cg_begin_kernel, lo word 48 more), scipy's recurrences and its
 // stopping test |r| < rtol |b| at the top of every iteration.  Only the grouping of the floating-point partial sums of
@@ -72,7 +73,7 @@ extern "C" int64_t vican_cg_resident_lds_bytes(int32_t n_cam, int32_t max_rows, 
     const int64_t per_wave = (((int64_t)max_rows * 3 * (16LL * n_copy + 8)) + 15) & ~15LL;
     return 8LL * (6 * 3 * (int64_t)n_cam + n_cam) + CGR_NW * per_wave + 4LL * 24 * rows_per_wg + 256;
 }
-extern "C" int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg) { return 9LL * n_cam + 4LL * n_wg + 8 + 16; }
+extern "C" int64_t vican_cg_resident_ws_doubles(int32_t n_cam, int32_t n_wg) { return 18LL * n_cam + 4LL * n_wg + 8 + 16; }
 
 template <int EPL>
 struct CgrEdges { uint32_t id[EPL]; double w[EPL]; };
@@ -104,9 +105,11 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
     u64* qt = (u64*)wbase;                      // [2][RW * 3][ncopy] striped row accumulators (this wavefront's): hi, lo
     const int lo_t = 3 * RW * ncopy;
     double* dps = (double*)(qt + (size_t)2 * lo_t);           // [RW * 3] deg_t p of the chunk's rows
-    // workspace: [3][3C] folded camera sums (hi in two halves, lo: fix3_add), [nwg][4] partials (r.r, max|r_t|, p.q, max|p_t|), barrier counter
-    u64* qc_sum = (u64*)ws;
-    double* part = ws + 3 * n3;
+    // workspace: two sets (alternate iterations) of [3][3C] camera sums (hi in two halves, lo: what fix3_add accumulates) that the
+    // workgroups ADD their slabs into (agent-scope integer atomics: exact, any order), [nwg][4] partials (r.r, max|r_t|, p.q, max|p_t|),
+    // barrier counter
+    u64* qc_acc = (u64*)ws;
+    double* part = ws + 6 * n3;
     unsigned int* sync = (unsigned int*)(part + 4 * (size_t)nwg);
     unsigned int nbar = 0;
     const vican_sync_t sy = {sync, abort_word, spin_limit};
@@ -157,6 +160,9 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
         if (comp == 0) dgc[cam] = deg_c[cam];
     }
     for (int i = lane; i < 2 * lo_t; i += 64) qt[i] = 0ull;
+    for (int e = j0 + tid; e < j1; e += CGR_THREADS)            // both accumulator sets start at zero (this workgroup's slice; the barrier below publishes it)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cgr_st(qc_acc + (size_t)q * n3 + e, 0ull);
     Cgr6 t = cgr_reduce6(s, sc, 0.0, m, mc, 0.0, red);
     if (tid == 0) { cgr_st(part + 4 * wg, t.s0); cgr_st(part + 4 * wg + 1, t.a); }
     double rr_cam = t.s1, rmax_cam = t.b, pcmax = t.b;
@@ -272,26 +278,34 @@ __global__ __launch_bounds__(CGR_THREADS) void cg_resident_kernel(
             for (kc += CGR_NW; kc < c1; kc += CGR_NW) { CgrEdges<EPL> e; load_edges(e, kc); chunk(e, kc); }
         }
         __syncthreads();
-        for (int j = tid; j < 2 * n3; j += CGR_THREADS) cgr_st(slab + (size_t)wg * 2 * n3 + j, qc[j]);
+        // ---- this workgroup's camera sums INTO the iteration's accumulator set: the three integers fix3_add forms from a slab's
+        // (hi, lo) words, added with agent-scope atomics - exact integer sums, so the totals are the ones a fold over the slabs
+        // gives, whatever the order (round 5 wrote slabs, met at a barrier, folded a slice per workgroup and met again: one grid
+        // barrier and one round of dependent loads more per iteration)
+        u64* const acc = qc_acc + (size_t)(k & 1) * 3 * n3;
+        for (int j = tid; j < n3; j += CGR_THREADS) {
+            long long h = (long long)qc[j], l = (long long)qc[n3 + j];
+            const long long c = l >> lob;
+            h += c; l -= c << lob;
+            __hip_atomic_fetch_add(acc + j, (u64)(h >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(acc + n3 + j, (u64)(h & 0xFFFFFFFFll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(acc + 2 * n3 + j, (u64)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const double pq_loc = cgr_sum(pqs, red);
         if (tid == 0) cgr_st(part + 4 * wg + 2, pq_loc);
         if (!gsync()) return;
-
-        // ---- fold this workgroup's slice of the camera sums over all slabs (8 lanes per element; exact, overflow-proof integer sums)
-        for (int e = j0 + (tid >> 3); e < j1; e += CGR_THREADS / 8) {
-            Fix3 a = {0, 0, 0};
-            for (int q = tid & 7; q < nwg; q += 8)
-                fix3_add(a, (long long)cgr_ld(slab + (size_t)q * 2 * n3 + e), (long long)cgr_ld(slab + (size_t)q * 2 * n3 + n3 + e), lob);
-            const u64 st_ = stripe_sum((u64)a.top, 8), sb_ = stripe_sum((u64)a.bot, 8), sl_ = stripe_sum((u64)a.lo, 8);
-            if ((tid & 7) == 0) { cgr_st(qc_sum + e, st_); cgr_st(qc_sum + n3 + e, sb_); cgr_st(qc_sum + 2 * n3 + e, sl_); }
+        // (the OTHER set - read by everybody an iteration ago, added into an iteration from now - is zeroed here: every workgroup
+        //  is past the barriers that ended those reads, and passes another one before the next adds)
+        {
+            u64* const nxt = qc_acc + (size_t)((k + 1) & 1) * 3 * n3;
+            for (int e = j0 + tid; e < j1; e += CGR_THREADS) { cgr_st(nxt + e, 0ull); cgr_st(nxt + n3 + e, 0ull); cgr_st(nxt + 2 * n3 + e, 0ull); }
         }
-        if (!gsync()) return;
 
         // ---- alpha, x += alpha p, r -= alpha q (camera side replicated, timestep side on the own rows)
         double sq = tid < nwg ? cgr_ld(part + 4 * tid + 2) : 0.0;               // p.q: timestep partials + camera terms
         for (int j = tid; j < n3; j += CGR_THREADS) {
             const int comp = j / C, cam = j - comp * C;
-            const double q = dgc[cam] * pcs[j] - fix3_value((long long)cgr_ld(qc_sum + j), (long long)cgr_ld(qc_sum + n3 + j), (long long)cgr_ld(qc_sum + 2 * n3 + j), lob, inv);
+            const double q = dgc[cam] * pcs[j] - fix3_value((long long)cgr_ld(acc + j), (long long)cgr_ld(acc + n3 + j), (long long)cgr_ld(acc + 2 * n3 + j), lob, inv);
             qcs[j] = q; sq += pcs[j] * q;
         }
         pq = cgr_sum(sq, red);
