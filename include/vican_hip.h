@@ -98,7 +98,7 @@ typedef struct vican_graph {
 } vican_graph_t;
 
 const char* vican_last_error(void);
-#define VICAN_ABI_VERSION 30            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
+#define VICAN_ABI_VERSION 31            /* the one place the number lives: the library returns it, vican_amd/_lib.py parses it */
 int vican_abi_version(void);            /* VICAN_ABI_VERSION of the sources the library was built from */
 
 /* Launch gate (state of the calling host thread).  While a non-NULL device pointer is set, the
@@ -402,6 +402,14 @@ int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double* V, int32_t
                            const double* z, double* ws, double* Hcol, double* beta, double* x_out,
                            double pivot_floor, uint32_t* sync_ws, const void* zpart, int32_t n_slab,
                            const double* pa, const double* pb, int32_t fenced, void* stream);
+
+/* One Lanczos step of a single rank behind one host call: vican_block_op (the sweep, slabs into zpart) + vican_lanczos_cam_coop folding
+ * them (n_slab = g->n_wg, pa = fx + 3, pb = fx + 7).  x: the step's operand [3C][3] (x_out of the previous step; may equal x_out).
+ * VICAN_ERR_CAPACITY: the sweep has run, the cooperative grid was refused - fold the slabs (vican_slab_reduce_fx) and call
+ * vican_lanczos_cam_step.                                                                                                    */
+int vican_lanczos_step_slabs(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx,
+                             const double* lamC, double* V, int32_t ld, int32_t j, double* ws, double* Hcol, double* beta,
+                             double* x_out, double pivot_floor, uint32_t* sync_ws, int32_t fenced, void* stream);
 
 /* Ritz step on the device (replaces the shift-invert ARPACK call of bipgo.py:288 together with the
  * Lanczos steps).  HB[steps][row_stride]: row j = projected column V^T L Q_j ([hw/3][3] row-major,

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "vican_set_launch_events": (C.c_int, [_vp, _vp]),
     "vican_lanczos_coop_ws_doubles": (_i64, [_i32]),
     "vican_lanczos_cam_coop": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "vican_lanczos_step_slabs": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, _vp, _i32, _vp]),
     "vican_jacobi_scale": (C.c_int, [_i32, _vp, _vp, _vp]),
     "vican_row_scale": (C.c_int, [_i32, _i32, _vp, _vp, _vp]),
     "vican_scale_weights": (C.c_int, [_G, _vp, _vp, _vp, _vp, _vp]),

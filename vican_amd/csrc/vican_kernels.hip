@@ -791,6 +791,19 @@ extern "C" int vican_lanczos_cam_coop(int32_t n_cam, const double* lamC, double*
     return VICAN_OK;
 }
 
+// One Lanczos step of a single rank behind ONE host call: the operator sweep (vican_block_op: slabs) and the cooperative camera-side
+// step that folds them itself.  Capture-sized graphs are bound by the host's launch rate once their kernels take 10-15 us each
+// (large_shop: 97 launches in 1.19 ms of GPU time); a ctypes call costs the Python driver ~5 us.  VICAN_ERR_CAPACITY: the sweep
+// HAS run (its slabs are in zpart), the cooperative grid was refused - fold the slabs and take vican_lanczos_cam_step.
+extern "C" int vican_lanczos_step_slabs(const vican_graph_t* g, const double* lamT_inv, const double* x, void* zpart, double* fx,
+                                        const double* lamC, double* V, int32_t ld, int32_t j, double* ws, double* Hcol, double* beta,
+                                        double* x_out, double pivot_floor, uint32_t* sync_ws, int32_t fenced, void* stream) {
+    if (!g || !fx) return set_err(VICAN_ERR_ARG, "vican_lanczos_step_slabs: bad argument");
+    if (int rc = vican_block_op(g, lamT_inv, x, zpart, fx, stream)) return rc;
+    return vican_lanczos_cam_coop(g->n_cam, lamC, V, ld, j, nullptr, ws, Hcol, beta, x_out, pivot_floor, sync_ws, zpart, g->n_wg, fx + 3, fx + 7,
+                                  fenced, stream);
+}
+
 extern "C" int vican_lanczos_cam_step(int32_t n_cam, const double* lamC, double* V, int32_t ld, int32_t j,
                                       const double* z, double* R, double* H, double* G, double* Hcol, double* beta,
                                       double* x_out, double pivot_floor, double* ws, int64_t ws_doubles, void* stream) {

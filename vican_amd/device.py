@@ -201,6 +201,24 @@ class HipBackend:
         """The sweep of P x only: the result stays in the fixed-point slabs for lanczos_cam_step(from_slabs=True)."""
         self.block_op_raw(lamT_inv, x)
 
+    def lanczos_step_slabs(self, lamT_inv, lamC, V, ld, j, Hcol, beta, x, pivot_floor):
+        """Sweep + cooperative camera-side step behind ONE host call (x: operand in, next operand out).  False: the sweep has run
+        (slabs in zpart) but the cooperative step is not available - the caller folds and takes lanczos_cam_step."""
+        if not self.coop_cam_step:
+            self.block_op_raw(lamT_inv, x)
+            return False
+        if self._coop_ws is None:
+            self._coop_ws = torch.zeros(int(self.lib.vican_lanczos_coop_ws_doubles(self.C)), dtype=torch.float64, device=self.dev)
+            self._coop_sync = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        rc = self.lib.vican_lanczos_step_slabs(self._gref, _ptr(lamT_inv), _ptr(x), _ptr(self.zpart), _ptr(self.g.fx), _ptr(lamC), _ptr(V), ld, j,
+                                               _ptr(self._coop_ws), _ptr(Hcol), _ptr(beta), _ptr(x), float(pivot_floor), _ptr(self._coop_sync),
+                                               int(self.g.n_wg <= 64), _stream())
+        if rc == _lib.ERR_CAPACITY:
+            self.cooperative_failed("vican_lanczos_cam_coop")
+            return False
+        self._ck(rc, "vican_lanczos_step_slabs")
+        return True
+
     def lanczos_cam_step(self, lamC, V, ld, j, z, R, H, G, Hcol, beta, x_out, pivot_floor, from_slabs=False):
         n_nodes = lamC.numel() // 9             # C for the eliminated solver, C + T for the general one
         if self.coop_cam_step and n_nodes == self.C:

@@ -488,14 +488,26 @@ class RotationSolver:
             while True:
                 j = steps
                 in_slabs = False
-                if not (j == 0 and have_z):
+                one_call = (not (j == 0 and have_z) and not self.comm.sharded and self.fold_in_step and self.N == self.C
+                            and hasattr(K, "lanczos_step_slabs"))
+                if one_call:
+                    # single rank, few slabs: sweep and cooperative camera-side step behind ONE host call (capture-sized graphs
+                    # are bound by the launch rate of the host once their kernels take 10-15 us each)
+                    self.stats["sweeps"] += 1
+                    if not K.lanczos_step_slabs(self.lamT, self.lamC, self.V, ld, j, self.HB[j, : self.hw], self.HB[j, self.hw:],
+                                                self.xrow, self.pivot_floor):
+                        K.fold_z(self.z)                       # (cooperative grid refused: the sweep has run - fold, launch sequence)
+                        K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
+                                           self.HB[j, self.hw:], self.xrow, self.pivot_floor)
+                elif not (j == 0 and have_z):
                     # (j == 0 with a warm start from rc: P rc was formed by the fused dual update of the previous
                     #  primal-dual iteration - one pass over the blocks instead of two - and normalised by the seed)
                     in_slabs = bool(self.apply_P(self.xrow, self.z))
                 # camera side of the step: A Q_j = Lambda_C Q_j - z, two Gram-Schmidt passes against the
                 # whole basis (coefficients -> Hbuf[j]), Cholesky-QR -> block j+1, beta_j, next sweep input
-                K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
-                                   self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
+                if not one_call:
+                    K.lanczos_cam_step(self.lamC, self.V, ld, j, self.z, self.R, self.H, self.G, self.HB[j, : self.hw],
+                                       self.HB[j, self.hw:], self.xrow, self.pivot_floor, **({"from_slabs": True} if in_slabs else {}))
                 steps += 1
                 total_steps += 1
                 if steps >= next_check or steps >= self.m_max:
