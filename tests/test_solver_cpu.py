@@ -151,3 +151,33 @@ def test_flatten_arrays_equals_the_dict_front_end():
         frontend.flatten_arrays([], [], [], np.zeros((0, 3, 3)), np.zeros((0, 3)), [], [], cons)
     with pytest.raises(KeyError):                                      # unknown marker id, as bipgo.py:209
         frontend.flatten_arrays(cams[:3], times[:3], ["nope"] * 3, R[:3], t[:3], [1.0] * 3, [1.0] * 3, cons)
+
+
+@pytest.mark.parametrize("name", ["g2_small", "g3_medium"])
+def test_check_positions_walk_down_to_the_smallest_counts_on_the_host_logic(name):
+    """The schedule hints of capture-sized graphs (vican_amd/solver.py RotationSolver.spectral: checks every fourth step on the
+    first solve, one step fewer per later solve of the same object until a check fails) on the NumPy backend: step counts never
+    grow from solve to solve, settle, and the rotations are those of a solver that checks after every step (f64: to 1e-10)."""
+    from vican_amd.solver import RotationSolver
+    g, case, prob = flatten_case(name, "float64")
+    K = NumpyBackend(prob.n_cam, prob.row_ptr, prob.col, prob.blk, prob.a, prob.w, prob.u, prob.v, storage=np.float64,
+                     deg_t=prob.deg_t, deg_c=prob.deg_c)
+    rot = RotationSolver(K, Comm())
+    rot.small_graph, rot.min_steps, rot.warm_min_steps, rot.check_every = True, 8, 4, 4      # (what a GPU graph below 2 M edges gets)
+    hist, outs = [], []
+    for _ in range(8):
+        rot.stats = dict(sweeps=0, lanczos_steps=[], evals=[], restarts=0, resid=[])
+        rc, Rt = rot.run(gc.MAXITER)
+        hist.append(list(rot.stats["lanczos_steps"]))
+        outs.append((rc.detach().cpu().numpy().copy(), Rt.detach().cpu().numpy().copy()))
+    tot = [sum(h) for h in hist]
+    assert all(b <= a for a, b in zip(tot, tot[1:])), hist
+    assert hist[-1] == hist[-2] and tot[-1] <= tot[0], hist
+    ref = RotationSolver(K, Comm())
+    ref.min_steps = ref.warm_min_steps = ref.check_every = 1
+    rc_ref, Rt_ref = ref.run(gc.MAXITER)
+    assert all(a <= b for a, b in zip(hist[-1], ref.stats["lanczos_steps"])), (hist[-1], ref.stats["lanczos_steps"])
+    for a, b in zip(outs[-1], (rc_ref.detach().cpu().numpy(), Rt_ref.detach().cpu().numpy())):
+        assert np.abs(a - b).max() < 1e-9
+    for a, b in zip(outs[0], outs[-1]):
+        assert np.abs(a - b).max() < 1e-9
